@@ -1,0 +1,93 @@
+/*
+ * recnext_amd -- C ABI of the MI355X (gfx950) RecConv2d / RecAttn2d token-mixer kernels.
+ *
+ * The reference (suous/RecNeXt) has no FFI layer: its boundary for this path is the Python class
+ *     RecConv2d(in_channels, kernel_size=5, bias=False, level=2, mode='bilinear')   model/recnext.py:9
+ *     RecAttn2d(dim, num_heads, kernel_size=5, stage=1, mode="nearest")             model/recattn.py:55
+ * whose bodies are chains of ATen calls.  This header is what a binding for that class would
+ * call instead (see INTEGRATION.md for the ctypes stub); each entry point cites the reference
+ * lines it replaces.
+ *
+ * Conventions
+ *   - Activations: device pointers to NHWC-contiguous memory (the storage of a torch.channels_last
+ *     tensor of logical shape N x C x H x W).  dtype: RCX_DTYPE_F32 or RCX_DTYPE_BF16.
+ *   - Weights: float32 device memory, *packed* tap-major (k,k,C) by rcx_pack_dw_weight from the
+ *     reference's (C,1,k,k) parameter layout; biases float32 (C).  A RecConv2d parameter pack is
+ *     (level+2) such blocks back to back: [down, convs[0], ..., convs[level]]  (convs[0] pairs with
+ *     the coarsest level, model/recnext.py:32-34).
+ *   - The library never allocates, frees, synchronises or retains pointers; all work is enqueued
+ *     on the hipStream_t passed as `stream` (NULL = the default stream).  Calls are re-entrant.
+ *   - Return value: 0 ok; <0 argument / unsupported-configuration error; >0 a hipError_t.
+ *     rcx_last_error() returns a thread-local message for the last non-zero return.
+ */
+#ifndef RECNEXT_AMD_H
+#define RECNEXT_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCX_ABI_VERSION 1
+
+enum { RCX_DTYPE_F32 = 0, RCX_DTYPE_BF16 = 1 };
+enum { RCX_MODE_BILINEAR = 0, RCX_MODE_NEAREST = 1 };   /* F.interpolate(mode=...), model/recnext.py:33 */
+enum { RCX_MAX_LEVEL = 8 };
+
+enum {
+    RCX_ERR_BAD_ARG = -1,       /* null pointer, non-positive extent, even k, level out of range */
+    RCX_ERR_UNSUPPORTED = -2,   /* configuration outside what the kernels implement */
+    RCX_ERR_WORKSPACE = -3      /* workspace smaller than rcx_recconv2d_fwd_workspace_bytes() */
+};
+
+int rcx_abi_version(void);
+const char* rcx_last_error(void);
+
+/* Name of the kernel schedule rcx_recconv2d_fwd would use for this problem ("generic", "plane", ...);
+ * static string, for logs and benchmarks. */
+const char* rcx_recconv2d_fwd_plan(int N, int C, int H, int W, int level, int k, int mode, int dtype);
+
+/* Repack one depthwise weight (C,1,k,k) [dtype f32|bf16] -> float32 (k,k,C).
+ * Replaces nothing in the reference (layout plumbing for nn.Conv2d(groups=C).weight, model/recnext.py:21-22). */
+int rcx_pack_dw_weight(const void* w_ckk, float* dst_kkc, int C, int k, int dtype, void* stream);
+/* Convert one bias vector (C) [dtype f32|bf16] -> float32 (C). */
+int rcx_pack_bias(const void* b, float* dst, int C, int dtype, void* stream);
+
+/* Scratch bytes rcx_recconv2d_fwd needs for this problem (may be 0). */
+size_t rcx_recconv2d_fwd_workspace_bytes(int N, int C, int H, int W, int level, int k, int dtype);
+
+/*
+ * RecConv2d.forward -- model/recnext.py:24-34 (down ladder :27-29, up recursion :31-33, final conv :34).
+ *   x, y    : N x H x W x C activations of `dtype` (y may not alias x)
+ *   wpack   : (level+2, k, k, C) float32, [down, convs[0..level]]
+ *   bpack   : (level+2, C) float32 or NULL (bias=False)
+ *   level>=0, k odd, mode RCX_MODE_*.
+ */
+int rcx_recconv2d_fwd(const void* x, void* y, const float* wpack, const float* bpack,
+                      void* workspace, size_t workspace_bytes,
+                      int N, int C, int H, int W, int level, int k, int mode, int dtype, void* stream);
+
+/*
+ * Depthwise conv, zero padding k/2, stride 1 or 2 -- nn.Conv2d(groups=C) as used at
+ * model/recnext.py:21-22 and by RecAttn2d's ConvNorm(dw k5 s2) after BN folding (model/recattn.py:61, :89-111).
+ *   x: N x H x W x C (in_dtype);  y: N x Ho x Wo x C (out_dtype), Ho = (H + 2*(k/2) - k)/stride + 1.
+ */
+int rcx_dwconv2d_fwd(const void* x, void* y, const float* w_kkc, const float* bias,
+                     int N, int C, int H, int W, int k, int stride,
+                     int in_dtype, int out_dtype, void* stream);
+
+/*
+ * y = dwconv_k(x + resize(coarse -> (H,W), mode)) -- the body of one up-recursion step
+ * (model/recnext.py:33-34) and the tail of RecAttn2d.forward (model/recattn.py:67).
+ *   x: N x H x W x C (x_dtype); coarse: N x Hc x Wc x C (coarse_dtype) or NULL (then y = dwconv_k(x));
+ *   y: N x H x W x C (out_dtype).
+ */
+int rcx_upadd_dwconv_fwd(const void* x, const void* coarse, void* y, const float* w_kkc, const float* bias,
+                         int N, int C, int H, int W, int Hc, int Wc, int k, int mode,
+                         int x_dtype, int coarse_dtype, int out_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECNEXT_AMD_H */

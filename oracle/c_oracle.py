@@ -33,7 +33,7 @@ def lib():
         _lib.rcx_oracle_recconv2d_nhwc_f32.restype = ctypes.c_int
         _lib.rcx_oracle_dwconv2d_nhwc_f32.argtypes = [fp, fp, fp, fp] + [ctypes.c_int] * 6
         _lib.rcx_oracle_dwconv2d_nhwc_f32.restype = None
-        _lib.rcx_oracle_add_resized_nhwc_f32.argtypes = [fp, fp, fp] + [ctypes.c_int] * 8
+        _lib.rcx_oracle_add_resized_nhwc_f32.argtypes = [fp, fp, fp] + [ctypes.c_int] * 7
         _lib.rcx_oracle_add_resized_nhwc_f32.restype = None
     return _lib
 

@@ -1,0 +1,61 @@
+"""ctypes binding of librecnext_amd.so (include/recnext_amd.h).
+
+The library is built in-tree by ``recnext_amd.build`` (``recnext_amd/lib/librecnext_amd.so``).  There is
+no fallback: if it is missing or fails to load, every entry point raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librecnext_amd.so")
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+MODE_BILINEAR, MODE_NEAREST = 0, 1
+MODES = {"bilinear": MODE_BILINEAR, "nearest": MODE_NEAREST}
+MAX_LEVEL = 8
+ABI_VERSION = 1
+
+_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+
+# name -> (restype, argtypes); every symbol include/recnext_amd.h declares
+SIGNATURES = {
+    "rcx_abi_version": (_i, []),
+    "rcx_last_error": (ctypes.c_char_p, []),
+    "rcx_recconv2d_fwd_plan": (ctypes.c_char_p, [_i] * 8),
+    "rcx_pack_dw_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "rcx_pack_bias": (_i, [_vp, _vp, _i, _i, _vp]),
+    "rcx_recconv2d_fwd_workspace_bytes": (_sz, [_i] * 7),
+    "rcx_recconv2d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 8 + [_vp]),
+    "rcx_dwconv2d_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
+    "rcx_upadd_dwconv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
+}
+
+_lib = None
+
+
+class RcxError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the shared library; raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RcxError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(or `make -C recnext_amd/csrc`). There is no fallback path.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        got = lib.rcx_abi_version()
+        if got != ABI_VERSION:
+            raise RcxError(f"librecnext_amd ABI {got} != binding ABI {ABI_VERSION}; rebuild the library")
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().rcx_last_error().decode("utf-8", "replace")
+        raise RcxError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,169 @@
+// C ABI of librecnext_amd.so (include/recnext_amd.h): argument checking, schedule selection,
+// error reporting.  No allocation, no synchronisation, no retained pointers.
+#include "../../include/recnext_amd.h"
+#include "rcx_launch.h"
+
+#include <cstdarg>
+#include <cstdio>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+
+inline int down_size(int h, int k) { const int p = k / 2; return (h + 2 * p - k) / 2 + 1; }
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Ladder {
+    int h[RCX_MAX_LEVEL + 1], w[RCX_MAX_LEVEL + 1];
+    size_t f_off[RCX_MAX_LEVEL + 1];   // workspace offsets of F_1..F_level (float)
+    size_t c_off[2];                   // two ping-pong conv-output buffers (float), each sized for level 1
+    size_t total;
+};
+
+Ladder make_ladder(int N, int C, int H, int W, int level, int k)
+{
+    Ladder L{};
+    L.h[0] = H; L.w[0] = W;
+    size_t off = 0;
+    for (int l = 1; l <= level; ++l) {
+        L.h[l] = down_size(L.h[l - 1], k);
+        L.w[l] = down_size(L.w[l - 1], k);
+        L.f_off[l] = off;
+        off += align256(sizeof(float) * (size_t)N * C * L.h[l] * L.w[l]);
+    }
+    const size_t c1 = level >= 1 ? align256(sizeof(float) * (size_t)N * C * L.h[1] * L.w[1]) : 0;
+    const size_t c2 = level >= 2 ? align256(sizeof(float) * (size_t)N * C * L.h[2] * L.w[2]) : 0;
+    L.c_off[0] = off; off += c1;       // holds C_1, C_3, ...
+    L.c_off[1] = off; off += c2;       // holds C_2, C_4, ...
+    L.total = off;
+    return L;
+}
+
+int check_common(const void* x, const void* y, int N, int C, int H, int W, int k, int dtype)
+{
+    if (!x || !y) return fail(RCX_ERR_BAD_ARG, "null activation pointer");
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive extent N=%d C=%d H=%d W=%d", N, C, H, W);
+    if (k <= 0 || (k & 1) == 0) return fail(RCX_ERR_BAD_ARG, "kernel_size must be odd and positive, got %d", k);
+    if (dtype != RCX_DTYPE_F32 && dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rcx_abi_version(void) { return RCX_ABI_VERSION; }
+
+const char* rcx_last_error(void) { return g_err; }
+
+const char* rcx_recconv2d_fwd_plan(int, int, int, int, int, int, int, int) { return "generic"; }
+
+int rcx_pack_dw_weight(const void* w_ckk, float* dst_kkc, int C, int k, int dtype, void* stream)
+{
+    if (!w_ckk || !dst_kkc || C <= 0 || k <= 0) return fail(RCX_ERR_BAD_ARG, "rcx_pack_dw_weight: bad argument");
+    if (dtype != RCX_DTYPE_F32 && dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
+    hipError_t e = rcx::pack_dw_weight(w_ckk, dst_kkc, C, k, dtype, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "rcx_pack_dw_weight");
+}
+
+int rcx_pack_bias(const void* b, float* dst, int C, int dtype, void* stream)
+{
+    if (!b || !dst || C <= 0) return fail(RCX_ERR_BAD_ARG, "rcx_pack_bias: bad argument");
+    if (dtype != RCX_DTYPE_F32 && dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
+    hipError_t e = rcx::pack_bias(b, dst, C, dtype, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "rcx_pack_bias");
+}
+
+size_t rcx_recconv2d_fwd_workspace_bytes(int N, int C, int H, int W, int level, int k, int /*dtype*/)
+{
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0) return 0;
+    return make_ladder(N, C, H, W, level, k).total;
+}
+
+int rcx_recconv2d_fwd(const void* x, void* y, const float* wpack, const float* bpack,
+                      void* workspace, size_t workspace_bytes,
+                      int N, int C, int H, int W, int level, int k, int mode, int dtype, void* stream)
+{
+    if (int rc = check_common(x, y, N, C, H, W, k, dtype)) return rc;
+    if (!wpack) return fail(RCX_ERR_BAD_ARG, "null weight pack");
+    if (x == y) return fail(RCX_ERR_BAD_ARG, "y must not alias x");
+    if (level < 0 || level > RCX_MAX_LEVEL) return fail(RCX_ERR_BAD_ARG, "level %d outside [0,%d]", level, RCX_MAX_LEVEL);
+    if (mode != RCX_MODE_BILINEAR && mode != RCX_MODE_NEAREST) return fail(RCX_ERR_BAD_ARG, "unknown mode %d", mode);
+    const Ladder L = make_ladder(N, C, H, W, level, k);
+    if (L.total > 0 && (!workspace || workspace_bytes < L.total))
+        return fail(RCX_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", L.total, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t wsz = (size_t)k * k * C;
+    auto W_ = [&](int i) { return wpack + (size_t)i * wsz; };                       // 0 = down, 1+j = convs[j]
+    auto B_ = [&](int i) { return bpack ? bpack + (size_t)i * C : nullptr; };
+    char* ws = (char*)workspace;
+    auto F_ = [&](int l) { return (float*)(ws + L.f_off[l]); };
+    auto Cb = [&](int l) { return (float*)(ws + L.c_off[(l + 1) & 1]); };           // C_1 -> buf 0, C_2 -> buf 1, ...
+    hipError_t e;
+    // down ladder, shared weight (model/recnext.py:27-29); F_l kept in float32
+    for (int l = 1; l <= level; ++l) {
+        const void* src = l == 1 ? x : (const void*)F_(l - 1);
+        e = rcx::generic_dwconv(src, F_(l), W_(0), B_(0), N, C, L.h[l - 1], L.w[l - 1], k, 2,
+                                l == 1 ? dtype : RCX_DTYPE_F32, RCX_DTYPE_F32, s);
+        if (e != hipSuccess) return hip_fail(e, "down ladder");
+    }
+    // up recursion, coarsest first (model/recnext.py:31-33): C_l = conv_j(F_l + resize(C_{l+1}))
+    for (int l = level, j = 0; l >= 1; --l, ++j) {
+        const float* coarse = l == level ? nullptr : Cb(l + 1);
+        e = rcx::generic_upadd_dwconv(F_(l), coarse, Cb(l), W_(1 + j), B_(1 + j), N, C, L.h[l], L.w[l],
+                                      l == level ? 0 : L.h[l + 1], l == level ? 0 : L.w[l + 1], k, mode,
+                                      RCX_DTYPE_F32, RCX_DTYPE_F32, RCX_DTYPE_F32, s);
+        if (e != hipSuccess) return hip_fail(e, "up recursion");
+    }
+    // final conv (model/recnext.py:34)
+    e = rcx::generic_upadd_dwconv(x, level >= 1 ? Cb(1) : nullptr, y, W_(1 + level), B_(1 + level), N, C, H, W,
+                                  level >= 1 ? L.h[1] : 0, level >= 1 ? L.w[1] : 0, k, mode,
+                                  dtype, RCX_DTYPE_F32, dtype, s);
+    if (e != hipSuccess) return hip_fail(e, "final conv");
+    return 0;
+}
+
+int rcx_dwconv2d_fwd(const void* x, void* y, const float* w_kkc, const float* bias,
+                     int N, int C, int H, int W, int k, int stride, int in_dtype, int out_dtype, void* stream)
+{
+    if (int rc = check_common(x, y, N, C, H, W, k, in_dtype)) return rc;
+    if (out_dtype != RCX_DTYPE_F32 && out_dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", out_dtype);
+    if (!w_kkc) return fail(RCX_ERR_BAD_ARG, "null weight");
+    if (stride != 1 && stride != 2) return fail(RCX_ERR_UNSUPPORTED, "stride %d not supported (1 or 2)", stride);
+    hipError_t e = rcx::generic_dwconv(x, y, w_kkc, bias, N, C, H, W, k, stride, in_dtype, out_dtype, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "rcx_dwconv2d_fwd");
+}
+
+int rcx_upadd_dwconv_fwd(const void* x, const void* coarse, void* y, const float* w_kkc, const float* bias,
+                         int N, int C, int H, int W, int Hc, int Wc, int k, int mode,
+                         int x_dtype, int coarse_dtype, int out_dtype, void* stream)
+{
+    if (int rc = check_common(x, y, N, C, H, W, k, x_dtype)) return rc;
+    if (out_dtype != RCX_DTYPE_F32 && out_dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", out_dtype);
+    if (!w_kkc) return fail(RCX_ERR_BAD_ARG, "null weight");
+    if (mode != RCX_MODE_BILINEAR && mode != RCX_MODE_NEAREST) return fail(RCX_ERR_BAD_ARG, "unknown mode %d", mode);
+    if (coarse) {
+        if (Hc <= 0 || Wc <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive coarse extent %dx%d", Hc, Wc);
+        if (coarse_dtype != RCX_DTYPE_F32 && coarse_dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", coarse_dtype);
+    }
+    hipError_t e = rcx::generic_upadd_dwconv(x, coarse, y, w_kkc, bias, N, C, H, W, Hc, Wc, k, mode,
+                                             x_dtype, coarse_dtype, out_dtype, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "rcx_upadd_dwconv_fwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,239 @@
+// Generic (any shape, any odd k, any C) depthwise kernels for gfx950.
+//
+//   k_dwconv        y = dwconv_{k,stride}(x)                         model/recnext.py:21-22,28
+//   k_upadd_dwconv  y = dwconv_{k,1}(x + resize(coarse -> size(x)))  model/recnext.py:33-34, model/recattn.py:67
+//
+// These are the schedule of last resort: one launch per ladder step, inputs read straight from
+// global memory (L1/L2 absorb the k x k window reuse), every thread producing R horizontally
+// adjacent outputs for a vector of V channels so the window is read once per row instead of once
+// per tap.  NHWC puts channels on consecutive lanes: every wave-load is a run of whole pixels.
+// The fused single-launch schedules live in rcx_plane.hip; rcx_api.hip picks between them.
+#include "rcx_common.h"
+#include "rcx_launch.h"
+
+namespace rcx {
+
+template <typename T> struct DT;
+template <> struct DT<float> { static constexpr int id = 0; };
+template <> struct DT<bf16_t> { static constexpr int id = 1; };
+
+struct ConvGeom {
+    int N, C, H, W;       // input extent (of x)
+    int Ho, Wo;           // output extent
+    int Hc, Wc;           // coarse extent (upadd only)
+    int k, stride;
+    int strips;           // ceil(Wo / R)
+    int cvecs;            // C / V
+    float sy, sx;         // Hc/H, Wc/W resize scales (upadd only)
+};
+
+// T(n, iy, ix, c..c+V) = x + resize(coarse), zero outside the plane (the conv's zero padding
+// applies to the *sum*, as in conv(f + x) at model/recnext.py:33).
+template <typename TX, typename TC, int V, int MODE, bool HAS_COARSE>
+__device__ __forceinline__ void fetch_sum(const TX* __restrict__ xn, const TC* __restrict__ cn, const ConvGeom& g,
+                                          int iy, int ix, int c, float (&out)[V])
+{
+    load_vec<V>(xn + ((size_t)iy * g.W + ix) * g.C + c, out);
+    if constexpr (HAS_COARSE) {
+        if constexpr (MODE == 1) {
+            int cy = nearest_src(iy, g.Hc, g.sy), cx = nearest_src(ix, g.Wc, g.sx);
+            float t[V];
+            load_vec<V>(cn + ((size_t)cy * g.Wc + cx) * g.C + c, t);
+#pragma unroll
+            for (int i = 0; i < V; ++i) out[i] += t[i];
+        } else {
+            Lerp ly = bilinear_src(iy, g.Hc, g.sy), lx = bilinear_src(ix, g.Wc, g.sx);
+            float a[V], b[V], d[V], e[V];
+            load_vec<V>(cn + ((size_t)ly.i0 * g.Wc + lx.i0) * g.C + c, a);
+            load_vec<V>(cn + ((size_t)ly.i0 * g.Wc + lx.i1) * g.C + c, b);
+            load_vec<V>(cn + ((size_t)ly.i1 * g.Wc + lx.i0) * g.C + c, d);
+            load_vec<V>(cn + ((size_t)ly.i1 * g.Wc + lx.i1) * g.C + c, e);
+            const float wy1 = ly.lam, wy0 = 1.f - ly.lam, wx1 = lx.lam, wx0 = 1.f - lx.lam;
+#pragma unroll
+            for (int i = 0; i < V; ++i)
+                out[i] += wy0 * (wx0 * a[i] + wx1 * b[i]) + wy1 * (wx0 * d[i] + wx1 * e[i]);
+        }
+    }
+}
+
+// One thread: V channels x R adjacent output columns of one output row.
+// K == 0 selects the runtime-k body.
+template <typename TX, typename TC, typename TO, int K, int STRIDE, int V, int R, int MODE, bool HAS_COARSE>
+__global__ void __launch_bounds__(256)
+k_conv_generic(const TX* __restrict__ x, const TC* __restrict__ coarse, TO* __restrict__ y,
+               const float* __restrict__ w, const float* __restrict__ bias, ConvGeom g)
+{
+    const int k = K ? K : g.k;
+    const int p = k / 2;
+    const long long total = (long long)g.N * g.Ho * g.strips * g.cvecs;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        long long r = t;
+        const int cv = (int)(r % g.cvecs); r /= g.cvecs;
+        const int st = (int)(r % g.strips); r /= g.strips;
+        const int oy = (int)(r % g.Ho);
+        const int n = (int)(r / g.Ho);
+        const int c = cv * V;
+        const int ox0 = st * R;
+        const TX* xn = x + (size_t)n * g.H * g.W * g.C;
+        const TC* cn = HAS_COARSE ? coarse + (size_t)n * g.Hc * g.Wc * g.C : nullptr;
+
+        float acc[R][V];
+        {
+            float b[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) b[i] = 0.f;
+            if (bias) load_vec<V>(bias + c, b);
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+#pragma unroll
+                for (int i = 0; i < V; ++i) acc[j][i] = b[i];
+        }
+        const int span = (R - 1) * STRIDE + k;           // input columns touched by the strip
+        for (int u = 0; u < k; ++u) {
+            const int iy = oy * STRIDE + u - p;
+            if (iy < 0 || iy >= g.H) continue;
+            for (int s = 0; s < span; ++s) {
+                const int ix = ox0 * STRIDE + s - p;
+                if (ix < 0 || ix >= g.W) continue;
+                float in[V];
+                fetch_sum<TX, TC, V, MODE, HAS_COARSE>(xn, cn, g, iy, ix, c, in);
+                // input column s feeds output j through tap v = s - j*STRIDE
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const int v = s - j * STRIDE;
+                    if (v >= 0 && v < k) {
+                        float wv[V];
+                        load_vec<V>(w + ((size_t)u * k + v) * g.C + c, wv);
+#pragma unroll
+                        for (int i = 0; i < V; ++i) acc[j][i] = fmaf(wv[i], in[i], acc[j][i]);
+                    }
+                }
+            }
+        }
+        TO* yo = y + (((size_t)n * g.Ho + oy) * g.Wo + ox0) * g.C + c;
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (ox0 + j < g.Wo) store_vec<V>(yo + (size_t)j * g.C, acc[j]);
+    }
+}
+
+template <typename TX, typename TC, typename TO, int K, int STRIDE, int V, int MODE, bool HAS_COARSE>
+static hipError_t launch_rv(const void* x, const void* coarse, void* y, const float* w, const float* b,
+                            ConvGeom g, hipStream_t stream)
+{
+    constexpr int R = 4;
+    g.strips = (g.Wo + R - 1) / R;
+    g.cvecs = g.C / V;
+    const long long total = (long long)g.N * g.Ho * g.strips * g.cvecs;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256LL * 64) blocks = 256LL * 64;         // grid-stride beyond 64 blocks per CU
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((k_conv_generic<TX, TC, TO, K, STRIDE, V, R, MODE, HAS_COARSE>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                       (const TX*)x, (const TC*)coarse, (TO*)y, w, b, g);
+    return hipGetLastError();
+}
+
+template <typename TX, typename TC, typename TO, int K, int STRIDE, int MODE, bool HAS_COARSE>
+static hipError_t launch_v(const void* x, const void* coarse, void* y, const float* w, const float* b,
+                           const ConvGeom& g, hipStream_t s)
+{
+    // widest channel vector that divides C and keeps 16-byte loads on the narrowest operand
+    if (g.C % 8 == 0 && sizeof(TX) == 2 && sizeof(TO) == 2)
+        return launch_rv<TX, TC, TO, K, STRIDE, 8, MODE, HAS_COARSE>(x, coarse, y, w, b, g, s);
+    if (g.C % 4 == 0) return launch_rv<TX, TC, TO, K, STRIDE, 4, MODE, HAS_COARSE>(x, coarse, y, w, b, g, s);
+    if (g.C % 2 == 0) return launch_rv<TX, TC, TO, K, STRIDE, 2, MODE, HAS_COARSE>(x, coarse, y, w, b, g, s);
+    return launch_rv<TX, TC, TO, K, STRIDE, 1, MODE, HAS_COARSE>(x, coarse, y, w, b, g, s);
+}
+
+template <typename TX, typename TC, typename TO, int STRIDE, int MODE, bool HAS_COARSE>
+static hipError_t launch_k(const void* x, const void* coarse, void* y, const float* w, const float* b,
+                           const ConvGeom& g, hipStream_t s)
+{
+    switch (g.k) {
+    case 3: return launch_v<TX, TC, TO, 3, STRIDE, MODE, HAS_COARSE>(x, coarse, y, w, b, g, s);
+    case 5: return launch_v<TX, TC, TO, 5, STRIDE, MODE, HAS_COARSE>(x, coarse, y, w, b, g, s);
+    case 7: return launch_v<TX, TC, TO, 7, STRIDE, MODE, HAS_COARSE>(x, coarse, y, w, b, g, s);
+    default: return launch_v<TX, TC, TO, 0, STRIDE, MODE, HAS_COARSE>(x, coarse, y, w, b, g, s);
+    }
+}
+
+template <typename TX, typename TO>
+static hipError_t dwconv_io(const void* x, void* y, const float* w, const float* b, const ConvGeom& g, hipStream_t s)
+{
+    if (g.stride == 2) return launch_k<TX, float, TO, 2, 0, false>(x, nullptr, y, w, b, g, s);
+    return launch_k<TX, float, TO, 1, 0, false>(x, nullptr, y, w, b, g, s);
+}
+
+hipError_t generic_dwconv(const void* x, void* y, const float* w, const float* b,
+                          int N, int C, int H, int W, int k, int stride, int in_dt, int out_dt, hipStream_t s)
+{
+    ConvGeom g{};
+    g.N = N; g.C = C; g.H = H; g.W = W; g.k = k; g.stride = stride;
+    const int p = k / 2;
+    g.Ho = (H + 2 * p - k) / stride + 1;
+    g.Wo = (W + 2 * p - k) / stride + 1;
+    if (in_dt == 0 && out_dt == 0) return dwconv_io<float, float>(x, y, w, b, g, s);
+    if (in_dt == 1 && out_dt == 0) return dwconv_io<bf16_t, float>(x, y, w, b, g, s);
+    if (in_dt == 0 && out_dt == 1) return dwconv_io<float, bf16_t>(x, y, w, b, g, s);
+    return dwconv_io<bf16_t, bf16_t>(x, y, w, b, g, s);
+}
+
+template <typename TX, typename TC, typename TO>
+static hipError_t upadd_io(const void* x, const void* c, void* y, const float* w, const float* b,
+                           const ConvGeom& g, int mode, hipStream_t s)
+{
+    if (mode == 0) return launch_k<TX, TC, TO, 1, 0, true>(x, c, y, w, b, g, s);
+    return launch_k<TX, TC, TO, 1, 1, true>(x, c, y, w, b, g, s);
+}
+
+hipError_t generic_upadd_dwconv(const void* x, const void* coarse, void* y, const float* w, const float* b,
+                                int N, int C, int H, int W, int Hc, int Wc, int k, int mode,
+                                int x_dt, int c_dt, int out_dt, hipStream_t s)
+{
+    if (!coarse) return generic_dwconv(x, y, w, b, N, C, H, W, k, 1, x_dt, out_dt, s);
+    ConvGeom g{};
+    g.N = N; g.C = C; g.H = H; g.W = W; g.Ho = H; g.Wo = W; g.Hc = Hc; g.Wc = Wc; g.k = k; g.stride = 1;
+    g.sy = (float)Hc / (float)H;
+    g.sx = (float)Wc / (float)W;
+    const int key = x_dt * 4 + c_dt * 2 + out_dt;
+    switch (key) {
+    case 0: return upadd_io<float, float, float>(x, coarse, y, w, b, g, mode, s);
+    case 1: return upadd_io<float, float, bf16_t>(x, coarse, y, w, b, g, mode, s);
+    case 2: return upadd_io<float, bf16_t, float>(x, coarse, y, w, b, g, mode, s);
+    case 3: return upadd_io<float, bf16_t, bf16_t>(x, coarse, y, w, b, g, mode, s);
+    case 4: return upadd_io<bf16_t, float, float>(x, coarse, y, w, b, g, mode, s);
+    case 5: return upadd_io<bf16_t, float, bf16_t>(x, coarse, y, w, b, g, mode, s);
+    case 6: return upadd_io<bf16_t, bf16_t, float>(x, coarse, y, w, b, g, mode, s);
+    default: return upadd_io<bf16_t, bf16_t, bf16_t>(x, coarse, y, w, b, g, mode, s);
+    }
+}
+
+// ---- parameter packing ----
+template <typename T>
+__global__ void k_pack_dw_weight(const T* __restrict__ w, float* __restrict__ dst, int C, int kk)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // index into dst (tap-major)
+    if (i >= C * kk) return;
+    const int tap = i / C, c = i % C;
+    float v;
+    if constexpr (sizeof(T) == 2) v = bf16_to_f32(w[(size_t)c * kk + tap]); else v = w[(size_t)c * kk + tap];
+    dst[i] = v;
+}
+
+hipError_t pack_dw_weight(const void* w, float* dst, int C, int k, int dt, hipStream_t s)
+{
+    const int n = C * k * k;
+    if (dt == 0) hipLaunchKernelGGL(k_pack_dw_weight<float>, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)w, dst, C, k * k);
+    else hipLaunchKernelGGL(k_pack_dw_weight<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16_t*)w, dst, C, k * k);
+    return hipGetLastError();
+}
+
+hipError_t pack_bias(const void* b, float* dst, int C, int dt, hipStream_t s)
+{
+    // a bias is a (C,1,1,1) weight with one tap
+    if (dt == 0) hipLaunchKernelGGL(k_pack_dw_weight<float>, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)b, dst, C, 1);
+    else hipLaunchKernelGGL(k_pack_dw_weight<bf16_t>, dim3((C + 255) / 256), dim3(256), 0, s, (const bf16_t*)b, dst, C, 1);
+    return hipGetLastError();
+}
+
+}  // namespace rcx

@@ -1,0 +1,157 @@
+"""Tensor-level front-end of the C ABI: torch supplies device memory and the HIP stream, nothing else.
+
+Every function here requires CUDA(ROCm) tensors and the built HIP library; there is no CPU or
+PyTorch-operator fallback (calling with a CPU tensor raises).
+"""
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16}
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"recnext_amd kernels take float32 or bfloat16 tensors, got {t.dtype}") from None
+
+
+def _require_gpu(t, name):
+    if not t.is_cuda:
+        raise _lib.RcxError(f"{name} is on {t.device}: the recnext_amd token mixers only run as HIP kernels on a GPU "
+                            "(no CPU fallback exists in the product path)")
+
+
+def _nhwc(t, name="x"):
+    """Logical N x C x H x W tensor whose storage is N x H x W x C contiguous (torch.channels_last)."""
+    if t.dim() != 4:
+        raise ValueError(f"{name} must be 4-D (N,C,H,W), got shape {tuple(t.shape)}")
+    _require_gpu(t, name)
+    n, c, h, w = t.shape
+    want = (h * w * c, 1, w * c, c)
+    ok = all(sz == 1 or st == wt for sz, st, wt in zip(t.shape, t.stride(), want))
+    if not ok:
+        t = t.contiguous(memory_format=torch.channels_last)
+        if not all(sz == 1 or st == wt for sz, st, wt in zip(t.shape, t.stride(), want)):
+            t = t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)   # degenerate-stride corner (C==1 / H==W==1)
+    return t
+
+
+def _empty_nhwc(n, c, h, w, dtype, device):
+    return torch.empty((n, h, w, c), dtype=dtype, device=device).permute(0, 3, 1, 2)
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def down_size(h, k):
+    p = k // 2
+    return (h + 2 * p - k) // 2 + 1
+
+
+def pack_dw_weight(w, out=None):
+    """(C,1,k,k) or (C,k,k) f32/bf16 parameter -> float32 (k,k,C) on the same device."""
+    _require_gpu(w, "weight")
+    c, k = w.shape[0], w.shape[-1]
+    w = w.detach().contiguous()
+    if out is None:
+        out = torch.empty(k * k * c, dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.load().rcx_pack_dw_weight(w.data_ptr(), out.data_ptr(), c, k, _dt(w), _stream(w.device)),
+                   "rcx_pack_dw_weight")
+    return out
+
+
+def pack_bias(b, out=None):
+    _require_gpu(b, "bias")
+    b = b.detach().contiguous()
+    if out is None:
+        out = torch.empty(b.numel(), dtype=torch.float32, device=b.device)
+    with torch.cuda.device(b.device):
+        _lib.check(_lib.load().rcx_pack_bias(b.data_ptr(), out.data_ptr(), b.numel(), _dt(b), _stream(b.device)),
+                   "rcx_pack_bias")
+    return out
+
+
+def pack_recconv_params(w_down, w_convs, b_down=None, b_convs=None):
+    """-> (wpack (level+2, k*k*C) f32, bpack (level+2, C) f32 | None): [down, convs[0], ..., convs[level]]."""
+    ws = [w_down] + list(w_convs)
+    c, k = w_down.shape[0], w_down.shape[-1]
+    wpack = torch.empty((len(ws), k * k * c), dtype=torch.float32, device=w_down.device)
+    for i, w in enumerate(ws):
+        if tuple(w.shape[-2:]) != (k, k) or w.shape[0] != c:
+            raise ValueError("all RecConv2d weights must share (C,1,k,k)")
+        pack_dw_weight(w, wpack[i])
+    bpack = None
+    if b_down is not None:
+        bs = [b_down] + list(b_convs)
+        bpack = torch.empty((len(bs), c), dtype=torch.float32, device=w_down.device)
+        for i, b in enumerate(bs):
+            pack_bias(b, bpack[i])
+    return wpack, bpack
+
+
+def recconv2d_plan(n, c, h, w, level, k, mode, dtype):
+    return _lib.load().rcx_recconv2d_fwd_plan(n, c, h, w, level, k, _lib.MODES[mode], _DT[dtype]).decode()
+
+
+def recconv2d_forward(x, wpack, bpack, level, k, mode="bilinear"):
+    """RecConv2d.forward (model/recnext.py:24-34) on the HIP kernels. Returns a channels_last tensor like x."""
+    x = _nhwc(x)
+    n, c, h, w = x.shape
+    if mode not in _lib.MODES:
+        raise ValueError(f"mode must be 'bilinear' or 'nearest', got {mode!r}")
+    if wpack.numel() != (level + 2) * k * k * c or wpack.dtype != torch.float32:
+        raise ValueError("wpack must be float32 of (level+2)*k*k*C elements (see pack_recconv_params)")
+    lib = _lib.load()
+    dt = _dt(x)
+    y = _empty_nhwc(n, c, h, w, x.dtype, x.device)
+    nbytes = lib.rcx_recconv2d_fwd_workspace_bytes(n, c, h, w, level, k, dt)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.rcx_recconv2d_fwd(x.data_ptr(), y.data_ptr(), wpack.data_ptr(),
+                                   bpack.data_ptr() if bpack is not None else None,
+                                   ws.data_ptr(), nbytes, n, c, h, w, level, k, _lib.MODES[mode], dt, _stream(x.device))
+    _lib.check(rc, "rcx_recconv2d_fwd")
+    return y
+
+
+def dwconv2d(x, w_kkc, bias=None, k=5, stride=1, out_dtype=None):
+    """Depthwise conv (pad k//2, stride 1|2) with packed float32 (k,k,C) weights."""
+    x = _nhwc(x)
+    n, c, h, w = x.shape
+    out_dtype = out_dtype or x.dtype
+    p = k // 2
+    ho, wo = (h + 2 * p - k) // stride + 1, (w + 2 * p - k) // stride + 1
+    y = _empty_nhwc(n, c, ho, wo, out_dtype, x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().rcx_dwconv2d_fwd(x.data_ptr(), y.data_ptr(), w_kkc.data_ptr(),
+                                          bias.data_ptr() if bias is not None else None,
+                                          n, c, h, w, k, stride, _dt(x), _DT[out_dtype], _stream(x.device))
+    _lib.check(rc, "rcx_dwconv2d_fwd")
+    return y
+
+
+def upadd_dwconv(x, coarse, w_kkc, bias=None, k=5, mode="nearest", out_dtype=None):
+    """dwconv_k(x + resize(coarse -> size(x), mode)); coarse may be None."""
+    x = _nhwc(x)
+    n, c, h, w = x.shape
+    out_dtype = out_dtype or x.dtype
+    hc = wc = 0
+    cdt = _lib.DTYPE_F32
+    if coarse is not None:
+        coarse = _nhwc(coarse, "coarse")
+        if coarse.shape[0] != n or coarse.shape[1] != c:
+            raise ValueError("coarse must share N and C with x")
+        hc, wc = coarse.shape[2:]
+        cdt = _dt(coarse)
+    y = _empty_nhwc(n, c, h, w, out_dtype, x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().rcx_upadd_dwconv_fwd(x.data_ptr(), coarse.data_ptr() if coarse is not None else None, y.data_ptr(),
+                                              w_kkc.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                              n, c, h, w, hc, wc, k, _lib.MODES[mode], _dt(x), cdt, _DT[out_dtype],
+                                              _stream(x.device))
+    _lib.check(rc, "rcx_upadd_dwconv_fwd")
+    return y

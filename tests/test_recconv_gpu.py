@@ -1,0 +1,230 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors and the C oracle.
+
+Bars (BASELINE.json north_star): float32 max|err| <= 1e-3; bfloat16 allclose(atol=1e-2, rtol=1e-2)
+against the float32 oracle evaluated on the bf16-rounded inputs.
+The float32 assertions below are tightened to 1e-4: the kernels accumulate in float32 like ATen.
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+import recnext_amd
+from recnext_amd import ops
+from oracle import c_oracle
+from tests.util import bf16_round_np, load_recconv, recconv_cases
+
+pytestmark = pytest.mark.gpu
+
+F32_BAR = 1e-3
+F32_TIGHT = 1e-4
+BF16_ATOL = BF16_RTOL = 1e-2
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def make_module(d, m, device, round_bf16=False):
+    mod = recnext_amd.RecConv2d(m["C"], kernel_size=m["k"], bias=m["bias"], level=m["level"], mode=m["mode"])
+    r = bf16_round_np if round_bf16 else (lambda a: a)
+    sd = {"down.weight": r(d["w_down"]), **{f"convs.{i}.weight": r(w) for i, w in enumerate(d["w_convs"])}}
+    if m["bias"]:
+        sd.update({"down.bias": r(d["b_down"]), **{f"convs.{i}.bias": r(b) for i, b in enumerate(d["b_convs"])}})
+    mod.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+    return mod.to(device).eval()
+
+
+@pytest.mark.parametrize("name", recconv_cases())
+def test_fp32_matches_reference_golden(name):
+    d, m = load_recconv(name)
+    mod = make_module(d, m, dev())
+    x = torch.from_numpy(d["x"]).to(dev())
+    with torch.no_grad():
+        y_cl = mod(x.contiguous(memory_format=torch.channels_last))
+        y_nchw = mod(x)                                   # NCHW-contiguous input is converted, same numbers
+    assert y_cl.shape == x.shape and y_cl.dtype == torch.float32
+    err = float((y_cl.cpu() - torch.from_numpy(d["y"])).abs().max())
+    assert err < F32_TIGHT < F32_BAR, err
+    assert torch.equal(y_cl, y_nchw)
+
+
+@pytest.mark.parametrize("name", recconv_cases())
+def test_bf16_matches_fp32_oracle_on_rounded_inputs(name):
+    d, m = load_recconv(name)
+    mod = make_module(d, m, dev(), round_bf16=True)
+    x = torch.from_numpy(d["x"]).to(dev()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y = mod(x)
+        y_bfmod = mod.to(torch.bfloat16)(x)                   # bf16 parameters (model.to(bf16)) give the same packs
+    assert y.dtype == torch.bfloat16
+    got = y.float().cpu().numpy()
+    assert np.allclose(got, d["y_bf16in_f32"], atol=BF16_ATOL, rtol=BF16_RTOL), np.abs(got - d["y_bf16in_f32"]).max()
+    # the only rounding is the final store: error <= half a bf16 ulp of the value
+    assert np.all(np.abs(got - d["y_bf16in_f32"]) <= np.abs(d["y_bf16in_f32"]) * 2 ** -8 + 1e-6)
+    assert torch.equal(y, y_bfmod)
+
+
+def _rand_case(rng, n, c, h, w, level, k, bias):
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wd = (rng.standard_normal((c, 1, k, k)) * 0.2).astype(np.float32)
+    wc = [(rng.standard_normal((c, 1, k, k)) * 0.2).astype(np.float32) for _ in range(level + 1)]
+    bd = rng.standard_normal(c).astype(np.float32) if bias else None
+    bc = [rng.standard_normal(c).astype(np.float32) for _ in range(level + 1)] if bias else None
+    return x, wd, wc, bd, bc
+
+
+def _run_hip(x, wd, wc, bd, bc, level, k, mode, dtype):
+    t = lambda a: torch.from_numpy(a).to(dev())
+    wpack, bpack = ops.pack_recconv_params(t(wd), [t(w) for w in wc], None if bd is None else t(bd),
+                                           None if bc is None else [t(b) for b in bc])
+    xin = t(x).to(dtype).contiguous(memory_format=torch.channels_last)
+    return ops.recconv2d_forward(xin, wpack, bpack, level, k, mode).float().cpu().numpy()
+
+
+# ragged / odd / tiny shapes and channel counts that are not multiples of the vector widths
+SWEEP = [
+    # n, c, h, w, level, k, mode, bias
+    (1, 1, 1, 1, 0, 5, "bilinear", False),
+    (1, 1, 1, 1, 2, 5, "bilinear", True),
+    (2, 3, 5, 9, 1, 3, "bilinear", True),
+    (1, 5, 8, 8, 2, 5, "nearest", False),
+    (3, 6, 11, 4, 2, 7, "bilinear", True),
+    (1, 10, 2, 31, 3, 5, "bilinear", False),
+    (2, 12, 31, 2, 1, 5, "nearest", True),
+    (1, 20, 19, 23, 4, 5, "bilinear", False),
+    (1, 8, 33, 33, 2, 9, "bilinear", False),         # runtime-k path
+    (2, 48, 56, 56, 4, 5, "bilinear", False),         # M1 stage 0
+    (2, 192, 14, 14, 2, 5, "bilinear", False),        # M1 stage 2
+    (2, 640, 7, 7, 1, 5, "bilinear", False),          # M5 stage 3
+    (1, 64, 128, 128, 4, 5, "bilinear", False),       # M3 @512 stage 0
+    (1, 128, 64, 64, 3, 5, "nearest", False),
+    (1, 16, 25, 13, 3, 5, "bilinear", True),          # COCO-like 25 -> 13 -> 7 -> 4
+]
+
+
+@pytest.mark.parametrize("case", SWEEP, ids=lambda c: "x".join(map(str, c)))
+def test_sweep_against_c_oracle(case):
+    n, c, h, w, level, k, mode, bias = case
+    rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
+    x, wd, wc, bd, bc = _rand_case(rng, n, c, h, w, level, k, bias)
+    ref = c_oracle.recconv2d(x, wd, wc, bd, bc, level, mode)
+    got = _run_hip(x, wd, wc, bd, bc, level, k, mode, torch.float32)
+    assert np.abs(got - ref).max() < F32_TIGHT
+    xr = bf16_round_np(x)
+    refb = c_oracle.recconv2d(xr, wd, wc, bd, bc, level, mode)
+    gotb = _run_hip(xr, wd, wc, bd, bc, level, k, mode, torch.bfloat16)
+    assert np.allclose(gotb, refb, atol=BF16_ATOL, rtol=BF16_RTOL)
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("k", [3, 5, 7])
+@pytest.mark.parametrize("dtypes", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32),
+                                    (torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16)])
+def test_dwconv_piece(stride, k, dtypes):
+    din, dout = dtypes
+    rng = np.random.default_rng(k * 10 + stride)
+    x = bf16_round_np(rng.standard_normal((2, 24, 13, 10)).astype(np.float32))
+    w = (rng.standard_normal((24, 1, k, k)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(24).astype(np.float32)
+    ref = c_oracle.dwconv2d(x, w, b, stride)
+    t = lambda a: torch.from_numpy(a).to(dev())
+    y = ops.dwconv2d(t(x).to(din), ops.pack_dw_weight(t(w)), ops.pack_bias(t(b)), k=k, stride=stride, out_dtype=dout)
+    assert y.dtype == dout and tuple(y.shape) == ref.shape
+    tol = dict(atol=1e-5, rtol=1e-5) if dout == torch.float32 else dict(atol=BF16_ATOL, rtol=BF16_RTOL)
+    assert np.allclose(y.float().cpu().numpy(), ref, **tol)
+
+
+@pytest.mark.parametrize("mode", ["bilinear", "nearest"])
+@pytest.mark.parametrize("shape", [((7, 7), (4, 4)), ((14, 14), (7, 7)), ((9, 12), (5, 6)), ((16, 16), (8, 8)), ((5, 3), (1, 1))])
+@pytest.mark.parametrize("cdtype", [torch.float32, torch.bfloat16])
+def test_upadd_dwconv_piece(mode, shape, cdtype):
+    (h, w), (hc, wc) = shape
+    rng = np.random.default_rng(h * 100 + w)
+    x = bf16_round_np(rng.standard_normal((2, 16, h, w)).astype(np.float32))
+    cs = bf16_round_np(rng.standard_normal((2, 16, hc, wc)).astype(np.float32))
+    wt = (rng.standard_normal((16, 1, 5, 5)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(16).astype(np.float32)
+    ref = c_oracle.dwconv2d(c_oracle.add_resized(x, cs, mode), wt, b, 1)
+    t = lambda a: torch.from_numpy(a).to(dev())
+    for xdt in (torch.float32, torch.bfloat16):
+        y = ops.upadd_dwconv(t(x).to(xdt), t(cs).to(cdtype), ops.pack_dw_weight(t(wt)), ops.pack_bias(t(b)), k=5, mode=mode,
+                             out_dtype=torch.float32)
+        assert np.allclose(y.cpu().numpy(), ref, atol=2e-5, rtol=1e-5), np.abs(y.cpu().numpy() - ref).max()
+    y0 = ops.upadd_dwconv(t(x), None, ops.pack_dw_weight(t(wt)), None, k=5, mode=mode)
+    assert np.allclose(y0.cpu().numpy(), c_oracle.dwconv2d(x, wt, None, 1), atol=2e-5, rtol=1e-5)
+
+
+# ---- full BASELINE sizes: size-independent properties + spot checks against the oracle ----
+FULL = [
+    ("M1 cfg2 stage1", 256, 96, 28, 28, 3),
+    ("M3 stage0", 256, 64, 56, 56, 4),
+    ("M3 stage2", 256, 256, 14, 14, 2),
+    ("M3 stage3", 256, 512, 7, 7, 1),
+    ("M5 stage0", 128, 80, 56, 56, 4),
+    ("M3@512 stage0", 16, 64, 128, 128, 4),
+]
+
+
+@pytest.mark.parametrize("case", FULL, ids=lambda c: c[0])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_full_size_properties(case, dtype):
+    _, n, c, h, w, level = case
+    torch.manual_seed(1)
+    mod = recnext_amd.RecConv2d(c, kernel_size=5, level=level).to(dev()).eval()
+    x = torch.randn(n, c, h, w, device=dev()).to(dtype).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y = mod(x)
+        y2 = mod(x)
+        assert torch.equal(y, y2), "not deterministic"
+        # images are independent: any batch shard gives bit-identical rows
+        lo, hi = n // 3, n // 3 + 5
+        assert torch.equal(mod(x[lo:hi]), y[lo:hi]), "batch shard differs from full batch"
+        # homogeneity (no bias): scaling the input by a power of two scales the output exactly
+        assert torch.equal(mod(x * 4), y * 4)
+    assert torch.isfinite(y.float()).all()
+    # spot check three images against the oracle
+    sd = {k: v.float().cpu().numpy() for k, v in mod.state_dict().items()}
+    idx = [0, n // 2, n - 1]
+    xs = x[idx].float().cpu().numpy()
+    ref = c_oracle.recconv2d(xs, sd["down.weight"], [sd[f"convs.{i}.weight"] for i in range(level + 1)], level=level)
+    got = y[idx].float().cpu().numpy()
+    if dtype == torch.float32:
+        assert np.abs(got - ref).max() < F32_TIGHT
+    else:
+        assert np.allclose(got, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
+
+
+def test_errors_surface_as_exceptions():
+    mod = recnext_amd.RecConv2d(8, level=1).to(dev())
+    with pytest.raises(TypeError):
+        mod(torch.randn(1, 8, 7, 7, device=dev(), dtype=torch.float16))
+    with pytest.raises(ValueError):
+        mod(torch.randn(8, 7, 7, device=dev()))
+    with pytest.raises(recnext_amd._lib.RcxError):
+        ops.recconv2d_forward(torch.randn(1, 8, 7, 7, device=dev()), torch.zeros(3 * 25 * 8, device=dev()), None, 99, 5)
+
+
+def test_weight_update_invalidates_pack():
+    mod = recnext_amd.RecConv2d(8, level=1).to(dev()).eval()
+    x = torch.randn(1, 8, 7, 7, device=dev())
+    with torch.no_grad():
+        y0 = mod(x)
+        mod.convs[1].weight.mul_(2.0)
+        y1 = mod(x)
+    assert torch.allclose(y1, 2 * y0, atol=1e-6)
+
+
+def test_runs_on_a_side_stream():
+    mod = recnext_amd.RecConv2d(16, level=2).to(dev()).eval()
+    x = torch.randn(2, 16, 14, 14, device=dev())
+    with torch.no_grad():
+        y0 = mod(x)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            y1 = mod(x)
+        torch.cuda.current_stream().wait_stream(s)
+    assert torch.equal(y0, y1)
