@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of RecNeXt-M3 224x224 bf16 with the HIP RecConv2d token mixers.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one forward pass of the BN-folded, channels_last RecNeXt-M3 over one synthetic batch of
+256 images per GPU (weak scaling: batch-sharded, no collective in the timed region -- SURVEY 8e).
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+
+  roofline      the fused RecConv2d forward of the dominant block shape: ALGORITHMIC bytes
+                (2*N*C*H*W*b + (level+2)*C*k*k*b) / its mean duration measured with HIP
+                events on the launch stream inside the timed region, against the 8 TB/s HBM peak.
+  token_mixers  the same accounting summed over all 21 RecConv2d calls of the model.
+  cpu_baseline  the reference's CPU path (oracle/torch_eager.py: the same ATen operators on the host
+                cores) timed on a bounded sample of the same workload; rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--model", default="recnext_m3")
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--resolution", type=int, default=224)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+class MixerTimers:
+    """HIP events around every RecConv2d call (recorded on the stream the kernels are launched on)."""
+
+    def __init__(self, net, torch, RecConv2d):
+        self.torch = torch
+        self.records = []          # (module_key, start, end)
+        self.enabled = False
+        self.keys = {}
+        for name, m in net.named_modules():
+            if isinstance(m, RecConv2d):
+                self.keys[m] = name
+                m.register_forward_pre_hook(self._pre)
+                m.register_forward_hook(self._post)
+        self._open = {}
+
+    def _pre(self, m, args):
+        if self.enabled:
+            e = self.torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._open[m] = (e, tuple(args[0].shape))
+
+    def _post(self, m, args, out):
+        if self.enabled:
+            e = self.torch.cuda.Event(enable_timing=True)
+            e.record()
+            s, shape = self._open.pop(m)
+            self.records.append((m, shape, s, e))
+
+    def summarize(self, elem_bytes):
+        by_shape = {}
+        for m, shape, s, e in self.records:
+            n, c, h, w = shape
+            key = (c, h, w, m.level, m.kernel_size)
+            ent = by_shape.setdefault(key, {"ms": 0.0, "calls": 0, "N": n})
+            ent["ms"] += s.elapsed_time(e)
+            ent["calls"] += 1
+        out = []
+        for (c, h, w, level, k), ent in by_shape.items():
+            n = ent["N"]
+            alg = 2 * n * c * h * w * elem_bytes + (level + 2) * c * k * k * elem_bytes
+            avg_ms = ent["ms"] / ent["calls"]
+            out.append({"C": c, "H": h, "W": w, "level": level, "k": k, "N": n, "calls": ent["calls"],
+                        "total_ms": ent["ms"], "avg_ms": avg_ms, "algorithmic_bytes": alg,
+                        "achieved_GBs": alg / (avg_ms * 1e-3) / 1e9})
+        out.sort(key=lambda r: -r["total_ms"])
+        return out
+
+
+def cpu_baseline(model_name, resolution, seconds, torch):
+    """Reference CPU path on the host cores: same skeleton, ATen token mixers (oracle/torch_eager.py), fp32."""
+    from oracle.torch_eager import eager_token_mixer
+    from recnext_amd import models
+    from recnext_amd.speed import build_inference_model, synthetic_batch
+    fam = models.CONFIGS[model_name]["family"]
+    bs = 8
+    net = build_inference_model(model_name, "cpu", torch.float32, token_mixer=eager_token_mixer(fam))
+    x = synthetic_batch(bs, resolution, "cpu", torch.float32)
+    with torch.no_grad():
+        net(x)                                                   # warm-up (mkldnn primitive creation)
+        t0 = time.perf_counter()
+        iters = 0
+        while time.perf_counter() - t0 < seconds and iters < 200:
+            net(x)
+            iters += 1
+        dt = time.perf_counter() - t0
+    return {"value": bs * iters / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host_cpus": os.cpu_count(),
+            "sample": f"{iters} forward passes of {model_name} {resolution}x{resolution}, batch {bs}, fp32 (BN-folded), "
+                      f"token mixers = reference ATen ops (depthwise conv2d + interpolate + add) restated in "
+                      f"oracle/torch_eager.py, {dt:.1f} s wall"}
+
+
+def load_traffic(plan, shape_key):
+    """HBM bytes per launch from committed PMC profiles (profiles/*traffic*.json), if one matches this kernel."""
+    import glob
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+        try:
+            for rec in json.load(open(p)).get("kernels", []):
+                if rec.get("shape") == shape_key and rec.get("plan") == plan:
+                    best = rec.get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
+    return best
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    import recnext_amd
+    from recnext_amd import models, ops
+    from recnext_amd.speed import build_inference_model, synthetic_batch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)      # "nccl" is RCCL on ROCm
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    elem = 2 if args.dtype == "bf16" else 4
+    torch.backends.cudnn.benchmark = True
+    net = build_inference_model(args.model, device, dtype, seed=0)       # identical weights on every rank
+    x = synthetic_batch(args.batch, args.resolution, device, dtype, seed=rank)
+    timers = MixerTimers(net, torch, recnext_amd.RecConv2d)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            net(x)
+        barrier()
+        timers.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            net(x)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        timers.enabled = False
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        images = world * args.batch * args.steps
+        value = images / elapsed
+        per_shape = timers.summarize(elem)
+        dom = per_shape[0]
+        plan = ops.recconv2d_plan(dom["N"], dom["C"], dom["H"], dom["W"], dom["level"], dom["k"], "bilinear", dtype)
+        shape_key = f"{dom['N']}x{dom['C']}x{dom['H']}x{dom['W']}_L{dom['level']}_k{dom['k']}_{args.dtype}"
+        mixer_ms_per_step = sum(r["total_ms"] for r in per_shape) / args.steps
+        mixer_bytes = models.token_mixer_algorithmic_bytes(args.model, args.resolution, elem) * args.batch \
+            if models.CONFIGS[args.model]["family"] == "m" else None
+        out = {
+            "metric": f"images/sec RecNeXt-{args.model.split('_')[1].upper()} {args.resolution}x{args.resolution} {args.dtype}",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.model} forward, BN-folded, channels_last, {args.resolution}x{args.resolution}, "
+                                   f"batch {args.batch}/GPU, random-init weights, HIP RecConv2d token mixers",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world} (batch-sharded replicas, no collective in the timed region)"},
+            "roofline": {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": load_traffic(plan, shape_key),
+                         "kernel": f"rcx_recconv2d_fwd[{plan}] {shape_key}", "avg_launch_ms": dom["avg_ms"],
+                         "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "launches_timed": dom["calls"]},
+            "token_mixers": {"ms_per_step": mixer_ms_per_step, "share_of_step": mixer_ms_per_step / (elapsed / args.steps * 1e3),
+                             "algorithmic_bytes_per_step": mixer_bytes,
+                             "achieved_GBs": (mixer_bytes / (mixer_ms_per_step * 1e-3) / 1e9) if mixer_bytes else None,
+                             "frac_of_hbm_peak": (mixer_bytes / (mixer_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if mixer_bytes else None,
+                             "images_per_s_mixers_only": args.batch / (mixer_ms_per_step * 1e-3),
+                             "per_shape": [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()} for r in per_shape]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.model, args.resolution, args.cpu_seconds, torch)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

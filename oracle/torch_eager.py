@@ -58,3 +58,32 @@ def upadd_dwconv_eager(x, coarse, w, b=None, mode="nearest"):
 def dwconv_eager(x, w, b=None, stride=1):
     k = w.shape[-1]
     return F.conv2d(x, w, b, stride=stride, padding=k // 2, groups=x.shape[1])
+
+
+class EagerRecAttn2d(nn.Module):
+    """RecAttn2d (model/recattn.py:54-67) on ATen ops with the reference's parameter names.
+
+    Built from the same host-side plumbing modules (ConvNorm, LinearAttention) as the product skeleton;
+    only the token-mixer arithmetic differs (ATen here, HIP kernels there).
+    """
+
+    def __init__(self, dim, num_heads, kernel_size=5, stage=1, mode="nearest"):
+        super().__init__()
+        from recnext_amd.layers import ConvNorm
+        from recnext_amd.recattn import LinearAttention
+        self.mode = mode
+        self.down = nn.Sequential(
+            ConvNorm(dim, dim, kernel_size=kernel_size, padding=kernel_size // 2, stride=2, groups=dim),
+            LinearAttention(dim=dim, num_heads=num_heads, variant=2 if stage >= 3 else 1),
+        )
+        self.conv = ConvNorm(dim, dim, kernel_size=kernel_size, padding=kernel_size // 2, groups=dim)
+
+    def forward(self, x):
+        return self.conv(x + F.interpolate(self.down(x), size=x.shape[2:], mode=self.mode))
+
+
+def eager_token_mixer(family):
+    """token_mixer factory for recnext_amd.models.RecNext hosting the ATen restatements (CPU baseline / tests)."""
+    if family == "m":
+        return lambda dim, stage: EagerRecConv2d(dim, level=4 - stage, kernel_size=5)
+    return lambda dim, stage: EagerRecAttn2d(dim, num_heads=2 ** (stage + 1), stage=stage)

@@ -1,0 +1,71 @@
+"""Host-side building blocks around the token mixers (plain PyTorch-ROCm modules, no kernels here).
+
+Parameter names follow the reference so its checkpoints load unchanged:
+``ConvNorm`` = {conv, norm} (model/recnext.py:56-97), ``NormLinear`` = {norm, linear} (:100-122).
+"""
+import torch
+import torch.nn as nn
+
+
+def _bn_affine(norm):
+    scale = norm.weight / torch.sqrt(norm.running_var + norm.eps)
+    return scale, norm.bias - scale * norm.running_mean
+
+
+class ConvNorm(nn.Sequential):
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1, padding=0, dilation=1, groups=1,
+                 bias=False, bn_weight_init=1):
+        super().__init__()
+        self.add_module("conv", nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias=bias))
+        self.add_module("norm", nn.BatchNorm2d(out_channels))
+        nn.init.constant_(self.norm.weight, bn_weight_init)
+        nn.init.constant_(self.norm.bias, 0)
+
+    @torch.no_grad()
+    def fuse(self):
+        """Eval-mode BN folded into a biased conv: w' = w*g/sqrt(var+eps), b' = beta - mean*g/sqrt(var+eps)."""
+        conv = self.conv
+        scale, shift = _bn_affine(self.norm)
+        if conv.bias is not None:
+            shift = shift + scale * conv.bias
+        out = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, stride=conv.stride, padding=conv.padding,
+                        dilation=conv.dilation, groups=conv.groups, bias=True, device=conv.weight.device,
+                        dtype=conv.weight.dtype)
+        out.weight.copy_(conv.weight * scale.view(-1, 1, 1, 1))
+        out.bias.copy_(shift)
+        return out
+
+
+class NormLinear(nn.Sequential):
+    def __init__(self, in_channels, out_channels, bias=True, std=0.02):
+        super().__init__()
+        self.add_module("norm", nn.BatchNorm1d(in_channels))
+        self.add_module("linear", nn.Linear(in_channels, out_channels, bias=bias))
+        nn.init.trunc_normal_(self.linear.weight, std=std)
+        if bias:
+            nn.init.constant_(self.linear.bias, 0)
+
+    @torch.no_grad()
+    def fuse(self):
+        lin = self.linear
+        scale, shift = _bn_affine(self.norm)
+        out = nn.Linear(lin.in_features, lin.out_features, bias=True, device=lin.weight.device, dtype=lin.weight.dtype)
+        out.weight.copy_(lin.weight * scale.view(1, -1))
+        b = lin.weight @ shift
+        out.bias.copy_(b if lin.bias is None else b + lin.bias)
+        return out
+
+
+class DropPath(nn.Module):
+    """Stochastic depth (timm.layers.DropPath semantics); identity in eval mode."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if not self.training or self.drop_prob == 0.0:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        return x * mask.div_(keep)

@@ -1,0 +1,108 @@
+"""Drop-in ``RecAttn2d`` (A-series token mixer, model/recattn.py:54-67).
+
+    y = conv( x + interpolate( LinearAttention( down(x) ), size=x.shape[2:], mode ) )
+
+``down[0]`` (depthwise k x k, stride 2) and ``conv`` (depthwise k x k) are ``ConvNorm`` pairs in the
+reference; in eval mode their BatchNorm is a per-channel affine, which is folded into the packed
+weights here whether or not ``replace_batchnorm`` has already replaced the pair by a biased
+``nn.Conv2d`` (model/recattn.py:89-111).  The HIP kernels cover the two depthwise convs and the fused
+nearest-resize + add + conv; the linear attention at the coarse level (two small batched matmuls
+around a grouped 1x1 conv, model/recattn.py:16-28 / 39-51) stays on PyTorch-ROCm operators for now
+(SURVEY.md section 8f row 4).  Parameter names and shapes equal the reference's.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .layers import ConvNorm
+
+
+class LinearAttention(nn.Module):
+    """LinearAttention1 (variant 1, model/recattn.py:8-28) and LinearAttention2 (variant 2, :31-51).
+
+    The two are the same function (the reference asserts it, lsnet/model/recattn.py:481-501); variant 2
+    materialises the n x n map and is what stage >= 3 uses.
+    """
+
+    def __init__(self, dim, num_heads, variant=1):
+        super().__init__()
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.variant = variant
+        self.qk = ConvNorm(dim, dim * 2, kernel_size=1, groups=2)
+        self.pe = ConvNorm(dim, dim, kernel_size=3, padding=1, groups=dim)
+
+    def forward(self, x):
+        b, c, h, w = x.shape
+        n = h * w
+        s = n ** -0.5
+        qk = F.elu(self.qk(x)) + 1.0
+        q, k = qk.reshape(b, 2, self.num_heads, self.head_dim, n).unbind(dim=1)
+        v = x.reshape(b, self.num_heads, self.head_dim, n)
+        q_t, v_t = q.transpose(-1, -2), v.transpose(-1, -2)
+        if self.variant == 1:
+            kv = (k * s) @ (v_t * s)
+            out = q_t @ kv / (q_t @ k.mean(dim=-1, keepdim=True) + 1e-6)
+        else:
+            a = q_t @ k
+            a = a / (a.mean(dim=-1, keepdim=True) + 1e-6)
+            out = (a * s) @ (v_t * s)
+        return out.transpose(-1, -2).reshape(b, c, h, w) + self.pe(x)
+
+
+def _folded(m):
+    """(weight, bias) of a ConvNorm in eval mode or of its fused nn.Conv2d."""
+    if isinstance(m, nn.Conv2d):
+        return m.weight, m.bias
+    conv, norm = m.conv, m.norm
+    s = norm.weight / torch.sqrt(norm.running_var + norm.eps)
+    b = norm.bias - s * norm.running_mean
+    if conv.bias is not None:
+        b = b + s * conv.bias
+    return conv.weight * s[:, None, None, None], b
+
+
+class RecAttn2d(nn.Module):
+    def __init__(self, dim, num_heads, kernel_size=5, stage=1, mode="nearest"):
+        super().__init__()
+        self.mode = mode
+        self.kernel_size = kernel_size
+        variant = 2 if stage >= 3 else 1                      # model/recattn.py:59
+        self.down = nn.Sequential(
+            ConvNorm(dim, dim, kernel_size=kernel_size, padding=kernel_size // 2, stride=2, groups=dim),
+            LinearAttention(dim=dim, num_heads=num_heads, variant=variant),
+        )
+        self.conv = ConvNorm(dim, dim, kernel_size=kernel_size, padding=kernel_size // 2, groups=dim)
+        self._pack_key = None
+        self._pack = None
+
+    def _tensors(self):
+        out = []
+        for m in (self.down[0], self.conv):
+            out += [m.weight, m.bias] if isinstance(m, nn.Conv2d) else \
+                [m.conv.weight, m.norm.weight, m.norm.bias, m.norm.running_mean, m.norm.running_var]
+        return [t for t in out if t is not None]
+
+    def packed_params(self):
+        key = tuple((t.data_ptr(), t._version, t.dtype, str(t.device)) for t in self._tensors())
+        if key != self._pack_key:
+            with torch.no_grad():
+                wd, bd = _folded(self.down[0])
+                wc, bc = _folded(self.conv)
+                self._pack = (ops.pack_dw_weight(wd.float()), None if bd is None else ops.pack_bias(bd.float()),
+                              ops.pack_dw_weight(wc.float()), None if bc is None else ops.pack_bias(bc.float()))
+            self._pack_key = key
+        return self._pack
+
+    def forward(self, x):
+        if self.training:
+            raise NotImplementedError("recnext_amd.RecAttn2d runs in eval mode only (BatchNorm is folded into the "
+                                      "HIP depthwise kernels); call .eval()")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("recnext_amd.RecAttn2d has no backward yet; run under torch.no_grad()")
+        wd, bd, wc, bc = self.packed_params()
+        k = self.kernel_size
+        d = ops.dwconv2d(x, wd, bd, k=k, stride=2)                                  # ConvNorm(dw k5 s2), :61
+        a = self.down[1](d)                                                         # linear attention, :62
+        return ops.upadd_dwconv(x, a, wc, bc, k=k, mode=self.mode)                  # conv(x + resize(.)), :67

@@ -1,0 +1,75 @@
+"""Throughput harness -- the MI355X counterpart of the reference's speed_gpu.py (speed_gpu.py:11-27, :39-51).
+
+    python -m recnext_amd.speed --model recnext_m3 --resolution 224 --batch-size 256 [--dtype bf16]
+
+Same procedure: build the registered model, fold BatchNorm (utils.replace_batchnorm), eval mode, random
+input created once on the device, T0 seconds of warm-up, then iterate with a device synchronise per
+iteration until T1 seconds have accumulated; print ``name device images/s @ batch size B``.
+Additions: ``--dtype`` (the reference runs fp32 only) and channels_last storage, which is what the HIP
+token mixers consume zero-copy.  There is no CPU mode here: the product path is GPU-only.
+"""
+import argparse
+import time
+
+import torch
+
+from . import models
+
+T0 = 5
+T1 = 10
+
+DTYPES = {"fp32": torch.float32, "f32": torch.float32, "bf16": torch.bfloat16}
+
+
+def build_inference_model(name, device, dtype=torch.bfloat16, token_mixer=None, seed=0):
+    """create_model -> replace_batchnorm -> device/eval, as speed_gpu.py:47-50 (plus dtype + channels_last)."""
+    torch.manual_seed(seed)
+    net = models.create_model(name, num_classes=1000, token_mixer=token_mixer)
+    models.replace_batchnorm(net)
+    net = net.to(device=device, dtype=dtype).eval()
+    if torch.device(device).type == "cuda":
+        net = net.to(memory_format=torch.channels_last)
+    return net
+
+
+def synthetic_batch(batch_size, resolution, device, dtype=torch.bfloat16, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(batch_size, 3, resolution, resolution, generator=g).to(device=device, dtype=dtype)
+    return x.contiguous(memory_format=torch.channels_last) if torch.device(device).type == "cuda" else x
+
+
+@torch.no_grad()
+def throughput(name, model, device, batch_size, resolution=224, dtype=torch.bfloat16, t0=T0, t1=T1):
+    inputs = synthetic_batch(batch_size, resolution, device, dtype)
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    start = time.time()
+    while time.time() - start < t0:
+        model(inputs)
+    timing = []
+    torch.cuda.synchronize()
+    while sum(timing) < t1:
+        start = time.time()
+        model(inputs)
+        torch.cuda.synchronize()
+        timing.append(time.time() - start)
+    rate = batch_size / (sum(timing) / len(timing))
+    print(name, device, rate, "images/s @ batch size", batch_size)
+    return rate
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="recnext_m1", type=str)
+    ap.add_argument("--resolution", default=224, type=int)
+    ap.add_argument("--batch-size", default=2048, type=int)
+    ap.add_argument("--dtype", default="bf16", choices=sorted(DTYPES))
+    args = ap.parse_args(argv)
+    torch.autograd.set_grad_enabled(False)
+    device = "cuda:0"
+    net = build_inference_model(args.model, device, DTYPES[args.dtype])
+    throughput(args.model, net, device, args.batch_size, args.resolution, DTYPES[args.dtype])
+
+
+if __name__ == "__main__":
+    main()

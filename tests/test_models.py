@@ -1,0 +1,113 @@
+"""Model skeleton: parameter-count known answers, state-dict compatibility, BN folding, tiny-model logits.
+
+CPU tests host the oracle's ATen token mixers in the product skeleton (the HIP modules refuse CPU tensors);
+GPU tests run the same fixtures through the HIP token mixers.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from recnext_amd import models
+from oracle.torch_eager import eager_token_mixer
+from tests.util import GOLDEN
+
+KAT = json.load(open(os.path.join(GOLDEN, "param_counts.json")))
+
+
+@pytest.mark.parametrize("name", sorted(models.CONFIGS))
+def test_parameter_counts_match_reference_logs(name):
+    # first JSON line of logs/{normal,distill}/recnext_*.txt (n_parameters) and README "Params" after fusion
+    net = models.create_model(name)
+    assert sum(p.numel() for p in net.parameters() if p.requires_grad) == KAT[name]["n_parameters"]
+    models.replace_batchnorm(net)
+    assert sum(p.numel() for p in net.parameters()) == KAT[name]["n_parameters_fused"]
+
+
+def _tiny(fam, token_mixer=None):
+    return models.RecNext(family=fam, embed_dim=(8, 16, 32, 64), depth=(1, 1, 1, 1), num_classes=10, token_mixer=token_mixer)
+
+
+def _load_tiny(fam):
+    d = np.load(os.path.join(GOLDEN, f"tiny_model_{fam}.npz"))
+    sd = {k[4:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("sd::")}
+    return d, sd
+
+
+@pytest.mark.parametrize("fam", ["m", "a"])
+def test_tiny_model_logits_cpu_with_eager_token_mixers(fam):
+    d, sd = _load_tiny(fam)
+    net = _tiny(fam, eager_token_mixer(fam)).eval()
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
+    x = torch.from_numpy(d["x"])
+    with torch.no_grad():
+        assert np.abs(net(x).numpy() - d["logits"]).max() < 1e-5
+        models.replace_batchnorm(net)
+        assert np.abs(net(x).numpy() - d["logits_fused"]).max() < 1e-5
+    # replace_batchnorm leaves the plain BatchNorm2d of MetaNeXtBlock / Downsample in place (utils.py:227-234)
+    n_bn = sum(isinstance(m, torch.nn.BatchNorm2d) for m in net.modules())
+    assert n_bn == (4 + 3 if fam == "m" else 3)
+
+
+def test_hip_skeleton_has_reference_state_dict_keys():
+    for fam in ("m", "a"):
+        _, sd = _load_tiny(fam)
+        keys = {k for k in _tiny(fam).state_dict() if not k.endswith("num_batches_tracked")}
+        assert keys == set(sd)
+
+
+def test_token_mixer_shapes_and_algorithmic_bytes():
+    assert models.token_mixer_shapes("recnext_m3") == [(64, 56, 56, 4, 3), (128, 28, 28, 3, 3), (256, 14, 14, 2, 13), (512, 7, 7, 1, 2)]
+    # SURVEY 8d / BASELINE.md section 3 (MB per image)
+    assert abs(models.token_mixer_algorithmic_bytes("recnext_m3") / 1e6 - 7.395) < 1e-3
+    assert abs(models.token_mixer_algorithmic_bytes("recnext_m1") / 1e6 - 5.924) < 1e-3
+    assert abs(models.token_mixer_algorithmic_bytes("recnext_m5") / 1e6 - 22.449) < 1e-3
+    assert abs(models.token_mixer_algorithmic_bytes("recnext_m3", 512) / 1e6 - 34.527) < 1e-3
+    assert abs(models.token_mixer_algorithmic_bytes("recnext_m0", elem_bytes=4) / 1e6 - 6.194) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fam", ["m", "a"])
+def test_tiny_model_logits_gpu_with_hip_token_mixers(fam):
+    d, sd = _load_tiny(fam)
+    dev = torch.device("cuda:0")
+    net = _tiny(fam).eval()
+    net.load_state_dict(sd, strict=False)
+    net = net.to(dev).to(memory_format=torch.channels_last)
+    x = torch.from_numpy(d["x"]).to(dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        assert np.abs(net(x).cpu().numpy() - d["logits"]).max() < 1e-4
+        models.replace_batchnorm(net)
+        assert np.abs(net(x).cpu().numpy() - d["logits_fused"]).max() < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["recnext_m0", "recnext_a0"])
+def test_full_model_hip_vs_eager_gpu(name):
+    """Whole registered model at 224: HIP token mixers vs the ATen restatement, same weights, fp32 and bf16."""
+    dev = torch.device("cuda:0")
+    fam = models.CONFIGS[name]["family"]
+    torch.manual_seed(0)
+    ref = models.create_model(name, token_mixer=eager_token_mixer(fam)).eval()
+    for m in ref.modules():                                       # non-trivial BN statistics
+        if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    net = models.create_model(name).eval()
+    net.load_state_dict(ref.state_dict(), strict=True)
+    models.replace_batchnorm(ref)
+    models.replace_batchnorm(net)
+    ref, net = ref.to(dev), net.to(dev).to(memory_format=torch.channels_last)
+    x = torch.randn(2, 3, 224, 224, device=dev)
+    with torch.no_grad():
+        a, b = ref(x), net(x.contiguous(memory_format=torch.channels_last))
+        assert (a - b).abs().max() < 1e-3 * max(1.0, float(a.abs().max()))
+        ab = ref.bfloat16()(x.bfloat16()).float()
+        bb = net.bfloat16()(x.bfloat16().contiguous(memory_format=torch.channels_last)).float()
+    # bf16 end-to-end: both paths round everywhere outside the token mixer; compare loosely to the fp32 logits
+    scale = float(a.abs().max())
+    assert (bb - a).abs().max() < 0.1 * scale + 0.05
+    assert (bb - a).abs().max() <= 1.5 * (ab - a).abs().max() + 0.02 * scale

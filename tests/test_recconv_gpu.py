@@ -204,7 +204,7 @@ def test_errors_surface_as_exceptions():
     with pytest.raises(ValueError):
         mod(torch.randn(8, 7, 7, device=dev()))
     with pytest.raises(recnext_amd._lib.RcxError):
-        ops.recconv2d_forward(torch.randn(1, 8, 7, 7, device=dev()), torch.zeros(3 * 25 * 8, device=dev()), None, 99, 5)
+        ops.recconv2d_forward(torch.randn(1, 8, 7, 7, device=dev()), torch.zeros(101 * 25 * 8, device=dev()), None, 99, 5)
 
 
 def test_weight_update_invalidates_pack():

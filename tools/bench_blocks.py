@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Per-block micro-benchmark of rcx_recconv2d_fwd on the BASELINE stage shapes (development tool).
+
+Prints, per shape and dtype: mean launch duration (HIP events on the launch stream, interleaved rounds),
+algorithmic GB/s (2*N*C*H*W*b + weights) and the fraction of the 8 TB/s HBM peak.
+``--eager`` adds the reference's operator chain (ATen on the GPU: MIOpen depthwise conv + upsample + add).
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch
+
+import recnext_amd
+from recnext_amd import ops
+
+SHAPES = {
+    "m3": [(256, 64, 56, 56, 4), (256, 128, 28, 28, 3), (256, 256, 14, 14, 2), (256, 512, 7, 7, 1)],
+    "m1": [(256, 48, 56, 56, 4), (256, 96, 28, 28, 3), (256, 192, 14, 14, 2), (256, 384, 7, 7, 1)],
+    "m5": [(256, 80, 56, 56, 4), (256, 160, 28, 28, 3), (256, 320, 14, 14, 2), (256, 640, 7, 7, 1)],
+    "m3_512": [(32, 64, 128, 128, 4), (32, 128, 64, 64, 3), (32, 256, 32, 32, 2), (32, 512, 16, 16, 1)],
+}
+
+
+def time_fn(fn, iters, rounds=3):
+    best = []
+    for _ in range(rounds):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        best.append(s.elapsed_time(e) / iters)
+    best.sort()
+    return best[len(best) // 2], best[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sets", default="m3")
+    ap.add_argument("--dtypes", default="bf16,fp32")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--eager", action="store_true")
+    ap.add_argument("--mode", default="bilinear")
+    ap.add_argument("--json", default=None)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    rows = []
+    for sname in args.sets.split(","):
+        for (n, c, h, w, level) in SHAPES[sname]:
+            for dname in args.dtypes.split(","):
+                dtype = torch.bfloat16 if dname == "bf16" else torch.float32
+                eb = 2 if dname == "bf16" else 4
+                torch.manual_seed(0)
+                mod = recnext_amd.RecConv2d(c, kernel_size=5, level=level, mode=args.mode).to(dev).eval()
+                x = torch.randn(n, c, h, w, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+                with torch.no_grad():
+                    for _ in range(3):
+                        mod(x)
+                    torch.cuda.synchronize()
+                    med, mn = time_fn(lambda: mod(x), args.iters)
+                    alg = 2 * n * c * h * w * eb + (level + 2) * c * 25 * eb
+                    row = {"set": sname, "shape": [n, c, h, w], "level": level, "dtype": dname,
+                           "plan": ops.recconv2d_plan(n, c, h, w, level, 5, args.mode, dtype),
+                           "ms": med, "ms_min": mn, "alg_GBs": alg / med / 1e6, "frac_8TBs": alg / med / 1e6 / 8000}
+                    if args.eager:
+                        from oracle.torch_eager import EagerRecConv2d
+                        ref = EagerRecConv2d(c, 5, False, level, args.mode).to(dev).to(dtype).to(memory_format=torch.channels_last).eval()
+                        for _ in range(3):
+                            ref(x)
+                        torch.cuda.synchronize()
+                        row["eager_ms"], _ = time_fn(lambda: ref(x), max(3, args.iters // 4))
+                rows.append(row)
+                print(json.dumps(row), flush=True)
+    if args.json:
+        json.dump(rows, open(args.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
