@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librecnext_amd.so")
+# RCX_LIBRARY points development tools at a diagnostic build of the same ABI (tools/stamps.py)
+LIB_PATH = os.environ.get("RCX_LIBRARY") or os.path.join(_HERE, "lib", "librecnext_amd.so")
 
 DTYPE_F32, DTYPE_BF16 = 0, 1
 MODE_BILINEAR, MODE_NEAREST = 0, 1

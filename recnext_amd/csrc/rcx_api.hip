@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -63,7 +64,20 @@ int check_common(const void* x, const void* y, int N, int C, int H, int W, int k
     return 0;
 }
 
+// Schedule choice: the fused plane kernel whenever it applies; RCX_FORCE_GENERIC=1 pins the
+// one-launch-per-ladder-step schedule (used by tests to cover both, and for A/B timing).
+bool use_plane(int N, int C, int H, int W, int level, int k, int dtype)
+{
+    const char* f = getenv("RCX_FORCE_GENERIC");
+    if (f && *f && *f != '0') return false;
+    return rcx::plane_applicable(N, C, H, W, level, k, dtype);
+}
+
 }  // namespace
+
+#ifdef RCX_STAMPS
+namespace rcx { hipError_t set_stamp_buffer(void* p); }
+#endif
 
 extern "C" {
 
@@ -71,7 +85,11 @@ int rcx_abi_version(void) { return RCX_ABI_VERSION; }
 
 const char* rcx_last_error(void) { return g_err; }
 
-const char* rcx_recconv2d_fwd_plan(int, int, int, int, int, int, int, int) { return "generic"; }
+const char* rcx_recconv2d_fwd_plan(int N, int C, int H, int W, int level, int k, int /*mode*/, int dtype)
+{
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0) return "invalid";
+    return use_plane(N, C, H, W, level, k, dtype) ? "plane" : "generic";
+}
 
 int rcx_pack_dw_weight(const void* w_ckk, float* dst_kkc, int C, int k, int dtype, void* stream)
 {
@@ -89,9 +107,10 @@ int rcx_pack_bias(const void* b, float* dst, int C, int dtype, void* stream)
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_pack_bias");
 }
 
-size_t rcx_recconv2d_fwd_workspace_bytes(int N, int C, int H, int W, int level, int k, int /*dtype*/)
+size_t rcx_recconv2d_fwd_workspace_bytes(int N, int C, int H, int W, int level, int k, int dtype)
 {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0) return 0;
+    if (use_plane(N, C, H, W, level, k, dtype)) return 0;          // the fused schedule keeps every intermediate in LDS
     return make_ladder(N, C, H, W, level, k).total;
 }
 
@@ -104,6 +123,10 @@ int rcx_recconv2d_fwd(const void* x, void* y, const float* wpack, const float* b
     if (x == y) return fail(RCX_ERR_BAD_ARG, "y must not alias x");
     if (level < 0 || level > RCX_MAX_LEVEL) return fail(RCX_ERR_BAD_ARG, "level %d outside [0,%d]", level, RCX_MAX_LEVEL);
     if (mode != RCX_MODE_BILINEAR && mode != RCX_MODE_NEAREST) return fail(RCX_ERR_BAD_ARG, "unknown mode %d", mode);
+    if (use_plane(N, C, H, W, level, k, dtype)) {
+        hipError_t pe = rcx::plane_recconv(x, y, wpack, bpack, N, C, H, W, level, k, mode, dtype, (hipStream_t)stream);
+        return pe == hipSuccess ? 0 : hip_fail(pe, "plane schedule");
+    }
     const Ladder L = make_ladder(N, C, H, W, level, k);
     if (L.total > 0 && (!workspace || workspace_bytes < L.total))
         return fail(RCX_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", L.total, workspace_bytes);
@@ -165,5 +188,10 @@ int rcx_upadd_dwconv_fwd(const void* x, const void* coarse, void* y, const float
                                              x_dtype, coarse_dtype, out_dtype, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_upadd_dwconv_fwd");
 }
+
+#ifdef RCX_STAMPS
+/* diagnostic build only: not part of include/recnext_amd.h */
+int rcx_debug_set_stamp_buffer(void* p) { return (int)rcx::set_stamp_buffer(p); }
+#endif
 
 }  // extern "C"

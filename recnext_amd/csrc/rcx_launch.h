@@ -14,4 +14,9 @@ hipError_t generic_upadd_dwconv(const void* x, const void* coarse, void* y, cons
 hipError_t pack_dw_weight(const void* w, float* dst, int C, int k, int dt, hipStream_t s);
 hipError_t pack_bias(const void* b, float* dst, int C, int dt, hipStream_t s);
 
+// rcx_plane.hip -- fused single-launch schedule (k=5, C%8==0, pyramid fits in LDS)
+bool plane_applicable(int N, int C, int H, int W, int level, int k, int dtype);
+hipError_t plane_recconv(const void* x, void* y, const float* wpack, const float* bpack,
+                         int N, int C, int H, int W, int level, int k, int mode, int dtype, hipStream_t s);
+
 }  // namespace rcx
