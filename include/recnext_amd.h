@@ -44,8 +44,8 @@ enum {
 int rcx_abi_version(void);
 const char* rcx_last_error(void);
 
-/* Name of the kernel schedule rcx_recconv2d_fwd would use for this problem ("generic", "plane", ...);
- * static string, for logs and benchmarks. */
+/* Description of the kernel schedule rcx_recconv2d_fwd would use for this problem, e.g. "generic" or
+ * "plane(cb=16,band8,nt=512,lds=157760)"; thread-local storage, valid until the next call on this thread. */
 const char* rcx_recconv2d_fwd_plan(int N, int C, int H, int W, int level, int k, int mode, int dtype);
 
 /* Repack one depthwise weight (C,1,k,k) [dtype f32|bf16] -> float32 (k,k,C).

@@ -88,7 +88,10 @@ const char* rcx_last_error(void) { return g_err; }
 const char* rcx_recconv2d_fwd_plan(int N, int C, int H, int W, int level, int k, int /*mode*/, int dtype)
 {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0) return "invalid";
-    return use_plane(N, C, H, W, level, k, dtype) ? "plane" : "generic";
+    if (!use_plane(N, C, H, W, level, k, dtype)) return "generic";
+    static thread_local char desc[96];
+    if (rcx::plane_describe(N, C, H, W, level, k, dtype, desc, (int)sizeof(desc)) <= 0) return "generic";
+    return desc;
 }
 
 int rcx_pack_dw_weight(const void* w_ckk, float* dst_kkc, int C, int k, int dtype, void* stream)

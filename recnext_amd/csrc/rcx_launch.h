@@ -16,6 +16,7 @@ hipError_t pack_bias(const void* b, float* dst, int C, int dt, hipStream_t s);
 
 // rcx_plane.hip -- fused single-launch schedule (k=5, C%8==0, pyramid fits in LDS)
 bool plane_applicable(int N, int C, int H, int W, int level, int k, int dtype);
+int plane_describe(int N, int C, int H, int W, int level, int k, int dtype, char* buf, int len);
 hipError_t plane_recconv(const void* x, void* y, const float* wpack, const float* bpack,
                          int N, int C, int H, int W, int level, int k, int mode, int dtype, hipStream_t s);
 

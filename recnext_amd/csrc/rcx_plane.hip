@@ -23,6 +23,7 @@
 #include "rcx_common.h"
 #include "rcx_launch.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace rcx {
@@ -36,8 +37,10 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
         if (threadIdx.x == 0 && g_stamp_buf && blockIdx.x < 256)                                        \
             g_stamp_buf[blockIdx.x * 64 + (id)] = __builtin_readcyclecounter();                         \
     } while (0)
+#define RCX_ABLATE(a, bit) (((a).ablate >> (bit)) & 1)
 #else
 #define RCX_STAMP(id) do { } while (0)
+#define RCX_ABLATE(a, bit) 0
 #endif
 
 constexpr int PL_MAXL = 8;
@@ -46,7 +49,6 @@ constexpr int PL_P = 2;
 constexpr int PL_TW = 7;       // outputs per thread along x in the stride-1 strip convs
 constexpr int PL_TW2 = 4;      // ... and in the stride-2 pass (its window spans 2*TW+3 columns)
 constexpr int PL_NT = 512;     // max threads per workgroup
-constexpr int PL_D = 3;        // prefetch depth in bands
 constexpr int PL_IPB = 2;      // max 16-byte staging items per thread per band
 
 struct PlaneArgs {
@@ -56,6 +58,8 @@ struct PlaneArgs {
     int c_off[PL_MAXL + 1];   // float2 offsets of C_l (l >= 1) in LDS
     int band_off;             // float2 offset of the row band
     int taps_off;             // float2 offset of the (level+2) tap sets
+    int tab_off;              // float2 offset of the resize tables
+    int tr_off[PL_MAXL + 1], tc_off[PL_MAXL + 1];   // AxisTab index of the row / column table of level l (from level l+1)
     int band_rows;            // NR: rows in the circular band
     int band_wp;              // padded row width in pixels
     int B2;                   // output rows per band, pass 2 (stride 1)
@@ -64,6 +68,7 @@ struct PlaneArgs {
     int has_bias;
     int mode;                 // 0 bilinear, 1 nearest
     int single;               // 1: the whole zero-bordered plane lives in the band; pass 2 reuses it in place
+    int ablate;               // diagnostic build only: bit mask of work to skip (results are then wrong)
 };
 
 // q / d for 0 <= q < 2^20 via a float reciprocal: (q + 0.5) / d is never within rounding distance of an integer
@@ -128,23 +133,32 @@ __device__ __forceinline__ void preload_taps(float2* __restrict__ taps, const fl
     }
 }
 
+// Per-axis resize tables, built once per workgroup in LDS: entry d of an axis holds the two source
+// indices and their weights (bilinear: (1-lam, lam); nearest: (1, 0) with i1 == i0).  Index and lambda
+// arithmetic is ATen's (float), done H+W times per level instead of once per pixel.
+struct __attribute__((aligned(16))) AxisTab { int i0, i1; float w0, w1; };
+
+__device__ __forceinline__ void build_axis(AxisTab* __restrict__ tab, int n_out, int n_in, int mode)
+{
+    const float scale = (float)n_in / (float)n_out;
+    for (int d = threadIdx.x; d < n_out; d += blockDim.x) {
+        AxisTab t;
+        if (mode == 1) { t.i0 = t.i1 = nearest_src(d, n_in, scale); t.w0 = 1.f; t.w1 = 0.f; }
+        else { const Lerp l = bilinear_src(d, n_in, scale); t.i0 = l.i0; t.i1 = l.i1; t.w0 = 1.f - l.lam; t.w1 = l.lam; }
+        tab[d] = t;
+    }
+}
+
 // Source taps of resize(src (hs x ws) -> dst) at (y, x): four corner offsets (in pixels) and weights.
 struct UpTap { int o00, o01, o10, o11; float w00, w01, w10, w11; };
 
-__device__ __forceinline__ UpTap up_tap(int mode, int hs, int ws, float sy, float sx, int y, int x)
+__device__ __forceinline__ UpTap up_tap(const AxisTab* __restrict__ rows, const AxisTab* __restrict__ cols, int ws, int y, int x)
 {
+    const AxisTab ry = rows[y], cx = cols[x];
     UpTap t;
-    if (mode == 1) {
-        const int cy = nearest_src(y, hs, sy), cx = nearest_src(x, ws, sx);
-        t.o00 = t.o01 = t.o10 = t.o11 = cy * ws + cx;
-        t.w00 = 1.f; t.w01 = t.w10 = t.w11 = 0.f;
-    } else {
-        const Lerp ly = bilinear_src(y, hs, sy), lx = bilinear_src(x, ws, sx);
-        t.o00 = ly.i0 * ws + lx.i0; t.o01 = ly.i0 * ws + lx.i1;
-        t.o10 = ly.i1 * ws + lx.i0; t.o11 = ly.i1 * ws + lx.i1;
-        const float wx1 = lx.lam, wx0 = 1.f - lx.lam, wy1 = ly.lam, wy0 = 1.f - ly.lam;
-        t.w00 = wy0 * wx0; t.w01 = wy0 * wx1; t.w10 = wy1 * wx0; t.w11 = wy1 * wx1;
-    }
+    t.o00 = ry.i0 * ws + cx.i0; t.o01 = ry.i0 * ws + cx.i1;
+    t.o10 = ry.i1 * ws + cx.i0; t.o11 = ry.i1 * ws + cx.i1;
+    t.w00 = ry.w0 * cx.w0; t.w01 = ry.w0 * cx.w1; t.w10 = ry.w1 * cx.w0; t.w11 = ry.w1 * cx.w1;
     return t;
 }
 
@@ -166,7 +180,7 @@ struct Stage {
     static constexpr int G = LPP / CPL;            // 16-byte groups per pixel of this block
     static_assert(LPP % CPL == 0, "channel block narrower than one 16-byte chunk");
 
-    const TIO* xn; int c0; int H, W, C, wp, nr;
+    const TIO* xn; int c0; int H, W, C, wp, nr; int ablate;
 
     __device__ __forceinline__ bool decode(int it, int r0, int& r, int& px, int& g, float inv_row) const
     {
@@ -196,15 +210,15 @@ __device__ __forceinline__ void stage_issue(const Stage<LPP, TIO>& sg, uint4 (&p
         const int it = threadIdx.x + j * blockDim.x;
         int r, px, g;
         pre[j] = make_uint4(0u, 0u, 0u, 0u);
-        if (it < items && sg.decode(it, r0, r, px, g, inv_row)) pre[j] = sg.load(r, px, g);
+        if (it < items && sg.decode(it, r0, r, px, g, inv_row) && !RCX_ABLATE(sg, 5)) pre[j] = sg.load(r, px, g);
     }
 }
 
 // convert a FIFO slot (+ resize(coarse) when HAS_COARSE) and write it to the band
 template <int LPP, bool HAS_COARSE, typename TIO>
 __device__ __forceinline__ void stage_write(const Stage<LPP, TIO>& sg, float2* __restrict__ band, const uint4 (&pre)[PL_IPB],
-                                            int r0, int r1, const float2* __restrict__ coarse, int hc, int wc,
-                                            float sy, float sx, int mode)
+                                            int r0, int r1, const float2* __restrict__ coarse, int wc,
+                                            const AxisTab* __restrict__ trow, const AxisTab* __restrict__ tcol)
 {
     constexpr int CPL = Stage<LPP, TIO>::CPL;
     const int per_row = sg.wp * Stage<LPP, TIO>::G;
@@ -220,14 +234,15 @@ __device__ __forceinline__ void stage_write(const Stage<LPP, TIO>& sg, float2* _
         float2 v[CPL];
         IO<TIO>::unpack(pre[j], v);                          // zeros when outside (issue stored zeros)
         if constexpr (HAS_COARSE) {
-            if (inside) {
-                const UpTap t = up_tap(mode, hc, wc, sy, sx, r, px - PL_P);
+            if (inside && !RCX_ABLATE(sg, 3)) {
+                const UpTap t = up_tap(trow, tcol, wc, r, px - PL_P);
 #pragma unroll
                 for (int i = 0; i < CPL; ++i) v[i] = add2(v[i], up_sample<LPP>(coarse, t, g * CPL + i));
             }
         }
         const int slot = wrap(slot0 + (r - r0), sg.nr);
         float2* dst = band + ((size_t)slot * sg.wp + px) * LPP + g * CPL;
+        if (RCX_ABLATE(sg, 4) && v[0].x != 123456.f) continue;
 #pragma unroll
         for (int i = 0; i < CPL; i += 2) *reinterpret_cast<float4*>(dst + i) = make_float4(v[i].x, v[i].y, v[i + 1].x, v[i + 1].y);
     }
@@ -270,8 +285,8 @@ __device__ __forceinline__ void stage_direct(const Stage<LPP, TIO>& sg, float2* 
 
 // band[r][x] += resize(coarse)(r, x) over the real plane (single-band mode, pass 2)
 template <int LPP>
-__device__ __forceinline__ void band_upadd(float2* __restrict__ band, const PlaneArgs& a, const float2* __restrict__ coarse,
-                                           int hc, int wc, float sy, float sx)
+__device__ __forceinline__ void band_upadd(float2* __restrict__ band, const PlaneArgs& a, const float2* __restrict__ coarse, int wc,
+                                           const AxisTab* __restrict__ trow, const AxisTab* __restrict__ tcol)
 {
     const int nq = a.H * a.W;
     const float inv_w = 1.0f / (float)a.W;
@@ -280,7 +295,7 @@ __device__ __forceinline__ void band_upadd(float2* __restrict__ band, const Plan
     for (int q = threadIdx.x / LPP; q < nq; q += qstep) {
         const int y = fast_div(q, inv_w);
         const int x = q - y * a.W;
-        const UpTap t = up_tap(a.mode, hc, wc, sy, sx, y, x);
+        const UpTap t = up_tap(trow, tcol, wc, y, x);
         const int slot = mod_pos(y, a.band_rows);
         float2* p = band + ((size_t)slot * a.band_wp + x + PL_P) * LPP + cp;
         *p = add2(*p, up_sample<LPP>(coarse, t, cp));
@@ -288,154 +303,171 @@ __device__ __forceinline__ void band_upadd(float2* __restrict__ band, const Plan
 }
 
 // ---------------- strip convs ----------------
-// 5x5 conv of band rows -> output rows [o0, o1) (stride S), TW outputs per thread, no bounds logic:
-// the band carries 2 zero columns left and enough right padding for the last partial strip.
-template <int LPP, int S, bool TO_GLOBAL, typename TIO>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+constexpr int PL_TH = 2;       // output rows per thread in the banded convs
+
+// 5x5 conv of band rows -> output rows [o0, o1) (stride S): each thread produces a TH x TW register tile,
+// so one window row read from LDS feeds TH output rows and TW outputs -- 0.19 (S=1) / 0.39 (S=2) LDS
+// reads per packed FMA, under the ~0.27 where LDS bandwidth, not the VALU, sets the pace on gfx950.
+// No bounds logic: the band carries 2 zero columns left and enough right padding for the last strip.
+// `hook` runs exactly once per call, after the FMAs of the thread's first item and before its stores
+// (or after the loop for a thread without items): the banded passes use it to retire the prefetched
+// loads of the next band while the only younger memory operations are old ones.
+template <int LPP, int S, bool TO_GLOBAL, typename TIO, typename Hook = NoHook>
 __device__ __forceinline__ void conv_band(const float2* __restrict__ band, const PlaneArgs& a, const float2* __restrict__ tp,
-                                          int o0, int o1, int Wo, float2* __restrict__ dst_lds, TIO* __restrict__ yn, int c0)
+                                          int o0, int o1, int Wo, float2* __restrict__ dst_lds, TIO* __restrict__ yn, int c0,
+                                          Hook hook = Hook())
 {
     constexpr int TW = S == 1 ? PL_TW : PL_TW2;
+    constexpr int TH = PL_TH;
     constexpr int SPAN = (TW - 1) * S + PL_K;
+    constexpr int NIN = (TH - 1) * S + PL_K;              // window rows per tile
+    bool hooked = false;
     const int wp = a.band_wp;
     const int strips = (Wo + TW - 1) / TW;
-    const int nq = (o1 - o0) * strips;
+    const int rgroups = (o1 - o0 + TH - 1) / TH;
+    const int nq = rgroups * strips;
     const float inv_strips = 1.0f / (float)strips;
     const int slot_base = mod_pos(o0 * S - PL_P, a.band_rows);
     const int cp = threadIdx.x % LPP;
     const int qstep = blockDim.x / LPP;
+    int q = threadIdx.x / LPP;
+    if (q < nq) {
+        // the 25 taps of this channel pair stay in registers for the whole call
+        float2 tw[PL_K * PL_K];
+#pragma unroll
+        for (int i = 0; i < PL_K * PL_K; ++i) tw[i] = tp[i * LPP + cp];
+        const float2 bias = tp[PL_K * PL_K * LPP + cp];
+        for (; q < nq; q += qstep) {
+            const int dg = fast_div(q, inv_strips);
+            const int st = q - dg * strips;
+            const int oy = o0 + dg * TH;
+            const int ox0 = st * TW;
+            int slot = slot_base + dg * TH * S;
+            while (slot >= a.band_rows) slot -= a.band_rows;
+            float2 acc[TH][TW];
+#pragma unroll
+            for (int t = 0; t < TH; ++t)
+#pragma unroll
+                for (int j = 0; j < TW; ++j) acc[t][j] = bias;
+            // padded column of input ix is ix + 2, so the window of output ox starts at padded column ox*S.
+            // Rows are software-pipelined by hand (row i+1 is loaded while row i is multiplied) and the
+            // order is pinned: left alone, the scheduler hoists every row's loads and spills.
+            float2 cur[SPAN], nxt[SPAN];
+            {
+                const float2* row = band + ((size_t)slot * wp + ox0 * S) * LPP + cp;
+#pragma unroll
+                for (int s = 0; s < SPAN; ++s) cur[s] = row[s * LPP];
+            }
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) {
+                if (i + 1 < NIN && !RCX_ABLATE(a, 2)) {
+                    slot = wrap(slot + 1, a.band_rows);
+                    const float2* row = band + ((size_t)slot * wp + ox0 * S) * LPP + cp;
+#pragma unroll
+                    for (int s = 0; s < SPAN; ++s) nxt[s] = row[s * LPP];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < TH; ++t) {
+                    const int u = i - t * S;              // window row of output row t fed by input row i
+                    if (u < 0 || u >= PL_K || RCX_ABLATE(a, 1)) continue;
+#pragma unroll
+                    for (int s = 0; s < SPAN; ++s) {
+#pragma unroll
+                        for (int j = 0; j < TW; ++j) {
+                            const int tap = s - j * S;
+                            if (tap >= 0 && tap < PL_K) acc[t][j] = fma2(tw[u * PL_K + tap], cur[s], acc[t][j]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < SPAN; ++s) cur[s] = nxt[s];
+            }
+            if (!hooked) { hook(); hooked = true; }
+#pragma unroll
+            for (int t = 0; t < TH; ++t) {
+                if (oy + t >= o1 || (RCX_ABLATE(a, 0) && acc[t][0].x != 123456.f)) continue;
+#pragma unroll
+                for (int j = 0; j < TW; ++j) {
+                    const int ox = ox0 + j;
+                    if (ox < Wo) {
+                        if constexpr (TO_GLOBAL) IO<TIO>::st2(yn + ((size_t)(oy + t) * Wo + ox) * a.C + c0 + 2 * cp, acc[t][j]);
+                        else dst_lds[((oy + t) * Wo + ox) * LPP + cp] = acc[t][j];
+                    }
+                }
+            }
+        }
+    }
+    if (!hooked) hook();
+}
+
+// LDS plane -> LDS plane 5x5 conv, stride S, strips of TW outputs, zero padding by predication.
+// All 5 window rows are loaded (predicated) before any of them is used, so a thread pays one LDS
+// round trip per item instead of one per tap: these planes are small and latency, not bandwidth,
+// is what they cost.
+template <int LPP, int S>
+__device__ __forceinline__ void conv_lds(const float2* __restrict__ src, int hs, int ws, float2* __restrict__ dst, int hd, int wd,
+                                         const float2* __restrict__ tp)
+{
+    constexpr int TW = S == 1 ? PL_TW : PL_TW2;
+    constexpr int SPAN = (TW - 1) * S + PL_K;
+    const int strips = (wd + TW - 1) / TW;
+    const int nq = hd * strips;
+    const float inv_strips = 1.0f / (float)strips;
+    const int cp = threadIdx.x % LPP;
+    const int qstep = blockDim.x / LPP;
     for (int q = threadIdx.x / LPP; q < nq; q += qstep) {
-        const int dr = fast_div(q, inv_strips);
-        const int st = q - dr * strips;
-        const int oy = o0 + dr;
-        const int ox0 = st * TW;
-        int slot = wrap(wrap(slot_base + dr * S, a.band_rows), a.band_rows);
+        const int oy = fast_div(q, inv_strips);
+        const int ox0 = (q - oy * strips) * TW;
         float2 acc[TW];
         {
             const float2 bias = tp[PL_K * PL_K * LPP + cp];
 #pragma unroll
             for (int j = 0; j < TW; ++j) acc[j] = bias;
         }
-        // padded column of input ix is ix + 2, so the window of output ox starts at padded column ox*S.
-        // Rows are software-pipelined by hand (row u+1 is loaded while row u is multiplied) and the
-        // order is pinned: left alone, the scheduler hoists all 5 rows of loads and spills.
-        float2 cur[SPAN], nxt[SPAN];
-        {
-            const float2* row = band + ((size_t)slot * wp + ox0 * S) * LPP + cp;
+        bool colok[SPAN];
 #pragma unroll
-            for (int s = 0; s < SPAN; ++s) cur[s] = row[s * LPP];
+        for (int s = 0; s < SPAN; ++s) { const int ix = ox0 * S + s - PL_P; colok[s] = ix >= 0 && ix < ws; }
+        const float2* base = src + ((size_t)(oy * S - PL_P) * ws + ox0 * S - PL_P) * LPP + cp;
+        float2 win[PL_K][SPAN];
+#pragma unroll
+        for (int u = 0; u < PL_K; ++u) {
+            const int iy = oy * S + u - PL_P;
+            const bool rowok = iy >= 0 && iy < hs;
+#pragma unroll
+            for (int s = 0; s < SPAN; ++s) {
+                float2 v = make_float2(0.f, 0.f);
+                if (rowok && colok[s]) v = base[((size_t)u * ws + s) * LPP];
+                win[u][s] = v;
+            }
         }
 #pragma unroll
         for (int u = 0; u < PL_K; ++u) {
-            if (u + 1 < PL_K) {
-                slot = wrap(slot + 1, a.band_rows);
-                const float2* row = band + ((size_t)slot * wp + ox0 * S) * LPP + cp;
-#pragma unroll
-                for (int s = 0; s < SPAN; ++s) nxt[s] = row[s * LPP];
-            }
             float2 tw[PL_K];
 #pragma unroll
             for (int i = 0; i < PL_K; ++i) tw[i] = tp[(u * PL_K + i) * LPP + cp];
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < SPAN; ++s) {
 #pragma unroll
                 for (int j = 0; j < TW; ++j) {
                     const int tap = s - j * S;
-                    if (tap >= 0 && tap < PL_K) acc[j] = fma2(tw[tap], cur[s], acc[j]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < SPAN; ++s) cur[s] = nxt[s];
-        }
-#pragma unroll
-        for (int j = 0; j < TW; ++j) {
-            const int ox = ox0 + j;
-            if (ox < Wo) {
-                if constexpr (TO_GLOBAL) IO<TIO>::st2(yn + ((size_t)oy * Wo + ox) * a.C + c0 + 2 * cp, acc[j]);
-                else dst_lds[(oy * Wo + ox) * LPP + cp] = acc[j];
-            }
-        }
-    }
-}
-
-// LDS plane -> LDS plane, stride 1, TW-wide strips, zero padding by predication (C_l = conv_j(T_l))
-template <int LPP>
-__device__ __forceinline__ void conv_plane_strips(const float2* __restrict__ src, int hs, int ws, float2* __restrict__ dst,
-                                                  const float2* __restrict__ tp)
-{
-    const int strips = (ws + PL_TW - 1) / PL_TW;
-    const int nq = hs * strips;
-    const float inv_strips = 1.0f / (float)strips;
-    const int cp = threadIdx.x % LPP;
-    const int qstep = blockDim.x / LPP;
-    for (int q = threadIdx.x / LPP; q < nq; q += qstep) {
-        const int oy = fast_div(q, inv_strips);
-        const int ox0 = (q - oy * strips) * PL_TW;
-        float2 acc[PL_TW];
-        {
-            const float2 bias = tp[PL_K * PL_K * LPP + cp];
-#pragma unroll
-            for (int j = 0; j < PL_TW; ++j) acc[j] = bias;
-        }
-#pragma unroll
-        for (int u = 0; u < PL_K; ++u) {
-            const int iy = oy + u - PL_P;
-            if (iy < 0 || iy >= hs) continue;
-            const float2* row = src + (size_t)iy * ws * LPP + cp;
-            float2 tw[PL_K];
-#pragma unroll
-            for (int i = 0; i < PL_K; ++i) tw[i] = tp[(u * PL_K + i) * LPP + cp];
-#pragma unroll
-            for (int s = 0; s < PL_TW + PL_K - 1; ++s) {
-                const int ix = ox0 + s - PL_P;
-                float2 v = make_float2(0.f, 0.f);
-                if (ix >= 0 && ix < ws) v = row[ix * LPP];
-#pragma unroll
-                for (int j = 0; j < PL_TW; ++j) {
-                    const int tap = s - j;
-                    if (tap >= 0 && tap < PL_K) acc[j] = fma2(tw[tap], v, acc[j]);
+                    if (tap >= 0 && tap < PL_K) acc[j] = fma2(tw[tap], win[u][s], acc[j]);
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < PL_TW; ++j)
-            if (ox0 + j < ws) dst[(oy * ws + ox0 + j) * LPP + cp] = acc[j];
-    }
-}
-
-// LDS plane -> LDS plane, stride 2, one output per thread (the small levels of the down ladder)
-template <int LPP>
-__device__ __forceinline__ void down_plane(const float2* __restrict__ src, int hs, int ws, float2* __restrict__ dst, int hd, int wd,
-                                           const float2* __restrict__ tp)
-{
-    const int nq = hd * wd;
-    const float inv_wd = 1.0f / (float)wd;
-    const int cp = threadIdx.x % LPP;
-    const int qstep = blockDim.x / LPP;
-    for (int q = threadIdx.x / LPP; q < nq; q += qstep) {
-        const int oy = fast_div(q, inv_wd);
-        const int ox = q - oy * wd;
-        float2 acc = tp[PL_K * PL_K * LPP + cp];
-#pragma unroll
-        for (int u = 0; u < PL_K; ++u) {
-            const int iy = oy * 2 + u - PL_P;
-            if (iy < 0 || iy >= hs) continue;
-#pragma unroll
-            for (int v = 0; v < PL_K; ++v) {
-                const int ix = ox * 2 + v - PL_P;
-                if (ix < 0 || ix >= ws) continue;
-                acc = fma2(tp[(u * PL_K + v) * LPP + cp], src[(iy * ws + ix) * LPP + cp], acc);
-            }
-        }
-        dst[q * LPP + cp] = acc;
+        for (int j = 0; j < TW; ++j)
+            if (ox0 + j < wd) dst[(oy * wd + ox0 + j) * LPP + cp] = acc[j];
     }
 }
 
 template <int LPP>
-__device__ __forceinline__ void upadd_plane(const float2* __restrict__ coarse, int hc, int wc, float2* __restrict__ fine, int hf, int wf, int mode)
+__device__ __forceinline__ void upadd_plane(const float2* __restrict__ coarse, int wc, float2* __restrict__ fine, int hf, int wf,
+                                            const AxisTab* __restrict__ trow, const AxisTab* __restrict__ tcol)
 {
-    const float sy = (float)hc / (float)hf, sx = (float)wc / (float)wf;
     const int nq = hf * wf;
     const float inv_wf = 1.0f / (float)wf;
     const int cp = threadIdx.x % LPP;
@@ -443,7 +475,7 @@ __device__ __forceinline__ void upadd_plane(const float2* __restrict__ coarse, i
     for (int q = threadIdx.x / LPP; q < nq; q += qstep) {
         const int y = fast_div(q, inv_wf);
         const int x = q - y * wf;
-        const UpTap t = up_tap(mode, hc, wc, sy, sx, y, x);
+        const UpTap t = up_tap(trow, tcol, wc, y, x);
         fine[q * LPP + cp] = add2(fine[q * LPP + cp], up_sample<LPP>(coarse, t, cp));
     }
 }
@@ -459,7 +491,7 @@ struct Pass {
     const Stage<LPP, TIO>& sg;
     float2* band;
     const float2* tp;
-    const float2* coarse; int hc, wc; float sy, sx;
+    const float2* coarse; int wc; const AxisTab* trow; const AxisTab* tcol;
     float2* dst_lds; TIO* yn; int c0;
     int Ho, Wo, Bo, nb;
 
@@ -467,42 +499,37 @@ struct Pass {
     __device__ __forceinline__ int first(int b) const { return b * Bo * S + (S == 2 ? 1 : PL_P); }
     __device__ __forceinline__ int row_end(int b) const { const int e = first(b + 1); const int lim = a.H + PL_P; return e < lim ? e : lim; }
 
-    template <int SLOT>
-    __device__ __forceinline__ void step(uint4 (&fifo)[PL_D][PL_IPB], int b) const
-    {
-        if (b >= nb) return;
-        __syncthreads();                                  // band b-1's readers are done with the slots we overwrite
-        if (S == 1 && b < 8) RCX_STAMP(8 + 3 * b);
-        stage_write<LPP, HAS_COARSE, TIO>(sg, band, fifo[SLOT], first(b), row_end(b), coarse, hc, wc, sy, sx, a.mode);
-        if (S == 1 && b == 2) RCX_STAMP(40);
-        if (b + PL_D < nb) stage_issue<LPP, TIO>(sg, fifo[SLOT], first(b + PL_D), row_end(b + PL_D));
-        if (S == 1 && b == 2) RCX_STAMP(41);
-        __syncthreads();
-        if (S == 1 && b < 8) RCX_STAMP(9 + 3 * b);
-        const int o0 = b * Bo, o1 = min(o0 + Bo, Ho);
-        conv_band<LPP, S, S == 1, TIO>(band, a, tp, o0, o1, Wo, dst_lds, yn, c0);
-        if (S == 1 && b == 2) RCX_STAMP(42);
-    }
-
     __device__ __forceinline__ void run() const
     {
-        uint4 fifo[PL_D][PL_IPB];
-        // rows [-2, first(0)) synchronously (zero rows + the first real row(s)), then prime the FIFO
+        uint4 pre[PL_IPB];        // loads in flight: the NEXT band's new rows
+        uint4 cur[PL_IPB];        // the band about to be written to LDS (already arrived)
+        // rows [-2, first(0)): zero rows and the first real row(s)
         if constexpr (HAS_COARSE) {
-            // the prologue rows need resize(coarse) too: route them through issue/write
-            stage_issue<LPP, TIO>(sg, fifo[0], -PL_P, first(0));
-            stage_write<LPP, true, TIO>(sg, band, fifo[0], -PL_P, first(0), coarse, hc, wc, sy, sx, a.mode);
+            stage_issue<LPP, TIO>(sg, cur, -PL_P, first(0));
+            stage_write<LPP, true, TIO>(sg, band, cur, -PL_P, first(0), coarse, wc, trow, tcol);
         } else {
             stage_direct<LPP, TIO>(sg, band, -PL_P, first(0));
         }
-        stage_issue<LPP, TIO>(sg, fifo[0], first(0), row_end(0));
-        if (1 < nb) stage_issue<LPP, TIO>(sg, fifo[1], first(1), row_end(1));
-        if (2 < nb) stage_issue<LPP, TIO>(sg, fifo[2], first(2), row_end(2));
-        static_assert(PL_D == 3, "FIFO priming is written for depth 3");
-        for (int b = 0; b < nb; b += PL_D) {
-            step<0>(fifo, b);
-            step<1>(fifo, b + 1);
-            step<2>(fifo, b + 2);
+        stage_issue<LPP, TIO>(sg, cur, first(0), row_end(0));
+        for (int b = 0; b < nb; ++b) {
+            __syncthreads();                              // band b-1's readers are done with the slots we overwrite
+            if (S == 1 && b < 8) RCX_STAMP(8 + 3 * b);
+            // one band ahead: these loads have the whole of band b's staging + conv to arrive
+            if (b + 1 < nb) stage_issue<LPP, TIO>(sg, pre, first(b + 1), row_end(b + 1));
+            stage_write<LPP, HAS_COARSE, TIO>(sg, band, cur, first(b), row_end(b), coarse, wc, trow, tcol);
+            __syncthreads();
+            if (S == 1 && b < 8) RCX_STAMP(9 + 3 * b);
+            const int o0 = b * Bo, o1 = min(o0 + Bo, Ho);
+            // Retire the prefetch between this band's FMAs and its stores: the wait then covers loads issued
+            // a whole band ago and no store that was issued a moment ago (vmcnt counts both on gfx950).
+            conv_band<LPP, S, S == 1, TIO>(band, a, tp, o0, o1, Wo, dst_lds, yn, c0, [&]() {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < PL_IPB; ++j) cur[j] = pre[j];
+#pragma unroll
+                for (int j = 0; j < PL_IPB; ++j) asm volatile("" : "+v"(cur[j].x), "+v"(cur[j].y), "+v"(cur[j].z), "+v"(cur[j].w));
+                __builtin_amdgcn_sched_barrier(0);
+            });
         }
     }
 };
@@ -530,11 +557,17 @@ k_recconv_plane(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __r
     float2* taps = lds + a.taps_off;
     const int L = a.level;
     auto taps_of = [&](int i) { return taps + (size_t)i * PL_TAPROWS * LPP; };
-    const Stage<LPP, TIO> sg{xn, c0, a.H, a.W, a.C, a.band_wp, a.band_rows};
+    const Stage<LPP, TIO> sg{xn, c0, a.H, a.W, a.C, a.band_wp, a.band_rows, a.ablate};
 
-    // all (L+2) tap sets of this channel block, once; first read is behind the first staging barrier
+    // all (L+2) tap sets of this channel block and the resize tables, once; their first readers are
+    // behind the first staging barrier
     RCX_STAMP(0);
     preload_taps<LPP>(taps, wpack, a.has_bias ? bpack : nullptr, a.C, c0, L + 2);
+    AxisTab* tabs = reinterpret_cast<AxisTab*>(lds + a.tab_off);
+    for (int l = 0; l < L; ++l) {
+        build_axis(tabs + a.tr_off[l], a.h[l], a.h[l + 1], a.mode);
+        build_axis(tabs + a.tc_off[l], a.w[l], a.w[l + 1], a.mode);
+    }
 
     if (L >= 1) {
         // ---- pass 1: F_1 = down(x) ----
@@ -544,7 +577,7 @@ k_recconv_plane(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __r
             __syncthreads();
             conv_band<LPP, 2, false, TIO>(band, a, taps_of(0), 0, a.h[1], a.w[1], F1, nullptr, c0);
         } else {
-            const Pass<LPP, 2, false, TIO> p1{a, sg, band, taps_of(0), nullptr, 0, 0, 0.f, 0.f, F1, nullptr, c0,
+            const Pass<LPP, 2, false, TIO> p1{a, sg, band, taps_of(0), nullptr, 0, nullptr, nullptr, F1, nullptr, c0,
                                               a.h[1], a.w[1], a.B1, (a.h[1] + a.B1 - 1) / a.B1};
             p1.run();
         }
@@ -552,17 +585,18 @@ k_recconv_plane(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __r
         RCX_STAMP(1);
         // ---- ladder: F_{l+1} = down(F_l) ----
         for (int l = 1; l < L; ++l) {
-            down_plane<LPP>(lds + a.f_off[l], a.h[l], a.w[l], lds + a.f_off[l + 1], a.h[l + 1], a.w[l + 1], taps_of(0));
+            conv_lds<LPP, 2>(lds + a.f_off[l], a.h[l], a.w[l], lds + a.f_off[l + 1], a.h[l + 1], a.w[l + 1], taps_of(0));
             __syncthreads();
         }
         RCX_STAMP(2);
         // ---- up recursion, coarsest first: C_l = conv_j(T_l); T_{l-1} = F_{l-1} + resize(C_l) ----
         for (int l = L, j = 0; l >= 1; --l, ++j) {
             if (l == 1) RCX_STAMP(3);
-            conv_plane_strips<LPP>(lds + a.f_off[l], a.h[l], a.w[l], lds + a.c_off[l], taps_of(1 + j));
+            conv_lds<LPP, 1>(lds + a.f_off[l], a.h[l], a.w[l], lds + a.c_off[l], a.h[l], a.w[l], taps_of(1 + j));
             __syncthreads();
             if (l > 1) {
-                upadd_plane<LPP>(lds + a.c_off[l], a.h[l], a.w[l], lds + a.f_off[l - 1], a.h[l - 1], a.w[l - 1], a.mode);
+                upadd_plane<LPP>(lds + a.c_off[l], a.w[l], lds + a.f_off[l - 1], a.h[l - 1], a.w[l - 1],
+                                 tabs + a.tr_off[l - 1], tabs + a.tc_off[l - 1]);
                 __syncthreads();
             }
         }
@@ -570,18 +604,20 @@ k_recconv_plane(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __r
     RCX_STAMP(4);
     // ---- pass 2: y = conv_L(x + resize(C_1)) ----
     const float2* C1 = L >= 1 ? lds + a.c_off[1] : nullptr;
-    const int hc = L >= 1 ? a.h[1] : 1, wc = L >= 1 ? a.w[1] : 1;
-    const float sy = (float)hc / (float)a.H, sx = (float)wc / (float)a.W;
-    if (L >= 1 && a.single) {
-        band_upadd<LPP>(band, a, C1, hc, wc, sy, sx);
+    const int wc = L >= 1 ? a.w[1] : 1;
+    const AxisTab* trow = tabs + a.tr_off[0];
+    const AxisTab* tcol = tabs + a.tc_off[0];
+    if (a.single) {
+        if (L >= 1) band_upadd<LPP>(band, a, C1, wc, trow, tcol);       // the band still holds x from pass 1
+        else stage_direct<LPP, TIO>(sg, band, -PL_P, a.H + PL_P);       // level 0: y = conv_0(x)
         __syncthreads();
         conv_band<LPP, 1, true, TIO>(band, a, taps_of(1 + L), 0, a.H, a.W, nullptr, yn, c0);
     } else if (L >= 1) {
-        const Pass<LPP, 1, true, TIO> p2{a, sg, band, taps_of(1 + L), C1, hc, wc, sy, sx, nullptr, yn, c0,
+        const Pass<LPP, 1, true, TIO> p2{a, sg, band, taps_of(1 + L), C1, wc, trow, tcol, nullptr, yn, c0,
                                          a.H, a.W, a.B2, (a.H + a.B2 - 1) / a.B2};
         p2.run();
     } else {
-        const Pass<LPP, 1, false, TIO> p2{a, sg, band, taps_of(1 + L), nullptr, 0, 0, 0.f, 0.f, nullptr, yn, c0,
+        const Pass<LPP, 1, false, TIO> p2{a, sg, band, taps_of(1 + L), nullptr, 0, nullptr, nullptr, nullptr, yn, c0,
                                           a.H, a.W, a.B2, (a.H + a.B2 - 1) / a.B2};
         p2.run();
     }
@@ -609,21 +645,8 @@ static void fill_args(PlaneArgs& a, int N, int C, int H, int W, int level, int l
 {
     a.N = N; a.C = C; a.H = H; a.W = W; a.level = level;
     a.h[0] = H; a.w[0] = W;
-    size_t pix = 0;                                // LDS pixels (each lpp float2 wide)
-    for (int l = 1; l <= level; ++l) {
-        a.h[l] = down_size5(a.h[l - 1]); a.w[l] = down_size5(a.w[l - 1]);
-        a.f_off[l] = (int)(pix * lpp);
-        pix += (size_t)a.h[l] * a.w[l];
-    }
-    // C region: C_1 from its start; C_2, C_3, ... packed from its start too (all dead before C_1 is written)
-    const size_t cbase = pix;
-    size_t csmall = 0;
-    for (int l = 2; l <= level; ++l) { a.c_off[l] = (int)((cbase + csmall) * lpp); csmall += (size_t)a.h[l] * a.w[l]; }
-    size_t creg = 0;
-    if (level >= 1) { a.c_off[1] = (int)(cbase * lpp); creg = (size_t)a.h[1] * a.w[1]; }
-    if (csmall > creg) creg = csmall;
-    pix += creg;
-    a.band_off = (int)(pix * lpp);
+    for (int l = 1; l <= level; ++l) { a.h[l] = down_size5(a.h[l - 1]); a.w[l] = down_size5(a.w[l - 1]); }
+    // band geometry first: the small levels may alias it
     a.single = B2cand >= H ? 1 : 0;
     a.B2 = a.single ? H : B2cand;
     a.band_rows = a.B2 + 2 * PL_P;
@@ -639,10 +662,37 @@ static void fill_args(PlaneArgs& a, int N, int C, int H, int W, int level, int l
         if (wp1 > wp) wp = wp1;
     }
     a.band_wp = wp;
-    pix += (size_t)a.band_rows * wp;
+    const size_t band_px = (size_t)a.band_rows * wp;
+
+    size_t pix = 0;                                // LDS pixels (each lpp float2 wide)
+    size_t small = 0;                              // F_2 .. F_level
+    for (int l = 2; l <= level; ++l) small += (size_t)a.h[l] * a.w[l];
+    // F_1 (which becomes T_1) is live from pass 1 to the end of the up recursion: its own region.
+    if (level >= 1) { a.f_off[1] = 0; pix += (size_t)a.h[1] * a.w[1]; }
+    // C region: C_1 from its start; C_2, C_3, ... packed from its start too (all dead before C_1 is written)
+    const size_t cbase = pix;
+    size_t csmall = 0;
+    for (int l = 2; l <= level; ++l) { a.c_off[l] = (int)((cbase + csmall) * lpp); csmall += (size_t)a.h[l] * a.w[l]; }
+    size_t creg = 0;
+    if (level >= 1) { a.c_off[1] = (int)(cbase * lpp); creg = (size_t)a.h[1] * a.w[1]; }
+    if (csmall > creg) creg = csmall;
+    pix += creg;
+    a.band_off = (int)(pix * lpp);
+    pix += band_px;
+    // F_2 .. F_level are only live between the two passes: they overlay the (then idle) band, unless the
+    // band is the whole plane that pass 2 reuses in place
+    size_t fbase = pix;
+    if (!a.single && small <= band_px) fbase = (size_t)a.band_off / lpp;
+    else pix += small;
+    size_t fo = 0;
+    for (int l = 2; l <= level; ++l) { a.f_off[l] = (int)((fbase + fo) * lpp); fo += (size_t)a.h[l] * a.w[l]; }
     a.taps_off = (int)(pix * lpp);
     pix += (size_t)(level + 2) * PL_TAPROWS;
-    lds_bytes = pix * lpp * sizeof(float2);
+    // resize tables: 16-byte entries = 2 float2 each
+    a.tab_off = (int)(pix * lpp);
+    int ent = 0;
+    for (int l = 0; l < level; ++l) { a.tr_off[l] = ent; ent += a.h[l]; a.tc_off[l] = ent; ent += a.w[l]; }
+    lds_bytes = pix * lpp * sizeof(float2) + (size_t)ent * 16;
 }
 
 // 16-byte staging items of the largest band (prologue included); must fit PL_IPB per thread
@@ -658,7 +708,7 @@ static int pick_threads(const PlaneArgs& a, int lpp, int cpl)
     // enough threads that one band's staging fits PL_IPB 16-byte items per thread, and that the
     // widest strip conv has about one item per thread
     const int stage_items = band_stage_items(a, lpp, cpl);
-    const int conv_items = (a.single ? a.H : a.B2) * ((a.W + PL_TW - 1) / PL_TW) * lpp;
+    const int conv_items = (((a.single ? a.H : a.B2) + PL_TH - 1) / PL_TH) * ((a.W + PL_TW - 1) / PL_TW) * lpp;
     int nt = 64;
     while (nt < PL_NT && (conv_items > nt || (!a.single && stage_items > nt * PL_IPB))) nt *= 2;
     if (nt < lpp) nt = lpp;
@@ -667,50 +717,48 @@ static int pick_threads(const PlaneArgs& a, int lpp, int cpl)
 
 PlanePlan plan_plane(int N, int C, int H, int W, int level, int k, int dtype)
 {
-    PlanePlan p{};
-    p.ok = false;
-    if (k != PL_K || level < 0 || level > PL_MAXL || (C % 8) != 0) return p;
-    if ((long long)H * W > (1 << 18)) return p;           // fast_div range
+    PlanePlan none{};
+    none.ok = false;
+    if (k != PL_K || level < 0 || level > PL_MAXL || (C % 8) != 0) return none;
+    if ((long long)H * W > (1 << 18)) return none;        // fast_div range
     const size_t LDS_CU = 160 * 1024;
     const int cpl = dtype == 1 ? 4 : 2;                    // channel pairs per 16-byte chunk
     const int force_lpp = env_int("RCX_PLANE_LPP", 0), force_b2 = env_int("RCX_PLANE_B2", 0);
     const int force_nt = env_int("RCX_PLANE_NT", 0);
     static const int lpps[] = {32, 16, 8, 4};
-    static const int b2s[] = {1 << 20, 8, 4, 2};          // first candidate: the whole plane in the band
-    PlanePlan best{};
-    best.ok = false;
-    double best_score = -1.0;
-    for (int lpp : lpps) {
-        if (C % (2 * lpp) || lpp < cpl) continue;
-        if (force_lpp && lpp != force_lpp) continue;
-        for (int B2 : b2s) {
-            if (force_b2 && (B2 > 64 ? H : B2) != force_b2) continue;
-            if (B2 < 64 && B2 >= H) continue;              // same as the whole-plane candidate
-            PlaneArgs a{};
-            size_t bytes = 0;
-            fill_args(a, N, C, H, W, level, lpp, B2, bytes);
-            if (bytes > LDS_CU) continue;
-            a.nblk = C / (2 * lpp);
-            PlanePlan cand{};
-            cand.ok = true; cand.lpp = lpp; cand.lds_bytes = bytes; cand.args = a;
-            cand.nt = force_nt ? force_nt : pick_threads(a, lpp, cpl);
-            if (cand.nt < 64 || cand.nt > PL_NT || cand.nt % 64 || cand.nt % lpp) cand.nt = 256;
-            if (!a.single && band_stage_items(a, lpp, cpl) > cand.nt * PL_IPB) continue;   // FIFO slot too small
-            // score: resident waves per CU (latency hiding across workgroups), with a bonus for wide
-            // channel blocks (fuller HBM/L2 lines) and a penalty when the grid cannot fill the chip
-            int wg_cu = (int)(LDS_CU / bytes);
-            const int by_waves = 16 / (cand.nt / 64);      // <= 16 waves/CU at ~128+ VGPRs
-            if (wg_cu > by_waves) wg_cu = by_waves;
-            if (wg_cu < 1) wg_cu = 1;
-            const long long wgs = (long long)N * a.nblk;
-            double waves = (double)wg_cu * (cand.nt / 64);
-            double fill = (double)wgs / (256.0 * wg_cu);
-            if (fill > 1.0) fill = 1.0;
-            double score = waves * fill * (lpp >= 16 ? 1.25 : (lpp == 8 ? 1.0 : 0.7)) * (a.single ? 1.2 : 1.0);
-            if (score > best_score) { best_score = score; best = cand; }
-        }
-    }
-    return best;
+    constexpr int WHOLE = 1 << 20;
+
+    auto try_cfg = [&](int lpp, int B2, PlanePlan& out) -> bool {
+        if (C % (2 * lpp) || lpp < cpl) return false;
+        if (force_lpp && lpp != force_lpp) return false;
+        if (force_b2 && (B2 == WHOLE ? H : B2) != force_b2) return false;
+        if (B2 != WHOLE && B2 >= H) return false;           // same thing as the whole-plane candidate
+        PlaneArgs a{};
+        size_t bytes = 0;
+        fill_args(a, N, C, H, W, level, lpp, B2, bytes);
+        if (bytes > LDS_CU) return false;
+        a.nblk = C / (2 * lpp);
+        out.ok = true; out.lpp = lpp; out.lds_bytes = bytes; out.args = a;
+        out.nt = force_nt ? force_nt : pick_threads(a, lpp, cpl);
+        if (out.nt < 64 || out.nt > PL_NT || out.nt % 64 || out.nt % lpp) out.nt = 256;
+        if (!a.single && band_stage_items(a, lpp, cpl) > out.nt * PL_IPB) return false;   // FIFO slot too small
+        return true;
+    };
+
+    // Measured on MI355X (tools/sweep_plane.py, profiles/): small planes run best with the widest channel
+    // block whose whole zero-bordered plane fits the band (x is then read once, no band loop); larger
+    // planes with the widest block that fits at all, and the tallest band that fits with it.
+    PlanePlan p{};
+    if ((long long)H * W <= 1024 || force_b2 == H)
+        for (int lpp : lpps)
+            if (try_cfg(lpp, WHOLE, p)) return p;
+    static const int b2s[] = {8, 4, 2};
+    for (int lpp : lpps)
+        for (int B2 : b2s)
+            if (try_cfg(lpp, B2, p)) return p;
+    for (int lpp : lpps)                                   // large planes that happen to fit whole
+        if (try_cfg(lpp, WHOLE, p)) return p;
+    return none;
 }
 
 template <int LPP, typename TIO>
@@ -724,6 +772,11 @@ static hipError_t launch_plane_t(const void* x, void* y, const float* wpack, con
     PlaneArgs a = p.args;
     a.has_bias = bpack != nullptr;
     a.mode = mode;
+#ifdef RCX_STAMPS
+    a.ablate = env_int("RCX_PLANE_ABLATE", 0);
+#else
+    a.ablate = 0;
+#endif
     const int groups = (a.N + 7) / 8;
     const unsigned grid = (unsigned)(groups * 8 * a.nblk);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(p.nt), p.lds_bytes, s, (const TIO*)x, (TIO*)y, wpack, bpack, a);
@@ -744,6 +797,15 @@ static hipError_t launch_plane_l(const void* x, void* y, const float* wpack, con
 }
 
 bool plane_applicable(int N, int C, int H, int W, int level, int k, int dtype) { return plan_plane(N, C, H, W, level, k, dtype).ok; }
+
+// human-readable description of the chosen schedule (logs / benchmarks)
+int plane_describe(int N, int C, int H, int W, int level, int k, int dtype, char* buf, int len)
+{
+    const PlanePlan p = plan_plane(N, C, H, W, level, k, dtype);
+    if (!p.ok) return 0;
+    return snprintf(buf, len, "plane(cb=%d,%s,nt=%d,lds=%zu)", 2 * p.lpp,
+                    p.args.single ? "whole-plane" : (p.args.B2 == 8 ? "band8" : (p.args.B2 == 4 ? "band4" : "band2")), p.nt, p.lds_bytes);
+}
 
 #ifdef RCX_STAMPS
 hipError_t set_stamp_buffer(void* p)

@@ -39,7 +39,7 @@ def main():
                     os.environ["RCX_PLANE_B2"] = str(h if b2 == "0" else b2)
                     os.environ["RCX_PLANE_NT"] = nt
                     try:
-                        if recnext_amd.ops.recconv2d_plan(n, c, h, w, level, 5, "bilinear", dtype) != "plane":
+                        if not recnext_amd.ops.recconv2d_plan(n, c, h, w, level, 5, "bilinear", dtype).startswith("plane"):
                             continue
                         y = mod(x)
                         torch.cuda.synchronize()
