@@ -70,7 +70,8 @@ class MixerTimers:
             s, shape = self._open.pop(m)
             self.records.append((m, shape, s, e))
 
-    def summarize(self, elem_bytes):
+    def summarize(self, elem_bytes, plan_of):
+        """Per block shape, and per kernel instantiation (what rocprofv3 --stats aggregates by)."""
         by_shape = {}
         for m, shape, s, e in self.records:
             n, c, h, w = shape
@@ -78,16 +79,36 @@ class MixerTimers:
             ent = by_shape.setdefault(key, {"ms": 0.0, "calls": 0, "N": n})
             ent["ms"] += s.elapsed_time(e)
             ent["calls"] += 1
-        out = []
+        shapes, kernels = [], {}
         for (c, h, w, level, k), ent in by_shape.items():
             n = ent["N"]
             alg = 2 * n * c * h * w * elem_bytes + (level + 2) * c * k * k * elem_bytes
             avg_ms = ent["ms"] / ent["calls"]
-            out.append({"C": c, "H": h, "W": w, "level": level, "k": k, "N": n, "calls": ent["calls"],
-                        "total_ms": ent["ms"], "avg_ms": avg_ms, "algorithmic_bytes": alg,
-                        "achieved_GBs": alg / (avg_ms * 1e-3) / 1e9})
-        out.sort(key=lambda r: -r["total_ms"])
-        return out
+            plan = plan_of(n, c, h, w, level, k)
+            shapes.append({"C": c, "H": h, "W": w, "level": level, "k": k, "N": n, "calls": ent["calls"], "plan": plan,
+                           "total_ms": ent["ms"], "avg_ms": avg_ms, "algorithmic_bytes": alg,
+                           "achieved_GBs": alg / (avg_ms * 1e-3) / 1e9})
+            kn = kernel_name(plan, elem_bytes)
+            kk = kernels.setdefault(kn, {"kernel": kn, "total_ms": 0.0, "launches": 0, "algorithmic_bytes": 0, "shapes": []})
+            kk["total_ms"] += ent["ms"]
+            kk["launches"] += ent["calls"]
+            kk["algorithmic_bytes"] += alg * ent["calls"]
+            kk["shapes"].append(f"{n}x{c}x{h}x{w}_L{level}")
+        shapes.sort(key=lambda r: -r["total_ms"])
+        kernels = sorted(kernels.values(), key=lambda r: -r["total_ms"])
+        for kk in kernels:
+            kk["avg_launch_ms"] = kk["total_ms"] / kk["launches"]
+            kk["achieved_GBs"] = kk["algorithmic_bytes"] / (kk["total_ms"] * 1e-3) / 1e9
+        return shapes, kernels
+
+
+def kernel_name(plan, elem_bytes):
+    """Device-kernel name rocprofv3 reports for a plan string such as 'plane(cb=64,whole-plane,nt=512,lds=...)'."""
+    t = "unsigned short" if elem_bytes == 2 else "float"
+    if plan.startswith("plane(cb="):
+        lpp = int(plan[len("plane(cb="):].split(",")[0]) // 2
+        return f"rcx::k_recconv_plane<{lpp}, {t}>"
+    return "rcx::k_conv_generic<...> (one launch per ladder step)"
 
 
 def cpu_baseline(model_name, resolution, seconds, torch):
@@ -114,14 +135,14 @@ def cpu_baseline(model_name, resolution, seconds, torch):
                       f"oracle/torch_eager.py, {dt:.1f} s wall"}
 
 
-def load_traffic(plan, shape_key):
-    """HBM bytes per launch from committed PMC profiles (profiles/*traffic*.json), if one matches this kernel."""
+def load_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC profile (profiles/*traffic*.json), or None."""
     import glob
     best = None
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
         try:
             for rec in json.load(open(p)).get("kernels", []):
-                if rec.get("shape") == shape_key and rec.get("plan") == plan:
+                if rec.get("kernel") == kernel:
                     best = rec.get("hbm_bytes_per_launch")
         except (OSError, ValueError):
             pass
@@ -131,64 +152,49 @@ def load_traffic(plan, shape_key):
 def main():
     args = parse_args()
     import torch
-    import torch.distributed as dist
     import recnext_amd
     from recnext_amd import models, ops
     from recnext_amd.speed import build_inference_model, synthetic_batch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+    from recnext_amd import dist as rdist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)      # "nccl" is RCCL on ROCm
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus > 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 bench.py --gpus N ...")
+    r = rdist.init("cuda")                                  # backend "nccl" == RCCL over xGMI
+    world, rank, device = r.world, r.rank, r.device
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     elem = 2 if args.dtype == "bf16" else 4
     torch.backends.cudnn.benchmark = True
     net = build_inference_model(args.model, device, dtype, seed=0)       # identical weights on every rank
-    x = synthetic_batch(args.batch, args.resolution, device, dtype, seed=rank)
+    x = synthetic_batch(args.batch, args.resolution, device, dtype, seed=rank)   # this rank's shard of the global batch
     timers = MixerTimers(net, torch, recnext_amd.RecConv2d)
-
-    def barrier():
-        if world > 1:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
 
     with torch.no_grad():
         for _ in range(args.warmup):
             net(x)
-        barrier()
+        timers.enabled = False
+        rdist.barrier(r)
         timers.enabled = True
         t0 = time.perf_counter()
         for _ in range(args.steps):
             net(x)
-        barrier()
-        elapsed = time.perf_counter() - t0
+        rdist.barrier(r)
+        elapsed = rdist.max_over_ranks(r, time.perf_counter() - t0)
         timers.enabled = False
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     if rank == 0:
         images = world * args.batch * args.steps
         value = images / elapsed
-        per_shape = timers.summarize(elem)
-        dom = per_shape[0]
-        plan = ops.recconv2d_plan(dom["N"], dom["C"], dom["H"], dom["W"], dom["level"], dom["k"], "bilinear", dtype)
-        shape_key = f"{dom['N']}x{dom['C']}x{dom['H']}x{dom['W']}_L{dom['level']}_k{dom['k']}_{args.dtype}"
-        mixer_ms_per_step = sum(r["total_ms"] for r in per_shape) / args.steps
+        plan_of = lambda n, c, h, w, level, k: ops.recconv2d_plan(n, c, h, w, level, k, "bilinear", dtype)
+        per_shape, per_kernel = timers.summarize(elem, plan_of)
+        dom = per_kernel[0]                                   # the kernel instantiation with the most time in the step
+        mixer_ms_per_step = sum(rr["total_ms"] for rr in per_shape) / args.steps
         mixer_bytes = models.token_mixer_algorithmic_bytes(args.model, args.resolution, elem) * args.batch \
             if models.CONFIGS[args.model]["family"] == "m" else None
+        rnd = lambda d: {k: (round(v, 5) if isinstance(v, float) else v) for k, v in d.items()}
         out = {
             "metric": f"images/sec RecNeXt-{args.model.split('_')[1].upper()} {args.resolution}x{args.resolution} {args.dtype}",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -199,23 +205,25 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world} (batch-sharded replicas, no collective in the timed region)"},
             "roofline": {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": load_traffic(plan, shape_key),
-                         "kernel": f"rcx_recconv2d_fwd[{plan}] {shape_key}", "avg_launch_ms": dom["avg_ms"],
-                         "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "launches_timed": dom["calls"]},
+                         "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": load_traffic(dom["kernel"]),
+                         "kernel": dom["kernel"], "shapes": dom["shapes"], "avg_launch_ms": dom["avg_launch_ms"],
+                         "algorithmic_bytes_per_launch": dom["algorithmic_bytes"] / dom["launches"],
+                         "launches_timed": dom["launches"],
+                         "note": "HIP events on the launch stream around each launch inside the timed region; "
+                                 "algorithmic bytes = 2*N*C*H*W*b + (level+2)*C*k*k*b per launch (SURVEY 8d)"},
             "token_mixers": {"ms_per_step": mixer_ms_per_step, "share_of_step": mixer_ms_per_step / (elapsed / args.steps * 1e3),
                              "algorithmic_bytes_per_step": mixer_bytes,
                              "achieved_GBs": (mixer_bytes / (mixer_ms_per_step * 1e-3) / 1e9) if mixer_bytes else None,
                              "frac_of_hbm_peak": (mixer_bytes / (mixer_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if mixer_bytes else None,
                              "images_per_s_mixers_only": args.batch / (mixer_ms_per_step * 1e-3),
-                             "per_shape": [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()} for r in per_shape]},
+                             "per_kernel": [rnd({k: v for k, v in kk.items()}) for kk in per_kernel],
+                             "per_shape": [rnd(rr) for rr in per_shape]},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, args.resolution, args.cpu_seconds, torch)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
-        dist.barrier(device_ids=[local_rank])
-        dist.destroy_process_group()
+    rdist.finish(r)
 
 
 if __name__ == "__main__":

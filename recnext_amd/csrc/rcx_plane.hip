@@ -47,7 +47,7 @@ constexpr int PL_MAXL = 8;
 constexpr int PL_K = 5;
 constexpr int PL_P = 2;
 constexpr int PL_TW = 7;       // outputs per thread along x in the stride-1 strip convs
-constexpr int PL_TW2 = 4;      // ... and in the stride-2 pass (its window spans 2*TW+3 columns)
+constexpr int PL_TW2 = 2;      // ... and in the stride-2 pass (its window spans 2*TW+3 columns)
 constexpr int PL_NT = 512;     // max threads per workgroup
 constexpr int PL_IPB = 2;      // max 16-byte staging items per thread per band
 
@@ -305,7 +305,7 @@ __device__ __forceinline__ void band_upadd(float2* __restrict__ band, const Plan
 // ---------------- strip convs ----------------
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
-constexpr int PL_TH = 2;       // output rows per thread in the banded convs
+constexpr int PL_TH = 1;       // output rows per thread in the banded convs
 
 // 5x5 conv of band rows -> output rows [o0, o1) (stride S): each thread produces a TH x TW register tile,
 // so one window row read from LDS feeds TH output rows and TW outputs -- 0.19 (S=1) / 0.39 (S=2) LDS

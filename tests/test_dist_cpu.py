@@ -1,0 +1,79 @@
+"""CPU, world_size 2 over gloo: the one-process-per-GPU plumbing (sharding, barrier-bracketed timing, reductions).
+
+The HIP kernels cannot run here, so the replicas host the oracle's ATen token mixer; what is under test is
+recnext_amd.dist and the property the scaling path relies on: batch shards computed by independent ranks,
+concatenated, equal the full batch (images never mix).
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from recnext_amd import dist as rdist
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from oracle.torch_eager import EagerRecConv2d
+    r = rdist.init(device_type="cpu")
+    assert (r.rank, r.world) == (rank, world)
+    torch.manual_seed(0)                                   # identical weights on every rank
+    mod = EagerRecConv2d(8, level=2).eval()
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(5, 8, 14, 14, generator=g)             # identical global batch; 5 does not divide by 2
+    lo, hi = rdist.shard_bounds(x.shape[0], r.rank, r.world)
+    calls = {"n": 0}
+
+    def step():
+        calls["n"] += 1
+        with torch.no_grad():
+            return mod(x[lo:hi])
+
+    elapsed = rdist.timed_steps(r, step, steps=3, warmup=2)
+    assert calls["n"] == 5 and elapsed > 0
+    total = rdist.sum_over_ranks(r, hi - lo)
+    assert total == x.shape[0]
+    assert rdist.max_over_ranks(r, float(rank)) == world - 1
+    torch.save({"lo": lo, "hi": hi, "y": step(), "elapsed": elapsed}, os.path.join(out_dir, f"rank{rank}.pt"))
+    if rank == 0:
+        with torch.no_grad():
+            torch.save(mod(x), os.path.join(out_dir, "full.pt"))
+    rdist.finish(r)
+
+
+def test_two_process_gloo_shards_equal_full_batch(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(tmp_path / f"rank{i}.pt") for i in range(world)]
+    full = torch.load(tmp_path / "full.pt")
+    assert [(p["lo"], p["hi"]) for p in parts] == [(0, 3), (3, 5)]
+    assert torch.equal(torch.cat([p["y"] for p in parts]), full)
+    assert parts[0]["elapsed"] == parts[1]["elapsed"]       # both ranks report the MAX
+
+
+@pytest.mark.parametrize("n,world", [(256, 8), (10, 4), (3, 8), (2048, 8)])
+def test_shard_bounds_partition_the_batch(n, world):
+    spans = [rdist.shard_bounds(n, r, world) for r in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == n
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    sizes = [hi - lo for lo, hi in spans]
+    assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_is_a_noop():
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    r = rdist.init(device_type="cpu")
+    assert r.world == 1 and r.is_main
+    assert rdist.max_over_ranks(r, 2.5) == 2.5
+    rdist.barrier(r)
+    rdist.finish(r)

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Condense raw rocprofv3 output (tools/collect_profiles.sh) into the small files kept under profiles/.
+
+  <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of `python3 bench.py ...` (top kernels)
+  <tag>_traffic.json       per kernel: mean FETCH_SIZE / WRITE_SIZE per launch and HBM bytes per launch with the
+                           gfx950 corrections of MI355X_MICROARCH.md (FETCH_SIZE counts half of a 16-B/lane
+                           streaming read: doubled; both counters are in KiB)
+  <tag>_bench.json         the JSON line bench.py printed in the profiled run
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+tag, raw, out = sys.argv[1], sys.argv[2], sys.argv[3]
+os.makedirs(out, exist_ok=True)
+
+
+def short(name):
+    name = name.replace("void ", "")
+    cut = name.find("(")
+    return name[:cut] if cut > 0 else name
+
+
+stats = glob.glob(os.path.join(raw, "kt", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    rows = list(csv.DictReader(open(stats[0])))
+    with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows[:40]:
+            w.writerow([short(r["Name"])[:160], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+
+pmc = defaultdict(lambda: defaultdict(list))
+for sub in ("pmc_fetch", "pmc_write"):
+    for f in glob.glob(os.path.join(raw, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "rcx::" in r.get("Kernel_Name", ""):
+                pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+kernels = []
+for k, d in sorted(pmc.items()):
+    fetch = sum(d["FETCH_SIZE"]) / max(1, len(d["FETCH_SIZE"])) if "FETCH_SIZE" in d else None
+    write = sum(d["WRITE_SIZE"]) / max(1, len(d["WRITE_SIZE"])) if "WRITE_SIZE" in d else None
+    rec = {"kernel": k, "launches_sampled": len(d.get("FETCH_SIZE", [])), "FETCH_SIZE_KiB_per_launch": fetch,
+           "WRITE_SIZE_KiB_per_launch": write}
+    if fetch is not None and write is not None:
+        rec["hbm_bytes_per_launch"] = (2.0 * fetch + write) * 1024.0
+        rec["correction"] = "2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)"
+    kernels.append(rec)
+json.dump({"tag": tag, "command": "python3 bench.py --steps 20 --warmup 10 --no-cpu-baseline", "kernels": kernels},
+          open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
+
+for log in ("kt_bench.log",):
+    p = os.path.join(raw, log)
+    if os.path.exists(p):
+        for line in open(p):
+            if line.startswith('{"metric"'):
+                open(os.path.join(out, f"{tag}_bench.json"), "w").write(line)
+print("wrote", sorted(os.listdir(out)))
