@@ -44,7 +44,12 @@ def test_abi_version_and_argument_errors_without_gpu():
     assert b"odd" in lib.rcx_last_error()
     assert lib.rcx_recconv2d_fwd(one, two, one, None, None, 0, 1, 8, 7, 7, 99, 5, 0, 0, None) == -1     # level
     assert lib.rcx_recconv2d_fwd(one, two, one, None, None, 0, 1, 8, 7, 7, 1, 5, 7, 0, None) == -1      # mode
-    assert lib.rcx_recconv2d_fwd(one, two, one, None, None, 0, 1, 8, 7, 7, 1, 5, 0, 0, None) == -3      # workspace
+    # k=3 takes the generic schedule, which needs a caller-provided workspace (the fused k=5 schedule needs none)
+    assert lib.rcx_recconv2d_fwd_workspace_bytes(1, 8, 7, 7, 1, 3, 0) > 0
+    assert lib.rcx_recconv2d_fwd(one, two, one, None, None, 0, 1, 8, 7, 7, 1, 3, 0, 0, None) == -3      # workspace
+    assert lib.rcx_recconv2d_fwd_workspace_bytes(256, 64, 56, 56, 4, 5, 1) == 0
+    assert lib.rcx_recconv2d_fwd_plan(256, 64, 56, 56, 4, 5, 0, 1).startswith(b"plane(")
+    assert lib.rcx_recconv2d_fwd_plan(1, 8, 7, 7, 1, 3, 0, 0) == b"generic"
     assert lib.rcx_recconv2d_fwd(one, one, one, None, None, 0, 1, 8, 7, 7, 0, 5, 0, 0, None) == -1      # alias
     assert lib.rcx_dwconv2d_fwd(one, two, one, None, 1, 8, 7, 7, 5, 3, 0, 0, None) == -2                # stride 3
 
