@@ -107,7 +107,8 @@ def kernel_name(plan, elem_bytes):
     t = "unsigned short" if elem_bytes == 2 else "float"
     if plan.startswith("plane(cb="):
         lpp = int(plan[len("plane(cb="):].split(",")[0]) // 2
-        return f"rcx::k_recconv_plane<{lpp}, {t}>"
+        kern = "k_recconv_whole" if "whole-plane" in plan else "k_recconv_plane"
+        return f"rcx::{kern}<{lpp}, {t}>"
     return "rcx::k_conv_generic<...> (one launch per ladder step)"
 
 

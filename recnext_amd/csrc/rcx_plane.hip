@@ -50,6 +50,7 @@ constexpr int PL_TW = 7;       // outputs per thread along x in the stride-1 str
 constexpr int PL_TW2 = 2;      // ... and in the stride-2 pass (its window spans 2*TW+3 columns)
 constexpr int PL_NT = 512;     // max threads per workgroup
 constexpr int PL_IPB = 2;      // max 16-byte staging items per thread per band
+constexpr int PL_DIRECT = 8;   // 16-byte loads in flight per thread when a whole plane is staged at once
 
 struct PlaneArgs {
     int N, C, H, W, level;
@@ -122,14 +123,26 @@ __device__ __forceinline__ void preload_taps(float2* __restrict__ taps, const fl
                                              int C, int c0, int nsets)
 {
     const int total = nsets * PL_TAPROWS * LPP;
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-        const int cp = i % LPP;
-        const int row = (i / LPP) % PL_TAPROWS;
-        const int set = i / (LPP * PL_TAPROWS);
-        float2 v = make_float2(0.f, 0.f);
-        if (row < PL_K * PL_K) v = *reinterpret_cast<const float2*>(wpack + ((size_t)set * PL_K * PL_K + row) * C + c0 + 2 * cp);
-        else if (bpack) v = *reinterpret_cast<const float2*>(bpack + (size_t)set * C + c0 + 2 * cp);
-        taps[i] = v;
+    constexpr int B = 8;                                   // loads in flight per thread
+    for (int base = threadIdx.x; base < total; base += B * blockDim.x) {
+        float2 v[B];
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            const int i = base + j * blockDim.x;
+            v[j] = make_float2(0.f, 0.f);
+            if (i < total) {
+                const int cp = i % LPP;
+                const int row = (i / LPP) % PL_TAPROWS;
+                const int set = i / (LPP * PL_TAPROWS);
+                if (row < PL_K * PL_K) v[j] = *reinterpret_cast<const float2*>(wpack + ((size_t)set * PL_K * PL_K + row) * C + c0 + 2 * cp);
+                else if (bpack) v[j] = *reinterpret_cast<const float2*>(bpack + (size_t)set * C + c0 + 2 * cp);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            const int i = base + j * blockDim.x;
+            if (i < total) taps[i] = v[j];
+        }
     }
 }
 
@@ -248,38 +261,56 @@ __device__ __forceinline__ void stage_write(const Stage<LPP, TIO>& sg, float2* _
     }
 }
 
-// any number of rows, loads batched PL_IPB deep (prologue rows and the single-band mode)
+// Whole-plane / prologue staging: any number of rows, PL_DIRECT 16-byte loads in flight per thread, so a
+// small plane costs one HBM round trip.  Split into issue / write halves so the caller can put other
+// latency (tap and table preload) under the same round trip.
+struct DirectBatch { uint4 raw[PL_DIRECT]; int rr[PL_DIRECT], pp[PL_DIRECT], gg[PL_DIRECT]; };
+
 template <int LPP, typename TIO>
-__device__ __forceinline__ void stage_direct(const Stage<LPP, TIO>& sg, float2* __restrict__ band, int r0, int r1)
+__device__ __forceinline__ void direct_issue(const Stage<LPP, TIO>& sg, DirectBatch& b, int r0, int r1, int base)
 {
-    constexpr int CPL = Stage<LPP, TIO>::CPL;
     const int per_row = sg.wp * Stage<LPP, TIO>::G;
     const int items = (r1 - r0) * per_row;
     const float inv_row = 1.0f / (float)per_row;
+#pragma unroll
+    for (int j = 0; j < PL_DIRECT; ++j) {
+        const int it = base + j * blockDim.x;
+        b.raw[j] = make_uint4(0u, 0u, 0u, 0u);
+        b.rr[j] = r0; b.pp[j] = 0; b.gg[j] = 0;
+        if (it < items && sg.decode(it, r0, b.rr[j], b.pp[j], b.gg[j], inv_row)) b.raw[j] = sg.load(b.rr[j], b.pp[j], b.gg[j]);
+    }
+}
+
+template <int LPP, typename TIO>
+__device__ __forceinline__ void direct_write(const Stage<LPP, TIO>& sg, float2* __restrict__ band, const DirectBatch& b, int r0, int r1, int base)
+{
+    constexpr int CPL = Stage<LPP, TIO>::CPL;
+    const int items = (r1 - r0) * sg.wp * Stage<LPP, TIO>::G;
     const int slot0 = mod_pos(r0, sg.nr);
-    for (int base = threadIdx.x; base < items; base += PL_IPB * blockDim.x) {
-        uint4 raw[PL_IPB];
-        int rr[PL_IPB], pp[PL_IPB], gg[PL_IPB];
 #pragma unroll
-        for (int j = 0; j < PL_IPB; ++j) {
-            const int it = base + j * blockDim.x;
-            raw[j] = make_uint4(0u, 0u, 0u, 0u);
-            rr[j] = r0; pp[j] = 0; gg[j] = 0;
-            if (it < items && sg.decode(it, r0, rr[j], pp[j], gg[j], inv_row)) raw[j] = sg.load(rr[j], pp[j], gg[j]);
+    for (int j = 0; j < PL_DIRECT; ++j) {
+        const int it = base + j * blockDim.x;
+        if (it < items) {
+            float2 v[CPL];
+            IO<TIO>::unpack(b.raw[j], v);
+            int slot = slot0 + (b.rr[j] - r0);
+            while (slot >= sg.nr) slot -= sg.nr;
+            float2* dst = band + ((size_t)slot * sg.wp + b.pp[j]) * LPP + b.gg[j] * CPL;
+#pragma unroll
+            for (int i = 0; i < CPL; i += 2) *reinterpret_cast<float4*>(dst + i) = make_float4(v[i].x, v[i].y, v[i + 1].x, v[i + 1].y);
         }
-#pragma unroll
-        for (int j = 0; j < PL_IPB; ++j) {
-            const int it = base + j * blockDim.x;
-            if (it < items) {
-                float2 v[CPL];
-                IO<TIO>::unpack(raw[j], v);
-                int slot = slot0 + (rr[j] - r0);
-                while (slot >= sg.nr) slot -= sg.nr;
-                float2* dst = band + ((size_t)slot * sg.wp + pp[j]) * LPP + gg[j] * CPL;
-#pragma unroll
-                for (int i = 0; i < CPL; i += 2) *reinterpret_cast<float4*>(dst + i) = make_float4(v[i].x, v[i].y, v[i + 1].x, v[i + 1].y);
-            }
-        }
+    }
+}
+
+// batches starting at item `first_base + threadIdx.x`
+template <int LPP, typename TIO>
+__device__ __forceinline__ void stage_direct(const Stage<LPP, TIO>& sg, float2* __restrict__ band, int r0, int r1, int first_base = 0)
+{
+    const int items = (r1 - r0) * sg.wp * Stage<LPP, TIO>::G;
+    for (int base = first_base + threadIdx.x; base < items; base += PL_DIRECT * blockDim.x) {
+        DirectBatch b;
+        direct_issue<LPP, TIO>(sg, b, r0, r1, base);
+        direct_write<LPP, TIO>(sg, band, b, r0, r1, base);
     }
 }
 
@@ -292,6 +323,7 @@ __device__ __forceinline__ void band_upadd(float2* __restrict__ band, const Plan
     const float inv_w = 1.0f / (float)a.W;
     const int cp = threadIdx.x % LPP;
     const int qstep = blockDim.x / LPP;
+#pragma unroll 4
     for (int q = threadIdx.x / LPP; q < nq; q += qstep) {
         const int y = fast_div(q, inv_w);
         const int x = q - y * a.W;
@@ -408,11 +440,10 @@ __device__ __forceinline__ void conv_band(const float2* __restrict__ band, const
 // All 5 window rows are loaded (predicated) before any of them is used, so a thread pays one LDS
 // round trip per item instead of one per tap: these planes are small and latency, not bandwidth,
 // is what they cost.
-template <int LPP, int S>
-__device__ __forceinline__ void conv_lds(const float2* __restrict__ src, int hs, int ws, float2* __restrict__ dst, int hd, int wd,
-                                         const float2* __restrict__ tp)
+template <int LPP, int S, int TW>
+__device__ __forceinline__ void conv_lds_tw(const float2* __restrict__ src, int hs, int ws, float2* __restrict__ dst, int hd, int wd,
+                                            const float2* __restrict__ tp)
 {
-    constexpr int TW = S == 1 ? PL_TW : PL_TW2;
     constexpr int SPAN = (TW - 1) * S + PL_K;
     const int strips = (wd + TW - 1) / TW;
     const int nq = hd * strips;
@@ -432,20 +463,22 @@ __device__ __forceinline__ void conv_lds(const float2* __restrict__ src, int hs,
 #pragma unroll
         for (int s = 0; s < SPAN; ++s) { const int ix = ox0 * S + s - PL_P; colok[s] = ix >= 0 && ix < ws; }
         const float2* base = src + ((size_t)(oy * S - PL_P) * ws + ox0 * S - PL_P) * LPP + cp;
-        float2 win[PL_K][SPAN];
-#pragma unroll
-        for (int u = 0; u < PL_K; ++u) {
+        // window rows are pipelined one ahead (row u+1 loads while row u multiplies): 2*SPAN live values
+        auto load_row = [&](int u, float2 (&dst_row)[SPAN]) {
             const int iy = oy * S + u - PL_P;
             const bool rowok = iy >= 0 && iy < hs;
 #pragma unroll
             for (int s = 0; s < SPAN; ++s) {
                 float2 v = make_float2(0.f, 0.f);
                 if (rowok && colok[s]) v = base[((size_t)u * ws + s) * LPP];
-                win[u][s] = v;
+                dst_row[s] = v;
             }
-        }
+        };
+        float2 cur[SPAN], nxt[SPAN];
+        load_row(0, cur);
 #pragma unroll
         for (int u = 0; u < PL_K; ++u) {
+            if (u + 1 < PL_K) load_row(u + 1, nxt);
             float2 tw[PL_K];
 #pragma unroll
             for (int i = 0; i < PL_K; ++i) tw[i] = tp[(u * PL_K + i) * LPP + cp];
@@ -454,14 +487,30 @@ __device__ __forceinline__ void conv_lds(const float2* __restrict__ src, int hs,
 #pragma unroll
                 for (int j = 0; j < TW; ++j) {
                     const int tap = s - j * S;
-                    if (tap >= 0 && tap < PL_K) acc[j] = fma2(tw[tap], win[u][s], acc[j]);
+                    if (tap >= 0 && tap < PL_K) acc[j] = fma2(tw[tap], cur[s], acc[j]);
                 }
             }
+#pragma unroll
+            for (int s = 0; s < SPAN; ++s) cur[s] = nxt[s];
         }
 #pragma unroll
         for (int j = 0; j < TW; ++j)
             if (ox0 + j < wd) dst[(oy * wd + ox0 + j) * LPP + cp] = acc[j];
     }
+}
+
+// Small planes have few outputs: a wide strip would leave most threads idle behind one long dependent
+// chain per active thread.  Pick the widest strip that still gives every thread an item.
+template <int LPP, int S>
+__device__ __forceinline__ void conv_lds(const float2* __restrict__ src, int hs, int ws, float2* __restrict__ dst, int hd, int wd,
+                                         const float2* __restrict__ tp)
+{
+    const int lanes = blockDim.x / LPP;                    // strip items that run concurrently
+    const int rows = hd;
+    if (S == 1 && rows * ((wd + 6) / 7) >= lanes) conv_lds_tw<LPP, S, 7>(src, hs, ws, dst, hd, wd, tp);
+    else if (rows * ((wd + 3) / 4) >= lanes) conv_lds_tw<LPP, S, 4>(src, hs, ws, dst, hd, wd, tp);
+    else if (rows * ((wd + 1) / 2) >= lanes) conv_lds_tw<LPP, S, 2>(src, hs, ws, dst, hd, wd, tp);
+    else conv_lds_tw<LPP, S, 1>(src, hs, ws, dst, hd, wd, tp);
 }
 
 template <int LPP>
@@ -472,6 +521,7 @@ __device__ __forceinline__ void upadd_plane(const float2* __restrict__ coarse, i
     const float inv_wf = 1.0f / (float)wf;
     const int cp = threadIdx.x % LPP;
     const int qstep = blockDim.x / LPP;
+#pragma unroll 4
     for (int q = threadIdx.x / LPP; q < nq; q += qstep) {
         const int y = fast_div(q, inv_wf);
         const int x = q - y * wf;
@@ -559,6 +609,10 @@ k_recconv_plane(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __r
     auto taps_of = [&](int i) { return taps + (size_t)i * PL_TAPROWS * LPP; };
     const Stage<LPP, TIO> sg{xn, c0, a.H, a.W, a.C, a.band_wp, a.band_rows, a.ablate};
 
+    // Whole-plane mode: put the first batch of x loads in flight before anything else, so the tap / table
+    // preload below (L2 round trips) hides under the same HBM round trip.
+    DirectBatch first;
+    if (a.single) direct_issue<LPP, TIO>(sg, first, -PL_P, a.H + PL_P, threadIdx.x);
     // all (L+2) tap sets of this channel block and the resize tables, once; their first readers are
     // behind the first staging barrier
     RCX_STAMP(0);
@@ -568,12 +622,15 @@ k_recconv_plane(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __r
         build_axis(tabs + a.tr_off[l], a.h[l], a.h[l + 1], a.mode);
         build_axis(tabs + a.tc_off[l], a.w[l], a.w[l + 1], a.mode);
     }
+    if (a.single) {
+        direct_write<LPP, TIO>(sg, band, first, -PL_P, a.H + PL_P, threadIdx.x);
+        stage_direct<LPP, TIO>(sg, band, -PL_P, a.H + PL_P, PL_DIRECT * blockDim.x);     // the rest, if the plane is larger
+    }
 
     if (L >= 1) {
         // ---- pass 1: F_1 = down(x) ----
         float2* F1 = lds + a.f_off[1];
         if (a.single) {
-            stage_direct<LPP, TIO>(sg, band, -PL_P, a.H + PL_P);
             __syncthreads();
             conv_band<LPP, 2, false, TIO>(band, a, taps_of(0), 0, a.h[1], a.w[1], F1, nullptr, c0);
         } else {
@@ -608,9 +665,8 @@ k_recconv_plane(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __r
     const AxisTab* trow = tabs + a.tr_off[0];
     const AxisTab* tcol = tabs + a.tc_off[0];
     if (a.single) {
-        if (L >= 1) band_upadd<LPP>(band, a, C1, wc, trow, tcol);       // the band still holds x from pass 1
-        else stage_direct<LPP, TIO>(sg, band, -PL_P, a.H + PL_P);       // level 0: y = conv_0(x)
-        __syncthreads();
+        if (L >= 1) band_upadd<LPP>(band, a, C1, wc, trow, tcol);       // the band still holds x (staged at kernel start)
+        __syncthreads();                                                // level 0: y = conv_0(x) straight from the staged plane
         conv_band<LPP, 1, true, TIO>(band, a, taps_of(1 + L), 0, a.H, a.W, nullptr, yn, c0);
     } else if (L >= 1) {
         const Pass<LPP, 1, true, TIO> p2{a, sg, band, taps_of(1 + L), C1, wc, trow, tcol, nullptr, yn, c0,
@@ -622,6 +678,67 @@ k_recconv_plane(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __r
         p2.run();
     }
     RCX_STAMP(5);
+}
+
+// Whole-plane planes only (the zero-bordered plane is the band): same phases as k_recconv_plane's `single`
+// path, but compiled on its own so the register allocator is not dragged to 200+ VGPRs by the banded
+// machinery (capping it at 128 VGPRs for 4 waves/SIMD still spills into the hot loops: see DESIGN.md section 6).
+#ifndef RCX_WHOLE_WAVES
+#define RCX_WHOLE_WAVES 2
+#endif
+template <int LPP, typename TIO>
+__global__ void __launch_bounds__(PL_NT, RCX_WHOLE_WAVES)
+k_recconv_whole(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack,
+                PlaneArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* lds = reinterpret_cast<float2*>(smem_raw);
+    const int b = blockIdx.x;
+    const int xcd = b & 7, q = b >> 3;
+    const int blk = q % a.nblk;
+    const int n = (q / a.nblk) * 8 + xcd;
+    if (n >= a.N) return;
+    const int c0 = blk * 2 * LPP;
+    const TIO* xn = x + (size_t)n * a.H * a.W * a.C;
+    TIO* yn = y + (size_t)n * a.H * a.W * a.C;
+    float2* band = lds + a.band_off;
+    float2* taps = lds + a.taps_off;
+    const int L = a.level;
+    auto taps_of = [&](int i) { return taps + (size_t)i * PL_TAPROWS * LPP; };
+    const Stage<LPP, TIO> sg{xn, c0, a.H, a.W, a.C, a.band_wp, a.band_rows, 0};
+    {
+        DirectBatch first;
+        direct_issue<LPP, TIO>(sg, first, -PL_P, a.H + PL_P, threadIdx.x);
+        preload_taps<LPP>(taps, wpack, a.has_bias ? bpack : nullptr, a.C, c0, L + 2);
+        direct_write<LPP, TIO>(sg, band, first, -PL_P, a.H + PL_P, threadIdx.x);
+    }
+    AxisTab* tabs = reinterpret_cast<AxisTab*>(lds + a.tab_off);
+    for (int l = 0; l < L; ++l) {
+        build_axis(tabs + a.tr_off[l], a.h[l], a.h[l + 1], a.mode);
+        build_axis(tabs + a.tc_off[l], a.w[l], a.w[l + 1], a.mode);
+    }
+    stage_direct<LPP, TIO>(sg, band, -PL_P, a.H + PL_P, PL_DIRECT * blockDim.x);
+    __syncthreads();
+    if (L >= 1) {
+        conv_band<LPP, 2, false, TIO>(band, a, taps_of(0), 0, a.h[1], a.w[1], lds + a.f_off[1], nullptr, c0);
+        __syncthreads();
+        for (int l = 1; l < L; ++l) {
+            conv_lds<LPP, 2>(lds + a.f_off[l], a.h[l], a.w[l], lds + a.f_off[l + 1], a.h[l + 1], a.w[l + 1], taps_of(0));
+            __syncthreads();
+        }
+        for (int l = L, j = 0; l >= 1; --l, ++j) {
+            conv_lds<LPP, 1>(lds + a.f_off[l], a.h[l], a.w[l], lds + a.c_off[l], a.h[l], a.w[l], taps_of(1 + j));
+            __syncthreads();
+            if (l > 1) {
+                upadd_plane<LPP>(lds + a.c_off[l], a.w[l], lds + a.f_off[l - 1], a.h[l - 1], a.w[l - 1],
+                                 tabs + a.tr_off[l - 1], tabs + a.tc_off[l - 1]);
+                __syncthreads();
+            }
+        }
+        band_upadd<LPP>(band, a, lds + a.c_off[1], a.w[1], tabs + a.tr_off[0], tabs + a.tc_off[0]);
+        __syncthreads();
+    }
+    conv_band<LPP, 1, true, TIO>(band, a, taps_of(1 + L), 0, a.H, a.W, nullptr, yn, c0);
 }
 
 // ---------------- host side ----------------
@@ -764,7 +881,7 @@ PlanePlan plan_plane(int N, int C, int H, int W, int level, int k, int dtype)
 template <int LPP, typename TIO>
 static hipError_t launch_plane_t(const void* x, void* y, const float* wpack, const float* bpack, const PlanePlan& p, int mode, hipStream_t s)
 {
-    auto kfn = k_recconv_plane<LPP, TIO>;
+    auto kfn = p.args.single ? k_recconv_whole<LPP, TIO> : k_recconv_plane<LPP, TIO>;
     if (p.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
         if (e != hipSuccess) return e;
