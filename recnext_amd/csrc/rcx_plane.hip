@@ -47,8 +47,8 @@ constexpr int PL_MAXL = 8;
 constexpr int PL_K = 5;
 constexpr int PL_P = 2;
 constexpr int PL_TW = 7;       // outputs per thread along x in the stride-1 strip convs
-constexpr int PL_TW2 = 2;      // ... and in the stride-2 pass (its window spans 2*TW+3 columns)
-constexpr int PL_NT = 512;     // max threads per workgroup
+constexpr int PL_TW2 = 3;      // ... and in the stride-2 pass (window spans 2*TW+3 columns; odd keeps bank conflicts at 2-way)
+constexpr int PL_NT = 1024;    // max threads per workgroup (16 waves; the kernels need < 128 VGPRs)
 constexpr int PL_IPB = 2;      // max 16-byte staging items per thread per band
 constexpr int PL_DIRECT = 8;   // 16-byte loads in flight per thread when a whole plane is staged at once
 
@@ -134,8 +134,8 @@ __device__ __forceinline__ void preload_taps(float2* __restrict__ taps, const fl
                 const int cp = i % LPP;
                 const int row = (i / LPP) % PL_TAPROWS;
                 const int set = i / (LPP * PL_TAPROWS);
-                if (row < PL_K * PL_K) v[j] = *reinterpret_cast<const float2*>(wpack + ((size_t)set * PL_K * PL_K + row) * C + c0 + 2 * cp);
-                else if (bpack) v[j] = *reinterpret_cast<const float2*>(bpack + (size_t)set * C + c0 + 2 * cp);
+                if (row < PL_K * PL_K) v[j] = *reinterpret_cast<const float2*>(wpack + ((set * PL_K * PL_K + row) * C + c0 + 2 * cp));
+                else if (bpack) v[j] = *reinterpret_cast<const float2*>(bpack + (set * C + c0 + 2 * cp));
             }
         }
 #pragma unroll
@@ -151,13 +151,15 @@ __device__ __forceinline__ void preload_taps(float2* __restrict__ taps, const fl
 // arithmetic is ATen's (float), done H+W times per level instead of once per pixel.
 struct __attribute__((aligned(16))) AxisTab { int i0, i1; float w0, w1; };
 
-__device__ __forceinline__ void build_axis(AxisTab* __restrict__ tab, int n_out, int n_in, int mode)
+// `pitch` = 1 for a column table, = coarse row width for a row table (entries are then row offsets in pixels)
+__device__ __forceinline__ void build_axis(AxisTab* __restrict__ tab, int n_out, int n_in, int mode, int pitch)
 {
     const float scale = (float)n_in / (float)n_out;
     for (int d = threadIdx.x; d < n_out; d += blockDim.x) {
         AxisTab t;
         if (mode == 1) { t.i0 = t.i1 = nearest_src(d, n_in, scale); t.w0 = 1.f; t.w1 = 0.f; }
         else { const Lerp l = bilinear_src(d, n_in, scale); t.i0 = l.i0; t.i1 = l.i1; t.w0 = 1.f - l.lam; t.w1 = l.lam; }
+        t.i0 *= pitch; t.i1 *= pitch;
         tab[d] = t;
     }
 }
@@ -165,12 +167,12 @@ __device__ __forceinline__ void build_axis(AxisTab* __restrict__ tab, int n_out,
 // Source taps of resize(src (hs x ws) -> dst) at (y, x): four corner offsets (in pixels) and weights.
 struct UpTap { int o00, o01, o10, o11; float w00, w01, w10, w11; };
 
-__device__ __forceinline__ UpTap up_tap(const AxisTab* __restrict__ rows, const AxisTab* __restrict__ cols, int ws, int y, int x)
+__device__ __forceinline__ UpTap up_tap(const AxisTab* __restrict__ rows, const AxisTab* __restrict__ cols, int /*ws*/, int y, int x)
 {
     const AxisTab ry = rows[y], cx = cols[x];
     UpTap t;
-    t.o00 = ry.i0 * ws + cx.i0; t.o01 = ry.i0 * ws + cx.i1;
-    t.o10 = ry.i1 * ws + cx.i0; t.o11 = ry.i1 * ws + cx.i1;
+    t.o00 = ry.i0 + cx.i0; t.o01 = ry.i0 + cx.i1;          // row entries are already multiplied by ws
+    t.o10 = ry.i1 + cx.i0; t.o11 = ry.i1 + cx.i1;
     t.w00 = ry.w0 * cx.w0; t.w01 = ry.w0 * cx.w1; t.w10 = ry.w1 * cx.w0; t.w11 = ry.w1 * cx.w1;
     return t;
 }
@@ -206,7 +208,7 @@ struct Stage {
     }
     __device__ __forceinline__ uint4 load(int r, int px, int g) const
     {
-        const TIO* p = xn + ((size_t)r * W + (px - PL_P)) * C + c0 + g * (2 * CPL);
+        const TIO* p = xn + ((r * W + (px - PL_P)) * C + c0 + g * (2 * CPL));     // per-image offsets fit 32 bits (checked on the host)
         return *reinterpret_cast<const uint4*>(p);
     }
 };
@@ -254,7 +256,7 @@ __device__ __forceinline__ void stage_write(const Stage<LPP, TIO>& sg, float2* _
             }
         }
         const int slot = wrap(slot0 + (r - r0), sg.nr);
-        float2* dst = band + ((size_t)slot * sg.wp + px) * LPP + g * CPL;
+        float2* dst = band + ((slot * sg.wp + px) * LPP + g * CPL);
         if (RCX_ABLATE(sg, 4) && v[0].x != 123456.f) continue;
 #pragma unroll
         for (int i = 0; i < CPL; i += 2) *reinterpret_cast<float4*>(dst + i) = make_float4(v[i].x, v[i].y, v[i + 1].x, v[i + 1].y);
@@ -295,7 +297,7 @@ __device__ __forceinline__ void direct_write(const Stage<LPP, TIO>& sg, float2* 
             IO<TIO>::unpack(b.raw[j], v);
             int slot = slot0 + (b.rr[j] - r0);
             while (slot >= sg.nr) slot -= sg.nr;
-            float2* dst = band + ((size_t)slot * sg.wp + b.pp[j]) * LPP + b.gg[j] * CPL;
+            float2* dst = band + ((slot * sg.wp + b.pp[j]) * LPP + b.gg[j] * CPL);
 #pragma unroll
             for (int i = 0; i < CPL; i += 2) *reinterpret_cast<float4*>(dst + i) = make_float4(v[i].x, v[i].y, v[i + 1].x, v[i + 1].y);
         }
@@ -329,7 +331,7 @@ __device__ __forceinline__ void band_upadd(float2* __restrict__ band, const Plan
         const int x = q - y * a.W;
         const UpTap t = up_tap(trow, tcol, wc, y, x);
         const int slot = mod_pos(y, a.band_rows);
-        float2* p = band + ((size_t)slot * a.band_wp + x + PL_P) * LPP + cp;
+        float2* p = band + ((slot * a.band_wp + x + PL_P) * LPP + cp);
         *p = add2(*p, up_sample<LPP>(coarse, t, cp));
     }
 }
@@ -337,11 +339,8 @@ __device__ __forceinline__ void band_upadd(float2* __restrict__ band, const Plan
 // ---------------- strip convs ----------------
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
-constexpr int PL_TH = 1;       // output rows per thread in the banded convs
 
-// 5x5 conv of band rows -> output rows [o0, o1) (stride S): each thread produces a TH x TW register tile,
-// so one window row read from LDS feeds TH output rows and TW outputs -- 0.19 (S=1) / 0.39 (S=2) LDS
-// reads per packed FMA, under the ~0.27 where LDS bandwidth, not the VALU, sets the pace on gfx950.
+// 5x5 conv of band rows -> output rows [o0, o1) (stride S): each thread produces a strip of TW outputs.
 // No bounds logic: the band carries 2 zero columns left and enough right padding for the last strip.
 // `hook` runs exactly once per call, after the FMAs of the thread's first item and before its stores
 // (or after the loop for a thread without items): the banded passes use it to retire the prefetched
@@ -352,82 +351,70 @@ __device__ __forceinline__ void conv_band(const float2* __restrict__ band, const
                                           Hook hook = Hook())
 {
     constexpr int TW = S == 1 ? PL_TW : PL_TW2;
-    constexpr int TH = PL_TH;
     constexpr int SPAN = (TW - 1) * S + PL_K;
-    constexpr int NIN = (TH - 1) * S + PL_K;              // window rows per tile
     bool hooked = false;
     const int wp = a.band_wp;
     const int strips = (Wo + TW - 1) / TW;
-    const int rgroups = (o1 - o0 + TH - 1) / TH;
-    const int nq = rgroups * strips;
+    const int nq = (o1 - o0) * strips;
     const float inv_strips = 1.0f / (float)strips;
     const int slot_base = mod_pos(o0 * S - PL_P, a.band_rows);
+    const int row_stride = wp * LPP, ring_span = a.band_rows * wp * LPP;
     const int cp = threadIdx.x % LPP;
     const int qstep = blockDim.x / LPP;
     int q = threadIdx.x / LPP;
     if (q < nq) {
-        // the 25 taps of this channel pair stay in registers for the whole call
-        float2 tw[PL_K * PL_K];
-#pragma unroll
-        for (int i = 0; i < PL_K * PL_K; ++i) tw[i] = tp[i * LPP + cp];
         const float2 bias = tp[PL_K * PL_K * LPP + cp];
         for (; q < nq; q += qstep) {
             const int dg = fast_div(q, inv_strips);
             const int st = q - dg * strips;
-            const int oy = o0 + dg * TH;
+            const int oy = o0 + dg;
             const int ox0 = st * TW;
-            int slot = slot_base + dg * TH * S;
+            int slot = slot_base + dg * S;
             while (slot >= a.band_rows) slot -= a.band_rows;
-            float2 acc[TH][TW];
+            int roff = (slot * wp + ox0 * S) * LPP + cp;   // LDS index of the window's first element; advanced row by row
+            float2 acc[TW];
 #pragma unroll
-            for (int t = 0; t < TH; ++t)
-#pragma unroll
-                for (int j = 0; j < TW; ++j) acc[t][j] = bias;
+            for (int j = 0; j < TW; ++j) acc[j] = bias;
             // padded column of input ix is ix + 2, so the window of output ox starts at padded column ox*S.
-            // Rows are software-pipelined by hand (row i+1 is loaded while row i is multiplied) and the
-            // order is pinned: left alone, the scheduler hoists every row's loads and spills.
-            float2 cur[SPAN], nxt[SPAN];
-            {
-                const float2* row = band + ((size_t)slot * wp + ox0 * S) * LPP + cp;
+            // The 5 window rows are a ROLLED loop (taps come from LDS, so nothing needs a static row index):
+            // one row + the accumulators are live (~70 VGPRs), and latency is hidden by occupancy
+            // (4 waves/SIMD), not by hoisting five rows of loads into 250 registers.
+#pragma unroll 1
+            for (int u = 0; u < PL_K; ++u) {
+                const float2* row = band + roff;
+                const float2* trow_ = tp + (u * PL_K * LPP + cp);
+                float2 v[SPAN], tw[PL_K];
+                if (!RCX_ABLATE(a, 2)) {
 #pragma unroll
-                for (int s = 0; s < SPAN; ++s) cur[s] = row[s * LPP];
-            }
+                    for (int s = 0; s < SPAN; ++s) v[s] = row[s * LPP];
+                } else {
 #pragma unroll
-            for (int i = 0; i < NIN; ++i) {
-                if (i + 1 < NIN && !RCX_ABLATE(a, 2)) {
-                    slot = wrap(slot + 1, a.band_rows);
-                    const float2* row = band + ((size_t)slot * wp + ox0 * S) * LPP + cp;
-#pragma unroll
-                    for (int s = 0; s < SPAN; ++s) nxt[s] = row[s * LPP];
+                    for (int s = 0; s < SPAN; ++s) v[s] = make_float2(1.f, 1.f);
                 }
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < TH; ++t) {
-                    const int u = i - t * S;              // window row of output row t fed by input row i
-                    if (u < 0 || u >= PL_K || RCX_ABLATE(a, 1)) continue;
+                for (int i = 0; i < PL_K; ++i) tw[i] = trow_[i * LPP];
+                if (!RCX_ABLATE(a, 1)) {
 #pragma unroll
                     for (int s = 0; s < SPAN; ++s) {
 #pragma unroll
                         for (int j = 0; j < TW; ++j) {
                             const int tap = s - j * S;
-                            if (tap >= 0 && tap < PL_K) acc[t][j] = fma2(tw[u * PL_K + tap], cur[s], acc[t][j]);
+                            if (tap >= 0 && tap < PL_K) acc[j] = fma2(tw[tap], v[s], acc[j]);
                         }
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int s = 0; s < SPAN; ++s) cur[s] = nxt[s];
+                ++slot;
+                roff += row_stride;
+                if (slot == a.band_rows) { slot = 0; roff -= ring_span; }
             }
             if (!hooked) { hook(); hooked = true; }
-#pragma unroll
-            for (int t = 0; t < TH; ++t) {
-                if (oy + t >= o1 || (RCX_ABLATE(a, 0) && acc[t][0].x != 123456.f)) continue;
+            if (!(RCX_ABLATE(a, 0) && acc[0].x != 123456.f)) {
 #pragma unroll
                 for (int j = 0; j < TW; ++j) {
                     const int ox = ox0 + j;
                     if (ox < Wo) {
-                        if constexpr (TO_GLOBAL) IO<TIO>::st2(yn + ((size_t)(oy + t) * Wo + ox) * a.C + c0 + 2 * cp, acc[t][j]);
-                        else dst_lds[((oy + t) * Wo + ox) * LPP + cp] = acc[t][j];
+                        if constexpr (TO_GLOBAL) IO<TIO>::st2(yn + ((oy * Wo + ox) * a.C + c0 + 2 * cp), acc[j]);
+                        else dst_lds[(oy * Wo + ox) * LPP + cp] = acc[j];
                     }
                 }
             }
@@ -462,36 +449,30 @@ __device__ __forceinline__ void conv_lds_tw(const float2* __restrict__ src, int 
         bool colok[SPAN];
 #pragma unroll
         for (int s = 0; s < SPAN; ++s) { const int ix = ox0 * S + s - PL_P; colok[s] = ix >= 0 && ix < ws; }
-        const float2* base = src + ((size_t)(oy * S - PL_P) * ws + ox0 * S - PL_P) * LPP + cp;
-        // window rows are pipelined one ahead (row u+1 loads while row u multiplies): 2*SPAN live values
-        auto load_row = [&](int u, float2 (&dst_row)[SPAN]) {
+        const int base = ((oy * S - PL_P) * ws + ox0 * S - PL_P) * LPP + cp;      // may be negative: only dereferenced where valid
+        // rolled window rows: one row + accumulators live, occupancy hides the LDS latency (see conv_band)
+#pragma unroll 1
+        for (int u = 0; u < PL_K; ++u) {
             const int iy = oy * S + u - PL_P;
-            const bool rowok = iy >= 0 && iy < hs;
+            if (iy < 0 || iy >= hs) continue;              // zero padding: the whole row contributes nothing
+            const float2* row = src + (base + u * ws * LPP);
+            const float2* trow_ = tp + (u * PL_K * LPP + cp);
+            float2 v[SPAN], tw[PL_K];
 #pragma unroll
             for (int s = 0; s < SPAN; ++s) {
-                float2 v = make_float2(0.f, 0.f);
-                if (rowok && colok[s]) v = base[((size_t)u * ws + s) * LPP];
-                dst_row[s] = v;
+                v[s] = make_float2(0.f, 0.f);
+                if (colok[s]) v[s] = row[s * LPP];
             }
-        };
-        float2 cur[SPAN], nxt[SPAN];
-        load_row(0, cur);
 #pragma unroll
-        for (int u = 0; u < PL_K; ++u) {
-            if (u + 1 < PL_K) load_row(u + 1, nxt);
-            float2 tw[PL_K];
-#pragma unroll
-            for (int i = 0; i < PL_K; ++i) tw[i] = tp[(u * PL_K + i) * LPP + cp];
+            for (int i = 0; i < PL_K; ++i) tw[i] = trow_[i * LPP];
 #pragma unroll
             for (int s = 0; s < SPAN; ++s) {
 #pragma unroll
                 for (int j = 0; j < TW; ++j) {
                     const int tap = s - j * S;
-                    if (tap >= 0 && tap < PL_K) acc[j] = fma2(tw[tap], cur[s], acc[j]);
+                    if (tap >= 0 && tap < PL_K) acc[j] = fma2(tw[tap], v[s], acc[j]);
                 }
             }
-#pragma unroll
-            for (int s = 0; s < SPAN; ++s) cur[s] = nxt[s];
         }
 #pragma unroll
         for (int j = 0; j < TW; ++j)
@@ -507,9 +488,11 @@ __device__ __forceinline__ void conv_lds(const float2* __restrict__ src, int hs,
 {
     const int lanes = blockDim.x / LPP;                    // strip items that run concurrently
     const int rows = hd;
+    // Odd widths only: consecutive lane groups then sit an odd number of pixels apart, which spreads their
+    // 8-byte reads over all LDS banks (an even pitch folds them onto the same banks: 2- to 4-way conflicts).
     if (S == 1 && rows * ((wd + 6) / 7) >= lanes) conv_lds_tw<LPP, S, 7>(src, hs, ws, dst, hd, wd, tp);
-    else if (rows * ((wd + 3) / 4) >= lanes) conv_lds_tw<LPP, S, 4>(src, hs, ws, dst, hd, wd, tp);
-    else if (rows * ((wd + 1) / 2) >= lanes) conv_lds_tw<LPP, S, 2>(src, hs, ws, dst, hd, wd, tp);
+    else if (rows * ((wd + 4) / 5) >= lanes) conv_lds_tw<LPP, S, 5>(src, hs, ws, dst, hd, wd, tp);
+    else if (rows * ((wd + 2) / 3) >= lanes) conv_lds_tw<LPP, S, 3>(src, hs, ws, dst, hd, wd, tp);
     else conv_lds_tw<LPP, S, 1>(src, hs, ws, dst, hd, wd, tp);
 }
 
@@ -606,7 +589,7 @@ k_recconv_plane(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __r
     float2* band = lds + a.band_off;
     float2* taps = lds + a.taps_off;
     const int L = a.level;
-    auto taps_of = [&](int i) { return taps + (size_t)i * PL_TAPROWS * LPP; };
+    auto taps_of = [&](int i) { return taps + i * PL_TAPROWS * LPP; };
     const Stage<LPP, TIO> sg{xn, c0, a.H, a.W, a.C, a.band_wp, a.band_rows, a.ablate};
 
     // Whole-plane mode: put the first batch of x loads in flight before anything else, so the tap / table
@@ -619,8 +602,8 @@ k_recconv_plane(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __r
     preload_taps<LPP>(taps, wpack, a.has_bias ? bpack : nullptr, a.C, c0, L + 2);
     AxisTab* tabs = reinterpret_cast<AxisTab*>(lds + a.tab_off);
     for (int l = 0; l < L; ++l) {
-        build_axis(tabs + a.tr_off[l], a.h[l], a.h[l + 1], a.mode);
-        build_axis(tabs + a.tc_off[l], a.w[l], a.w[l + 1], a.mode);
+        build_axis(tabs + a.tr_off[l], a.h[l], a.h[l + 1], a.mode, a.w[l + 1]);
+        build_axis(tabs + a.tc_off[l], a.w[l], a.w[l + 1], a.mode, 1);
     }
     if (a.single) {
         direct_write<LPP, TIO>(sg, band, first, -PL_P, a.H + PL_P, threadIdx.x);
@@ -704,7 +687,7 @@ k_recconv_whole(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __r
     float2* band = lds + a.band_off;
     float2* taps = lds + a.taps_off;
     const int L = a.level;
-    auto taps_of = [&](int i) { return taps + (size_t)i * PL_TAPROWS * LPP; };
+    auto taps_of = [&](int i) { return taps + i * PL_TAPROWS * LPP; };
     const Stage<LPP, TIO> sg{xn, c0, a.H, a.W, a.C, a.band_wp, a.band_rows, 0};
     {
         DirectBatch first;
@@ -714,8 +697,8 @@ k_recconv_whole(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __r
     }
     AxisTab* tabs = reinterpret_cast<AxisTab*>(lds + a.tab_off);
     for (int l = 0; l < L; ++l) {
-        build_axis(tabs + a.tr_off[l], a.h[l], a.h[l + 1], a.mode);
-        build_axis(tabs + a.tc_off[l], a.w[l], a.w[l + 1], a.mode);
+        build_axis(tabs + a.tr_off[l], a.h[l], a.h[l + 1], a.mode, a.w[l + 1]);
+        build_axis(tabs + a.tc_off[l], a.w[l], a.w[l + 1], a.mode, 1);
     }
     stage_direct<LPP, TIO>(sg, band, -PL_P, a.H + PL_P, PL_DIRECT * blockDim.x);
     __syncthreads();
@@ -825,7 +808,7 @@ static int pick_threads(const PlaneArgs& a, int lpp, int cpl)
     // enough threads that one band's staging fits PL_IPB 16-byte items per thread, and that the
     // widest strip conv has about one item per thread
     const int stage_items = band_stage_items(a, lpp, cpl);
-    const int conv_items = (((a.single ? a.H : a.B2) + PL_TH - 1) / PL_TH) * ((a.W + PL_TW - 1) / PL_TW) * lpp;
+    const int conv_items = (a.single ? a.H : a.B2) * ((a.W + PL_TW - 1) / PL_TW) * lpp;
     int nt = 64;
     while (nt < PL_NT && (conv_items > nt || (!a.single && stage_items > nt * PL_IPB))) nt *= 2;
     if (nt < lpp) nt = lpp;
@@ -838,6 +821,7 @@ PlanePlan plan_plane(int N, int C, int H, int W, int level, int k, int dtype)
     none.ok = false;
     if (k != PL_K || level < 0 || level > PL_MAXL || (C % 8) != 0) return none;
     if ((long long)H * W > (1 << 18)) return none;        // fast_div range
+    if ((long long)H * W * C >= (1LL << 30)) return none; // per-image element offsets are 32-bit in the kernels
     const size_t LDS_CU = 160 * 1024;
     const int cpl = dtype == 1 ? 4 : 2;                    // channel pairs per 16-byte chunk
     const int force_lpp = env_int("RCX_PLANE_LPP", 0), force_b2 = env_int("RCX_PLANE_B2", 0);
