@@ -805,12 +805,15 @@ static int band_stage_items(const PlaneArgs& a, int lpp, int cpl)
 
 static int pick_threads(const PlaneArgs& a, int lpp, int cpl)
 {
-    // enough threads that one band's staging fits PL_IPB 16-byte items per thread, and that the
-    // widest strip conv has about one item per thread
+    // Measured (profiles/r01_plane_knob_sweep_*): these kernels are latency-bound, so about two threads per
+    // strip item of the widest conv (every item then has a partner wave to hide its LDS round trips), and in
+    // banded mode enough threads that one band's staging fits PL_IPB 16-byte items per thread.
     const int stage_items = band_stage_items(a, lpp, cpl);
     const int conv_items = (a.single ? a.H : a.B2) * ((a.W + PL_TW - 1) / PL_TW) * lpp;
-    int nt = 64;
-    while (nt < PL_NT && (conv_items > nt || (!a.single && stage_items > nt * PL_IPB))) nt *= 2;
+    int nt = 128;
+    while (nt < PL_NT && nt < conv_items) nt *= 2;
+    if (nt < PL_NT && (!a.single || conv_items <= 256)) nt *= 2;
+    while (nt < PL_NT && !a.single && stage_items > nt * PL_IPB) nt *= 2;
     if (nt < lpp) nt = lpp;
     return nt;
 }
@@ -846,18 +849,22 @@ PlanePlan plan_plane(int N, int C, int H, int W, int level, int k, int dtype)
         return true;
     };
 
-    // Measured on MI355X (tools/sweep_plane.py, profiles/): small planes run best with the widest channel
-    // block whose whole zero-bordered plane fits the band (x is then read once, no band loop); larger
-    // planes with the widest block that fits at all, and the tallest band that fits with it.
+    // Measured on MI355X (tools/sweep_plane.py, profiles/r01_plane_knob_sweep_*): planes up to 16x16 run best
+    // whole (x read once, no band loop) with the widest channel block that still lets two workgroups share a
+    // CU; larger planes run banded with the widest block that fits and the tallest band that fits with it.
     PlanePlan p{};
-    if ((long long)H * W <= 1024 || force_b2 == H)
+    const bool small = (long long)H * W <= 256 || force_b2 == H;
+    if (small) {
+        for (int lpp : lpps)
+            if (try_cfg(lpp, WHOLE, p) && p.lds_bytes <= LDS_CU / 2) return p;
         for (int lpp : lpps)
             if (try_cfg(lpp, WHOLE, p)) return p;
+    }
     static const int b2s[] = {8, 4, 2};
     for (int lpp : lpps)
         for (int B2 : b2s)
             if (try_cfg(lpp, B2, p)) return p;
-    for (int lpp : lpps)                                   // large planes that happen to fit whole
+    for (int lpp : lpps)                                   // planes that only fit whole
         if (try_cfg(lpp, WHOLE, p)) return p;
     return none;
 }
