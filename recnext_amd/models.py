@@ -180,6 +180,30 @@ def replace_batchnorm(net):
     return net
 
 
+@torch.no_grad()
+def fold_token_mixer_norms(net):
+    """Inference-only: absorb each MetaNeXtBlock's eval-mode ``norm`` (a per-channel affine that
+    ``replace_batchnorm`` leaves in place, utils.py:227-234) into its HIP token mixer's final conv.
+
+    x + mlp(norm(mixer(x)))  ==  x + mlp(mixer'(x))  with  convs[level]' = scale*convs[level] + shift.
+    Returns the number of BatchNorm layers removed (21 for RecNeXt-M3).  SURVEY.md section 8f row 2.
+    """
+    n = 0
+    for m in net.modules():
+        if isinstance(m, MetaNeXtBlock) and m._has_norm and isinstance(m.norm, nn.BatchNorm2d) \
+                and isinstance(m.token_mixer, RecConv2d):
+            if m.norm.training:
+                raise RuntimeError("fold_token_mixer_norms needs eval mode (running statistics)")
+            bn = m.norm
+            scale = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
+            shift = bn.bias.float() - scale * bn.running_mean.float()
+            m.token_mixer.fold_output_affine(scale, shift)
+            m.norm = nn.Identity()
+            m._has_norm = False
+            n += 1
+    return n
+
+
 def token_mixer_shapes(name, resolution=224):
     """[(C, H, W, level|None, count)] of every token mixer call in one forward pass (SURVEY 8 model tables)."""
     cfg = CONFIGS[name]

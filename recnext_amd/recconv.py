@@ -36,6 +36,24 @@ class RecConv2d(nn.Module):
         self.convs = nn.ModuleList([nn.Conv2d(**kwargs) for _ in range(level + 1)])
         self._pack_key = None
         self._pack = None
+        # Optional per-channel affine applied to the block's OUTPUT (y*scale + shift), folded into
+        # convs[level] when the packs are built: used to absorb the eval-mode BatchNorm that follows the
+        # token mixer in MetaNeXtBlock (model/recnext.py:153,158) -- SURVEY.md section 8f row 2.
+        # kept as plain float32 tensors (not buffers): .to(bfloat16) must not round them, and they follow
+        # the parameters' device when the packs are built
+        self.fold_scale = None
+        self.fold_shift = None
+
+    @torch.no_grad()
+    def fold_output_affine(self, scale, shift):
+        """Absorb y -> y*scale + shift (per channel) into the final conv; composes with an earlier fold."""
+        scale = scale.detach().float().clone()
+        shift = shift.detach().float().clone()
+        if self.fold_scale is not None:
+            shift = shift + scale * self.fold_shift.to(scale.device)
+            scale = scale * self.fold_scale.to(scale.device)
+        self.fold_scale, self.fold_shift = scale, shift
+        self._pack_key = None
 
     def _params(self):
         ws = [self.down.weight] + [cv.weight for cv in self.convs]
@@ -47,8 +65,18 @@ class RecConv2d(nn.Module):
         ws, bs = self._params()
         allp = ws + (bs or [])
         key = tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in allp)
+        if self.fold_scale is not None:
+            key += ((self.fold_scale.data_ptr(), self.fold_scale._version, self.fold_shift._version),)
         if key != self._pack_key:
-            self._pack = ops.pack_recconv_params(ws[0], ws[1:], bs[0] if bs else None, bs[1:] if bs else None)
+            wpack, bpack = ops.pack_recconv_params(ws[0], ws[1:], bs[0] if bs else None, bs[1:] if bs else None)
+            if self.fold_scale is not None:
+                c, k = self.in_channels, self.kernel_size
+                if bpack is None:
+                    bpack = torch.zeros((self.level + 2, c), dtype=torch.float32, device=wpack.device)
+                sc = self.fold_scale.to(wpack.device)
+                wpack[-1].view(k * k, c).mul_(sc)                    # tap-major (k*k, C): scale each channel's taps
+                bpack[-1].mul_(sc).add_(self.fold_shift.to(wpack.device))
+            self._pack = (wpack, bpack)
             self._pack_key = key
         return self._pack
 

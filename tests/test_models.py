@@ -111,3 +111,37 @@ def test_full_model_hip_vs_eager_gpu(name):
     scale = float(a.abs().max())
     assert (bb - a).abs().max() < 0.1 * scale + 0.05
     assert (bb - a).abs().max() <= 1.5 * (ab - a).abs().max() + 0.02 * scale
+
+
+def test_fold_token_mixer_norms_counts_and_is_noop_for_other_mixers():
+    net = models.create_model("recnext_m3").eval()
+    models.replace_batchnorm(net)
+    assert models.fold_token_mixer_norms(net) == 21
+    assert sum(isinstance(m, torch.nn.BatchNorm2d) for m in net.modules()) == 3      # the three Downsample norms remain
+    eager = models.create_model("recnext_m0", token_mixer=eager_token_mixer("m")).eval()
+    assert models.fold_token_mixer_norms(eager) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_folding_the_block_norm_preserves_the_function_gpu(dtype):
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    net = models.create_model("recnext_m0").eval()
+    for m in net.modules():
+        if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    models.replace_batchnorm(net)
+    net = net.to(dev).to(memory_format=torch.channels_last)
+    x = torch.randn(2, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        ref = net(x)                                            # fp32, norms still separate
+        assert models.fold_token_mixer_norms(net) == 14
+        got32 = net(x)
+        assert (got32 - ref).abs().max() < 1e-4 * max(1.0, float(ref.abs().max()))
+        if dtype == torch.bfloat16:
+            gotb = net.bfloat16()(x.bfloat16()).float()
+            assert (gotb - ref).abs().max() < 0.1 * float(ref.abs().max()) + 0.05
