@@ -78,6 +78,15 @@ int rcx_dwconv2d_fwd(const void* x, void* y, const float* w_kkc, const float* bi
                      int in_dtype, int out_dtype, void* stream);
 
 /*
+ * Depthwise conv with channel multiplier 2: nn.Conv2d(Cin, 2*Cin, k, stride, padding=k/2, groups=Cin), i.e. output
+ * channel o reads input channel o/2 -- Downsample.token_mixer, model/recnext.py:165 / model/recattn.py:178
+ * (with the eval-mode BatchNorm that follows it, :166/:170, folded into w/bias by the caller).
+ *   x: N x H x W x Cin ; y: N x Ho x Wo x 2*Cin ; w: (k,k,2*Cin) float32 packed ; x and y share `dtype`.
+ */
+int rcx_dwconv2d_mult2_fwd(const void* x, void* y, const float* w_kkc, const float* bias,
+                           int N, int Cin, int H, int W, int k, int stride, int dtype, void* stream);
+
+/*
  * y = dwconv_k(x + resize(coarse -> (H,W), mode)) -- the body of one up-recursion step
  * (model/recnext.py:33-34) and the tail of RecAttn2d.forward (model/recattn.py:67).
  *   x: N x H x W x C (x_dtype); coarse: N x Hc x Wc x C (coarse_dtype) or NULL (then y = dwconv_k(x));

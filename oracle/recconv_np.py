@@ -26,7 +26,7 @@ All arrays are logical NCHW like the reference's tensors.
 import numpy as np
 
 __all__ = [
-    "down_size", "ladder_sizes", "dwconv2d", "bilinear_axis_table", "nearest_axis_table",
+    "down_size", "ladder_sizes", "dwconv2d", "dwconv2d_mult", "bilinear_axis_table", "nearest_axis_table",
     "resize", "recconv2d", "recconv2d_trace", "fold_bn", "linear_attention", "recattn2d",
 ]
 
@@ -68,6 +68,13 @@ def dwconv2d(x, w, b=None, stride=1):
     if b is not None:
         out += np.asarray(b, dtype=x.dtype)[None, :, None, None]
     return out
+
+
+def dwconv2d_mult(x, w, b=None, stride=1, mult=2):
+    """nn.Conv2d(C, mult*C, k, stride, padding=k//2, groups=C): output channel o reads input channel o // mult
+    (Downsample.token_mixer, model/recnext.py:165)."""
+    x = np.asarray(x)
+    return dwconv2d(np.repeat(x, mult, axis=1), w, b, stride)
 
 
 def bilinear_axis_table(n_in, n_out):

@@ -28,6 +28,7 @@ SIGNATURES = {
     "rcx_recconv2d_fwd_workspace_bytes": (_sz, [_i] * 7),
     "rcx_recconv2d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 8 + [_vp]),
     "rcx_dwconv2d_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
+    "rcx_dwconv2d_mult2_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
     "rcx_upadd_dwconv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
 }
 

@@ -175,6 +175,16 @@ int rcx_dwconv2d_fwd(const void* x, void* y, const float* w_kkc, const float* bi
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_dwconv2d_fwd");
 }
 
+int rcx_dwconv2d_mult2_fwd(const void* x, void* y, const float* w_kkc, const float* bias,
+                           int N, int Cin, int H, int W, int k, int stride, int dtype, void* stream)
+{
+    if (int rc = check_common(x, y, N, Cin, H, W, k, dtype)) return rc;
+    if (!w_kkc) return fail(RCX_ERR_BAD_ARG, "null weight");
+    if (stride != 1 && stride != 2) return fail(RCX_ERR_UNSUPPORTED, "stride %d not supported (1 or 2)", stride);
+    hipError_t e = rcx::generic_dwconv_mult2(x, y, w_kkc, bias, N, Cin, H, W, k, stride, dtype, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "rcx_dwconv2d_mult2_fwd");
+}
+
 int rcx_upadd_dwconv_fwd(const void* x, const void* coarse, void* y, const float* w_kkc, const float* bias,
                          int N, int C, int H, int W, int Hc, int Wc, int k, int mode,
                          int x_dtype, int coarse_dtype, int out_dtype, void* stream)

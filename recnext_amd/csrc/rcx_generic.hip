@@ -18,7 +18,8 @@ template <> struct DT<float> { static constexpr int id = 0; };
 template <> struct DT<bf16_t> { static constexpr int id = 1; };
 
 struct ConvGeom {
-    int N, C, H, W;       // input extent (of x)
+    int N, C, H, W;       // input extent (of x); C = OUTPUT channels (= weights' channel count)
+    int Cin;              // input channels: C / MULT (channel-multiplier depthwise conv), else == C
     int Ho, Wo;           // output extent
     int Hc, Wc;           // coarse extent (upadd only)
     int k, stride;
@@ -29,11 +30,20 @@ struct ConvGeom {
 
 // T(n, iy, ix, c..c+V) = x + resize(coarse), zero outside the plane (the conv's zero padding
 // applies to the *sum*, as in conv(f + x) at model/recnext.py:33).
-template <typename TX, typename TC, int V, int MODE, bool HAS_COARSE>
+template <typename TX, typename TC, int V, int MODE, bool HAS_COARSE, int MULT = 1>
 __device__ __forceinline__ void fetch_sum(const TX* __restrict__ xn, const TC* __restrict__ cn, const ConvGeom& g,
                                           int iy, int ix, int c, float (&out)[V])
 {
-    load_vec<V>(xn + ((size_t)iy * g.W + ix) * g.C + c, out);
+    if constexpr (MULT == 1) {
+        load_vec<V>(xn + ((size_t)iy * g.W + ix) * g.C + c, out);
+    } else {
+        // grouped conv with groups = Cin: output channel o reads input channel o / MULT (nn.Conv2d semantics)
+        static_assert(V % MULT == 0 && !HAS_COARSE, "channel multiplier");
+        float t[V / MULT];
+        load_vec<V / MULT>(xn + ((size_t)iy * g.W + ix) * g.Cin + c / MULT, t);
+#pragma unroll
+        for (int i = 0; i < V; ++i) out[i] = t[i / MULT];
+    }
     if constexpr (HAS_COARSE) {
         if constexpr (MODE == 1) {
             int cy = nearest_src(iy, g.Hc, g.sy), cx = nearest_src(ix, g.Wc, g.sx);
@@ -58,7 +68,7 @@ __device__ __forceinline__ void fetch_sum(const TX* __restrict__ xn, const TC* _
 
 // One thread: V channels x R adjacent output columns of one output row.
 // K == 0 selects the runtime-k body.
-template <typename TX, typename TC, typename TO, int K, int STRIDE, int V, int R, int MODE, bool HAS_COARSE>
+template <typename TX, typename TC, typename TO, int K, int STRIDE, int V, int R, int MODE, bool HAS_COARSE, int MULT = 1>
 __global__ void __launch_bounds__(256)
 k_conv_generic(const TX* __restrict__ x, const TC* __restrict__ coarse, TO* __restrict__ y,
                const float* __restrict__ w, const float* __restrict__ bias, ConvGeom g)
@@ -74,7 +84,7 @@ k_conv_generic(const TX* __restrict__ x, const TC* __restrict__ coarse, TO* __re
         const int n = (int)(r / g.Ho);
         const int c = cv * V;
         const int ox0 = st * R;
-        const TX* xn = x + (size_t)n * g.H * g.W * g.C;
+        const TX* xn = x + (size_t)n * g.H * g.W * g.Cin;
         const TC* cn = HAS_COARSE ? coarse + (size_t)n * g.Hc * g.Wc * g.C : nullptr;
 
         float acc[R][V];
@@ -96,7 +106,7 @@ k_conv_generic(const TX* __restrict__ x, const TC* __restrict__ coarse, TO* __re
                 const int ix = ox0 * STRIDE + s - p;
                 if (ix < 0 || ix >= g.W) continue;
                 float in[V];
-                fetch_sum<TX, TC, V, MODE, HAS_COARSE>(xn, cn, g, iy, ix, c, in);
+                fetch_sum<TX, TC, V, MODE, HAS_COARSE, MULT>(xn, cn, g, iy, ix, c, in);
                 // input column s feeds output j through tap v = s - j*STRIDE
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
@@ -117,7 +127,7 @@ k_conv_generic(const TX* __restrict__ x, const TC* __restrict__ coarse, TO* __re
     }
 }
 
-template <typename TX, typename TC, typename TO, int K, int STRIDE, int V, int MODE, bool HAS_COARSE>
+template <typename TX, typename TC, typename TO, int K, int STRIDE, int V, int MODE, bool HAS_COARSE, int MULT = 1>
 static hipError_t launch_rv(const void* x, const void* coarse, void* y, const float* w, const float* b,
                             ConvGeom g, hipStream_t stream)
 {
@@ -128,7 +138,7 @@ static hipError_t launch_rv(const void* x, const void* coarse, void* y, const fl
     long long blocks = (total + 255) / 256;
     if (blocks > 256LL * 64) blocks = 256LL * 64;         // grid-stride beyond 64 blocks per CU
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((k_conv_generic<TX, TC, TO, K, STRIDE, V, R, MODE, HAS_COARSE>), dim3((unsigned)blocks), dim3(256), 0, stream,
+    hipLaunchKernelGGL((k_conv_generic<TX, TC, TO, K, STRIDE, V, R, MODE, HAS_COARSE, MULT>), dim3((unsigned)blocks), dim3(256), 0, stream,
                        (const TX*)x, (const TC*)coarse, (TO*)y, w, b, g);
     return hipGetLastError();
 }
@@ -168,7 +178,7 @@ hipError_t generic_dwconv(const void* x, void* y, const float* w, const float* b
                           int N, int C, int H, int W, int k, int stride, int in_dt, int out_dt, hipStream_t s)
 {
     ConvGeom g{};
-    g.N = N; g.C = C; g.H = H; g.W = W; g.k = k; g.stride = stride;
+    g.N = N; g.C = C; g.Cin = C; g.H = H; g.W = W; g.k = k; g.stride = stride;
     const int p = k / 2;
     g.Ho = (H + 2 * p - k) / stride + 1;
     g.Wo = (W + 2 * p - k) / stride + 1;
@@ -192,7 +202,7 @@ hipError_t generic_upadd_dwconv(const void* x, const void* coarse, void* y, cons
 {
     if (!coarse) return generic_dwconv(x, y, w, b, N, C, H, W, k, 1, x_dt, out_dt, s);
     ConvGeom g{};
-    g.N = N; g.C = C; g.H = H; g.W = W; g.Ho = H; g.Wo = W; g.Hc = Hc; g.Wc = Wc; g.k = k; g.stride = 1;
+    g.N = N; g.C = C; g.Cin = C; g.H = H; g.W = W; g.Ho = H; g.Wo = W; g.Hc = Hc; g.Wc = Wc; g.k = k; g.stride = 1;
     g.sy = (float)Hc / (float)H;
     g.sx = (float)Wc / (float)W;
     const int key = x_dt * 4 + c_dt * 2 + out_dt;
@@ -206,6 +216,47 @@ hipError_t generic_upadd_dwconv(const void* x, const void* coarse, void* y, cons
     case 6: return upadd_io<bf16_t, bf16_t, float>(x, coarse, y, w, b, g, mode, s);
     default: return upadd_io<bf16_t, bf16_t, bf16_t>(x, coarse, y, w, b, g, mode, s);
     }
+}
+
+// ---- depthwise conv with channel multiplier 2 (groups = Cin, Cout = 2*Cin): Downsample.token_mixer ----
+template <typename TX, typename TO, int K, int STRIDE>
+static hipError_t mult2_v(const void* x, void* y, const float* w, const float* b, const ConvGeom& g, hipStream_t s)
+{
+    if (g.C % 8 == 0) return launch_rv<TX, float, TO, K, STRIDE, 8, 0, false, 2>(x, nullptr, y, w, b, g, s);
+    if (g.C % 4 == 0) return launch_rv<TX, float, TO, K, STRIDE, 4, 0, false, 2>(x, nullptr, y, w, b, g, s);
+    return launch_rv<TX, float, TO, K, STRIDE, 2, 0, false, 2>(x, nullptr, y, w, b, g, s);
+}
+
+template <typename TX, typename TO>
+static hipError_t mult2_ks(const void* x, void* y, const float* w, const float* b, const ConvGeom& g, hipStream_t s)
+{
+    if (g.stride == 2) {
+        switch (g.k) {
+        case 7: return mult2_v<TX, TO, 7, 2>(x, y, w, b, g, s);
+        case 5: return mult2_v<TX, TO, 5, 2>(x, y, w, b, g, s);
+        case 3: return mult2_v<TX, TO, 3, 2>(x, y, w, b, g, s);
+        default: return mult2_v<TX, TO, 0, 2>(x, y, w, b, g, s);
+        }
+    }
+    switch (g.k) {
+    case 7: return mult2_v<TX, TO, 7, 1>(x, y, w, b, g, s);
+    case 5: return mult2_v<TX, TO, 5, 1>(x, y, w, b, g, s);
+    case 3: return mult2_v<TX, TO, 3, 1>(x, y, w, b, g, s);
+    default: return mult2_v<TX, TO, 0, 1>(x, y, w, b, g, s);
+    }
+}
+
+// x: N x H x W x Cin ; y: N x Ho x Wo x (2*Cin) ; w packed (k,k,2*Cin) ; same dtype in and out
+hipError_t generic_dwconv_mult2(const void* x, void* y, const float* w, const float* b,
+                                int N, int Cin, int H, int W, int k, int stride, int dt, hipStream_t s)
+{
+    ConvGeom g{};
+    g.N = N; g.C = 2 * Cin; g.Cin = Cin; g.H = H; g.W = W; g.k = k; g.stride = stride;
+    const int p = k / 2;
+    g.Ho = (H + 2 * p - k) / stride + 1;
+    g.Wo = (W + 2 * p - k) / stride + 1;
+    if (dt == 0) return mult2_ks<float, float>(x, y, w, b, g, s);
+    return mult2_ks<bf16_t, bf16_t>(x, y, w, b, g, s);
 }
 
 // ---- parameter packing ----

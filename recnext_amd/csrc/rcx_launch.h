@@ -11,6 +11,8 @@ hipError_t generic_dwconv(const void* x, void* y, const float* w, const float* b
 hipError_t generic_upadd_dwconv(const void* x, const void* coarse, void* y, const float* w, const float* b,
                                 int N, int C, int H, int W, int Hc, int Wc, int k, int mode,
                                 int x_dt, int c_dt, int out_dt, hipStream_t s);
+hipError_t generic_dwconv_mult2(const void* x, void* y, const float* w, const float* b,
+                                int N, int Cin, int H, int W, int k, int stride, int dt, hipStream_t s);
 hipError_t pack_dw_weight(const void* w, float* dst, int C, int k, int dt, hipStream_t s);
 hipError_t pack_bias(const void* b, float* dst, int C, int dt, hipStream_t s);
 

@@ -204,6 +204,22 @@ def fold_token_mixer_norms(net):
     return n
 
 
+@torch.no_grad()
+def use_hip_downsample(net):
+    """Inference-only: run each Downsample's depthwise 7x7 stride-2 conv (C -> 2C) and the eval-mode BatchNorm
+    after it as one HIP kernel.  Returns the number of layers replaced."""
+    from .dwconv import DownsampleDwConv
+    n = 0
+    for m in net.modules():
+        if isinstance(m, Downsample) and isinstance(m.token_mixer, nn.Conv2d) and isinstance(m.norm, nn.BatchNorm2d):
+            if m.norm.training:
+                raise RuntimeError("use_hip_downsample needs eval mode (running statistics)")
+            m.token_mixer = DownsampleDwConv(m.token_mixer, m.norm).eval()
+            m.norm = nn.Identity()
+            n += 1
+    return n
+
+
 def token_mixer_shapes(name, resolution=224):
     """[(C, H, W, level|None, count)] of every token mixer call in one forward pass (SURVEY 8 model tables)."""
     cfg = CONFIGS[name]

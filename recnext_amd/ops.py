@@ -155,3 +155,18 @@ def upadd_dwconv(x, coarse, w_kkc, bias=None, k=5, mode="nearest", out_dtype=Non
                                               _stream(x.device))
     _lib.check(rc, "rcx_upadd_dwconv_fwd")
     return y
+
+
+def dwconv2d_mult2(x, w_kkc, bias=None, k=7, stride=2):
+    """nn.Conv2d(C, 2C, k, stride, padding=k//2, groups=C) with packed float32 (k,k,2C) weights."""
+    x = _nhwc(x)
+    n, c, h, w = x.shape
+    p = k // 2
+    ho, wo = (h + 2 * p - k) // stride + 1, (w + 2 * p - k) // stride + 1
+    y = _empty_nhwc(n, 2 * c, ho, wo, x.dtype, x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().rcx_dwconv2d_mult2_fwd(x.data_ptr(), y.data_ptr(), w_kkc.data_ptr(),
+                                                bias.data_ptr() if bias is not None else None,
+                                                n, c, h, w, k, stride, _dt(x), _stream(x.device))
+    _lib.check(rc, "rcx_dwconv2d_mult2_fwd")
+    return y

@@ -21,11 +21,13 @@ T1 = 10
 DTYPES = {"fp32": torch.float32, "f32": torch.float32, "bf16": torch.bfloat16}
 
 
-def build_inference_model(name, device, dtype=torch.bfloat16, token_mixer=None, seed=0, fold_mixer_norm=True):
+def build_inference_model(name, device, dtype=torch.bfloat16, token_mixer=None, seed=0, fold_mixer_norm=True,
+                          hip_downsample=True):
     """create_model -> replace_batchnorm -> device/eval, as speed_gpu.py:47-50 (plus dtype + channels_last).
 
     ``fold_mixer_norm`` additionally absorbs the BatchNorm after each HIP token mixer into the mixer's last
-    conv (same function, one kernel less per block); it is a no-op for other token mixers.
+    conv (same function, one kernel less per block); it is a no-op for other token mixers.  ``hip_downsample``
+    runs the three strided depthwise Downsample convs (+ their BatchNorm) on the HIP kernels as well.
     """
     torch.manual_seed(seed)
     net = models.create_model(name, num_classes=1000, token_mixer=token_mixer)
@@ -33,6 +35,8 @@ def build_inference_model(name, device, dtype=torch.bfloat16, token_mixer=None, 
     net = net.eval()
     if fold_mixer_norm:
         models.fold_token_mixer_norms(net)
+    if hip_downsample and token_mixer is None and torch.device(device).type == "cuda":
+        models.use_hip_downsample(net)
     net = net.to(device=device, dtype=dtype).eval()
     if torch.device(device).type == "cuda":
         net = net.to(memory_format=torch.channels_last)

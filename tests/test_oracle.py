@@ -109,3 +109,14 @@ def test_recattn_oracle_matches_reference(name):
     # LA1 == LA2 algebraically (lsnet/model/recattn.py:481-501 asserts 1e-4)
     other = recconv_np.linear_attention(dn, d["w_qk"], d["b_qk"], d["w_pe"], d["b_pe"], m["heads"], 3 - m["variant"])
     assert np.abs(other - d["attn_out"]).max() < 1e-4
+
+
+def test_channel_multiplier_dwconv_matches_aten():
+    # Downsample.token_mixer: nn.Conv2d(C, 2C, 7, padding=3, groups=C, stride=2)  (model/recnext.py:165)
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(6, 12, 7, padding=3, groups=6, stride=2)
+    x = torch.randn(2, 6, 11, 9)
+    with torch.no_grad():
+        ref = conv(x).numpy()
+    got = recconv_np.dwconv2d_mult(x.numpy().astype(np.float64), conv.weight.detach().numpy(), conv.bias.detach().numpy(), stride=2)
+    assert np.abs(got - ref).max() < TOL

@@ -228,3 +228,35 @@ def test_runs_on_a_side_stream():
             y1 = mod(x)
         torch.cuda.current_stream().wait_stream(s)
     assert torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 11, 9), (2, 64, 56, 56), (1, 40, 28, 28), (3, 6, 7, 7)])
+@pytest.mark.parametrize("k,stride", [(7, 2), (5, 2), (3, 1)])
+def test_channel_multiplier_dwconv(shape, k, stride):
+    from oracle import recconv_np
+    n, c, h, w = shape
+    rng = np.random.default_rng(c * 100 + k)
+    x = bf16_round_np(rng.standard_normal(shape).astype(np.float32))
+    wt = (rng.standard_normal((2 * c, 1, k, k)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(2 * c).astype(np.float32)
+    ref = recconv_np.dwconv2d_mult(x.astype(np.float64), wt, b, stride=stride)
+    t = lambda a: torch.from_numpy(a).to(dev())
+    wp, bp = ops.pack_dw_weight(t(wt)), ops.pack_bias(t(b))
+    y32 = ops.dwconv2d_mult2(t(x), wp, bp, k=k, stride=stride)
+    assert tuple(y32.shape) == ref.shape
+    assert np.abs(y32.cpu().numpy() - ref).max() < F32_TIGHT
+    ybf = ops.dwconv2d_mult2(t(x).bfloat16(), wp, bp, k=k, stride=stride)
+    assert np.allclose(ybf.float().cpu().numpy(), ref, atol=BF16_ATOL, rtol=BF16_RTOL)
+
+
+def test_hip_downsample_module_folds_the_batchnorm():
+    from recnext_amd.dwconv import DownsampleDwConv
+    torch.manual_seed(1)
+    conv = torch.nn.Conv2d(16, 32, 7, padding=3, groups=16, stride=2).to(dev())
+    bn = torch.nn.BatchNorm2d(32).to(dev()).eval()
+    bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 1.5); bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_(0, 0.2)
+    x = torch.randn(2, 16, 28, 28, device=dev())
+    mod = DownsampleDwConv(conv, bn).eval()
+    with torch.no_grad():
+        ref = bn(conv(x))
+        assert (mod(x) - ref).abs().max() < 1e-4
