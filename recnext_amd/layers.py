@@ -69,3 +69,25 @@ class DropPath(nn.Module):
         keep = 1.0 - self.drop_prob
         mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
         return x * mask.div_(keep)
+
+
+class PointwiseLinear(nn.Module):
+    """A BN-folded 1x1 conv evaluated as ``F.linear`` on the (N*H*W, C) view of a channels_last tensor.
+
+    Same parameters (``weight`` (Cout,Cin,1,1), ``bias``) and same function as the ``nn.Conv2d`` it replaces; the
+    only difference is the library call: on ROCm the GEMM path (hipBLASLt) applies the bias in its epilogue, whereas
+    the MIOpen conv path launches a separate elementwise kernel for it.  Host-side plumbing, inference only.
+    """
+
+    def __init__(self, conv):
+        super().__init__()
+        if conv.kernel_size != (1, 1) or conv.groups != 1 or conv.stride != (1, 1) or conv.padding != (0, 0):
+            raise ValueError("PointwiseLinear replaces a dense 1x1, stride-1 convolution")
+        self.weight, self.bias = conv.weight, conv.bias
+        self.in_channels, self.out_channels = conv.in_channels, conv.out_channels
+
+    def forward(self, x):
+        n, c, h, w = x.shape
+        x2 = x.permute(0, 2, 3, 1)                       # a view when x is channels_last
+        y2 = torch.nn.functional.linear(x2.reshape(n * h * w, c), self.weight.view(self.out_channels, c), self.bias)
+        return y2.view(n, h, w, self.out_channels).permute(0, 3, 1, 2)

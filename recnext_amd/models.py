@@ -220,6 +220,21 @@ def use_hip_downsample(net):
     return n
 
 
+def use_linear_pointwise(net):
+    """Inference-only plumbing: evaluate the (BN-folded) 1x1 convs of every channel mixer through the GEMM library
+    (bias in the epilogue) instead of the conv library (bias as a separate kernel).  Returns the number replaced."""
+    from .layers import PointwiseLinear
+    n = 0
+    for m in net.modules():
+        if isinstance(m, (MetaNeXtBlock, Downsample)):
+            seq = m.channel_mixer
+            for i, sub in enumerate(seq):
+                if isinstance(sub, nn.Conv2d) and sub.kernel_size == (1, 1) and sub.groups == 1 and sub.bias is not None:
+                    seq[i] = PointwiseLinear(sub)
+                    n += 1
+    return n
+
+
 def token_mixer_shapes(name, resolution=224):
     """[(C, H, W, level|None, count)] of every token mixer call in one forward pass (SURVEY 8 model tables)."""
     cfg = CONFIGS[name]

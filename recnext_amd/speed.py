@@ -22,7 +22,7 @@ DTYPES = {"fp32": torch.float32, "f32": torch.float32, "bf16": torch.bfloat16}
 
 
 def build_inference_model(name, device, dtype=torch.bfloat16, token_mixer=None, seed=0, fold_mixer_norm=True,
-                          hip_downsample=True):
+                          hip_downsample=True, linear_pointwise=True):
     """create_model -> replace_batchnorm -> device/eval, as speed_gpu.py:47-50 (plus dtype + channels_last).
 
     ``fold_mixer_norm`` additionally absorbs the BatchNorm after each HIP token mixer into the mixer's last
@@ -40,6 +40,8 @@ def build_inference_model(name, device, dtype=torch.bfloat16, token_mixer=None, 
     net = net.to(device=device, dtype=dtype).eval()
     if torch.device(device).type == "cuda":
         net = net.to(memory_format=torch.channels_last)
+        if linear_pointwise:
+            models.use_linear_pointwise(net)
     return net
 
 

@@ -145,3 +145,16 @@ def test_folding_the_block_norm_preserves_the_function_gpu(dtype):
         if dtype == torch.bfloat16:
             gotb = net.bfloat16()(x.bfloat16()).float()
             assert (gotb - ref).abs().max() < 0.1 * float(ref.abs().max()) + 0.05
+
+
+def test_linear_pointwise_is_the_same_function_cpu():
+    torch.manual_seed(0)
+    net = models.create_model("recnext_m0", token_mixer=eager_token_mixer("m")).eval()
+    models.replace_batchnorm(net)
+    x = torch.randn(1, 3, 64, 64)
+    with torch.no_grad():
+        ref = net(x)
+        keys = set(net.state_dict())
+        assert models.use_linear_pointwise(net) == 2 * (14 + 3)
+        assert set(net.state_dict()) == keys                      # same parameter names
+        assert (net(x) - ref).abs().max() < 1e-5
