@@ -69,6 +69,24 @@ int rcx_recconv2d_fwd(const void* x, void* y, const float* wpack, const float* b
                       int N, int C, int H, int W, int level, int k, int mode, int dtype, void* stream);
 
 /*
+ * Training (engine.py:48-64): a forward that keeps the fp32 pyramid F_1..F_L, C_1..C_L in `saved`, and the backward pass.
+ *   rcx_recconv2d_fwd_train   same contract as rcx_recconv2d_fwd (always the per-level schedule); `saved` must hold
+ *                             rcx_recconv2d_train_saved_bytes() and stay untouched until rcx_recconv2d_bwd has run.
+ *   rcx_recconv2d_bwd         gy: N x H x W x C float32 (dL/dy);  gx: N x H x W x C of `dtype` (dL/dx);
+ *                             wpack_flipped: wpack with every k x k tap block rotated by 180 degrees (transpose convs);
+ *                             gwpack: (level+2, k, k, C) float32 = dL/d[down, convs[0..level]] in the packed layout, the
+ *                             shared down weight accumulated over all levels (model/recnext.py:21,28);
+ *                             gbpack: (level+2, C) float32 or NULL.  Needs C % 4 == 0.  Deterministic (no atomics).
+ */
+size_t rcx_recconv2d_train_saved_bytes(int N, int C, int H, int W, int level, int k);
+size_t rcx_recconv2d_bwd_workspace_bytes(int N, int C, int H, int W, int level, int k);
+int rcx_recconv2d_fwd_train(const void* x, void* y, const float* wpack, const float* bpack, void* saved, size_t saved_bytes,
+                            int N, int C, int H, int W, int level, int k, int mode, int dtype, void* stream);
+int rcx_recconv2d_bwd(const void* x, const float* gy, const float* wpack, const float* wpack_flipped, const void* saved,
+                      void* gx, float* gwpack, float* gbpack, void* workspace, size_t workspace_bytes,
+                      int N, int C, int H, int W, int level, int k, int mode, int dtype, void* stream);
+
+/*
  * Depthwise conv, zero padding k/2, stride 1 or 2 -- nn.Conv2d(groups=C) as used at
  * model/recnext.py:21-22 and by RecAttn2d's ConvNorm(dw k5 s2) after BN folding (model/recattn.py:61, :89-111).
  *   x: N x H x W x C (in_dtype);  y: N x Ho x Wo x C (out_dtype), Ho = (H + 2*(k/2) - k)/stride + 1.

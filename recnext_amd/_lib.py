@@ -27,6 +27,10 @@ SIGNATURES = {
     "rcx_pack_bias": (_i, [_vp, _vp, _i, _i, _vp]),
     "rcx_recconv2d_fwd_workspace_bytes": (_sz, [_i] * 7),
     "rcx_recconv2d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 8 + [_vp]),
+    "rcx_recconv2d_train_saved_bytes": (_sz, [_i] * 6),
+    "rcx_recconv2d_bwd_workspace_bytes": (_sz, [_i] * 6),
+    "rcx_recconv2d_fwd_train": (_i, [_vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 8 + [_vp]),
+    "rcx_recconv2d_bwd": (_i, [_vp] * 9 + [_sz] + [_i] * 8 + [_vp]),
     "rcx_dwconv2d_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "rcx_dwconv2d_mult2_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
     "rcx_upadd_dwconv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),

@@ -164,6 +164,142 @@ int rcx_recconv2d_fwd(const void* x, void* y, const float* wpack, const float* b
     return 0;
 }
 
+// ---- training: forward that keeps the fp32 pyramid, and the backward pass (rcx_bwd.hip) ----
+namespace {
+
+struct TrainLadder {
+    int h[RCX_MAX_LEVEL + 1], w[RCX_MAX_LEVEL + 1];
+    size_t f_off[RCX_MAX_LEVEL + 1], c_off[RCX_MAX_LEVEL + 1];   // F_l, C_l (l >= 1), all distinct
+    size_t saved_total;
+    size_t g_off[RCX_MAX_LEVEL + 1];                               // backward scratch: gT_0..gT_L
+    size_t gc_off, part_off, bwd_total;
+};
+
+TrainLadder make_train_ladder(int N, int C, int H, int W, int level, int k)
+{
+    TrainLadder L{};
+    L.h[0] = H; L.w[0] = W;
+    size_t off = 0;
+    for (int l = 1; l <= level; ++l) {
+        L.h[l] = down_size(L.h[l - 1], k); L.w[l] = down_size(L.w[l - 1], k);
+        const size_t b = align256(sizeof(float) * (size_t)N * C * L.h[l] * L.w[l]);
+        L.f_off[l] = off; off += b;
+        L.c_off[l] = off; off += b;
+    }
+    L.saved_total = off;
+    off = 0;
+    for (int l = 0; l <= level; ++l) { L.g_off[l] = off; off += align256(sizeof(float) * (size_t)N * C * L.h[l] * L.w[l]); }
+    L.gc_off = off; off += level >= 1 ? align256(sizeof(float) * (size_t)N * C * L.h[1] * L.w[1]) : 0;
+    L.part_off = off; off += align256(rcx::wgrad_partial_bytes(C, k));
+    L.bwd_total = off;
+    return L;
+}
+
+}  // namespace
+
+size_t rcx_recconv2d_train_saved_bytes(int N, int C, int H, int W, int level, int k)
+{
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0) return 0;
+    return make_train_ladder(N, C, H, W, level, k).saved_total;
+}
+
+size_t rcx_recconv2d_bwd_workspace_bytes(int N, int C, int H, int W, int level, int k)
+{
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0) return 0;
+    return make_train_ladder(N, C, H, W, level, k).bwd_total;
+}
+
+int rcx_recconv2d_fwd_train(const void* x, void* y, const float* wpack, const float* bpack, void* saved, size_t saved_bytes,
+                            int N, int C, int H, int W, int level, int k, int mode, int dtype, void* stream)
+{
+    if (int rc = check_common(x, y, N, C, H, W, k, dtype)) return rc;
+    if (!wpack) return fail(RCX_ERR_BAD_ARG, "null weight pack");
+    if (level < 0 || level > RCX_MAX_LEVEL) return fail(RCX_ERR_BAD_ARG, "level %d outside [0,%d]", level, RCX_MAX_LEVEL);
+    if (mode != RCX_MODE_BILINEAR && mode != RCX_MODE_NEAREST) return fail(RCX_ERR_BAD_ARG, "unknown mode %d", mode);
+    const TrainLadder L = make_train_ladder(N, C, H, W, level, k);
+    if (L.saved_total > 0 && (!saved || saved_bytes < L.saved_total))
+        return fail(RCX_ERR_WORKSPACE, "saved-activation buffer too small: need %zu bytes, got %zu", L.saved_total, saved_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t wsz = (size_t)k * k * C;
+    auto W_ = [&](int i) { return wpack + (size_t)i * wsz; };
+    auto B_ = [&](int i) { return bpack ? bpack + (size_t)i * C : nullptr; };
+    char* ws = (char*)saved;
+    auto F_ = [&](int l) { return (float*)(ws + L.f_off[l]); };
+    auto C_ = [&](int l) { return (float*)(ws + L.c_off[l]); };
+    hipError_t e;
+    for (int l = 1; l <= level; ++l) {
+        e = rcx::generic_dwconv(l == 1 ? x : (const void*)F_(l - 1), F_(l), W_(0), B_(0), N, C, L.h[l - 1], L.w[l - 1], k, 2,
+                                l == 1 ? dtype : RCX_DTYPE_F32, RCX_DTYPE_F32, s);
+        if (e != hipSuccess) return hip_fail(e, "train fwd: down ladder");
+    }
+    for (int l = level, j = 0; l >= 1; --l, ++j) {
+        e = rcx::generic_upadd_dwconv(F_(l), l == level ? nullptr : C_(l + 1), C_(l), W_(1 + j), B_(1 + j), N, C, L.h[l], L.w[l],
+                                      l == level ? 0 : L.h[l + 1], l == level ? 0 : L.w[l + 1], k, mode,
+                                      RCX_DTYPE_F32, RCX_DTYPE_F32, RCX_DTYPE_F32, s);
+        if (e != hipSuccess) return hip_fail(e, "train fwd: up recursion");
+    }
+    e = rcx::generic_upadd_dwconv(x, level >= 1 ? C_(1) : nullptr, y, W_(1 + level), B_(1 + level), N, C, H, W,
+                                  level >= 1 ? L.h[1] : 0, level >= 1 ? L.w[1] : 0, k, mode, dtype, RCX_DTYPE_F32, dtype, s);
+    return e == hipSuccess ? 0 : hip_fail(e, "train fwd: final conv");
+}
+
+int rcx_recconv2d_bwd(const void* x, const float* gy, const float* wpack, const float* wpack_flipped, const void* saved,
+                      void* gx, float* gwpack, float* gbpack, void* workspace, size_t workspace_bytes,
+                      int N, int C, int H, int W, int level, int k, int mode, int dtype, void* stream)
+{
+    if (int rc = check_common(x, gx, N, C, H, W, k, dtype)) return rc;
+    if (!gy || !wpack || !wpack_flipped || !gwpack) return fail(RCX_ERR_BAD_ARG, "null gradient / weight pointer");
+    if (level < 0 || level > RCX_MAX_LEVEL) return fail(RCX_ERR_BAD_ARG, "level %d outside [0,%d]", level, RCX_MAX_LEVEL);
+    if (mode != RCX_MODE_BILINEAR && mode != RCX_MODE_NEAREST) return fail(RCX_ERR_BAD_ARG, "unknown mode %d", mode);
+    if (C % 4) return fail(RCX_ERR_UNSUPPORTED, "the backward kernels need C %% 4 == 0, got C=%d", C);
+    const TrainLadder L = make_train_ladder(N, C, H, W, level, k);
+    if (level >= 1 && !saved) return fail(RCX_ERR_BAD_ARG, "null saved-activation buffer");
+    if (!workspace || workspace_bytes < L.bwd_total)
+        return fail(RCX_ERR_WORKSPACE, "backward workspace too small: need %zu bytes, got %zu", L.bwd_total, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t wsz = (size_t)k * k * C;
+    auto W_ = [&](int i) { return wpack + (size_t)i * wsz; };
+    auto Wf = [&](int i) { return wpack_flipped + (size_t)i * wsz; };
+    auto GW = [&](int i) { return gwpack + (size_t)i * wsz; };
+    auto GB = [&](int i) { return gbpack ? gbpack + (size_t)i * C : nullptr; };
+    const char* sv = (const char*)saved;
+    auto F_ = [&](int l) { return (const float*)(sv + L.f_off[l]); };
+    auto C_ = [&](int l) { return (const float*)(sv + L.c_off[l]); };
+    char* ws = (char*)workspace;
+    auto G_ = [&](int l) { return (float*)(ws + L.g_off[l]); };
+    float* gC = (float*)(ws + L.gc_off);
+    float* part = (float*)(ws + L.part_off);
+    hipError_t e;
+#define RCX_TRY(call, what) do { e = (call); if (e != hipSuccess) return hip_fail(e, what); } while (0)
+    // final conv (model/recnext.py:34): gT_0 = K_L^T gy ; gW_L = <x + R(C_1), gy>
+    if (level == 0) RCX_TRY(rcx::generic_dwconv(gy, gx, Wf(1), nullptr, N, C, H, W, k, 1, RCX_DTYPE_F32, dtype, s), "bwd: final conv input grad");
+    else RCX_TRY(rcx::generic_dwconv(gy, G_(0), Wf(1 + level), nullptr, N, C, H, W, k, 1, RCX_DTYPE_F32, RCX_DTYPE_F32, s), "bwd: final conv input grad");
+    RCX_TRY(rcx::bwd_wgrad(x, dtype, level >= 1 ? C_(1) : nullptr, gy, part, GW(1 + level), GB(1 + level), N, C, H, W,
+                           level >= 1 ? L.h[1] : 0, level >= 1 ? L.w[1] : 0, H, W, k, 1, mode, 0, s), "bwd: final conv weight grad");
+    // up recursion (:31-33), finest level first in the backward direction
+    for (int l = 1; l <= level; ++l) {
+        const int j = level - l;
+        RCX_TRY(rcx::bwd_resize(G_(l - 1), gC, N, C, L.h[l - 1], L.w[l - 1], L.h[l], L.w[l], mode, s), "bwd: resize adjoint");
+        RCX_TRY(rcx::generic_dwconv(gC, G_(l), Wf(1 + j), nullptr, N, C, L.h[l], L.w[l], k, 1, RCX_DTYPE_F32, RCX_DTYPE_F32, s), "bwd: conv input grad");
+        RCX_TRY(rcx::bwd_wgrad(F_(l), RCX_DTYPE_F32, l < level ? C_(l + 1) : nullptr, gC, part, GW(1 + j), GB(1 + j), N, C, L.h[l], L.w[l],
+                               l < level ? L.h[l + 1] : 0, l < level ? L.w[l + 1] : 0, L.h[l], L.w[l], k, 1, mode, 0, s), "bwd: conv weight grad");
+    }
+    // down ladder (:27-29), coarsest first: the shared weight accumulates over all levels
+    for (int l = level; l >= 1; --l) {
+        RCX_TRY(rcx::bwd_wgrad(l == 1 ? x : (const void*)F_(l - 1), l == 1 ? dtype : RCX_DTYPE_F32, nullptr, G_(l), part, GW(0), GB(0),
+                               N, C, L.h[l - 1], L.w[l - 1], 0, 0, L.h[l], L.w[l], k, 2, mode, l < level ? 1 : 0, s), "bwd: down weight grad");
+        RCX_TRY(rcx::bwd_down_input(G_(l - 1), G_(l), l == 1 ? gx : (void*)G_(l - 1), l == 1 ? dtype : RCX_DTYPE_F32, W_(0),
+                                    N, C, L.h[l - 1], L.w[l - 1], L.h[l], L.w[l], k, s), "bwd: down input grad");
+    }
+#undef RCX_TRY
+    if (level == 0) {   // no ladder: the shared down weight is unused, its gradient is zero
+        e = hipMemsetAsync(GW(0), 0, sizeof(float) * wsz, s);
+        if (e == hipSuccess && gbpack) e = hipMemsetAsync(GB(0), 0, sizeof(float) * C, s);
+        if (e != hipSuccess) return hip_fail(e, "bwd: zero down grad");
+    }
+    return 0;
+}
+
 int rcx_dwconv2d_fwd(const void* x, void* y, const float* w_kkc, const float* bias,
                      int N, int C, int H, int W, int k, int stride, int in_dtype, int out_dtype, void* stream)
 {

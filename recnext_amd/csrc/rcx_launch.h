@@ -22,4 +22,12 @@ int plane_describe(int N, int C, int H, int W, int level, int k, int dtype, char
 hipError_t plane_recconv(const void* x, void* y, const float* wpack, const float* bpack,
                          int N, int C, int H, int W, int level, int k, int mode, int dtype, hipStream_t s);
 
+// rcx_bwd.hip -- backward pieces (deterministic gathers + two-stage weight-gradient reduction)
+size_t wgrad_partial_bytes(int C, int k);
+hipError_t bwd_wgrad(const void* a, int a_dt, const float* coarse, const float* g, float* partial, float* gw, float* gb,
+                     int N, int C, int H, int W, int Hc, int Wc, int Ho, int Wo, int k, int stride, int mode, int accumulate, hipStream_t s);
+hipError_t bwd_down_input(const float* base, const float* g, void* out, int out_dt, const float* w,
+                          int N, int C, int H, int W, int Hc, int Wc, int k, hipStream_t s);
+hipError_t bwd_resize(const float* gfine, float* gcoarse, int N, int C, int H, int W, int Hc, int Wc, int mode, hipStream_t s);
+
 }  // namespace rcx

@@ -170,3 +170,40 @@ def dwconv2d_mult2(x, w_kkc, bias=None, k=7, stride=2):
                                                 n, c, h, w, k, stride, _dt(x), _stream(x.device))
     _lib.check(rc, "rcx_dwconv2d_mult2_fwd")
     return y
+
+
+def recconv2d_forward_train(x, wpack, bpack, level, k, mode="bilinear"):
+    """Training forward: same result as recconv2d_forward, plus the saved fp32 pyramid the backward needs."""
+    x = _nhwc(x)
+    n, c, h, w = x.shape
+    lib = _lib.load()
+    dt = _dt(x)
+    y = _empty_nhwc(n, c, h, w, x.dtype, x.device)
+    nbytes = lib.rcx_recconv2d_train_saved_bytes(n, c, h, w, level, k)
+    saved = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.rcx_recconv2d_fwd_train(x.data_ptr(), y.data_ptr(), wpack.data_ptr(),
+                                         bpack.data_ptr() if bpack is not None else None, saved.data_ptr(), nbytes,
+                                         n, c, h, w, level, k, _lib.MODES[mode], dt, _stream(x.device))
+    _lib.check(rc, "rcx_recconv2d_fwd_train")
+    return y, saved
+
+
+def recconv2d_backward(x, gy, wpack, saved, level, k, mode="bilinear", need_bias=False):
+    """-> (gx like x, gwpack (level+2, k*k*C) f32, gbpack (level+2, C) f32 | None). Deterministic."""
+    x = _nhwc(x)
+    n, c, h, w = x.shape
+    gy = _nhwc(gy.to(torch.float32), "grad_output")
+    lib = _lib.load()
+    wflip = wpack.view(level + 2, k, k, c).flip(1, 2).contiguous()
+    gx = _empty_nhwc(n, c, h, w, x.dtype, x.device)
+    gw = torch.empty_like(wpack)
+    gb = torch.empty((level + 2, c), dtype=torch.float32, device=x.device) if need_bias else None
+    nbytes = lib.rcx_recconv2d_bwd_workspace_bytes(n, c, h, w, level, k)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.rcx_recconv2d_bwd(x.data_ptr(), gy.data_ptr(), wpack.data_ptr(), wflip.data_ptr(), saved.data_ptr(),
+                                   gx.data_ptr(), gw.data_ptr(), gb.data_ptr() if gb is not None else None,
+                                   ws.data_ptr(), nbytes, n, c, h, w, level, k, _lib.MODES[mode], _dt(x), _stream(x.device))
+    _lib.check(rc, "rcx_recconv2d_bwd")
+    return gx, gw, gb

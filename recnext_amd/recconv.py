@@ -7,7 +7,7 @@ block (model/recnext.py:8-34), body executed by the gfx950 HIP kernels behind th
 ``convs[0]`` pairs with the coarsest level and ``convs[level]`` is the full-resolution conv, exactly as
 ``zip(self.convs, reversed(features))`` does at model/recnext.py:32-34.  ``level=0`` is legal.
 
-The forward pass accepts float32 or bfloat16 CUDA tensors (logical N x C x H x W; channels_last
+Forward and backward accept float32 or bfloat16 CUDA tensors (logical N x C x H x W; channels_last
 storage is consumed zero-copy, anything else is converted once) and returns a channels_last tensor
 of the same shape and dtype.  All arithmetic is float32 inside the kernels.  There is no CPU path.
 """
@@ -92,15 +92,36 @@ class RecConv2d(nn.Module):
 
 
 class _RecConv2dFn(torch.autograd.Function):
-    """Autograd wrapper. Forward = HIP kernels; backward is not implemented in this round and says so."""
+    """Autograd wrapper: forward and backward both run on the HIP kernels (rcx_recconv2d_fwd_train / rcx_recconv2d_bwd).
+
+    The training forward uses the per-level schedule, which leaves the fp32 pyramid in a buffer the backward reads;
+    parameter gradients come back in the packed (k,k,C) layout and are permuted to the reference's (C,1,k,k).
+    """
 
     @staticmethod
     def forward(ctx, x, module, *params):
+        if module.fold_scale is not None:
+            raise RuntimeError("RecConv2d.fold_output_affine is an inference transform; it cannot be trained through")
         wpack, bpack = module.packed_params()
-        return ops.recconv2d_forward(x, wpack, bpack, module.level, module.kernel_size, module.mode)
+        y, saved = ops.recconv2d_forward_train(x, wpack, bpack, module.level, module.kernel_size, module.mode)
+        ctx.module = module
+        ctx.save_for_backward(x, wpack, saved)
+        ctx.has_bias = bpack is not None
+        ctx.param_dtypes = [p.dtype for p in params]
+        return y
 
     @staticmethod
     def backward(ctx, grad_out):
-        raise NotImplementedError(
-            "recnext_amd.RecConv2d: the HIP backward pass is not implemented yet (SURVEY.md section 8f row 1); "
-            "run the forward under torch.no_grad() / inference_mode().")
+        x, wpack, saved = ctx.saved_tensors
+        m = ctx.module
+        k, c, L = m.kernel_size, m.in_channels, m.level
+        gx, gw, gb = ops.recconv2d_backward(x, grad_out, wpack, saved, L, k, m.mode, need_bias=ctx.has_bias)
+        gw = gw.view(L + 2, k, k, c).permute(0, 3, 1, 2).unsqueeze(2)        # (L+2, C, 1, k, k)
+        grads = []
+        # parameter order of nn.Module.parameters(): down.weight, [down.bias], convs.0.weight, [convs.0.bias], ...
+        for i in range(L + 2):
+            grads.append(gw[i])
+            if ctx.has_bias:
+                grads.append(gb[i])
+        grads = [g.to(dt) for g, dt in zip(grads, ctx.param_dtypes)]
+        return (gx if ctx.needs_input_grad[0] else None, None, *grads)
