@@ -73,6 +73,14 @@ bool use_plane(int N, int C, int H, int W, int level, int k, int dtype)
     return rcx::plane_applicable(N, C, H, W, level, k, dtype);
 }
 
+// the register-resident schedule takes precedence where it applies (RCX_LANES=0 switches it off)
+bool use_lanes(int N, int C, int H, int W, int level, int k, int dtype)
+{
+    const char* f = getenv("RCX_FORCE_GENERIC");
+    if (f && *f && *f != '0') return false;
+    return rcx::lanes_applicable(N, C, H, W, level, k, dtype);
+}
+
 }  // namespace
 
 #ifdef RCX_STAMPS
@@ -88,8 +96,9 @@ const char* rcx_last_error(void) { return g_err; }
 const char* rcx_recconv2d_fwd_plan(int N, int C, int H, int W, int level, int k, int /*mode*/, int dtype)
 {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0) return "invalid";
-    if (!use_plane(N, C, H, W, level, k, dtype)) return "generic";
     static thread_local char desc[96];
+    if (use_lanes(N, C, H, W, level, k, dtype) && rcx::lanes_describe(N, C, H, W, level, k, dtype, desc, (int)sizeof(desc)) > 0) return desc;
+    if (!use_plane(N, C, H, W, level, k, dtype)) return "generic";
     if (rcx::plane_describe(N, C, H, W, level, k, dtype, desc, (int)sizeof(desc)) <= 0) return "generic";
     return desc;
 }
@@ -113,6 +122,7 @@ int rcx_pack_bias(const void* b, float* dst, int C, int dtype, void* stream)
 size_t rcx_recconv2d_fwd_workspace_bytes(int N, int C, int H, int W, int level, int k, int dtype)
 {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0) return 0;
+    if (use_lanes(N, C, H, W, level, k, dtype)) return 0;          // registers only
     if (use_plane(N, C, H, W, level, k, dtype)) return 0;          // the fused schedule keeps every intermediate in LDS
     return make_ladder(N, C, H, W, level, k).total;
 }
@@ -126,6 +136,10 @@ int rcx_recconv2d_fwd(const void* x, void* y, const float* wpack, const float* b
     if (x == y) return fail(RCX_ERR_BAD_ARG, "y must not alias x");
     if (level < 0 || level > RCX_MAX_LEVEL) return fail(RCX_ERR_BAD_ARG, "level %d outside [0,%d]", level, RCX_MAX_LEVEL);
     if (mode != RCX_MODE_BILINEAR && mode != RCX_MODE_NEAREST) return fail(RCX_ERR_BAD_ARG, "unknown mode %d", mode);
+    if (use_lanes(N, C, H, W, level, k, dtype)) {
+        hipError_t le = rcx::lanes_recconv(x, y, wpack, bpack, N, C, H, W, level, k, mode, dtype, (hipStream_t)stream);
+        return le == hipSuccess ? 0 : hip_fail(le, "lanes schedule");
+    }
     if (use_plane(N, C, H, W, level, k, dtype)) {
         hipError_t pe = rcx::plane_recconv(x, y, wpack, bpack, N, C, H, W, level, k, mode, dtype, (hipStream_t)stream);
         return pe == hipSuccess ? 0 : hip_fail(pe, "plane schedule");

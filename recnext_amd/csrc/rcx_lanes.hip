@@ -1,0 +1,546 @@
+// Register-resident RecConv2d for the 7 * 2^k planes (7x7, 14x14, 28x28 ...): the whole pyramid of
+// model/recnext.py:24-34 lives in VGPRs, horizontal taps come from DPP lane shifts, vertical taps are
+// register indices.  LDS only transposes NHWC global memory <-> the lane layout.
+//
+// Lane layout.  A wave owns 64/LPC channels of one image; LPC consecutive lanes own one channel, LA of
+// them active (7 of 8, or 14 of 16) -- the inactive "guard" lanes are EXEC-disabled for the whole
+// compute section, so a DPP shift that crosses a channel boundary reads zero (bound_ctrl semantics,
+// tools/ubench/dpp_fmac.hip): the guard lanes ARE the horizontal zero padding.  At pyramid level l
+// (width W_l = W_0 / 2^l while that is >= LA) lane j of the group holds the B_l = W_l / LA adjacent
+// columns j*B_l .. j*B_l+B_l-1 of every row, as registers row[r][0..B_l-1].  The stride-2 convolution
+// maps (W, B) -> (W/2, B/2) with no lane movement at all: the de-interleave is free.  Below B = 1 the
+// levels are "dilated": column c of the 4-wide level sits in lane c*D.
+//
+// All shapes, row indices and the vertical resize tables are compile-time; the horizontal resize uses
+// per-lane weights computed once with ATen's float index arithmetic (rcx_common.h), so the border
+// clamping and the irregular 4 -> 7 step need no special code.
+#include <utility>
+
+#include "rcx_common.h"
+#include "rcx_launch.h"
+
+namespace rcx {
+namespace lanes {
+
+template <int I> using IC = std::integral_constant<int, I>;
+template <class F, int... Is>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, Is...>) { (f(IC<Is>{}), ...); }
+// compile-time loop: f(IC<0>) ... f(IC<N-1>)
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) { sfor_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
+#define RCX_INL __attribute__((always_inline))
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // plain vector loads/stores (HIP's uint4 copies as memcpy)
+
+// ------------------------------------------------------------------------------------------------
+// lane shifts inside a 16-lane DPP row; lanes shifted in from outside the row, or from an
+// EXEC-disabled lane, read 0
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// value held by the lane N below (LPC == 8: chained single steps, so a value never jumps over the guard lane)
+template <int N, int LPC>
+__device__ __forceinline__ float from_left(float v)
+{
+    if constexpr (N == 0) return v;
+    else if constexpr (LPC == 16) return dpp_mov<0x110 + N>(v);      // row_shr:N
+    else return from_left<N - 1, LPC>(dpp_mov<0x111>(v));
+}
+
+template <int N, int LPC>
+__device__ __forceinline__ float from_right(float v)
+{
+    if constexpr (N == 0) return v;
+    else if constexpr (LPC == 16) return dpp_mov<0x100 + N>(v);      // row_shl:N
+    else return from_right<N - 1, LPC>(dpp_mov<0x101>(v));
+}
+
+// ------------------------------------------------------------------------------------------------
+// compile-time geometry
+constexpr int down_size5(int h) { return (h + 4 - 5) / 2 + 1; }
+
+struct VT { int i0, i1; float l; };
+// vertical resize table entry, float arithmetic as ATen (and rcx_common.h bilinear_src / nearest_src)
+constexpr VT vtab(int mode, int n_in, int n_out, int d)
+{
+    const float scale = (float)n_in / (float)n_out;
+    if (mode == 1) {
+        int i = (int)((float)d * scale);
+        i = i < n_in - 1 ? i : n_in - 1;
+        return VT{i, i, 0.f};
+    }
+    float src = scale * ((float)d + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    int i0 = (int)src;
+    i0 = i0 < n_in - 1 ? i0 : n_in - 1;
+    return VT{i0, i0 + (i0 < n_in - 1 ? 1 : 0), src - (float)i0};
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-lane context
+struct Ctx {
+    int lane_in_group;       // 0 .. LPC-1
+    int mode;                // 0 bilinear, 1 nearest
+};
+
+// row with two halo columns each side: ext[0]=col-2, ext[1]=col-1, ext[2..B+1]=own, ext[B+2], ext[B+3]
+template <int LPC, int B, int D>
+__device__ __forceinline__ void make_ext(const float (&row)[B], float (&ext)[B + 4])
+{
+#pragma unroll
+    for (int j = 0; j < B; ++j) ext[2 + j] = row[j];
+    if constexpr (B >= 2) {
+        ext[1] = from_left<1, LPC>(row[B - 1]);
+        ext[0] = from_left<1, LPC>(row[B - 2]);
+        ext[B + 2] = from_right<1, LPC>(row[0]);
+        ext[B + 3] = from_right<1, LPC>(row[1]);
+    } else {
+        ext[1] = from_left<D, LPC>(row[0]);
+        ext[0] = from_left<D, LPC>(ext[1]);
+        ext[3] = from_right<D, LPC>(row[0]);
+        ext[4] = from_right<D, LPC>(ext[3]);
+    }
+}
+
+// 5x5 depthwise, stride 1, pad 2.  in_row(IC<r>, float(&)[B]) yields input row r (called once per row, in
+// order); out_row(IC<o>, const float(&)[B]) receives output row o as soon as it is complete.
+template <int LPC, int H, int B, int D, class InRow, class OutRow>
+__device__ __forceinline__ void conv5_s1(const float (&w)[25], float bias, InRow&& in_row, OutRow&& out_row)
+{
+    float acc[H][B];
+    sfor<H>([&](auto R) RCX_INL {
+        constexpr int r = decltype(R)::value;
+        float row[B], ext[B + 4];
+        in_row(R, row);
+        make_ext<LPC, B, D>(row, ext);
+        sfor<5>([&](auto U) RCX_INL {
+            constexpr int u = decltype(U)::value;
+            constexpr int o = r + 2 - u;
+            if constexpr (o >= 0 && o < H) {
+                constexpr bool first = (u == 0) || (r == 0);             // input row max(o-2, 0) is the first to reach output row o
+#pragma unroll
+                for (int j = 0; j < B; ++j) {
+                    float a = first ? bias : acc[o][j];
+#pragma unroll
+                    for (int v = 0; v < 5; ++v) a = fmaf(ext[j + v], w[u * 5 + v], a);
+                    acc[o][j] = a;
+                }
+            }
+        });
+        if constexpr (r >= 2) out_row(IC<r - 2>{}, acc[r - 2]);
+        if constexpr (r == H - 1) {
+            if constexpr (H >= 2) out_row(IC<H - 2>{}, acc[H - 2]);
+            out_row(IC<H - 1>{}, acc[H - 1]);
+        }
+    });
+}
+
+// 5x5 depthwise, stride 2, pad 2: (HI, BI) -> (HO, BO).  BI >= 2: BO = BI/2, same lanes.  BI == 1: the result is
+// valid in the lanes that are multiples of 2*D (horizontal stride-1 evaluation, every other lane is unused).
+template <int LPC, int HI, int BI, int D, int HO, int BO, class InRow>
+__device__ __forceinline__ void conv5_s2(const float (&w)[25], float bias, InRow&& in_row, float (&out)[HO][BO])
+{
+    sfor<HI>([&](auto R) RCX_INL {
+        constexpr int r = decltype(R)::value;
+        float row[BI], ext[BI + 4];
+        in_row(R, row);
+        make_ext<LPC, BI, D>(row, ext);
+        sfor<5>([&](auto U) RCX_INL {
+            constexpr int u = decltype(U)::value;
+            constexpr int t = r + 2 - u;                                 // = 2 * o
+            if constexpr (t >= 0 && (t % 2) == 0 && (t / 2) < HO) {
+                constexpr int o = t / 2;
+                constexpr bool is_first = (r == (2 * o - 2 > 0 ? 2 * o - 2 : 0));   // first input row that reaches output row o
+#pragma unroll
+                for (int i = 0; i < BO; ++i) {
+                    float a = is_first ? bias : out[o][i];
+#pragma unroll
+                    for (int v = 0; v < 5; ++v) a = fmaf(ext[(BI >= 2 ? 2 * i : 0) + v], w[u * 5 + v], a);
+                    out[o][i] = a;
+                }
+            }
+        });
+    });
+}
+
+// horizontal resize weights of the compact 2x step: fine column j of the lane reads coarse columns
+// cext[m + (j&1)] and cext[m + (j&1) + 1] (m = j/2, cext[0] = the lane's column -1)
+template <int BC, int BF>
+__device__ __forceinline__ void hweights_2x(const Ctx& c, int wc, int wf, float (&wt)[BF][2])
+{
+    const float scale = (float)wc / (float)wf;
+#pragma unroll
+    for (int j = 0; j < BF; ++j) {
+        const int xf = c.lane_in_group * BF + j;
+        int i0, i1;
+        float lam;
+        if (c.mode == 1) { i0 = i1 = nearest_src(xf, wc, scale); lam = 0.f; }
+        else { Lerp s = bilinear_src(xf, wc, scale); i0 = s.i0; i1 = s.i1; lam = s.lam; }
+        const int ca = c.lane_in_group * BC + j / 2 - 1 + (j & 1);
+        wt[j][0] = (ca == i0 ? 1.f - lam : 0.f) + (ca == i1 ? lam : 0.f);
+        wt[j][1] = (ca + 1 == i0 ? 1.f - lam : 0.f) + (ca + 1 == i1 ? lam : 0.f);
+    }
+}
+
+// horizontal resize weights towards a B = 1 level (fine lane stride DF, coarse lane stride 2*DF):
+// hrow = sum_{o=-2..2} wt[o+2] * value of the coarse row in lane (own + o*DF)
+template <int DF>
+__device__ __forceinline__ void hweights_off(const Ctx& c, int wc, int wf, float (&wt)[5])
+{
+    const float scale = (float)wc / (float)wf;
+    const int xf = c.lane_in_group / DF;
+    const bool lane_ok = (c.lane_in_group % DF) == 0 && xf < wf;
+    int i0, i1;
+    float lam;
+    if (c.mode == 1) { i0 = i1 = nearest_src(xf, wc, scale); lam = 0.f; }
+    else { Lerp s = bilinear_src(xf, wc, scale); i0 = s.i0; i1 = s.i1; lam = s.lam; }
+#pragma unroll
+    for (int o = -2; o <= 2; ++o) {
+        const int t = xf + o;                                            // coarse column * 2
+        const bool ok = lane_ok && t >= 0 && (t & 1) == 0;
+        const int i = t >> 1;
+        wt[o + 2] = ok ? ((i == i0 ? 1.f - lam : 0.f) + (i == i1 ? lam : 0.f)) : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// taps of one conv from the workgroup's LDS copy [26][CBW] (25 taps + bias row); tl already points at the lane's channel
+template <int CBW>
+__device__ __forceinline__ void load_taps(const float* __restrict__ tl, float (&w)[25], float& b)
+{
+#pragma unroll
+    for (int t = 0; t < 25; ++t) w[t] = tl[t * CBW];
+    b = tl[25 * CBW];
+}
+
+// Level l of the pyramid.  run_io() is the general form: in_row(IC<r>, row) yields row r of F_l (it is called
+// TWICE per row when l < LEVEL: once for the stride-2 conv, once to build T_l = F_l + resize(C_{l+1})), and
+// out_row(IC<o>, row) receives C_l = conv_{LEVEL-l}(T_l) row by row.  run() is the all-in-registers wrapper
+// used below level 0.  W is this level's width, (B, D) its lane layout.
+template <int LPC, int MODE, int LVL, int LEVEL, int W, int B, int D, int CBW>
+struct Level {
+    static constexpr int H = W;
+    static constexpr int WN = down_size5(W);
+    static constexpr int BN = B >= 2 ? B / 2 : 1;
+    static constexpr int DN = B >= 2 ? 1 : 2 * D;
+
+    template <class InRow, class OutRow>
+    static __device__ __forceinline__ void run_io(InRow&& in_row, OutRow&& out_row, const float* __restrict__ taps, const Ctx& c)
+    {
+        float w[25], b;
+        if constexpr (LVL < LEVEL) {
+            float Cn[WN][BN];
+            {
+                float Fn[WN][BN];
+                load_taps<CBW>(taps, w, b);                                // conv 0 of the pack = the shared `down`
+                conv5_s2<LPC, H, B, D, WN, BN>(w, b, in_row, Fn);
+                Level<LPC, MODE, LVL + 1, LEVEL, WN, BN, DN, CBW>::run(Fn, Cn, taps, c);
+            }
+            float hrow[WN][B];
+            hresize(Cn, hrow, c);
+            load_taps<CBW>(taps + (1 + LEVEL - LVL) * 26 * CBW, w, b);
+            conv5_s1<LPC, H, B, D>(w, b,
+                [&](auto R, float (&row)[B]) RCX_INL {
+                    in_row(R, row);
+                    constexpr VT t = vtab(MODE, WN, H, decltype(R)::value);
+#pragma unroll
+                    for (int j = 0; j < B; ++j) {
+                        if constexpr (MODE == 1 || t.i0 == t.i1) row[j] += hrow[t.i0][j];
+                        else row[j] += fmaf(t.l, hrow[t.i1][j], (1.f - t.l) * hrow[t.i0][j]);
+                    }
+                },
+                out_row);
+        } else {
+            load_taps<CBW>(taps + (1 + LEVEL - LVL) * 26 * CBW, w, b);
+            conv5_s1<LPC, H, B, D>(w, b, in_row, out_row);
+        }
+    }
+
+    static __device__ __forceinline__ void run(const float (&F)[H][B], float (&Cout)[H][B], const float* __restrict__ taps, const Ctx& c)
+    {
+        run_io(
+            [&](auto R, float (&row)[B]) RCX_INL {
+#pragma unroll
+                for (int j = 0; j < B; ++j) row[j] = F[decltype(R)::value][j];
+            },
+            [&](auto O, const float (&acc)[B]) RCX_INL {
+#pragma unroll
+                for (int j = 0; j < B; ++j) Cout[decltype(O)::value][j] = acc[j];
+            },
+            taps, c);
+    }
+
+    // hrow = C_{l+1} resized horizontally to this level's columns (rows still coarse)
+    static __device__ __forceinline__ void hresize(const float (&Cn)[WN][BN], float (&hrow)[WN][B], const Ctx& c)
+    {
+        if constexpr (B >= 2) {
+            float wt[B][2];
+            hweights_2x<BN, B>(c, WN, W, wt);
+            sfor<WN>([&](auto R) RCX_INL {
+                constexpr int r = decltype(R)::value;
+                float cext[BN + 2];
+                cext[0] = from_left<1, LPC>(Cn[r][BN - 1]);
+#pragma unroll
+                for (int i = 0; i < BN; ++i) cext[1 + i] = Cn[r][i];
+                cext[BN + 1] = from_right<1, LPC>(Cn[r][0]);
+#pragma unroll
+                for (int j = 0; j < B; ++j) hrow[r][j] = fmaf(wt[j][1], cext[j / 2 + (j & 1) + 1], wt[j][0] * cext[j / 2 + (j & 1)]);
+            });
+        } else {
+            float wt[5];
+            hweights_off<D>(c, WN, W, wt);
+            sfor<WN>([&](auto R) RCX_INL {
+                constexpr int r = decltype(R)::value;
+                const float v = Cn[r][0];
+                const float l1 = from_left<D, LPC>(v), l2 = from_left<D, LPC>(l1);
+                const float r1 = from_right<D, LPC>(v), r2 = from_right<D, LPC>(r1);
+                float a = wt[0] * l2;
+                a = fmaf(wt[1], l1, a);
+                a = fmaf(wt[2], v, a);
+                a = fmaf(wt[3], r1, a);
+                a = fmaf(wt[4], r2, a);
+                hrow[r][0] = a;
+            });
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+template <typename TIO> struct Raw;
+template <> struct Raw<float> {
+    static __device__ __forceinline__ float ld(const unsigned char* p) { return *reinterpret_cast<const float*>(p); }
+    static __device__ __forceinline__ void st(unsigned char* p, float v) { *reinterpret_cast<float*>(p) = v; }
+};
+template <> struct Raw<bf16_t> {
+    static __device__ __forceinline__ float ld(const unsigned char* p) { return bf16_to_f32(*reinterpret_cast<const bf16_t*>(p)); }
+    static __device__ __forceinline__ void st(unsigned char* p, float v) { *reinterpret_cast<bf16_t*>(p) = f32_to_bf16(v); }
+};
+
+struct LanesArgs {
+    int N, C;
+    int nblk;          // channel blocks per image (C / CBW)
+    int ni;            // images per workgroup (consecutive)
+    int has_bias;
+};
+
+// One workgroup of NW waves = (block of CBW = NW * 64/LPC channels, group of `ni` consecutive images).  Taps are staged
+// once per workgroup; the next image's 16-byte chunks are prefetched into registers while the current one is computed.
+// Every LDS offset is a compile-time constant (immediate offsets, no address registers).
+template <int W0, int LEVEL, int LPC, int MODE, int NW, typename TIO>
+__global__ __launch_bounds__(NW * 64)
+void k_recconv_lanes(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack, LanesArgs a)
+{
+    constexpr int LA = LPC == 8 ? 7 : 14;
+    constexpr int B0 = W0 / LA;
+    static_assert(B0 * LA == W0, "plane width must be LA * B0");
+    constexpr int HW = W0 * W0;
+    constexpr int CPW = 64 / LPC;                 // channels per wave
+    constexpr int CBW = NW * CPW;                 // channels per workgroup
+    constexpr int NT = NW * 64;
+    constexpr int NCONV = LEVEL + 2;
+    constexpr int ESZ = (int)sizeof(TIO);
+    constexpr int PITCH = CBW * ESZ + 16;         // bytes per pixel of the raw LDS image
+    constexpr int CPP = CBW * ESZ / 16;           // 16-byte chunks per pixel
+    static_assert(CPP >= 1 && (CPP & (CPP - 1)) == 0, "channel block must be a power-of-two number of 16-byte chunks");
+    constexpr int NCHUNKS = HW * CPP;
+    constexpr int STAGE = (NCHUNKS + NT - 1) / NT;   // chunks per thread and image
+    constexpr int TAPS_BYTES = NCONV * 26 * CBW * 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* taps = reinterpret_cast<float*>(smem);                 // [NCONV][26][CBW]
+    unsigned char* img = smem + TAPS_BYTES;                        // [HW][PITCH]
+
+    const int tid = threadIdx.x;
+    const int cb = blockIdx.x % a.nblk;
+    const int n0 = (blockIdx.x / a.nblk) * a.ni;
+    const int n1 = n0 + a.ni < a.N ? n0 + a.ni : a.N;
+    const int c0 = cb * CBW;
+    const size_t img_stride = (size_t)HW * a.C;               // elements per image
+
+    // chunk <-> (pixel, part) of this thread, fixed for all images
+    int g_off[STAGE], l_off[STAGE];
+    bool have[STAGE];
+    sfor<STAGE>([&](auto I) RCX_INL {
+        constexpr int i = decltype(I)::value;
+        int cidx = tid + i * NT;
+        have[i] = (i + 1) * NT <= NCHUNKS || cidx < NCHUNKS;
+        cidx = have[i] ? cidx : NCHUNKS - 1;
+        const int p = cidx / CPP, part = cidx % CPP;
+        g_off[i] = p * a.C * ESZ + part * 16;
+        l_off[i] = p * PITCH + part * 16;
+    });
+    u32x4 v[STAGE];
+    auto prefetch = [&](int n) RCX_INL {
+        const unsigned char* xg = reinterpret_cast<const unsigned char*>(x + (size_t)n * img_stride + c0);
+        sfor<STAGE>([&](auto I) RCX_INL { v[decltype(I)::value] = *reinterpret_cast<const u32x4*>(xg + g_off[decltype(I)::value]); });
+    };
+    if (n0 < n1) prefetch(n0);
+
+    // taps + bias rows -> LDS: rows of CBW floats, float4 per thread, all loads of a thread in flight together
+    {
+        constexpr int Q4 = CBW / 4;
+        constexpr int TOTAL = NCONV * 26 * Q4;
+        constexpr int TB = (TOTAL + NT - 1) / NT;
+        float4 t[TB];
+        sfor<TB>([&](auto I) RCX_INL {
+            constexpr int i = decltype(I)::value;
+            int idx = tid + i * NT;
+            idx = idx < TOTAL ? idx : TOTAL - 1;
+            const int row = idx / Q4, part = idx % Q4;
+            const int conv = row / 26, tap = row - conv * 26;
+            if (tap < 25) t[i] = *reinterpret_cast<const float4*>(wpack + ((size_t)conv * 25 + tap) * a.C + c0 + part * 4);
+            else if (a.has_bias) t[i] = *reinterpret_cast<const float4*>(bpack + (size_t)conv * a.C + c0 + part * 4);
+            else t[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        });
+        sfor<TB>([&](auto I) RCX_INL {
+            constexpr int i = decltype(I)::value;
+            const int idx = tid + i * NT;
+            if (idx < TOTAL) *reinterpret_cast<float4*>(taps + (size_t)idx * 4) = t[i];
+        });
+    }
+
+    const int lane = tid & 63, wave = tid >> 6;
+    Ctx c;
+    c.lane_in_group = lane % LPC;
+    c.mode = MODE;
+    const int ch = wave * CPW + lane / LPC;
+    const bool active = c.lane_in_group < LA;
+    unsigned char* mine = img + (c.lane_in_group * B0) * PITCH + ch * ESZ;
+    const float* my_taps = taps + ch;
+
+    for (int n = n0; n < n1; ++n) {
+        // ---- this image's chunks (already in registers) -> raw LDS image
+        sfor<STAGE>([&](auto I) RCX_INL {
+            constexpr int i = decltype(I)::value;
+            if (have[i]) *reinterpret_cast<u32x4*>(img + l_off[i]) = v[i];
+        });
+        __syncthreads();
+        if (n + 1 < n1) prefetch(n + 1);
+        // ---- the whole block in registers; every output row overwrites the lane's own (already consumed) x bytes
+        if (active) {
+            Level<LPC, MODE, 0, LEVEL, W0, B0, 1, CBW>::run_io(
+                [&](auto R, float (&row)[B0]) RCX_INL {
+#pragma unroll
+                    for (int j = 0; j < B0; ++j) row[j] = Raw<TIO>::ld(mine + (decltype(R)::value * W0 + j) * PITCH);
+                },
+                [&](auto O, const float (&acc)[B0]) RCX_INL {
+#pragma unroll
+                    for (int j = 0; j < B0; ++j) Raw<TIO>::st(mine + (decltype(O)::value * W0 + j) * PITCH, acc[j]);
+                },
+                my_taps, c);
+        }
+        __syncthreads();
+        // ---- y: raw LDS image -> coalesced 16-byte stores (same thread <-> chunk mapping as the loads, so the next
+        //      image's LDS writes need no barrier after these reads)
+        unsigned char* yg = reinterpret_cast<unsigned char*>(y + (size_t)n * img_stride + c0);
+        sfor<STAGE>([&](auto I) RCX_INL {
+            constexpr int i = decltype(I)::value;
+            if (have[i]) *reinterpret_cast<u32x4*>(yg + g_off[i]) = *reinterpret_cast<const u32x4*>(img + l_off[i]);
+        });
+    }
+}
+
+struct LanesPlan {
+    bool ok;
+    int w0, level, lpc, waves;
+    size_t lds;
+    LanesArgs args;
+};
+
+static int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+static LanesPlan plan(int N, int C, int H, int W, int level, int k, int dtype)
+{
+    LanesPlan p{};
+    if (env_int("RCX_LANES", 1) == 0) return p;
+    if (k != 5 || H != W) return p;
+    int natural = -1, lpc = 8;
+    if (W == 7) natural = 1;
+    else if (W == 14) natural = 2;
+    if (natural < 0 || level != natural) return p;
+    const int esz = dtype == 1 ? 2 : 4;
+    const int cpw = 64 / lpc;
+    int waves = env_int("RCX_LANES_WAVES", W == 14 ? 4 : 8);
+    if (waves != 8 && waves != 4 && waves != 2 && waves != 1) waves = 8;
+    while (waves > 1 && C % (waves * cpw) != 0) waves >>= 1;
+    const int cbw = waves * cpw;
+    if (C % cbw != 0 || (cbw * esz) % 16 != 0) return p;
+    p.lds = (size_t)(level + 2) * 26 * cbw * 4 + (size_t)H * W * (cbw * esz + 16);
+    if (p.lds > 160 * 1024) return p;
+    p.w0 = W; p.level = level; p.lpc = lpc; p.waves = waves;
+    p.args.N = N; p.args.C = C; p.args.nblk = C / cbw;
+    // enough workgroups to fill 256 CUs a few times over, the rest of the batch looped inside (taps staged once)
+    int ni = env_int("RCX_LANES_NI", 0);
+    if (ni <= 0) {
+        ni = 1;
+        while ((long)p.args.nblk * ((N + 2 * ni - 1) / (2 * ni)) >= 1024 && ni < 4) ni *= 2;
+    }
+    p.args.ni = ni;
+    p.ok = true;
+    return p;
+}
+
+template <int W0, int LEVEL, int LPC, int MODE, int NW, typename TIO>
+static hipError_t launch_w(const void* x, void* y, const float* wpack, const float* bpack, const LanesPlan& p, hipStream_t s)
+{
+    auto kfn = k_recconv_lanes<W0, LEVEL, LPC, MODE, NW, TIO>;
+    if (p.lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+        if (e != hipSuccess) return e;
+    }
+    LanesArgs a = p.args;
+    a.has_bias = bpack != nullptr;
+    const unsigned grid = (unsigned)(a.nblk * ((a.N + a.ni - 1) / a.ni));
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), p.lds, s, (const TIO*)x, (TIO*)y, wpack, bpack, a);
+    return hipGetLastError();
+}
+
+template <int W0, int LEVEL, int LPC, int MODE, typename TIO>
+static hipError_t launch_t(const void* x, void* y, const float* wpack, const float* bpack, const LanesPlan& p, hipStream_t s)
+{
+    switch (p.waves) {
+    case 8: return launch_w<W0, LEVEL, LPC, MODE, 8, TIO>(x, y, wpack, bpack, p, s);
+    case 4: return launch_w<W0, LEVEL, LPC, MODE, 4, TIO>(x, y, wpack, bpack, p, s);
+    case 2: return launch_w<W0, LEVEL, LPC, MODE, 2, TIO>(x, y, wpack, bpack, p, s);
+    default:
+        if constexpr (sizeof(TIO) * (64 / LPC) >= 16) return launch_w<W0, LEVEL, LPC, MODE, 1, TIO>(x, y, wpack, bpack, p, s);
+        return hipErrorInvalidConfiguration;
+    }
+}
+
+template <int MODE, typename TIO>
+static hipError_t launch_m(const void* x, void* y, const float* wpack, const float* bpack, const LanesPlan& p, hipStream_t s)
+{
+    if (p.w0 == 7) return launch_t<7, 1, 8, MODE, TIO>(x, y, wpack, bpack, p, s);
+    if (p.w0 == 14) return launch_t<14, 2, 8, MODE, TIO>(x, y, wpack, bpack, p, s);
+    return hipErrorInvalidConfiguration;
+}
+
+}  // namespace lanes
+
+bool lanes_applicable(int N, int C, int H, int W, int level, int k, int dtype) { return lanes::plan(N, C, H, W, level, k, dtype).ok; }
+
+int lanes_describe(int N, int C, int H, int W, int level, int k, int dtype, char* buf, int len)
+{
+    const lanes::LanesPlan p = lanes::plan(N, C, H, W, level, k, dtype);
+    if (!p.ok) return 0;
+    return snprintf(buf, len, "lanes(w=%d,lpc=%d,cb=%d,ni=%d,nt=%d,lds=%zu)", p.w0, p.lpc, p.waves * 64 / p.lpc, p.args.ni, p.waves * 64, p.lds);
+}
+
+hipError_t lanes_recconv(const void* x, void* y, const float* wpack, const float* bpack,
+                         int N, int C, int H, int W, int level, int k, int mode, int dtype, hipStream_t s)
+{
+    const lanes::LanesPlan p = lanes::plan(N, C, H, W, level, k, dtype);
+    if (!p.ok) return hipErrorInvalidConfiguration;
+    if (dtype == 1) return mode == 1 ? lanes::launch_m<1, bf16_t>(x, y, wpack, bpack, p, s) : lanes::launch_m<0, bf16_t>(x, y, wpack, bpack, p, s);
+    return mode == 1 ? lanes::launch_m<1, float>(x, y, wpack, bpack, p, s) : lanes::launch_m<0, float>(x, y, wpack, bpack, p, s);
+}
+
+}  // namespace rcx

@@ -22,6 +22,12 @@ int plane_describe(int N, int C, int H, int W, int level, int k, int dtype, char
 hipError_t plane_recconv(const void* x, void* y, const float* wpack, const float* bpack,
                          int N, int C, int H, int W, int level, int k, int mode, int dtype, hipStream_t s);
 
+// rcx_lanes.hip -- register-resident schedule for the 7*2^k planes (k=5, natural level)
+bool lanes_applicable(int N, int C, int H, int W, int level, int k, int dtype);
+int lanes_describe(int N, int C, int H, int W, int level, int k, int dtype, char* buf, int len);
+hipError_t lanes_recconv(const void* x, void* y, const float* wpack, const float* bpack,
+                         int N, int C, int H, int W, int level, int k, int mode, int dtype, hipStream_t s);
+
 // rcx_bwd.hip -- backward pieces (deterministic gathers + two-stage weight-gradient reduction)
 size_t wgrad_partial_bytes(int C, int k);
 hipError_t bwd_wgrad(const void* a, int a_dt, const float* coarse, const float* g, float* partial, float* gw, float* gb,
