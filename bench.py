@@ -109,6 +109,9 @@ def kernel_name(plan, elem_bytes):
         lpp = int(plan[len("plane(cb="):].split(",")[0]) // 2
         kern = "k_recconv_whole" if "whole-plane" in plan else "k_recconv_plane"
         return f"rcx::{kern}<{lpp}, {t}>"
+    if plan.startswith("lanes(k_recconv_lanes"):
+        kern = plan[len("lanes("):plan.index(">")]
+        return f"rcx::lanes::{kern}, {t}>"
     return "rcx::k_conv_generic<...> (one launch per ladder step)"
 
 

@@ -93,11 +93,11 @@ int rcx_abi_version(void) { return RCX_ABI_VERSION; }
 
 const char* rcx_last_error(void) { return g_err; }
 
-const char* rcx_recconv2d_fwd_plan(int N, int C, int H, int W, int level, int k, int /*mode*/, int dtype)
+const char* rcx_recconv2d_fwd_plan(int N, int C, int H, int W, int level, int k, int mode, int dtype)
 {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0) return "invalid";
-    static thread_local char desc[96];
-    if (use_lanes(N, C, H, W, level, k, dtype) && rcx::lanes_describe(N, C, H, W, level, k, dtype, desc, (int)sizeof(desc)) > 0) return desc;
+    static thread_local char desc[160];
+    if (use_lanes(N, C, H, W, level, k, dtype) && rcx::lanes_describe(N, C, H, W, level, k, mode == RCX_MODE_NEAREST ? 1 : 0, dtype, desc, (int)sizeof(desc)) > 0) return desc;
     if (!use_plane(N, C, H, W, level, k, dtype)) return "generic";
     if (rcx::plane_describe(N, C, H, W, level, k, dtype, desc, (int)sizeof(desc)) <= 0) return "generic";
     return desc;

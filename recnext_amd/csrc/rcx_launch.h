@@ -24,7 +24,7 @@ hipError_t plane_recconv(const void* x, void* y, const float* wpack, const float
 
 // rcx_lanes.hip -- register-resident schedule for the 7*2^k planes (k=5, natural level)
 bool lanes_applicable(int N, int C, int H, int W, int level, int k, int dtype);
-int lanes_describe(int N, int C, int H, int W, int level, int k, int dtype, char* buf, int len);
+int lanes_describe(int N, int C, int H, int W, int level, int k, int mode, int dtype, char* buf, int len);
 hipError_t lanes_recconv(const void* x, void* y, const float* wpack, const float* bpack,
                          int N, int C, int H, int W, int level, int k, int mode, int dtype, hipStream_t s);
 
