@@ -84,7 +84,7 @@ bool use_lanes(int N, int C, int H, int W, int level, int k, int dtype)
 }  // namespace
 
 #ifdef RCX_STAMPS
-namespace rcx { hipError_t set_stamp_buffer(void* p); }
+namespace rcx { hipError_t set_stamp_buffer(void* p); namespace lanes { hipError_t set_stamp_buffer(void* p); } }
 #endif
 
 extern "C" {
@@ -331,7 +331,12 @@ int rcx_dwconv2d_mult2_fwd(const void* x, void* y, const float* w_kkc, const flo
     if (int rc = check_common(x, y, N, Cin, H, W, k, dtype)) return rc;
     if (!w_kkc) return fail(RCX_ERR_BAD_ARG, "null weight");
     if (stride != 1 && stride != 2) return fail(RCX_ERR_UNSUPPORTED, "stride %d not supported (1 or 2)", stride);
-    hipError_t e = rcx::generic_dwconv_mult2(x, y, w_kkc, bias, N, Cin, H, W, k, stride, dtype, (hipStream_t)stream);
+    const char* f = getenv("RCX_FORCE_GENERIC");
+    hipError_t e;
+    if (!(f && *f && *f != '0') && rcx::down_lanes_applicable(N, Cin, H, W, k, stride, dtype))
+        e = rcx::down_lanes(x, y, w_kkc, bias, N, Cin, H, W, k, stride, dtype, (hipStream_t)stream);
+    else
+        e = rcx::generic_dwconv_mult2(x, y, w_kkc, bias, N, Cin, H, W, k, stride, dtype, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_dwconv2d_mult2_fwd");
 }
 
@@ -354,7 +359,7 @@ int rcx_upadd_dwconv_fwd(const void* x, const void* coarse, void* y, const float
 
 #ifdef RCX_STAMPS
 /* diagnostic build only: not part of include/recnext_amd.h */
-int rcx_debug_set_stamp_buffer(void* p) { return (int)rcx::set_stamp_buffer(p); }
+int rcx_debug_set_stamp_buffer(void* p) { int e = (int)rcx::set_stamp_buffer(p); return e ? e : (int)rcx::lanes::set_stamp_buffer(p); }
 #endif
 
 }  // extern "C"

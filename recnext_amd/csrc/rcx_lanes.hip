@@ -14,53 +14,24 @@
 // All shapes, row indices and the vertical resize tables are compile-time; the horizontal resize uses
 // per-lane weights computed once with ATen's float index arithmetic (rcx_common.h), so the border
 // clamping and the irregular 4 -> 7 step need no special code.
-#include <utility>
-
-#include "rcx_common.h"
+#include "rcx_lanes.h"
 #include "rcx_launch.h"
 
 namespace rcx {
 namespace lanes {
 
-template <int I> using IC = std::integral_constant<int, I>;
-template <class F, int... Is>
-__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, Is...>) { (f(IC<Is>{}), ...); }
-// compile-time loop: f(IC<0>) ... f(IC<N-1>)
-template <int N, class F>
-__device__ __forceinline__ void sfor(F&& f) { sfor_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
-
-#define RCX_INL __attribute__((always_inline))
-#ifndef RCX_ROW_FENCE
-#define RCX_ROW_FENCE __builtin_amdgcn_sched_barrier(0)
+// Diagnostic build only (-DRCX_STAMPS): thread 0 of the first workgroups records the cycle counter at phase boundaries
+// (tools/stamps_lanes.py).  The shipped library compiles these to nothing.
+#ifdef RCX_STAMPS
+__device__ unsigned long long* g_lane_stamps = nullptr;
+#define RCX_LSTAMP(id)                                                                                   \
+    do {                                                                                                \
+        if (threadIdx.x == 0 && g_lane_stamps && blockIdx.x < 256)                                      \
+            g_lane_stamps[blockIdx.x * 64 + (id)] = __builtin_readcyclecounter();                       \
+    } while (0)
+#else
+#define RCX_LSTAMP(id) do { } while (0)
 #endif
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // plain vector loads/stores (HIP's uint4 copies as memcpy)
-
-// ------------------------------------------------------------------------------------------------
-// lane shifts inside a 16-lane DPP row; lanes shifted in from outside the row, or from an
-// EXEC-disabled lane, read 0
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-
-// value held by the lane N below (LPC == 8: chained single steps, so a value never jumps over the guard lane)
-template <int N, int LPC>
-__device__ __forceinline__ float from_left(float v)
-{
-    if constexpr (N == 0) return v;
-    else if constexpr (LPC == 16) return dpp_mov<0x110 + N>(v);      // row_shr:N
-    else return from_left<N - 1, LPC>(dpp_mov<0x111>(v));
-}
-
-template <int N, int LPC>
-__device__ __forceinline__ float from_right(float v)
-{
-    if constexpr (N == 0) return v;
-    else if constexpr (LPC == 16) return dpp_mov<0x100 + N>(v);      // row_shl:N
-    else return from_right<N - 1, LPC>(dpp_mov<0x101>(v));
-}
 
 // ------------------------------------------------------------------------------------------------
 // compile-time geometry
@@ -323,17 +294,6 @@ struct Level {
     }
 };
 
-// ------------------------------------------------------------------------------------------------
-template <typename TIO> struct Raw;
-template <> struct Raw<float> {
-    static __device__ __forceinline__ float ld(const unsigned char* p) { return *reinterpret_cast<const float*>(p); }
-    static __device__ __forceinline__ void st(unsigned char* p, float v) { *reinterpret_cast<float*>(p) = v; }
-};
-template <> struct Raw<bf16_t> {
-    static __device__ __forceinline__ float ld(const unsigned char* p) { return bf16_to_f32(*reinterpret_cast<const bf16_t*>(p)); }
-    static __device__ __forceinline__ void st(unsigned char* p, float v) { *reinterpret_cast<bf16_t*>(p) = f32_to_bf16(v); }
-};
-
 struct LanesArgs {
     int N, C;
     int nblk;          // channel blocks per image (C / CBW)
@@ -384,7 +344,7 @@ void k_recconv_lanes(const TIO* __restrict__ x, TIO* __restrict__ y, const float
         cidx = have[i] ? cidx : NCHUNKS - 1;
         const int p = cidx / CPP, part = cidx % CPP;
         g_off[i] = p * a.C * ESZ + part * 16;
-        l_off[i] = p * PITCH + part * 16;
+        l_off[i] = lds_slot<W0, B0, LA>(p) * PITCH + part * 16;
     });
     u32x4 v[STAGE];
     auto prefetch = [&](int n) RCX_INL {
@@ -422,7 +382,7 @@ void k_recconv_lanes(const TIO* __restrict__ x, TIO* __restrict__ y, const float
     c.mode = MODE;
     const int ch = wave * CPW + lane / LPC;
     const bool active = c.lane_in_group < LA;
-    unsigned char* mine = img + (c.lane_in_group * B0) * PITCH + ch * ESZ;
+    unsigned char* mine = img + c.lane_in_group * PITCH + ch * ESZ;   // + (row * W0 + j * LA) * PITCH for column j of the lane
     const float* my_taps = taps + ch;
 
     for (int n = n0; n < n1; ++n) {
@@ -438,11 +398,11 @@ void k_recconv_lanes(const TIO* __restrict__ x, TIO* __restrict__ y, const float
             Level<LPC, MODE, 0, LEVEL, W0, B0, 1, CBW>::run_io(
                 [&](auto R, float (&row)[B0]) RCX_INL {
 #pragma unroll
-                    for (int j = 0; j < B0; ++j) row[j] = Raw<TIO>::ld(mine + (decltype(R)::value * W0 + j) * PITCH);
+                    for (int j = 0; j < B0; ++j) row[j] = Raw<TIO>::ld(mine + (decltype(R)::value * W0 + j * LA) * PITCH);
                 },
                 [&](auto O, const float (&acc)[B0]) RCX_INL {
 #pragma unroll
-                    for (int j = 0; j < B0; ++j) Raw<TIO>::st(mine + (decltype(O)::value * W0 + j) * PITCH, acc[j]);
+                    for (int j = 0; j < B0; ++j) Raw<TIO>::st(mine + (decltype(O)::value * W0 + j * LA) * PITCH, acc[j]);
                 },
                 my_taps, c);
         }
@@ -463,8 +423,11 @@ void k_recconv_lanes(const TIO* __restrict__ x, TIO* __restrict__ y, const float
 // final conv, y rows written back into the ring and stored band by band).  Levels >= 1 run in registers between the passes.
 // One __syncthreads per band; the partial sums that straddle a band boundary are carried in registers; the plane P is a
 // register array indexed through a uniform switch on the band number (only the taken case executes).
+#ifndef RCX_BANDED_WPE
+#define RCX_BANDED_WPE
+#endif
 template <int W0, int LEVEL, int LPC, int MODE, int NW, int SR, typename TIO>
-__global__ __launch_bounds__(NW * 64)
+__global__ __launch_bounds__(NW * 64) RCX_BANDED_WPE
 void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack, LanesArgs a)
 {
     constexpr int LA = LPC == 8 ? 7 : 14;
@@ -500,7 +463,7 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
         cidx = have[i] ? cidx : NCHUNKS - 1;
         const int p = cidx / CPP, part = cidx % CPP;
         g_off[i] = p * a.C * ESZ + part * 16;
-        l_off[i] = p * PITCH + part * 16;
+        l_off[i] = lds_slot<W0, B0, LA>(p) * PITCH + part * 16;
     });
     u32x4 v[STAGE];
     auto prefetch = [&](int n, int band) RCX_INL {
@@ -511,6 +474,19 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
         sfor<STAGE>([&](auto I) RCX_INL {
             constexpr int i = decltype(I)::value;
             if (have[i]) *reinterpret_cast<u32x4*>(slot + l_off[i]) = v[i];
+        });
+    };
+    // a finished y band leaves in two halves so that neither round trip is waited for: LDS -> registers right after the
+    // barrier, registers -> global memory after the band's arithmetic
+    u32x4 yv[STAGE];
+    auto lift_band = [&](const unsigned char* slot) RCX_INL {
+        sfor<STAGE>([&](auto I) RCX_INL { yv[decltype(I)::value] = *reinterpret_cast<const u32x4*>(slot + l_off[decltype(I)::value]); });
+    };
+    auto drop_band = [&](int n, int band) RCX_INL {
+        unsigned char* yg = reinterpret_cast<unsigned char*>(y + (size_t)n * img_stride + c0) + (size_t)band * band_stride;
+        sfor<STAGE>([&](auto I) RCX_INL {
+            constexpr int i = decltype(I)::value;
+            if (have[i]) *reinterpret_cast<u32x4*>(yg + g_off[i]) = yv[i];
         });
     };
     auto store_band = [&](int n, int band, const unsigned char* slot) RCX_INL {
@@ -548,10 +524,11 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
     c.mode = MODE;
     const int ch = wave * CPW + lane / LPC;
     const bool active = c.lane_in_group < LA;
-    const int mine = (c.lane_in_group * B0) * PITCH + ch * ESZ;       // byte offset of the lane's first column inside a band
+    const int mine = c.lane_in_group * PITCH + ch * ESZ;              // + (row * W0 + j * LA) * PITCH for column j of the lane
     const float* my_taps = taps + ch;
     constexpr VT te = vtab(MODE, H1, H0, 2), to = vtab(MODE, H1, H0, 3);   // vertical weights of an interior even / odd row
 
+    RCX_LSTAMP(0);
     int slot = 0;
     auto slot_ptr = [&](int k) RCX_INL { return ring + ((slot + k) % 3) * BAND_BYTES; };
 
@@ -560,24 +537,33 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
         // ================= pass 1: F_1 = down(x) =================
         {
             float A[2][B1];
+            float w[25], bias;
+            if (active) load_taps<CBW>(my_taps, w, bias);            // stays in registers for the whole pass
 #pragma unroll 1
             for (int s = 0; s < NS; ++s) {
                 unsigned char* cur = slot_ptr(0);
                 stage_in(cur);
+                if (n == n0 && s < 4) RCX_LSTAMP(8 + 3 * s);
                 __syncthreads();
+                if (n == n0 && s < 4) RCX_LSTAMP(9 + 3 * s);
                 prefetch(n, s + 1 < NS ? s + 1 : 0);
                 if (active) {
-                    float w[25], bias;
-                    load_taps<CBW>(my_taps, w, bias);
                     float L[HS + 2][B1];
 #pragma unroll
                     for (int cidx = 0; cidx < B1; ++cidx) { L[0][cidx] = s == 0 ? bias : A[0][cidx]; L[1][cidx] = s == 0 ? bias : A[1][cidx]; }
                     const unsigned char* xb = cur + mine;
+                    float nxt[B0];                                      // next row's x, loaded one row ahead of its use
+#pragma unroll
+                    for (int j = 0; j < B0; ++j) nxt[j] = Raw<TIO>::ld(xb + (j * LA) * PITCH);
                     sfor<SR>([&](auto I) RCX_INL {
                         constexpr int i = decltype(I)::value;
                         float row[B0], ext[B0 + 4];
 #pragma unroll
-                        for (int j = 0; j < B0; ++j) row[j] = Raw<TIO>::ld(xb + (i * W0 + j) * PITCH);
+                        for (int j = 0; j < B0; ++j) row[j] = nxt[j];
+                        if constexpr (i + 1 < SR) {
+#pragma unroll
+                            for (int j = 0; j < B0; ++j) nxt[j] = Raw<TIO>::ld(xb + ((i + 1) * W0 + j * LA) * PITCH);
+                        }
                         make_ext<LPC, B0, 1>(row, ext);
                         sfor<5>([&](auto U) RCX_INL {
                             constexpr int u = decltype(U)::value;
@@ -612,6 +598,7 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
 #pragma unroll
                     for (int q = 0; q < B1; ++q) { A[0][q] = L[HS][q]; A[1][q] = L[HS + 1][q]; }
                 }
+                if (n == n0 && s < 4) RCX_LSTAMP(10 + 3 * s);
                 slot = (slot + 1) % 3;
             }
             if (active) {
@@ -620,6 +607,7 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
             }
         }
         // ================= levels >= 1 in registers: P <- C_1 =================
+        if (n == n0) RCX_LSTAMP(1);
         float wt[B0][2];
         if (active) {
             float Q[H1][B1];
@@ -631,20 +619,24 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
             hweights_2x<B1, B0>(c, W1, W0, wt);
         }
         // ================= pass 2: y = conv_L(x + resize(C_1)) =================
+        if (n == n0) RCX_LSTAMP(2);
         {
             float Cy[4][B0];
+            float w[25], bias;
+            if (active) load_taps<CBW>(my_taps + (1 + LEVEL) * 26 * CBW, w, bias);
 #pragma unroll 1
             for (int s = 0; s < NS; ++s) {
                 unsigned char* cur = slot_ptr(0);
                 unsigned char* prev = slot_ptr(2);
                 stage_in(cur);
+                if (n == n0 && s < 4) RCX_LSTAMP(24 + 4 * s);
                 __syncthreads();
+                if (n == n0 && s < 4) RCX_LSTAMP(25 + 4 * s);
                 if (s + 1 < NS) prefetch(n, s + 1);
                 else if (n + 1 < n1) prefetch(n + 1, 0);
-                if (s >= 2) store_band(n, s - 2, slot_ptr(1));
+                if (s >= 2) lift_band(slot_ptr(1));
+                if (n == n0 && s < 4) RCX_LSTAMP(26 + 4 * s);
                 if (active) {
-                    float w[25], bias;
-                    load_taps<CBW>(my_taps + (1 + LEVEL) * 26 * CBW, w, bias);
                     // coarse rows HS*s - 1 .. HS*s + HS (clamped) out of the register plane, then resized horizontally.
                     // The empty asm keeps the resize inside the band loop (hoisted, it would hold every band's rows live).
                     float cw[HS + 2][B1], hw[HS + 2][B0];
@@ -671,16 +663,23 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
                         for (int j = 0; j < B0; ++j) L[k][j] = s == 0 ? bias : Cy[k][j];
                     unsigned char* xb = cur + mine;
                     unsigned char* pb = prev + mine;
+                    float nxt[B0];                                      // next row's x, loaded one row ahead of its use
+#pragma unroll
+                    for (int j = 0; j < B0; ++j) nxt[j] = Raw<TIO>::ld(xb + (j * LA) * PITCH);
                     sfor<SR>([&](auto I) RCX_INL {
                         constexpr int i = decltype(I)::value;
                         constexpr int mr = i / 2;
                         float row[B0], ext[B0 + 4];
 #pragma unroll
                         for (int j = 0; j < B0; ++j) {
-                            const float xv = Raw<TIO>::ld(xb + (i * W0 + j) * PITCH);
+                            const float xv = nxt[j];
                             if constexpr (MODE == 1) row[j] = xv + hw[mr + 1][j];
                             else if constexpr ((i & 1) == 0) row[j] = xv + fmaf(te.l, hw[mr + 1][j], (1.f - te.l) * hw[mr][j]);
                             else row[j] = xv + fmaf(to.l, hw[mr + 2][j], (1.f - to.l) * hw[mr + 1][j]);
+                        }
+                        if constexpr (i + 1 < SR) {
+#pragma unroll
+                            for (int j = 0; j < B0; ++j) nxt[j] = Raw<TIO>::ld(xb + ((i + 1) * W0 + j * LA) * PITCH);
                         }
                         make_ext<LPC, B0, 1>(row, ext);
                         sfor<5>([&](auto U) RCX_INL {
@@ -698,11 +697,11 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
                         if constexpr (i < 2) {
                             if (s > 0) {
 #pragma unroll
-                                for (int j = 0; j < B0; ++j) Raw<TIO>::st(pb + ((SR + i - 2) * W0 + j) * PITCH, L[i][j]);
+                                for (int j = 0; j < B0; ++j) Raw<TIO>::st(pb + ((SR + i - 2) * W0 + j * LA) * PITCH, L[i][j]);
                             }
                         } else {
 #pragma unroll
-                            for (int j = 0; j < B0; ++j) Raw<TIO>::st(xb + ((i - 2) * W0 + j) * PITCH, L[i][j]);
+                            for (int j = 0; j < B0; ++j) Raw<TIO>::st(xb + ((i - 2) * W0 + j * LA) * PITCH, L[i][j]);
                         }
                         RCX_ROW_FENCE;
                     });
@@ -711,6 +710,8 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
 #pragma unroll
                         for (int j = 0; j < B0; ++j) Cy[k][j] = L[SR + k][j];
                 }
+                if (s >= 2) drop_band(n, s - 2);
+                if (n == n0 && s < 4) RCX_LSTAMP(27 + 4 * s);
                 slot = (slot + 1) % 3;
             }
             // rows H0-2, H0-1 into the last band's slot
@@ -719,11 +720,12 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
 #pragma unroll
-                    for (int j = 0; j < B0; ++j) Raw<TIO>::st(pb + ((SR - 2 + k) * W0 + j) * PITCH, Cy[k][j]);
+                    for (int j = 0; j < B0; ++j) Raw<TIO>::st(pb + ((SR - 2 + k) * W0 + j * LA) * PITCH, Cy[k][j]);
             }
             __syncthreads();
             if (NS >= 2) store_band(n, NS - 2, slot_ptr(1));
             store_band(n, NS - 1, slot_ptr(2));
+            if (n == n0) RCX_LSTAMP(3);
         }
     }
 }
@@ -771,7 +773,7 @@ static LanesPlan plan(int N, int C, int H, int W, int level, int k, int dtype)
     int ni = env_int("RCX_LANES_NI", 0);
     if (ni <= 0) {
         ni = 1;
-        while ((long)p.args.nblk * ((N + 2 * ni - 1) / (2 * ni)) >= 1024 && ni < 4) ni *= 2;
+        while ((long)p.args.nblk * ((N + 2 * ni - 1) / (2 * ni)) >= 2048 && ni < 4) ni *= 2;
     }
     p.args.ni = ni;
     p.ok = true;
@@ -845,6 +847,14 @@ static hipError_t launch_m(const void* x, void* y, const float* wpack, const flo
     if (p.w0 == 56) return launch_b<56, 4, 16, MODE, 4, TIO>(x, y, wpack, bpack, p, s);
     return hipErrorInvalidConfiguration;
 }
+
+#ifdef RCX_STAMPS
+hipError_t set_stamp_buffer(void* p)
+{
+    unsigned long long* q = (unsigned long long*)p;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_lane_stamps), &q, sizeof(q));
+}
+#endif
 
 }  // namespace lanes
 

@@ -230,7 +230,8 @@ def test_runs_on_a_side_stream():
     assert torch.equal(y0, y1)
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 11, 9), (2, 64, 56, 56), (1, 40, 28, 28), (3, 6, 7, 7)])
+@pytest.mark.parametrize("shape", [(2, 8, 11, 9), (2, 64, 56, 56), (1, 40, 28, 28), (3, 6, 7, 7),
+                                   (3, 128, 28, 28), (2, 256, 14, 14), (5, 48, 14, 14), (3, 16, 56, 56)])
 @pytest.mark.parametrize("k,stride", [(7, 2), (5, 2), (3, 1)])
 def test_channel_multiplier_dwconv(shape, k, stride):
     from oracle import recconv_np
