@@ -57,8 +57,10 @@ void k_down_lanes(const TIO* __restrict__ x, TIO* __restrict__ y, const float* _
     unsigned char* oring = xring + 2 * XBAND;                              // [2][OBAND]
 
     const int tid = threadIdx.x;
-    const int cb = blockIdx.x % a.nblk;
-    const int n0 = (blockIdx.x / a.nblk) * a.ni;
+    // workgroup -> (channel block, image group): the channel blocks of one image group get ids that are equal mod 8,
+    // i.e. land on the same XCD (round-robin dispatch) close in time and share its L2 lines
+    const int cb = (blockIdx.x % (8 * a.nblk)) / 8;
+    const int n0 = ((blockIdx.x / (8 * a.nblk)) * 8 + blockIdx.x % 8) * a.ni;
     const int n1 = n0 + a.ni < a.N ? n0 + a.ni : a.N;
     const int ci0 = cb * ICB, co0 = 2 * ci0, Cout = 2 * a.Cin;
     const size_t ximg = (size_t)H0 * W0 * a.Cin, yimg = (size_t)H1 * W1 * Cout;
@@ -281,7 +283,7 @@ static hipError_t launch_down_w(const void* x, void* y, const float* w, const fl
     }
     DownArgs a = p.args;
     a.has_bias = b != nullptr;
-    const unsigned grid = (unsigned)(a.nblk * ((a.N + a.ni - 1) / a.ni));
+    const unsigned grid = (unsigned)(a.nblk * (((a.N + a.ni - 1) / a.ni + 7) / 8 * 8));
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), p.lds, s, (const TIO*)x, (TIO*)y, w, b, a);
     return hipGetLastError();
 }

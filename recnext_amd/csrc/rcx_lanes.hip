@@ -328,8 +328,10 @@ void k_recconv_lanes(const TIO* __restrict__ x, TIO* __restrict__ y, const float
     unsigned char* img = smem + TAPS_BYTES;                        // [HW][PITCH]
 
     const int tid = threadIdx.x;
-    const int cb = blockIdx.x % a.nblk;
-    const int n0 = (blockIdx.x / a.nblk) * a.ni;
+    // workgroup -> (channel block, image group): the channel blocks of one image group get ids that are equal mod 8,
+    // i.e. land on the same XCD (round-robin dispatch) close in time and share its L2 lines
+    const int cb = (blockIdx.x % (8 * a.nblk)) / 8;
+    const int n0 = ((blockIdx.x / (8 * a.nblk)) * 8 + blockIdx.x % 8) * a.ni;
     const int n1 = n0 + a.ni < a.N ? n0 + a.ni : a.N;
     const int c0 = cb * CBW;
     const size_t img_stride = (size_t)HW * a.C;               // elements per image
@@ -447,8 +449,10 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
     unsigned char* ring = smem + TAPS_BYTES;      // [3][BAND_PX][PITCH]
 
     const int tid = threadIdx.x;
-    const int cb = blockIdx.x % a.nblk;
-    const int n0 = (blockIdx.x / a.nblk) * a.ni;
+    // workgroup -> (channel block, image group): the channel blocks of one image group get ids that are equal mod 8,
+    // i.e. land on the same XCD (round-robin dispatch) close in time and share its L2 lines
+    const int cb = (blockIdx.x % (8 * a.nblk)) / 8;
+    const int n0 = ((blockIdx.x / (8 * a.nblk)) * 8 + blockIdx.x % 8) * a.ni;
     const int n1 = n0 + a.ni < a.N ? n0 + a.ni : a.N;
     const int c0 = cb * CBW;
     const size_t img_stride = (size_t)H0 * W0 * a.C;
@@ -529,6 +533,7 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
     constexpr VT te = vtab(MODE, H1, H0, 2), to = vtab(MODE, H1, H0, 3);   // vertical weights of an interior even / odd row
 
     RCX_LSTAMP(0);
+    __syncthreads();                               // taps are read (pass 1 keeps them in registers) before the first band barrier
     int slot = 0;
     auto slot_ptr = [&](int k) RCX_INL { return ring + ((slot + k) % 3) * BAND_BYTES; };
 
@@ -790,7 +795,7 @@ static hipError_t launch_w(const void* x, void* y, const float* wpack, const flo
     }
     LanesArgs a = p.args;
     a.has_bias = bpack != nullptr;
-    const unsigned grid = (unsigned)(a.nblk * ((a.N + a.ni - 1) / a.ni));
+    const unsigned grid = (unsigned)(a.nblk * (((a.N + a.ni - 1) / a.ni + 7) / 8 * 8));
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), p.lds, s, (const TIO*)x, (TIO*)y, wpack, bpack, a);
     return hipGetLastError();
 }
@@ -805,7 +810,7 @@ static hipError_t launch_bw(const void* x, void* y, const float* wpack, const fl
     }
     LanesArgs a = p.args;
     a.has_bias = bpack != nullptr;
-    const unsigned grid = (unsigned)(a.nblk * ((a.N + a.ni - 1) / a.ni));
+    const unsigned grid = (unsigned)(a.nblk * (((a.N + a.ni - 1) / a.ni + 7) / 8 * 8));
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), p.lds, s, (const TIO*)x, (TIO*)y, wpack, bpack, a);
     return hipGetLastError();
 }

@@ -197,6 +197,20 @@ def test_full_size_properties(case, dtype):
         assert np.allclose(got, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
 
 
+@pytest.mark.parametrize("case", [(256, 64, 56, 4), (256, 128, 28, 3), (256, 256, 14, 2), (256, 512, 7, 1)], ids=lambda c: "x".join(map(str, c)))
+def test_repeated_launches_are_bit_identical(case):
+    """Race hunting: a missing barrier in a fused kernel shows up as a rare whole-wave difference at full size
+    (tools/stress_lanes.py is the long version)."""
+    n, c, h, level = case
+    torch.manual_seed(3)
+    mod = recnext_amd.RecConv2d(c, kernel_size=5, level=level).to(dev()).eval()
+    x = torch.randn(n, c, h, h, device=dev()).bfloat16().contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y0 = mod(x).clone()
+        different = sum(0 if torch.equal(mod(x), y0) else 1 for _ in range(150))
+    assert different == 0
+
+
 def test_errors_surface_as_exceptions():
     mod = recnext_amd.RecConv2d(8, level=1).to(dev())
     with pytest.raises(TypeError):
