@@ -11,7 +11,8 @@
 //
 // K^T is the forward depthwise kernel with the taps flipped (the host passes a flipped pack); D^T (stride-2 adjoint)
 // and R^T (resize adjoint) are gathers, so every result is deterministic; weight gradients are reduced in two stages
-// (per-block partials, then a fixed-order sum).  These kernels favour clarity over speed: they are correct HIP, not tuned.
+// (per-block partials, then a fixed-order sum).  The k = 5 weight-gradient kernel (k_wgrad_rows5) is the tuned one; the
+// rest favour clarity over speed.
 #include "rcx_common.h"
 #include "rcx_launch.h"
 
@@ -176,6 +177,202 @@ k_wgrad_partial(const TA* __restrict__ a, const float* __restrict__ coarse, cons
     }
 }
 
+
+// ---- weight / bias gradients for k = 5, the fast path ----
+// One thread = (channel pair, row slot); all 25 tap sums (+ the bias sum) of its channel pair live in registers while it
+// walks whole image rows, so the output gradient is read five times from L1 and the input once per row:
+//   stride 1:  rows are INPUT rows (n, iy): T = a (+ resize(coarse)) is formed once per pixel and multiplied against a
+//              5-wide sliding window of each of the five output-gradient rows iy-2 .. iy+2;
+//   stride 2:  rows are OUTPUT rows (n, oy): for each of the five input rows a 5-wide window slides two pixels per output.
+// A block reduces its 8 row slots through LDS (fixed order) and writes one partial row; k_wgrad_reduce sums the partial
+// rows in a fixed order: bit-reproducible.
+constexpr int WR_LANES = 32, WR_SLOTS = 8;
+
+__device__ __forceinline__ void ld2(const float* p, float (&o)[2]) { float2 t = *reinterpret_cast<const float2*>(p); o[0] = t.x; o[1] = t.y; }
+__device__ __forceinline__ void ld2(const bf16_t* p, float (&o)[2])
+{
+    uint32_t t = *reinterpret_cast<const uint32_t*>(p);
+    o[0] = __uint_as_float(t << 16); o[1] = __uint_as_float(t & 0xffff0000u);
+}
+
+template <typename TA, int S, bool HAS_COARSE>
+__global__ void __launch_bounds__(WR_LANES * WR_SLOTS)
+k_wgrad_rows5(const TA* __restrict__ a, const float* __restrict__ coarse, const float* __restrict__ g,
+              float* __restrict__ partial, BwGeom q, int Ho, int Wo)
+{
+    constexpr int K = 5, P = 2, KK = 25;
+    __shared__ float red[WR_SLOTS][13][WR_LANES * 2];
+    const int cp = blockIdx.x * WR_LANES + threadIdx.x;
+    const bool ok = cp < q.C / 2;
+    const int c = (ok ? cp : 0) * 2;
+    const int slot = blockIdx.y * WR_SLOTS + threadIdx.y, nslots = gridDim.y * WR_SLOTS;
+    float acc[KK][2], accb[2] = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[t][0] = acc[t][1] = 0.f;
+
+    if (ok) {
+        if constexpr (S == 1) {
+            const int rows = q.N * q.H;
+            for (int row = slot; row < rows; row += nslots) {
+                const int n = row / q.H, iy = row - n * q.H;
+                const TA* arow = a + ((size_t)n * q.H + iy) * q.W * q.C + c;
+                const float* gimg = g + (size_t)n * Ho * Wo * q.C + c;
+                const float* cimg = HAS_COARSE ? coarse + (size_t)n * q.Hc * q.Wc * q.C + c : nullptr;
+                Lerp ly{0, 0, 0.f};
+                int ny = 0;
+                if constexpr (HAS_COARSE) {
+                    if (q.mode == 1) ny = nearest_src(iy, q.Hc, q.sy);
+                    else ly = bilinear_src(iy, q.Hc, q.sy);
+                }
+                // gw[u][d] = g(oy_u, ix - 2 + d), oy_u = iy - u + 2; rows outside the image contribute nothing
+                float gw[K][K][2];
+                const float* grow[K];
+                bool gok[K];
+#pragma unroll
+                for (int u = 0; u < K; ++u) {
+                    const int oy = iy - u + P;
+                    gok[u] = oy >= 0 && oy < Ho;
+                    grow[u] = gimg + (size_t)(gok[u] ? oy : 0) * Wo * q.C;
+#pragma unroll
+                    for (int d = 0; d < K; ++d) {
+                        const int ox = d - P;
+                        gw[u][d][0] = gw[u][d][1] = 0.f;
+                        if (gok[u] && ox >= 0 && ox < Wo) ld2(grow[u] + (size_t)ox * q.C, gw[u][d]);
+                    }
+                }
+                for (int ix = 0; ix < q.W; ++ix) {
+                    float t[2];
+                    ld2(arow + (size_t)ix * q.C, t);
+                    if constexpr (HAS_COARSE) {
+                        if (q.mode == 1) {
+                            float cv[2];
+                            ld2(cimg + ((size_t)ny * q.Wc + nearest_src(ix, q.Wc, q.sx)) * q.C, cv);
+                            t[0] += cv[0]; t[1] += cv[1];
+                        } else {
+                            const Lerp lx = bilinear_src(ix, q.Wc, q.sx);
+                            float a00[2], a01[2], a10[2], a11[2];
+                            ld2(cimg + ((size_t)ly.i0 * q.Wc + lx.i0) * q.C, a00);
+                            ld2(cimg + ((size_t)ly.i0 * q.Wc + lx.i1) * q.C, a01);
+                            ld2(cimg + ((size_t)ly.i1 * q.Wc + lx.i0) * q.C, a10);
+                            ld2(cimg + ((size_t)ly.i1 * q.Wc + lx.i1) * q.C, a11);
+                            const float wy1 = ly.lam, wy0 = 1.f - ly.lam, wx1 = lx.lam, wx0 = 1.f - lx.lam;
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) t[i] += wy0 * (wx0 * a00[i] + wx1 * a01[i]) + wy1 * (wx0 * a10[i] + wx1 * a11[i]);
+                        }
+                    }
+                    // tap (u, v) pairs input column ix with output column ix - v + 2, i.e. window slot d = 4 - v
+#pragma unroll
+                    for (int u = 0; u < K; ++u)
+#pragma unroll
+                        for (int v = 0; v < K; ++v) {
+                            acc[u * K + v][0] = fmaf(t[0], gw[u][K - 1 - v][0], acc[u * K + v][0]);
+                            acc[u * K + v][1] = fmaf(t[1], gw[u][K - 1 - v][1], acc[u * K + v][1]);
+                        }
+                    accb[0] += gw[P][P][0]; accb[1] += gw[P][P][1];       // g(iy, ix): every output pixel exactly once
+                    // slide the windows one column
+#pragma unroll
+                    for (int u = 0; u < K; ++u) {
+#pragma unroll
+                        for (int d = 0; d < K - 1; ++d) { gw[u][d][0] = gw[u][d + 1][0]; gw[u][d][1] = gw[u][d + 1][1]; }
+                        const int ox = ix + 1 + P;
+                        gw[u][K - 1][0] = gw[u][K - 1][1] = 0.f;
+                        if (gok[u] && ox < Wo) ld2(grow[u] + (size_t)ox * q.C, gw[u][K - 1]);
+                    }
+                }
+            }
+        } else {
+            const int rows = q.N * Ho;
+            for (int row = slot; row < rows; row += nslots) {
+                const int n = row / Ho, oy = row - n * Ho;
+                const float* grow = g + ((size_t)n * Ho + oy) * Wo * q.C + c;
+                const TA* aimg = a + (size_t)n * q.H * q.W * q.C + c;
+                // aw[u][d] = a(2*oy + u - 2, 2*ox - 2 + d)
+                float aw[K][K][2];
+                const TA* arow[K];
+                bool aok[K];
+#pragma unroll
+                for (int u = 0; u < K; ++u) {
+                    const int iy = 2 * oy + u - P;
+                    aok[u] = iy >= 0 && iy < q.H;
+                    arow[u] = aimg + (size_t)(aok[u] ? iy : 0) * q.W * q.C;
+#pragma unroll
+                    for (int d = 0; d < K; ++d) {
+                        const int ix = d - P;
+                        aw[u][d][0] = aw[u][d][1] = 0.f;
+                        if (aok[u] && ix >= 0 && ix < q.W) ld2(arow[u] + (size_t)ix * q.C, aw[u][d]);
+                    }
+                }
+                for (int ox = 0; ox < Wo; ++ox) {
+                    float gv[2];
+                    ld2(grow + (size_t)ox * q.C, gv);
+                    accb[0] += gv[0]; accb[1] += gv[1];
+#pragma unroll
+                    for (int u = 0; u < K; ++u)
+#pragma unroll
+                        for (int v = 0; v < K; ++v) {
+                            acc[u * K + v][0] = fmaf(aw[u][v][0], gv[0], acc[u * K + v][0]);
+                            acc[u * K + v][1] = fmaf(aw[u][v][1], gv[1], acc[u * K + v][1]);
+                        }
+#pragma unroll
+                    for (int u = 0; u < K; ++u) {
+#pragma unroll
+                        for (int d = 0; d < K - 2; ++d) { aw[u][d][0] = aw[u][d + 2][0]; aw[u][d][1] = aw[u][d + 2][1]; }
+#pragma unroll
+                        for (int d = K - 2; d < K; ++d) {
+                            const int ix = 2 * (ox + 1) - P + d;
+                            aw[u][d][0] = aw[u][d][1] = 0.f;
+                            if (aok[u] && ix < q.W) ld2(arow[u] + (size_t)ix * q.C, aw[u][d]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // block reduction over the row slots, 13 tap rows at a time (26 = 25 taps + bias), fixed order
+    float* prow = partial + (size_t)blockIdx.y * (KK + 1) * q.C + c;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            const int t = half * 13 + i;
+            red[threadIdx.y][i][threadIdx.x * 2 + 0] = t < KK ? acc[t < KK ? t : 0][0] : accb[0];
+            red[threadIdx.y][i][threadIdx.x * 2 + 1] = t < KK ? acc[t < KK ? t : 0][1] : accb[1];
+        }
+        __syncthreads();
+        // 13 * 64 sums, 256 threads
+        for (int e = threadIdx.y * WR_LANES + threadIdx.x; e < 13 * WR_LANES * 2; e += WR_LANES * WR_SLOTS) {
+            const int i = e / (WR_LANES * 2), l = e - i * (WR_LANES * 2);
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < WR_SLOTS; ++r) sum += red[r][i][l];
+            const int ch = blockIdx.x * WR_LANES * 2 + l;
+            if (ch < q.C) partial[((size_t)blockIdx.y * (KK + 1) + half * 13 + i) * q.C + ch] = sum;
+        }
+    }
+    (void)prow;
+}
+
+// stage 2, parallel form: 8 threads share one output (rows r = j mod 8 each), fixed-order combine through LDS
+__global__ void __launch_bounds__(256)
+k_wgrad_reduce8(const float* __restrict__ partial, float* __restrict__ gw, float* __restrict__ gb, int rows, int kk, int C, int accumulate)
+{
+    __shared__ float red[8][32];
+    const int i = blockIdx.x * 32 + threadIdx.x, j = threadIdx.y, total = (kk + 1) * C;
+    float s = 0.f;
+    if (i < total)
+        for (int r = j; r < rows; r += 8) s += partial[(size_t)r * total + i];
+    red[j][threadIdx.x] = s;
+    __syncthreads();
+    if (j == 0 && i < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += red[r][threadIdx.x];
+        if (i < kk * C) gw[i] = accumulate ? gw[i] + t : t;
+        else if (gb) gb[i - kk * C] = accumulate ? gb[i - kk * C] + t : t;
+    }
+}
+
 // stage 2: dst[i] (+)= sum over rows of partial[row][i], fixed order
 __global__ void __launch_bounds__(256)
 k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ gw, float* __restrict__ gb, int rows, int kk, int C, int accumulate)
@@ -199,12 +396,40 @@ static unsigned grid_for(long long total)
 constexpr int WG_ROWS_Y = 8;       // blockDim.y of k_wgrad_partial
 constexpr int WG_BLOCKS_Y = 64;    // gridDim.y
 
-size_t wgrad_partial_bytes(int C, int k) { return sizeof(float) * (size_t)WG_ROWS_Y * WG_BLOCKS_Y * (k * k + 1) * C; }
+// partial rows of the k = 5 path: about 1024 blocks in total whatever C is
+static int wr_grid_y(int C)
+{
+    const int gx = (C / 2 + WR_LANES - 1) / WR_LANES;
+    int gy = 1024 / gx;
+    return gy < 32 ? 32 : gy;
+}
+
+size_t wgrad_partial_bytes(int C, int k)
+{
+    const size_t old = sizeof(float) * (size_t)WG_ROWS_Y * WG_BLOCKS_Y * (k * k + 1) * C;
+    const size_t fast = sizeof(float) * (size_t)wr_grid_y(C) * 26 * C;
+    return old > fast ? old : fast;
+}
 
 template <typename TA>
 static hipError_t wgrad_launch(const void* a, const float* coarse, const float* g, float* partial, float* gw, float* gb,
                                BwGeom q, int Ho, int Wo, int stride, int accumulate, hipStream_t s)
 {
+    if (q.k == 5 && (q.C % 2) == 0) {
+        const int rows_total = stride == 2 ? q.N * Ho : q.N * q.H;
+        int gy = wr_grid_y(q.C);
+        const int need = (rows_total + WR_SLOTS - 1) / WR_SLOTS;
+        if (gy > need) gy = need < 1 ? 1 : need;
+        dim3 block(WR_LANES, WR_SLOTS), grid((q.C / 2 + WR_LANES - 1) / WR_LANES, gy);
+        if (stride == 2) hipLaunchKernelGGL((k_wgrad_rows5<TA, 2, false>), grid, block, 0, s, (const TA*)a, coarse, g, partial, q, Ho, Wo);
+        else if (coarse) hipLaunchKernelGGL((k_wgrad_rows5<TA, 1, true>), grid, block, 0, s, (const TA*)a, coarse, g, partial, q, Ho, Wo);
+        else hipLaunchKernelGGL((k_wgrad_rows5<TA, 1, false>), grid, block, 0, s, (const TA*)a, coarse, g, partial, q, Ho, Wo);
+        hipError_t e5 = hipGetLastError();
+        if (e5 != hipSuccess) return e5;
+        const int n5 = 26 * q.C;
+        hipLaunchKernelGGL(k_wgrad_reduce8, dim3((n5 + 31) / 32), dim3(32, 8), 0, s, partial, gw, gb, gy, 25, q.C, accumulate);
+        return hipGetLastError();
+    }
     const int cvecs = q.C / BW_V;
     dim3 block(32, WG_ROWS_Y), grid((cvecs + 31) / 32, WG_BLOCKS_Y);
     if (stride == 2) hipLaunchKernelGGL((k_wgrad_partial<TA, 2, false>), grid, block, 0, s, (const TA*)a, coarse, g, partial, q, Ho, Wo);

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Forward+backward time of one RecConv2d block: HIP autograd function vs the ATen operator chain (development tool)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import recnext_amd
+from oracle.torch_eager import EagerRecConv2d
+
+dev = torch.device("cuda:0")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+for dtype in (torch.bfloat16, torch.float32):
+    for c, h, level in [(64, 56, 4), (128, 28, 3), (256, 14, 2), (512, 7, 1)]:
+        res = {"shape": [n, c, h, h], "level": level, "dtype": str(dtype).split(".")[-1]}
+        for name, cls in (("hip", recnext_amd.RecConv2d), ("aten", EagerRecConv2d)):
+            torch.manual_seed(0)
+            mod = cls(c, kernel_size=5, level=level).to(dev).to(dtype).train()
+            x = torch.randn(n, c, h, h, device=dev).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            g = torch.randn(n, c, h, h, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+
+            def step():
+                y = mod(x)
+                y.backward(g)
+                x.grad = None
+                for p in mod.parameters():
+                    p.grad = None
+
+            for _ in range(3):
+                step()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(10):
+                step()
+            e.record()
+            torch.cuda.synchronize()
+            res[name + "_fwd_bwd_ms"] = round(s.elapsed_time(e) / 10, 3)
+        print(json.dumps(res), flush=True)
