@@ -114,6 +114,18 @@ int rcx_upadd_dwconv_fwd(const void* x, const void* coarse, void* y, const float
                          int N, int C, int H, int W, int Hc, int Wc, int k, int mode,
                          int x_dtype, int coarse_dtype, int out_dtype, void* stream);
 
+/*
+ * Linear-attention core of RecAttn2d's coarse level: everything after the grouped 1x1 `qk` conv of
+ * LinearAttention1.forward (model/recattn.py:21-28) / LinearAttention2.forward (:44-51; the same function):
+ *     q = elu(qpre)+1, k = elu(kpre)+1; out = q^T (k v^T) / (n * (q^T mean_n(k) + 1e-6)) + pe
+ *   qpre, kpre: B x n x C pre-activations of the q / k halves of the `qk` conv (BatchNorm folded, bias added);
+ *   v: B x n x C, the attention input itself (:22); pe: B x n x C, output of the `pe` depthwise 3x3 ConvNorm (:27);
+ *   out: B x n x C.  n = h*w tokens, token-major (= NHWC); head h owns channels [h*C/heads, (h+1)*C/heads).
+ *   All five tensors share `dtype`; C/heads at most 64 (at most 32 unless it is a multiple of 4).
+ */
+int rcx_linear_attention_fwd(const void* qpre, const void* kpre, const void* v, const void* pe, void* out,
+                             int B, int n, int C, int heads, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

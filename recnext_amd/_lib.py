@@ -34,6 +34,7 @@ SIGNATURES = {
     "rcx_dwconv2d_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "rcx_dwconv2d_mult2_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
     "rcx_upadd_dwconv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
+    "rcx_linear_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 5 + [_vp]),
 }
 
 _lib = None

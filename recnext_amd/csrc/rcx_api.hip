@@ -81,6 +81,29 @@ bool use_lanes(int N, int C, int H, int W, int level, int k, int dtype)
     return rcx::lanes_applicable(N, C, H, W, level, k, dtype);
 }
 
+bool lanes_off()
+{
+    const char* f = getenv("RCX_FORCE_GENERIC");
+    return f && *f && *f != '0';
+}
+
+// one ladder rung / one up-recursion step: the register-resident kernel where it applies, else the generic one
+hipError_t step_dwconv(const void* x, void* y, const float* w, const float* b, int N, int C, int H, int W, int k, int stride,
+                       int in_dt, int out_dt, hipStream_t s)
+{
+    if (!lanes_off() && rcx::down5_lanes_applicable(N, C, H, W, k, stride, in_dt, out_dt))
+        return rcx::down5_lanes(x, y, w, b, N, C, H, W, in_dt, out_dt, s);
+    return rcx::generic_dwconv(x, y, w, b, N, C, H, W, k, stride, in_dt, out_dt, s);
+}
+
+hipError_t step_upadd(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int H, int W,
+                      int Hc, int Wc, int k, int mode, int x_dt, int c_dt, int out_dt, hipStream_t s)
+{
+    if (coarse && !lanes_off() && rcx::upadd_lanes_applicable(N, C, H, W, Hc, Wc, k, x_dt, c_dt, out_dt))
+        return rcx::upadd_lanes(x, coarse, y, w, b, N, C, H, W, mode, x_dt, c_dt, s);
+    return rcx::generic_upadd_dwconv(x, coarse, y, w, b, N, C, H, W, Hc, Wc, k, mode, x_dt, c_dt, out_dt, s);
+}
+
 }  // namespace
 
 #ifdef RCX_STAMPS
@@ -242,18 +265,18 @@ int rcx_recconv2d_fwd_train(const void* x, void* y, const float* wpack, const fl
     auto C_ = [&](int l) { return (float*)(ws + L.c_off[l]); };
     hipError_t e;
     for (int l = 1; l <= level; ++l) {
-        e = rcx::generic_dwconv(l == 1 ? x : (const void*)F_(l - 1), F_(l), W_(0), B_(0), N, C, L.h[l - 1], L.w[l - 1], k, 2,
-                                l == 1 ? dtype : RCX_DTYPE_F32, RCX_DTYPE_F32, s);
+        e = step_dwconv(l == 1 ? x : (const void*)F_(l - 1), F_(l), W_(0), B_(0), N, C, L.h[l - 1], L.w[l - 1], k, 2,
+                        l == 1 ? dtype : RCX_DTYPE_F32, RCX_DTYPE_F32, s);
         if (e != hipSuccess) return hip_fail(e, "train fwd: down ladder");
     }
     for (int l = level, j = 0; l >= 1; --l, ++j) {
-        e = rcx::generic_upadd_dwconv(F_(l), l == level ? nullptr : C_(l + 1), C_(l), W_(1 + j), B_(1 + j), N, C, L.h[l], L.w[l],
-                                      l == level ? 0 : L.h[l + 1], l == level ? 0 : L.w[l + 1], k, mode,
-                                      RCX_DTYPE_F32, RCX_DTYPE_F32, RCX_DTYPE_F32, s);
+        e = step_upadd(F_(l), l == level ? nullptr : C_(l + 1), C_(l), W_(1 + j), B_(1 + j), N, C, L.h[l], L.w[l],
+                       l == level ? 0 : L.h[l + 1], l == level ? 0 : L.w[l + 1], k, mode,
+                       RCX_DTYPE_F32, RCX_DTYPE_F32, RCX_DTYPE_F32, s);
         if (e != hipSuccess) return hip_fail(e, "train fwd: up recursion");
     }
-    e = rcx::generic_upadd_dwconv(x, level >= 1 ? C_(1) : nullptr, y, W_(1 + level), B_(1 + level), N, C, H, W,
-                                  level >= 1 ? L.h[1] : 0, level >= 1 ? L.w[1] : 0, k, mode, dtype, RCX_DTYPE_F32, dtype, s);
+    e = step_upadd(x, level >= 1 ? C_(1) : nullptr, y, W_(1 + level), B_(1 + level), N, C, H, W,
+                   level >= 1 ? L.h[1] : 0, level >= 1 ? L.w[1] : 0, k, mode, dtype, RCX_DTYPE_F32, dtype, s);
     return e == hipSuccess ? 0 : hip_fail(e, "train fwd: final conv");
 }
 
@@ -321,7 +344,7 @@ int rcx_dwconv2d_fwd(const void* x, void* y, const float* w_kkc, const float* bi
     if (out_dtype != RCX_DTYPE_F32 && out_dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", out_dtype);
     if (!w_kkc) return fail(RCX_ERR_BAD_ARG, "null weight");
     if (stride != 1 && stride != 2) return fail(RCX_ERR_UNSUPPORTED, "stride %d not supported (1 or 2)", stride);
-    hipError_t e = rcx::generic_dwconv(x, y, w_kkc, bias, N, C, H, W, k, stride, in_dtype, out_dtype, (hipStream_t)stream);
+    hipError_t e = step_dwconv(x, y, w_kkc, bias, N, C, H, W, k, stride, in_dtype, out_dtype, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_dwconv2d_fwd");
 }
 
@@ -352,9 +375,21 @@ int rcx_upadd_dwconv_fwd(const void* x, const void* coarse, void* y, const float
         if (Hc <= 0 || Wc <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive coarse extent %dx%d", Hc, Wc);
         if (coarse_dtype != RCX_DTYPE_F32 && coarse_dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", coarse_dtype);
     }
-    hipError_t e = rcx::generic_upadd_dwconv(x, coarse, y, w_kkc, bias, N, C, H, W, Hc, Wc, k, mode,
-                                             x_dtype, coarse_dtype, out_dtype, (hipStream_t)stream);
+    hipError_t e = step_upadd(x, coarse, y, w_kkc, bias, N, C, H, W, Hc, Wc, k, mode, x_dtype, coarse_dtype, out_dtype, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_upadd_dwconv_fwd");
+}
+
+int rcx_linear_attention_fwd(const void* qpre, const void* kpre, const void* v, const void* pe, void* out,
+                             int B, int n, int C, int heads, int dtype, void* stream)
+{
+    if (!qpre || !kpre || !v || !pe || !out) return fail(RCX_ERR_BAD_ARG, "rcx_linear_attention_fwd: null pointer");
+    if (B <= 0 || n <= 0 || C <= 0 || heads <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive extent B=%d n=%d C=%d heads=%d", B, n, C, heads);
+    if (dtype != RCX_DTYPE_F32 && dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
+    if (C % heads) return fail(RCX_ERR_BAD_ARG, "C=%d is not a multiple of heads=%d", C, heads);
+    const int D = C / heads;
+    if (D > 64 || (D % 4 != 0 && D > 32)) return fail(RCX_ERR_UNSUPPORTED, "head dimension %d not supported (at most 64; at most 32 unless a multiple of 4)", D);
+    hipError_t e = rcx::linattn_core(qpre, kpre, v, pe, out, B, n, C, heads, dtype, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "rcx_linear_attention_fwd");
 }
 
 #ifdef RCX_STAMPS

@@ -1,0 +1,135 @@
+// Linear-attention core of RecAttn2d's coarse level (model/recattn.py:16-28 LinearAttention1, :39-51 LinearAttention2) as
+// one kernel per (image, head) -- SURVEY.md section 8f row 4.  The caller supplies the pre-activations of the grouped 1x1
+// conv (a plain GEMM, left to the GEMM library) in token-major layout; this kernel does everything after it:
+//
+//     q = elu(qpre) + 1,  k = elu(kpre) + 1                         (:21 / :44)
+//     kv = (k * s) @ (v^T * s),  kbar = mean_tokens(k),  s = n^-1/2  (:25 / :48-49 regrouped)
+//     out = q^T @ kv / (q^T @ kbar + 1e-6)  +  pe                   (:26-27 / :50)
+//
+// LinearAttention2 materialises the n x n map A = q^T k, divides by its row mean and multiplies by v: the same function
+// (the reference asserts it to 1e-4, lsnet/model/recattn.py:481-501), so both variants run this O(n d^2) form in fp32.
+// Layout: all five tensors are (B, n, C) = NHWC; head h owns channels [h*D, (h+1)*D), D = C / heads.  G = 4 output columns per
+// thread when D % 4 == 0 (D <= 64), else G = 1 (D <= 32).
+#include "rcx_common.h"
+#include "rcx_launch.h"
+
+namespace rcx {
+
+constexpr int LA_NT = 256;      // threads per block
+constexpr int LA_TT = 64;       // tokens per LDS tile
+constexpr int LA_DMAX = 64;     // largest head dimension
+constexpr int LA_ITEMS = LA_DMAX * LA_DMAX / 4 / LA_NT;   // (e1, e2-quad) items per thread in phase 1: 4
+
+__device__ __forceinline__ float la_ld(const float* p) { return *p; }
+__device__ __forceinline__ float la_ld(const bf16_t* p) { return bf16_to_f32(*p); }
+__device__ __forceinline__ void la_st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void la_st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+__device__ __forceinline__ float elu1(float x) { return (x > 0.f ? x : expm1f(x)) + 1.f; }
+
+template <typename T, int G>
+__global__ void __launch_bounds__(LA_NT)
+k_linattn_core(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* __restrict__ v, const T* __restrict__ pe,
+               T* __restrict__ out, int n, int C, int heads)
+{
+    __shared__ float a_s[LA_TT][LA_DMAX + 1];                 // k tile (phase 1) / q tile (phase 2); +1: odd pitch for column reads
+    __shared__ __attribute__((aligned(16))) float v_s[LA_TT][LA_DMAX];
+    __shared__ __attribute__((aligned(16))) float kv_s[LA_DMAX][LA_DMAX];
+    __shared__ float kbar_s[LA_DMAX];
+    __shared__ float den_s[LA_TT];
+    const int D = C / heads, Q = D / G;                        // Q = column groups per head row
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+    const size_t base = (size_t)b * n * C + (size_t)h * D;
+    const int tid = threadIdx.x;
+    const float s2 = 1.f / (float)n;                            // s * s
+    const int items = D * Q;                                    // (e1, e2-quad) pairs
+
+    // ---- phase 1: kv = sum_t k[t][e1] * v[t][e2] ; kbar = mean_t k[t][e1]
+    float acc[LA_ITEMS][G];
+#pragma unroll
+    for (int j = 0; j < LA_ITEMS; ++j)
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[j][g] = 0.f;
+    float ksum = 0.f;
+    for (int t0 = 0; t0 < n; t0 += LA_TT) {
+        const int tt = n - t0 < LA_TT ? n - t0 : LA_TT;
+        __syncthreads();
+        for (int i = tid; i < tt * D; i += LA_NT) {
+            const int t = i / D, e = i - t * D;
+            const size_t g = base + (size_t)(t0 + t) * C + e;
+            a_s[t][e] = elu1(la_ld(kpre + g));
+            v_s[t][e] = la_ld(v + g);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < LA_ITEMS; ++j) {
+            const int it = tid + j * LA_NT;
+            if (it < items) {
+                const int e1 = it / Q, q4 = (it - e1 * Q) * G;
+                for (int t = 0; t < tt; ++t) {
+                    const float kk = a_s[t][e1];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) acc[j][g] = fmaf(kk, v_s[t][q4 + g], acc[j][g]);
+                }
+            }
+        }
+        if (tid < D)
+            for (int t = 0; t < tt; ++t) ksum += a_s[t][tid];
+    }
+#pragma unroll
+    for (int j = 0; j < LA_ITEMS; ++j) {
+        const int it = tid + j * LA_NT;
+        if (it < items) {
+            const int e1 = it / Q, q4 = (it - e1 * Q) * G;
+#pragma unroll
+            for (int g = 0; g < G; ++g) kv_s[e1][q4 + g] = acc[j][g] * s2;
+        }
+    }
+    if (tid < D) kbar_s[tid] = ksum / (float)n;
+
+    // ---- phase 2: out[t][e2] = sum_e1 q[t][e1] * kv[e1][e2] / (sum_e1 q[t][e1] * kbar[e1] + 1e-6) + pe[t][e2]
+    for (int t0 = 0; t0 < n; t0 += LA_TT) {
+        const int tt = n - t0 < LA_TT ? n - t0 : LA_TT;
+        __syncthreads();
+        for (int i = tid; i < tt * D; i += LA_NT) {
+            const int t = i / D, e = i - t * D;
+            a_s[t][e] = elu1(la_ld(qpre + base + (size_t)(t0 + t) * C + e));
+        }
+        __syncthreads();
+        if (tid < tt) {
+            float d = 0.f;
+            for (int e = 0; e < D; ++e) d = fmaf(a_s[tid][e], kbar_s[e], d);
+            den_s[tid] = d + 1e-6f;
+        }
+        __syncthreads();
+        for (int it = tid; it < tt * Q; it += LA_NT) {
+            const int t = it / Q, q4 = (it - t * Q) * G;
+            float o[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) o[g] = 0.f;
+            for (int e = 0; e < D; ++e) {
+                const float qq = a_s[t][e];
+#pragma unroll
+                for (int g = 0; g < G; ++g) o[g] = fmaf(qq, kv_s[e][q4 + g], o[g]);
+            }
+            const float inv = 1.f / den_s[t];
+            const size_t gi = base + (size_t)(t0 + t) * C + q4;
+#pragma unroll
+            for (int g = 0; g < G; ++g) la_st(out + gi + g, fmaf(o[g], inv, la_ld(pe + gi + g)));
+        }
+    }
+}
+
+hipError_t linattn_core(const void* qpre, const void* kpre, const void* v, const void* pe, void* out,
+                        int B, int n, int C, int heads, int dtype, hipStream_t s)
+{
+    const dim3 grid((unsigned)(B * heads)), block(LA_NT);
+    const bool wide = ((C / heads) % 4) == 0;
+#define RCX_LA_LAUNCH(T, G) hipLaunchKernelGGL((k_linattn_core<T, G>), grid, block, 0, s, (const T*)qpre, (const T*)kpre, (const T*)v, \
+                                               (const T*)pe, (T*)out, n, C, heads)
+    if (dtype == 1) { if (wide) RCX_LA_LAUNCH(bf16_t, 4); else RCX_LA_LAUNCH(bf16_t, 1); }
+    else { if (wide) RCX_LA_LAUNCH(float, 4); else RCX_LA_LAUNCH(float, 1); }
+#undef RCX_LA_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace rcx

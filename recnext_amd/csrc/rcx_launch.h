@@ -32,6 +32,17 @@ hipError_t lanes_recconv(const void* x, void* y, const float* wpack, const float
 bool down_lanes_applicable(int N, int Cin, int H, int W, int k, int stride, int dtype);
 hipError_t down_lanes(const void* x, void* y, const float* w, const float* b, int N, int Cin, int H, int W, int k, int stride, int dtype, hipStream_t s);
 
+// rcx_upadd.hip -- register-resident single steps on the 7*2^k planes: conv5(x + resize(coarse)) and the stride-2 conv5
+bool upadd_lanes_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int x_dt, int c_dt, int out_dt);
+hipError_t upadd_lanes(const void* x, const void* coarse, void* y, const float* w, const float* b,
+                       int N, int C, int H, int W, int mode, int x_dt, int c_dt, hipStream_t s);
+bool down5_lanes_applicable(int N, int C, int H, int W, int k, int stride, int in_dt, int out_dt);
+hipError_t down5_lanes(const void* x, void* y, const float* w, const float* b, int N, int C, int H, int W, int in_dt, int out_dt, hipStream_t s);
+
+// rcx_attn.hip -- linear-attention core of RecAttn2d (after the qk projection)
+hipError_t linattn_core(const void* qpre, const void* kpre, const void* v, const void* pe, void* out,
+                        int B, int n, int C, int heads, int dtype, hipStream_t s);
+
 // rcx_bwd.hip -- backward pieces (deterministic gathers + two-stage weight-gradient reduction)
 size_t wgrad_partial_bytes(int C, int k);
 hipError_t bwd_wgrad(const void* a, int a_dt, const float* coarse, const float* g, float* partial, float* gw, float* gb,

@@ -172,6 +172,29 @@ def dwconv2d_mult2(x, w_kkc, bias=None, k=7, stride=2):
     return y
 
 
+def linear_attention_core(qpre, kpre, v, pe, heads):
+    """Everything after the qk projection of LinearAttention1/2 (model/recattn.py:21-28, :44-51).
+
+    qpre, kpre: (B, n, C) pre-activations; v, pe: N x C x h x w channels_last (viewed as (B, n, C)); returns channels_last like v.
+    """
+    v = _nhwc(v, "v")
+    pe = _nhwc(pe, "pe")
+    b, c, h, w = v.shape
+    n = h * w
+    for t, name in ((qpre, "qpre"), (kpre, "kpre")):
+        _require_gpu(t, name)
+        if tuple(t.shape) != (b, n, c) or not t.is_contiguous() or t.dtype != v.dtype:
+            raise ValueError(f"{name} must be a contiguous ({b}, {n}, {c}) tensor of {v.dtype}, got {tuple(t.shape)} {t.dtype}")
+    if pe.shape != v.shape or pe.dtype != v.dtype:
+        raise ValueError("pe must match v")
+    out = _empty_nhwc(b, c, h, w, v.dtype, v.device)
+    with torch.cuda.device(v.device):
+        rc = _lib.load().rcx_linear_attention_fwd(qpre.data_ptr(), kpre.data_ptr(), v.data_ptr(), pe.data_ptr(), out.data_ptr(),
+                                                  b, n, c, heads, _dt(v), _stream(v.device))
+    _lib.check(rc, "rcx_linear_attention_fwd")
+    return out
+
+
 def recconv2d_forward_train(x, wpack, bpack, level, k, mode="bilinear"):
     """Training forward: same result as recconv2d_forward, plus the saved fp32 pyramid the backward needs."""
     x = _nhwc(x)

@@ -6,9 +6,10 @@
 reference; in eval mode their BatchNorm is a per-channel affine, which is folded into the packed
 weights here whether or not ``replace_batchnorm`` has already replaced the pair by a biased
 ``nn.Conv2d`` (model/recattn.py:89-111).  The HIP kernels cover the two depthwise convs and the fused
-nearest-resize + add + conv; the linear attention at the coarse level (two small batched matmuls
-around a grouped 1x1 conv, model/recattn.py:16-28 / 39-51) stays on PyTorch-ROCm operators for now
-(SURVEY.md section 8f row 4).  Parameter names and shapes equal the reference's.
+nearest-resize + add + conv, the `pe` depthwise 3x3 and the linear-attention core (q/k activation,
+k v^T, normaliser, + pe: ``rcx_linear_attention_fwd``); only the grouped 1x1
+`qk` projection -- two plain GEMMs -- goes through the GEMM library.  ``LinearAttention.forward`` keeps the
+reference's operator chain for CPU tensors (tests, oracle).  Parameter names and shapes equal the reference's.
 """
 import torch
 import torch.nn as nn
@@ -79,7 +80,7 @@ class RecAttn2d(nn.Module):
 
     def _tensors(self):
         out = []
-        for m in (self.down[0], self.conv):
+        for m in (self.down[0], self.conv, self.down[1].qk, self.down[1].pe):
             out += [m.weight, m.bias] if isinstance(m, nn.Conv2d) else \
                 [m.conv.weight, m.norm.weight, m.norm.bias, m.norm.running_mean, m.norm.running_var]
         return [t for t in out if t is not None]
@@ -90,8 +91,17 @@ class RecAttn2d(nn.Module):
             with torch.no_grad():
                 wd, bd = _folded(self.down[0])
                 wc, bc = _folded(self.conv)
+                la = self.down[1]
+                wqk, bqk = _folded(la.qk)                       # (2C, C/2, 1, 1): rows [0,C) = q from channels [0,C/2), rows [C,2C) = k
+                wpe, bpe = _folded(la.pe)
+                c = wqk.shape[0] // 2
+                dt = wd.dtype
+                zeros = lambda b_, n_: torch.zeros(n_, device=wd.device) if b_ is None else b_.float()
                 self._pack = (ops.pack_dw_weight(wd.float()), None if bd is None else ops.pack_bias(bd.float()),
-                              ops.pack_dw_weight(wc.float()), None if bc is None else ops.pack_bias(bc.float()))
+                              ops.pack_dw_weight(wc.float()), None if bc is None else ops.pack_bias(bc.float()),
+                              wqk[:c, :, 0, 0].contiguous().to(dt), zeros(bqk, 2 * c)[:c].to(dt).contiguous(),
+                              wqk[c:, :, 0, 0].contiguous().to(dt), zeros(bqk, 2 * c)[c:].to(dt).contiguous(),
+                              ops.pack_dw_weight(wpe.float()), None if bpe is None else ops.pack_bias(bpe.float()))
             self._pack_key = key
         return self._pack
 
@@ -101,8 +111,15 @@ class RecAttn2d(nn.Module):
                                       "HIP depthwise kernels); call .eval()")
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError("recnext_amd.RecAttn2d has no backward yet; run under torch.no_grad()")
-        wd, bd, wc, bc = self.packed_params()
+        wd, bd, wc, bc, wq, bq, wk, bk, wpe, bpe = self.packed_params()
         k = self.kernel_size
+        la = self.down[1]
         d = ops.dwconv2d(x, wd, bd, k=k, stride=2)                                  # ConvNorm(dw k5 s2), :61
-        a = self.down[1](d)                                                         # linear attention, :62
+        b, c, h, w = d.shape
+        tok = d.permute(0, 2, 3, 1).reshape(b * h * w, c)                           # NHWC storage viewed token-major, no copy
+        dt = d.dtype
+        qpre = F.linear(tok[:, :c // 2], wq.to(dt), bq.to(dt)).view(b, h * w, c)    # grouped 1x1 conv = two GEMMs, :21 / :44
+        kpre = F.linear(tok[:, c // 2:], wk.to(dt), bk.to(dt)).view(b, h * w, c)
+        pe = ops.dwconv2d(d, wpe, bpe, k=3, stride=1)                               # ConvNorm(dw 3x3), :27 / :50
+        a = ops.linear_attention_core(qpre, kpre, d, pe, la.num_heads)              # :22-27 / :45-50
         return ops.upadd_dwconv(x, a, wc, bc, k=k, mode=self.mode)                  # conv(x + resize(.)), :67

@@ -4,6 +4,7 @@ Bars (BASELINE.json north_star): float32 max|err| <= 1e-3; bfloat16 allclose(ato
 against the float32 oracle evaluated on the bf16-rounded inputs.
 The float32 assertions below are tightened to 1e-4: the kernels accumulate in float32 like ATen.
 """
+import os
 import zlib
 
 import numpy as np
@@ -13,7 +14,7 @@ import torch
 import recnext_amd
 from recnext_amd import ops
 from oracle import c_oracle
-from tests.util import bf16_round_np, load_recconv, recconv_cases
+from tests.util import bf16_round_np, load_recconv, recattn_cases, recconv_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -275,3 +276,104 @@ def test_hip_downsample_module_folds_the_batchnorm():
     with torch.no_grad():
         ref = bn(conv(x))
         assert (mod(x) - ref).abs().max() < 1e-4
+
+
+# ---- RecAttn2d: linear-attention core on HIP ----
+@pytest.mark.parametrize("case", [(2, 16, 4, 4, 4), (3, 64, 2, 28, 28), (2, 80, 4, 14, 14), (2, 224, 8, 7, 7), (2, 640, 16, 4, 4),
+                                  (2, 32, 16, 4, 4), (1, 48, 2, 9, 5)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_linear_attention_core(case, dtype):
+    """q/k activation, k v^T, normaliser and + pe against the NumPy restatement of model/recattn.py:16-28 (both variants)."""
+    from oracle import recconv_np
+    b, c, heads, h, w = case
+    rng = np.random.default_rng(c + h)
+    d = bf16_round_np(rng.standard_normal((b, c, h, w)).astype(np.float32))
+    w_qk = bf16_round_np((rng.standard_normal((2 * c, c // 2, 1, 1)) * (2.0 / c) ** 0.5).astype(np.float32))
+    b_qk = bf16_round_np((rng.standard_normal(2 * c) * 0.1).astype(np.float32))
+    w_pe = (rng.standard_normal((c, 1, 3, 3)) * 0.2).astype(np.float32)
+    b_pe = (rng.standard_normal(c) * 0.1).astype(np.float32)
+    ref = recconv_np.linear_attention(d.astype(np.float64), w_qk, b_qk, w_pe, b_pe, heads, variant=1)
+    ref2 = recconv_np.linear_attention(d.astype(np.float64), w_qk, b_qk, w_pe, b_pe, heads, variant=2)
+    assert np.abs(ref - ref2).max() < 1e-6
+    t = lambda a: torch.from_numpy(a).to(dev())
+    dd = t(d).to(dtype).contiguous(memory_format=torch.channels_last)
+    tok = dd.permute(0, 2, 3, 1).reshape(b * h * w, c)
+    wq, wk = t(w_qk[:c, :, 0, 0]).to(dtype), t(w_qk[c:, :, 0, 0]).to(dtype)
+    qpre = torch.nn.functional.linear(tok[:, :c // 2], wq, t(b_qk[:c]).to(dtype)).view(b, h * w, c)
+    kpre = torch.nn.functional.linear(tok[:, c // 2:], wk, t(b_qk[c:]).to(dtype)).view(b, h * w, c)
+    pe = ops.dwconv2d(dd, ops.pack_dw_weight(t(w_pe)), ops.pack_bias(t(b_pe)), k=3, stride=1)
+    got = ops.linear_attention_core(qpre, kpre, dd, pe, heads).float().cpu().numpy()
+    if dtype == torch.float32:
+        assert np.abs(got - ref).max() < 2e-4
+    else:
+        assert np.allclose(got, ref, atol=3e-2, rtol=3e-2)      # the qk GEMM output and pe are rounded to bf16 on the way in
+
+
+@pytest.mark.parametrize("name", recattn_cases())
+def test_recattn2d_module_matches_reference_golden(name):
+    from tests.util import load_recattn
+    d, m = load_recattn(name)
+    from recnext_amd.recattn import RecAttn2d
+    mod = RecAttn2d(m["dim"], num_heads=m["heads"], stage=m["stage"]).eval()
+    with torch.no_grad():
+        for cn, wk_, bk_ in ((mod.down[0], "w_down", "b_down"), (mod.conv, "w_conv", "b_conv"), (mod.down[1].qk, "w_qk", "b_qk"), (mod.down[1].pe, "w_pe", "b_pe")):
+            cn.conv.weight.copy_(torch.from_numpy(d[wk_]))
+            cn.norm.weight.fill_(1.0); cn.norm.bias.copy_(torch.from_numpy(d[bk_]))
+            cn.norm.running_mean.zero_(); cn.norm.running_var.fill_(1.0 - cn.norm.eps)
+    mod = mod.to(dev())
+    x = torch.from_numpy(d["x"]).to(dev())
+    with torch.no_grad():
+        y = mod(x)
+    assert float((y.cpu() - torch.from_numpy(d["y"])).abs().max()) < 2e-4
+
+
+# ---- register-resident single-step kernels (rcx_upadd.hip) on the 7*2^k planes ----
+@pytest.mark.parametrize("mode", ["bilinear", "nearest"])
+@pytest.mark.parametrize("case", [(3, 64, 56), (2, 48, 56), (3, 96, 28), (5, 32, 28), (3, 256, 14), (2, 80, 14)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("dts", [("f32", "f32"), ("bf16", "f32"), ("bf16", "bf16")], ids=lambda d: "-".join(d))
+def test_upadd_step_kernel(mode, case, dts):
+    n, c, h = case
+    DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+    xdt, cdt = DT[dts[0]], DT[dts[1]]
+    rng = np.random.default_rng(c + h)
+    x = bf16_round_np(rng.standard_normal((n, c, h, h)).astype(np.float32))
+    cs = bf16_round_np(rng.standard_normal((n, c, h // 2, h // 2)).astype(np.float32))
+    wt = (rng.standard_normal((c, 1, 5, 5)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(c).astype(np.float32)
+    ref = c_oracle.dwconv2d(c_oracle.add_resized(x, cs, mode), wt, b, 1)
+    t = lambda a: torch.from_numpy(a).to(dev())
+    y = ops.upadd_dwconv(t(x).to(xdt), t(cs).to(cdt), ops.pack_dw_weight(t(wt)), ops.pack_bias(t(b)), k=5, mode=mode)
+    assert y.dtype == xdt
+    got = y.float().cpu().numpy()
+    if xdt == torch.float32:
+        assert np.abs(got - ref).max() < F32_TIGHT
+    else:
+        assert np.allclose(got, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
+    # same numbers as the generic schedule up to float reassociation
+    os.environ["RCX_FORCE_GENERIC"] = "1"
+    try:
+        yg = ops.upadd_dwconv(t(x).to(xdt), t(cs).to(cdt), ops.pack_dw_weight(t(wt)), ops.pack_bias(t(b)), k=5, mode=mode)
+    finally:
+        del os.environ["RCX_FORCE_GENERIC"]
+    assert np.allclose(yg.float().cpu().numpy(), got, atol=1e-2 if xdt == torch.bfloat16 else 1e-4, rtol=1e-2)
+
+
+@pytest.mark.parametrize("case", [(3, 64, 56), (2, 48, 56), (3, 96, 28), (5, 32, 28), (3, 256, 14), (2, 80, 14)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("dts", [("f32", "f32"), ("bf16", "f32"), ("bf16", "bf16")], ids=lambda d: "-".join(d))
+def test_down5_step_kernel(case, dts):
+    n, c, h = case
+    DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+    xdt, odt = DT[dts[0]], DT[dts[1]]
+    rng = np.random.default_rng(c * 3 + h)
+    x = bf16_round_np(rng.standard_normal((n, c, h, h)).astype(np.float32))
+    wt = (rng.standard_normal((c, 1, 5, 5)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(c).astype(np.float32)
+    ref = c_oracle.dwconv2d(x, wt, b, 2)
+    t = lambda a: torch.from_numpy(a).to(dev())
+    y = ops.dwconv2d(t(x).to(xdt), ops.pack_dw_weight(t(wt)), ops.pack_bias(t(b)), k=5, stride=2, out_dtype=odt)
+    assert y.dtype == odt and tuple(y.shape) == ref.shape
+    got = y.float().cpu().numpy()
+    if odt == torch.float32:
+        assert np.abs(got - ref).max() < F32_TIGHT
+    else:
+        assert np.allclose(got, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
