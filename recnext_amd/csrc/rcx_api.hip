@@ -93,6 +93,8 @@ hipError_t step_dwconv(const void* x, void* y, const float* w, const float* b, i
 {
     if (!lanes_off() && rcx::down5_lanes_applicable(N, C, H, W, k, stride, in_dt, out_dt))
         return rcx::down5_lanes(x, y, w, b, N, C, H, W, in_dt, out_dt, s);
+    if (!lanes_off() && stride == 1 && rcx::conv5_lanes_applicable(N, C, H, W, k, in_dt, out_dt))
+        return rcx::conv5_lanes(x, y, w, b, N, C, H, W, in_dt, s);
     return rcx::generic_dwconv(x, y, w, b, N, C, H, W, k, stride, in_dt, out_dt, s);
 }
 
@@ -101,6 +103,8 @@ hipError_t step_upadd(const void* x, const void* coarse, void* y, const float* w
 {
     if (coarse && !lanes_off() && rcx::upadd_lanes_applicable(N, C, H, W, Hc, Wc, k, x_dt, c_dt, out_dt))
         return rcx::upadd_lanes(x, coarse, y, w, b, N, C, H, W, mode, x_dt, c_dt, s);
+    if (!coarse && !lanes_off() && rcx::conv5_lanes_applicable(N, C, H, W, k, x_dt, out_dt))
+        return rcx::conv5_lanes(x, y, w, b, N, C, H, W, x_dt, s);
     return rcx::generic_upadd_dwconv(x, coarse, y, w, b, N, C, H, W, Hc, Wc, k, mode, x_dt, c_dt, out_dt, s);
 }
 
@@ -309,15 +313,15 @@ int rcx_recconv2d_bwd(const void* x, const float* gy, const float* wpack, const 
     hipError_t e;
 #define RCX_TRY(call, what) do { e = (call); if (e != hipSuccess) return hip_fail(e, what); } while (0)
     // final conv (model/recnext.py:34): gT_0 = K_L^T gy ; gW_L = <x + R(C_1), gy>
-    if (level == 0) RCX_TRY(rcx::generic_dwconv(gy, gx, Wf(1), nullptr, N, C, H, W, k, 1, RCX_DTYPE_F32, dtype, s), "bwd: final conv input grad");
-    else RCX_TRY(rcx::generic_dwconv(gy, G_(0), Wf(1 + level), nullptr, N, C, H, W, k, 1, RCX_DTYPE_F32, RCX_DTYPE_F32, s), "bwd: final conv input grad");
+    if (level == 0) RCX_TRY(step_dwconv(gy, gx, Wf(1), nullptr, N, C, H, W, k, 1, RCX_DTYPE_F32, dtype, s), "bwd: final conv input grad");
+    else RCX_TRY(step_dwconv(gy, G_(0), Wf(1 + level), nullptr, N, C, H, W, k, 1, RCX_DTYPE_F32, RCX_DTYPE_F32, s), "bwd: final conv input grad");
     RCX_TRY(rcx::bwd_wgrad(x, dtype, level >= 1 ? C_(1) : nullptr, gy, part, GW(1 + level), GB(1 + level), N, C, H, W,
                            level >= 1 ? L.h[1] : 0, level >= 1 ? L.w[1] : 0, H, W, k, 1, mode, 0, s), "bwd: final conv weight grad");
     // up recursion (:31-33), finest level first in the backward direction
     for (int l = 1; l <= level; ++l) {
         const int j = level - l;
         RCX_TRY(rcx::bwd_resize(G_(l - 1), gC, N, C, L.h[l - 1], L.w[l - 1], L.h[l], L.w[l], mode, s), "bwd: resize adjoint");
-        RCX_TRY(rcx::generic_dwconv(gC, G_(l), Wf(1 + j), nullptr, N, C, L.h[l], L.w[l], k, 1, RCX_DTYPE_F32, RCX_DTYPE_F32, s), "bwd: conv input grad");
+        RCX_TRY(step_dwconv(gC, G_(l), Wf(1 + j), nullptr, N, C, L.h[l], L.w[l], k, 1, RCX_DTYPE_F32, RCX_DTYPE_F32, s), "bwd: conv input grad");
         RCX_TRY(rcx::bwd_wgrad(F_(l), RCX_DTYPE_F32, l < level ? C_(l + 1) : nullptr, gC, part, GW(1 + j), GB(1 + j), N, C, L.h[l], L.w[l],
                                l < level ? L.h[l + 1] : 0, l < level ? L.w[l + 1] : 0, L.h[l], L.w[l], k, 1, mode, 0, s), "bwd: conv weight grad");
     }

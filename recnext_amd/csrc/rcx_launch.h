@@ -36,6 +36,8 @@ hipError_t down_lanes(const void* x, void* y, const float* w, const float* b, in
 bool upadd_lanes_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int x_dt, int c_dt, int out_dt);
 hipError_t upadd_lanes(const void* x, const void* coarse, void* y, const float* w, const float* b,
                        int N, int C, int H, int W, int mode, int x_dt, int c_dt, hipStream_t s);
+bool conv5_lanes_applicable(int N, int C, int H, int W, int k, int x_dt, int out_dt);
+hipError_t conv5_lanes(const void* x, void* y, const float* w, const float* b, int N, int C, int H, int W, int x_dt, hipStream_t s);
 bool down5_lanes_applicable(int N, int C, int H, int W, int k, int stride, int in_dt, int out_dt);
 hipError_t down5_lanes(const void* x, void* y, const float* w, const float* b, int N, int C, int H, int W, int in_dt, int out_dt, hipStream_t s);
 

@@ -21,7 +21,7 @@ struct StepArgs {
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <int W0, int LPC, int MODE, int NW, typename TX, typename TC>
+template <int W0, int LPC, int MODE, int NW, bool HAS_COARSE, typename TX, typename TC>
 __global__ __launch_bounds__(NW * 64)
 void k_upadd_lanes(const TX* __restrict__ x, const TC* __restrict__ coarse, TX* __restrict__ y,
                    const float* __restrict__ wk, const float* __restrict__ bk, StepArgs a)
@@ -79,7 +79,7 @@ void k_upadd_lanes(const TX* __restrict__ x, const TC* __restrict__ coarse, TX* 
             else xv[i] = u32x4{0u, 0u, 0u, 0u};
         });
         const unsigned char* cp = reinterpret_cast<const unsigned char*>(coarse + (size_t)n * cimg + c0);
-        sfor<CST>([&](auto I) RCX_INL {
+        if constexpr (HAS_COARSE) sfor<CST>([&](auto I) RCX_INL {
             constexpr int i = decltype(I)::value;
             int r = HS * band - 1 + crow[i];                        // coarse rows HS*band - 1 .. HS*band + HS, clamped
             r = r < 0 ? 0 : (r > H1 - 1 ? H1 - 1 : r);
@@ -91,7 +91,7 @@ void k_upadd_lanes(const TX* __restrict__ x, const TC* __restrict__ coarse, TX* 
             constexpr int i = decltype(I)::value;
             if (xhave[i]) *reinterpret_cast<u32x4*>(xs + xl[i]) = xv[i];
         });
-        sfor<CST>([&](auto I) RCX_INL {
+        if constexpr (HAS_COARSE) sfor<CST>([&](auto I) RCX_INL {
             constexpr int i = decltype(I)::value;
             if (chave[i]) *reinterpret_cast<u32x4*>(cs + cl[i]) = cv[i];
         });
@@ -144,7 +144,7 @@ void k_upadd_lanes(const TX* __restrict__ x, const TC* __restrict__ coarse, TX* 
         float w[25], bias = 0.f, wt[B0][2];
         if (active) {
             load_taps<CBW>(taps + ch, w, bias);
-            hweights_2x<B1, B0>(c, W1, W0, wt);
+            if constexpr (HAS_COARSE) hweights_2x<B1, B0>(c, W1, W0, wt);
         }
 #pragma unroll 1
         for (int s = 0; s < NS; ++s) {
@@ -159,7 +159,7 @@ void k_upadd_lanes(const TX* __restrict__ x, const TC* __restrict__ coarse, TX* 
             if (active) {
                 float hw[HS + 2][B0];
                 const unsigned char* cbp = ccur + cmine;
-                sfor<HS + 2>([&](auto K) RCX_INL {
+                if constexpr (HAS_COARSE) sfor<HS + 2>([&](auto K) RCX_INL {
                     float cw[B1];
 #pragma unroll
                     for (int q = 0; q < B1; ++q) cw[q] = Raw<TC>::ld(cbp + (decltype(K)::value * W1 + q * LA) * CPITCH);
@@ -182,7 +182,8 @@ void k_upadd_lanes(const TX* __restrict__ x, const TC* __restrict__ coarse, TX* 
 #pragma unroll
                     for (int j = 0; j < B0; ++j) {
                         const float xval = nxt[j];
-                        if constexpr (MODE == 1) row[j] = xval + hw[mr + 1][j];
+                        if constexpr (!HAS_COARSE) row[j] = xval;
+                        else if constexpr (MODE == 1) row[j] = xval + hw[mr + 1][j];
                         else if constexpr ((i & 1) == 0) row[j] = xval + fmaf(te.l, hw[mr + 1][j], (1.f - te.l) * hw[mr][j]);
                         else row[j] = xval + fmaf(to.l, hw[mr + 2][j], (1.f - to.l) * hw[mr + 1][j]);
                     }
@@ -479,7 +480,10 @@ static hipError_t upadd_w(const void* x, const void* coarse, void* y, const floa
 {
     constexpr int CBW = NW * 64 / LPC;
     const size_t lds = 26 * CBW * 4 + 3 * (size_t)4 * W0 * (CBW * sizeof(TX) + 16) + 2 * (size_t)4 * (W0 / 2) * (CBW * sizeof(TC) + 16);
-    return launch_step(k_upadd_lanes<W0, LPC, MODE, NW, TX, TC>, lds, p, b != nullptr, s, (const TX*)x, (const TC*)coarse, (TX*)y, w, b);
+    if (coarse) return launch_step(k_upadd_lanes<W0, LPC, MODE, NW, true, TX, TC>, lds, p, b != nullptr, s, (const TX*)x, (const TC*)coarse, (TX*)y, w, b);
+    if constexpr (MODE == 0 && sizeof(TC) == 4)      // plain conv5: one instantiation per x type is enough
+        return launch_step(k_upadd_lanes<W0, LPC, 0, NW, false, TX, TC>, lds, p, b != nullptr, s, (const TX*)x, (const TC*)x, (TX*)y, w, b);
+    return hipErrorInvalidConfiguration;
 }
 
 template <int W0, int LPC, int MODE, typename TX, typename TC>
@@ -525,6 +529,21 @@ static hipError_t down5_m(const void* x, void* y, const float* w, const float* b
 }  // namespace lanes
 
 // x and y share a dtype; coarse may be float32 or the same as x
+// plain stride-1 conv5 (no coarse operand) in the same kernel
+bool conv5_lanes_applicable(int N, int C, int H, int W, int k, int x_dt, int out_dt)
+{
+    if (k != 5 || out_dt != x_dt) return false;
+    return lanes::plan_step(N, C, H, W, x_dt == 1 ? 2 : 4).ok;
+}
+
+hipError_t conv5_lanes(const void* x, void* y, const float* w, const float* b, int N, int C, int H, int W, int x_dt, hipStream_t s)
+{
+    const lanes::StepPlan p = lanes::plan_step(N, C, H, W, x_dt == 1 ? 2 : 4);
+    if (!p.ok) return hipErrorInvalidConfiguration;
+    if (x_dt == 1) return lanes::upadd_m<0, bf16_t, float>(x, nullptr, y, w, b, p, s);
+    return lanes::upadd_m<0, float, float>(x, nullptr, y, w, b, p, s);
+}
+
 bool upadd_lanes_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int x_dt, int c_dt, int out_dt)
 {
     if (k != 5 || out_dt != x_dt || Hc * 2 != H || Wc * 2 != W) return false;
