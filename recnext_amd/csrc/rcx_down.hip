@@ -40,7 +40,7 @@ __global__ __launch_bounds__(NW * 64)
 void k_down_lanes(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bias_pack, DownArgs a)
 {
     static_assert(K == 7, "window rows per band are laid out for k = 7");
-    constexpr int LA = LPC == 8 ? 7 : 14;
+    constexpr int LA = lanes_active(W0, LPC);
     constexpr int B0 = W0 / LA, BO = B0 / 2, H0 = W0, W1 = W0 / 2, H1 = W1, PAD = K / 2;
     static_assert(B0 * LA == W0 && B0 >= 2 && (B0 % 2) == 0, "plane width must be LA * B0, B0 even");
     constexpr int SR = 4, NS = (H0 + SR - 1) / SR;   // rows past the plane (14 = 3.5 bands) are staged as zeros
@@ -252,7 +252,7 @@ static DownPlan plan_down(int N, int Cin, int H, int W, int k, int stride, int d
     if (env_int_d("RCX_LANES", 1) == 0) return p;
     if (k != 7 || stride != 2 || H != W) return p;
     int lpc;
-    if (W == 56) lpc = 16;
+    if (W == 56 || W == 128 || W == 64 || W == 32) lpc = 16;
     else if (W == 28 || W == 14) lpc = 8;
     else return p;
     const int esz = dtype == 1 ? 2 : 4;
@@ -309,6 +309,9 @@ template <typename TIO>
 static hipError_t launch_down(const void* x, void* y, const float* w, const float* b, const DownPlan& p, hipStream_t s)
 {
     if (p.w0 == 56) return launch_down_t<56, 16, TIO>(x, y, w, b, p, s);
+    if (p.w0 == 128) return launch_down_t<128, 16, TIO>(x, y, w, b, p, s);
+    if (p.w0 == 64) return launch_down_t<64, 16, TIO>(x, y, w, b, p, s);
+    if (p.w0 == 32) return launch_down_t<32, 16, TIO>(x, y, w, b, p, s);
     if (p.w0 == 28) return launch_down_t<28, 8, TIO>(x, y, w, b, p, s);
     if (p.w0 == 14) return launch_down_t<14, 8, TIO>(x, y, w, b, p, s);
     return hipErrorInvalidConfiguration;

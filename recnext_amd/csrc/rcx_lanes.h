@@ -48,6 +48,10 @@ __device__ __forceinline__ float from_right(float v)
     else return from_right<N - 1, LPC>(dpp_mov<0x101>(v));
 }
 
+// active lanes of a group of LPC: 7 of 8 / 14 of 16 on the 7*2^k planes (the rest are EXEC-disabled guard lanes), all 16 on
+// the 16*2^k planes (there a group fills a DPP row, whose boundary zero-fills)
+constexpr int lanes_active(int w0, int lpc) { return (w0 % 16 == 0) ? 16 : (lpc == 8 ? 7 : 14); }
+
 // ------------------------------------------------------------------------------------------------
 template <typename TIO> struct Raw;
 template <> struct Raw<float> {

@@ -28,6 +28,10 @@ int lanes_describe(int N, int C, int H, int W, int level, int k, int mode, int d
 hipError_t lanes_recconv(const void* x, void* y, const float* wpack, const float* bpack,
                          int N, int C, int H, int W, int level, int k, int mode, int dtype, hipStream_t s);
 
+// rcx_lanes16.hip -- the same schedule on the 16*2^k planes (called by lanes_recconv)
+hipError_t lanes16_recconv(const void* x, void* y, const float* wpack, const float* bpack,
+                           int N, int C, int H, int W, int level, int k, int mode, int dtype, hipStream_t s);
+
 // rcx_down.hip -- register-resident depthwise 7x7 stride-2 conv with channel multiplier 2 (Downsample) on the 7*2^k planes
 bool down_lanes_applicable(int N, int Cin, int H, int W, int k, int stride, int dtype);
 hipError_t down_lanes(const void* x, void* y, const float* w, const float* b, int N, int Cin, int H, int W, int k, int stride, int dtype, hipStream_t s);

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(NW * 64)
 void k_upadd_lanes(const TX* __restrict__ x, const TC* __restrict__ coarse, TX* __restrict__ y,
                    const float* __restrict__ wk, const float* __restrict__ bk, StepArgs a)
 {
-    constexpr int LA = LPC == 8 ? 7 : 14;
+    constexpr int LA = lanes_active(W0, LPC);
     constexpr int B0 = W0 / LA, H0 = W0, W1 = W0 / 2, H1 = W1, B1 = B0 / 2;
     static_assert(B0 * LA == W0 && B0 >= 2 && (B0 % 2) == 0, "plane width must be LA * B0, B0 even");
     constexpr int SR = 4, NS = (H0 + SR - 1) / SR, HS = SR / 2;
@@ -249,7 +249,7 @@ template <int W0, int LPC, int NW, typename TX, typename TO>
 __global__ __launch_bounds__(NW * 64)
 void k_down5_lanes(const TX* __restrict__ x, TO* __restrict__ y, const float* __restrict__ wk, const float* __restrict__ bk, StepArgs a)
 {
-    constexpr int LA = LPC == 8 ? 7 : 14;
+    constexpr int LA = lanes_active(W0, LPC);
     constexpr int B0 = W0 / LA, BO = B0 / 2, H0 = W0, W1 = W0 / 2, H1 = W1;
     static_assert(B0 * LA == W0 && B0 >= 2 && (B0 % 2) == 0, "plane width must be LA * B0, B0 even");
     constexpr int SR = 4, NS = (H0 + SR - 1) / SR, HS = SR / 2;
@@ -443,7 +443,7 @@ static StepPlan plan_step(int N, int C, int H, int W, int min_bytes_per_channel)
     if (off && *off == '0') return p;
     if (H != W) return p;
     int lpc;
-    if (W == 56) lpc = 16;
+    if (W == 56 || W == 64 || W == 32) lpc = 16;
     else if (W == 28 || W == 14) lpc = 8;
     else return p;
     const int cpw = 64 / lpc;
@@ -498,6 +498,8 @@ template <int MODE, typename TX, typename TC>
 static hipError_t upadd_m(const void* x, const void* coarse, void* y, const float* w, const float* b, const StepPlan& p, hipStream_t s)
 {
     if (p.w0 == 56) return upadd_t<56, 16, MODE, TX, TC>(x, coarse, y, w, b, p, s);
+    if (p.w0 == 64) return upadd_t<64, 16, MODE, TX, TC>(x, coarse, y, w, b, p, s);
+    if (p.w0 == 32) return upadd_t<32, 16, MODE, TX, TC>(x, coarse, y, w, b, p, s);
     if (p.w0 == 28) return upadd_t<28, 8, MODE, TX, TC>(x, coarse, y, w, b, p, s);
     return upadd_t<14, 8, MODE, TX, TC>(x, coarse, y, w, b, p, s);
 }
@@ -522,6 +524,8 @@ template <typename TX, typename TO>
 static hipError_t down5_m(const void* x, void* y, const float* w, const float* b, const StepPlan& p, hipStream_t s)
 {
     if (p.w0 == 56) return down5_t<56, 16, TX, TO>(x, y, w, b, p, s);
+    if (p.w0 == 64) return down5_t<64, 16, TX, TO>(x, y, w, b, p, s);
+    if (p.w0 == 32) return down5_t<32, 16, TX, TO>(x, y, w, b, p, s);
     if (p.w0 == 28) return down5_t<28, 8, TX, TO>(x, y, w, b, p, s);
     return down5_t<14, 8, TX, TO>(x, y, w, b, p, s);
 }

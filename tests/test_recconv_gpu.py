@@ -103,6 +103,12 @@ SWEEP = [
     (1, 64, 128, 128, 4, 5, "bilinear", False),       # M3 @512 stage 0
     (1, 128, 64, 64, 3, 5, "nearest", False),
     (1, 16, 25, 13, 3, 5, "bilinear", True),          # COCO-like 25 -> 13 -> 7 -> 4
+    (3, 64, 16, 16, 1, 5, "bilinear", True),          # register-resident kernels on the 16 * 2^k planes (256^2 / 512^2 inputs)
+    (2, 48, 16, 16, 1, 5, "nearest", False),
+    (2, 64, 32, 32, 2, 5, "bilinear", False),
+    (2, 32, 32, 32, 2, 5, "nearest", True),
+    (1, 128, 64, 64, 3, 5, "bilinear", True),
+    (1, 64, 64, 64, 3, 5, "nearest", False),
 ]
 
 
@@ -198,7 +204,8 @@ def test_full_size_properties(case, dtype):
         assert np.allclose(got, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
 
 
-@pytest.mark.parametrize("case", [(256, 64, 56, 4), (256, 128, 28, 3), (256, 256, 14, 2), (256, 512, 7, 1)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("case", [(256, 64, 56, 4), (256, 128, 28, 3), (256, 256, 14, 2), (256, 512, 7, 1), (32, 128, 64, 3), (32, 256, 32, 2),
+                                  (32, 512, 16, 1)], ids=lambda c: "x".join(map(str, c)))
 def test_repeated_launches_are_bit_identical(case):
     """Race hunting: a missing barrier in a fused kernel shows up as a rare whole-wave difference at full size
     (tools/stress_lanes.py is the long version)."""
@@ -246,7 +253,8 @@ def test_runs_on_a_side_stream():
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 11, 9), (2, 64, 56, 56), (1, 40, 28, 28), (3, 6, 7, 7),
-                                   (3, 128, 28, 28), (2, 256, 14, 14), (5, 48, 14, 14), (3, 16, 56, 56)])
+                                   (3, 128, 28, 28), (2, 256, 14, 14), (5, 48, 14, 14), (3, 16, 56, 56),
+                                   (1, 64, 128, 128), (2, 128, 64, 64), (2, 32, 32, 32)])
 @pytest.mark.parametrize("k,stride", [(7, 2), (5, 2), (3, 1)])
 def test_channel_multiplier_dwconv(shape, k, stride):
     from oracle import recconv_np
@@ -329,7 +337,8 @@ def test_recattn2d_module_matches_reference_golden(name):
 
 # ---- register-resident single-step kernels (rcx_upadd.hip) on the 7*2^k planes ----
 @pytest.mark.parametrize("mode", ["bilinear", "nearest"])
-@pytest.mark.parametrize("case", [(3, 64, 56), (2, 48, 56), (3, 96, 28), (5, 32, 28), (3, 256, 14), (2, 80, 14)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("case", [(3, 64, 56), (2, 48, 56), (3, 96, 28), (5, 32, 28), (3, 256, 14), (2, 80, 14), (2, 64, 64), (2, 32, 32)],
+                         ids=lambda c: "x".join(map(str, c)))
 @pytest.mark.parametrize("dts", [("f32", "f32"), ("bf16", "f32"), ("bf16", "bf16")], ids=lambda d: "-".join(d))
 def test_upadd_step_kernel(mode, case, dts):
     n, c, h = case
@@ -358,7 +367,8 @@ def test_upadd_step_kernel(mode, case, dts):
     assert np.allclose(yg.float().cpu().numpy(), got, atol=1e-2 if xdt == torch.bfloat16 else 1e-4, rtol=1e-2)
 
 
-@pytest.mark.parametrize("case", [(3, 64, 56), (2, 48, 56), (3, 96, 28), (5, 32, 28), (3, 256, 14), (2, 80, 14)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("case", [(3, 64, 56), (2, 48, 56), (3, 96, 28), (5, 32, 28), (3, 256, 14), (2, 80, 14), (2, 64, 64), (2, 32, 32)],
+                         ids=lambda c: "x".join(map(str, c)))
 @pytest.mark.parametrize("dts", [("f32", "f32"), ("bf16", "f32"), ("bf16", "bf16")], ids=lambda d: "-".join(d))
 def test_down5_step_kernel(case, dts):
     n, c, h = case
