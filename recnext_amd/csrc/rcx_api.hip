@@ -73,6 +73,22 @@ bool use_plane(int N, int C, int H, int W, int level, int k, int dtype)
     return rcx::plane_applicable(N, C, H, W, level, k, dtype);
 }
 
+// Split schedule for a plane whose level-1 plane does not fit the register file (128x128 / level 4): three launches,
+//   F_1 = down(x) (step kernel, float32) ; C_1 = RecConv2d_{level-1}(F_1) with the first level+1 packs (register-resident) ;
+//   y = conv_L(x + resize(C_1)) (step kernel).  F_1 and C_1 live in the caller's workspace.
+bool use_split(int N, int C, int H, int W, int level, int k, int dtype)
+{
+    const char* f = getenv("RCX_FORCE_GENERIC");
+    if (f && *f && *f != '0') return false;
+    if (level < 1 || k != 5 || H != W || (H & 1)) return false;
+    if (rcx::lanes_applicable(N, C, H, W, level, k, dtype)) return false;
+    return rcx::down5_lanes_applicable(N, C, H, W, k, 2, dtype, RCX_DTYPE_F32) &&
+           rcx::lanes_applicable(N, C, H / 2, W / 2, level - 1, k, RCX_DTYPE_F32) &&
+           rcx::upadd_lanes_applicable(N, C, H, W, H / 2, W / 2, k, dtype, RCX_DTYPE_F32, dtype);
+}
+
+size_t split_bytes(int N, int C, int H, int W) { return 2 * align256(sizeof(float) * (size_t)N * C * (H / 2) * (W / 2)); }
+
 // the register-resident schedule takes precedence where it applies (RCX_LANES=0 switches it off)
 bool use_lanes(int N, int C, int H, int W, int level, int k, int dtype)
 {
@@ -123,8 +139,14 @@ const char* rcx_last_error(void) { return g_err; }
 const char* rcx_recconv2d_fwd_plan(int N, int C, int H, int W, int level, int k, int mode, int dtype)
 {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0) return "invalid";
-    static thread_local char desc[160];
+    static thread_local char desc[256];
     if (use_lanes(N, C, H, W, level, k, dtype) && rcx::lanes_describe(N, C, H, W, level, k, mode == RCX_MODE_NEAREST ? 1 : 0, dtype, desc, (int)sizeof(desc)) > 0) return desc;
+    if (use_split(N, C, H, W, level, k, dtype)) {
+        char inner[128];
+        rcx::lanes_describe(N, C, H / 2, W / 2, level - 1, k, mode == RCX_MODE_NEAREST ? 1 : 0, RCX_DTYPE_F32, inner, (int)sizeof(inner));
+        snprintf(desc, sizeof(desc), "split(k_down5_lanes + %s + k_upadd_lanes)", inner);
+        return desc;
+    }
     if (!use_plane(N, C, H, W, level, k, dtype)) return "generic";
     if (rcx::plane_describe(N, C, H, W, level, k, dtype, desc, (int)sizeof(desc)) <= 0) return "generic";
     return desc;
@@ -150,6 +172,7 @@ size_t rcx_recconv2d_fwd_workspace_bytes(int N, int C, int H, int W, int level, 
 {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0) return 0;
     if (use_lanes(N, C, H, W, level, k, dtype)) return 0;          // registers only
+    if (use_split(N, C, H, W, level, k, dtype)) return split_bytes(N, C, H, W);
     if (use_plane(N, C, H, W, level, k, dtype)) return 0;          // the fused schedule keeps every intermediate in LDS
     return make_ladder(N, C, H, W, level, k).total;
 }
@@ -166,6 +189,22 @@ int rcx_recconv2d_fwd(const void* x, void* y, const float* wpack, const float* b
     if (use_lanes(N, C, H, W, level, k, dtype)) {
         hipError_t le = rcx::lanes_recconv(x, y, wpack, bpack, N, C, H, W, level, k, mode, dtype, (hipStream_t)stream);
         return le == hipSuccess ? 0 : hip_fail(le, "lanes schedule");
+    }
+    if (use_split(N, C, H, W, level, k, dtype)) {
+        const size_t need = split_bytes(N, C, H, W);
+        if (!workspace || workspace_bytes < need)
+            return fail(RCX_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+        hipStream_t s = (hipStream_t)stream;
+        float* f1 = (float*)workspace;
+        float* c1 = (float*)((char*)workspace + need / 2);
+        const size_t wsz = (size_t)k * k * C;
+        hipError_t e = rcx::down5_lanes(x, f1, wpack, bpack, N, C, H, W, dtype, RCX_DTYPE_F32, s);
+        if (e != hipSuccess) return hip_fail(e, "split schedule: down");
+        e = rcx::lanes_recconv(f1, c1, wpack, bpack, N, C, H / 2, W / 2, level - 1, k, mode, RCX_DTYPE_F32, s);
+        if (e != hipSuccess) return hip_fail(e, "split schedule: inner block");
+        e = rcx::upadd_lanes(x, c1, y, wpack + (size_t)(1 + level) * wsz, bpack ? bpack + (size_t)(1 + level) * C : nullptr,
+                             N, C, H, W, mode, dtype, RCX_DTYPE_F32, s);
+        return e == hipSuccess ? 0 : hip_fail(e, "split schedule: final conv");
     }
     if (use_plane(N, C, H, W, level, k, dtype)) {
         hipError_t pe = rcx::plane_recconv(x, y, wpack, bpack, N, C, H, W, level, k, mode, dtype, (hipStream_t)stream);

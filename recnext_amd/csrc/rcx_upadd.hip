@@ -443,11 +443,11 @@ static StepPlan plan_step(int N, int C, int H, int W, int min_bytes_per_channel)
     if (off && *off == '0') return p;
     if (H != W) return p;
     int lpc;
-    if (W == 56 || W == 64 || W == 32) lpc = 16;
+    if (W == 56 || W == 128 || W == 64 || W == 32) lpc = 16;
     else if (W == 28 || W == 14) lpc = 8;
     else return p;
     const int cpw = 64 / lpc;
-    int waves = lpc == 16 ? 8 : 4;
+    int waves = lpc == 16 ? (W == 128 ? 4 : 8) : 4;          // 128-wide bands: 16-channel blocks so that the rings fit 160 KB
     while (waves > 1 && C % (waves * cpw) != 0) waves >>= 1;
     const int cbw = waves * cpw;
     if (C % cbw != 0 || (cbw * min_bytes_per_channel) % 16 != 0) return p;
@@ -499,6 +499,10 @@ static hipError_t upadd_m(const void* x, const void* coarse, void* y, const floa
 {
     if (p.w0 == 56) return upadd_t<56, 16, MODE, TX, TC>(x, coarse, y, w, b, p, s);
     if (p.w0 == 64) return upadd_t<64, 16, MODE, TX, TC>(x, coarse, y, w, b, p, s);
+    if (p.w0 == 128) {
+        if (p.waves == 4) return upadd_w<128, 16, MODE, 4, TX, TC>(x, coarse, y, w, b, p, s);
+        return upadd_w<128, 16, MODE, 2, TX, TC>(x, coarse, y, w, b, p, s);
+    }
     if (p.w0 == 32) return upadd_t<32, 16, MODE, TX, TC>(x, coarse, y, w, b, p, s);
     if (p.w0 == 28) return upadd_t<28, 8, MODE, TX, TC>(x, coarse, y, w, b, p, s);
     return upadd_t<14, 8, MODE, TX, TC>(x, coarse, y, w, b, p, s);
@@ -525,9 +529,30 @@ static hipError_t down5_m(const void* x, void* y, const float* w, const float* b
 {
     if (p.w0 == 56) return down5_t<56, 16, TX, TO>(x, y, w, b, p, s);
     if (p.w0 == 64) return down5_t<64, 16, TX, TO>(x, y, w, b, p, s);
+    if (p.w0 == 128) return down5_w<128, 16, 4, TX, TO>(x, y, w, b, p, s);
     if (p.w0 == 32) return down5_t<32, 16, TX, TO>(x, y, w, b, p, s);
     if (p.w0 == 28) return down5_t<28, 8, TX, TO>(x, y, w, b, p, s);
     return down5_t<14, 8, TX, TO>(x, y, w, b, p, s);
+}
+
+// LDS footprint of k_upadd_lanes; a 128-wide plane with float32 operands only fits with 8-channel blocks (2 waves)
+static size_t upadd_lds(int W, int cbw, int xb, int cbytes)
+{
+    return (size_t)26 * cbw * 4 + 3 * (size_t)4 * W * (cbw * xb + 16) + 2 * (size_t)4 * (W / 2) * (cbw * cbytes + 16);
+}
+
+static StepPlan plan_upadd(int N, int C, int H, int W, int xb, int cbytes)
+{
+    StepPlan p = plan_step(N, C, H, W, xb < cbytes ? xb : cbytes);
+    if (!p.ok) return p;
+    const int cpw = 64 / p.lpc;
+    if (upadd_lds(W, p.waves * cpw, xb, cbytes) > 160 * 1024) {
+        if (W != 128 || p.waves != 4 || C % (2 * cpw) != 0) { p.ok = false; return p; }
+        p.waves = 2;
+        p.args.nblk = C / (2 * cpw);
+        if (upadd_lds(W, 2 * cpw, xb, cbytes) > 160 * 1024 || (2 * cpw * (xb < cbytes ? xb : cbytes)) % 16 != 0) p.ok = false;
+    }
+    return p;
 }
 
 }  // namespace lanes
@@ -537,12 +562,12 @@ static hipError_t down5_m(const void* x, void* y, const float* w, const float* b
 bool conv5_lanes_applicable(int N, int C, int H, int W, int k, int x_dt, int out_dt)
 {
     if (k != 5 || out_dt != x_dt) return false;
-    return lanes::plan_step(N, C, H, W, x_dt == 1 ? 2 : 4).ok;
+    return lanes::plan_upadd(N, C, H, W, x_dt == 1 ? 2 : 4, 4).ok;
 }
 
 hipError_t conv5_lanes(const void* x, void* y, const float* w, const float* b, int N, int C, int H, int W, int x_dt, hipStream_t s)
 {
-    const lanes::StepPlan p = lanes::plan_step(N, C, H, W, x_dt == 1 ? 2 : 4);
+    const lanes::StepPlan p = lanes::plan_upadd(N, C, H, W, x_dt == 1 ? 2 : 4, 4);
     if (!p.ok) return hipErrorInvalidConfiguration;
     if (x_dt == 1) return lanes::upadd_m<0, bf16_t, float>(x, nullptr, y, w, b, p, s);
     return lanes::upadd_m<0, float, float>(x, nullptr, y, w, b, p, s);
@@ -553,14 +578,14 @@ bool upadd_lanes_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, i
     if (k != 5 || out_dt != x_dt || Hc * 2 != H || Wc * 2 != W) return false;
     if (!(c_dt == x_dt || c_dt == 0)) return false;
     const int xb = x_dt == 1 ? 2 : 4, cbytes = c_dt == 1 ? 2 : 4;
-    return lanes::plan_step(N, C, H, W, xb < cbytes ? xb : cbytes).ok;
+    return lanes::plan_upadd(N, C, H, W, xb, cbytes).ok;
 }
 
 hipError_t upadd_lanes(const void* x, const void* coarse, void* y, const float* w, const float* b,
                        int N, int C, int H, int W, int mode, int x_dt, int c_dt, hipStream_t s)
 {
     const int xb = x_dt == 1 ? 2 : 4, cbytes = c_dt == 1 ? 2 : 4;
-    const lanes::StepPlan p = lanes::plan_step(N, C, H, W, xb < cbytes ? xb : cbytes);
+    const lanes::StepPlan p = lanes::plan_upadd(N, C, H, W, xb, cbytes);
     if (!p.ok) return hipErrorInvalidConfiguration;
 #define RCX_UP(TX, TC) (mode == 1 ? lanes::upadd_m<1, TX, TC>(x, coarse, y, w, b, p, s) : lanes::upadd_m<0, TX, TC>(x, coarse, y, w, b, p, s))
     if (x_dt == 1 && c_dt == 1) return RCX_UP(bf16_t, bf16_t);
