@@ -26,6 +26,12 @@ __device__ __forceinline__ void la_st(float* p, float v) { *p = v; }
 __device__ __forceinline__ void la_st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 __device__ __forceinline__ float elu1(float x) { return (x > 0.f ? x : expm1f(x)) + 1.f; }
 
+// G consecutive channels in one access (G = 4: 8 bytes of bf16 / 16 bytes of float32)
+template <int G> __device__ __forceinline__ void la_ldv(const float* p, float (&o)[G]) { load_vec<G>(p, o); }
+template <int G> __device__ __forceinline__ void la_ldv(const bf16_t* p, float (&o)[G]) { load_vec<G>(p, o); }
+template <int G> __device__ __forceinline__ void la_stv(float* p, const float (&o)[G]) { store_vec<G>(p, o); }
+template <int G> __device__ __forceinline__ void la_stv(bf16_t* p, const float (&o)[G]) { store_vec<G>(p, o); }
+
 template <typename T, int G>
 __global__ void __launch_bounds__(LA_NT)
 k_linattn_core(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* __restrict__ v, const T* __restrict__ pe,
@@ -53,11 +59,20 @@ k_linattn_core(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* 
     for (int t0 = 0; t0 < n; t0 += LA_TT) {
         const int tt = n - t0 < LA_TT ? n - t0 : LA_TT;
         __syncthreads();
-        for (int i = tid; i < tt * D; i += LA_NT) {
-            const int t = i / D, e = i - t * D;
+        for (int i = tid; i < tt * Q; i += LA_NT) {
+            const int t = i / Q, e = (i - t * Q) * G;
             const size_t g = base + (size_t)(t0 + t) * C + e;
-            a_s[t][e] = elu1(la_ld(kpre + g));
-            v_s[t][e] = la_ld(v + g);
+            float kk[G], vv[G];
+            la_ldv<G>(kpre + g, kk);
+            la_ldv<G>(v + g, vv);
+#pragma unroll
+            for (int j = 0; j < G; ++j) { a_s[t][e + j] = elu1(kk[j]); v_s[t][e + j] = vv[j]; }
+        }
+        const int tt8 = (tt + 7) & ~7;
+        for (int i = tt * Q + tid; i < tt8 * Q; i += LA_NT) {         // zero tail: the token loops below run in steps of 8
+            const int t = i / Q, e = (i - t * Q) * G;
+#pragma unroll
+            for (int j = 0; j < G; ++j) { a_s[t][e + j] = 0.f; v_s[t][e + j] = 0.f; }
         }
         __syncthreads();
 #pragma unroll
@@ -65,15 +80,22 @@ k_linattn_core(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* 
             const int it = tid + j * LA_NT;
             if (it < items) {
                 const int e1 = it / Q, q4 = (it - e1 * Q) * G;
-                for (int t = 0; t < tt; ++t) {
-                    const float kk = a_s[t][e1];
+                for (int t8 = 0; t8 < tt8; t8 += 8) {
 #pragma unroll
-                    for (int g = 0; g < G; ++g) acc[j][g] = fmaf(kk, v_s[t][q4 + g], acc[j][g]);
+                    for (int u = 0; u < 8; ++u) {
+                        const float kk = a_s[t8 + u][e1];
+#pragma unroll
+                        for (int g = 0; g < G; ++g) acc[j][g] = fmaf(kk, v_s[t8 + u][q4 + g], acc[j][g]);
+                    }
                 }
             }
         }
-        if (tid < D)
-            for (int t = 0; t < tt; ++t) ksum += a_s[t][tid];
+        if (tid < D) {
+            for (int t8 = 0; t8 < tt8; t8 += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ksum += a_s[t8 + u][tid];
+            }
+        }
     }
 #pragma unroll
     for (int j = 0; j < LA_ITEMS; ++j) {
@@ -90,13 +112,17 @@ k_linattn_core(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* 
     for (int t0 = 0; t0 < n; t0 += LA_TT) {
         const int tt = n - t0 < LA_TT ? n - t0 : LA_TT;
         __syncthreads();
-        for (int i = tid; i < tt * D; i += LA_NT) {
-            const int t = i / D, e = i - t * D;
-            a_s[t][e] = elu1(la_ld(qpre + base + (size_t)(t0 + t) * C + e));
+        for (int i = tid; i < tt * Q; i += LA_NT) {
+            const int t = i / Q, e = (i - t * Q) * G;
+            float qq[G];
+            la_ldv<G>(qpre + base + (size_t)(t0 + t) * C + e, qq);
+#pragma unroll
+            for (int j = 0; j < G; ++j) a_s[t][e + j] = elu1(qq[j]);
         }
         __syncthreads();
         if (tid < tt) {
             float d = 0.f;
+#pragma unroll 4
             for (int e = 0; e < D; ++e) d = fmaf(a_s[tid][e], kbar_s[e], d);
             den_s[tid] = d + 1e-6f;
         }
@@ -106,6 +132,7 @@ k_linattn_core(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* 
             float o[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) o[g] = 0.f;
+#pragma unroll 4
             for (int e = 0; e < D; ++e) {
                 const float qq = a_s[t][e];
 #pragma unroll
@@ -113,8 +140,11 @@ k_linattn_core(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* 
             }
             const float inv = 1.f / den_s[t];
             const size_t gi = base + (size_t)(t0 + t) * C + q4;
+            float pp[G];
+            la_ldv<G>(pe + gi, pp);
 #pragma unroll
-            for (int g = 0; g < G; ++g) la_st(out + gi + g, fmaf(o[g], inv, la_ld(pe + gi + g)));
+            for (int g = 0; g < G; ++g) o[g] = fmaf(o[g], inv, pp[g]);
+            la_stv<G>(out + gi, o);
         }
     }
 }
