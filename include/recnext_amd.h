@@ -115,6 +115,27 @@ int rcx_upadd_dwconv_fwd(const void* x, const void* coarse, void* y, const float
                          int x_dtype, int coarse_dtype, int out_dtype, void* stream);
 
 /*
+ * Backward of rcx_dwconv2d_fwd (a depthwise ConvNorm.conv of RecAttn2d in a training step, engine.py:48-64): what autograd
+ * derives for nn.Conv2d(groups=C, padding=k/2, stride 1|2), model/recattn.py:61,64 and model/recnext.py:21-22.
+ *   x: N x H x W x C (x_dtype); gy: N x Ho x Wo x C float32; w_kkc / w_flipped_kkc: (k,k,C) float32 packs, the second with
+ *   both tap axes reversed; gx: like x, may be NULL; gw: (k,k,C) float32, gb: (C) float32 or NULL -- both overwritten.
+ *   workspace: rcx_dwconv2d_bwd_workspace_bytes(C, k) bytes.  Deterministic.  C must be a multiple of 4.
+ */
+size_t rcx_dwconv2d_bwd_workspace_bytes(int C, int k);
+int rcx_dwconv2d_bwd(const void* x, const float* gy, const float* w_kkc, const float* w_flipped_kkc,
+                     void* gx, float* gw, float* gb, void* workspace, size_t workspace_bytes,
+                     int N, int C, int H, int W, int k, int stride, int x_dtype, void* stream);
+
+/*
+ * Backward of rcx_dwconv2d_mult2_fwd with stride 2 (Downsample.token_mixer, model/recnext.py:165, in a training step).
+ *   x: N x H x W x Cin (dtype); gy: N x Ho x Wo x 2*Cin float32; w_kkc: (k,k,2*Cin) float32; gx: like x or NULL;
+ *   gw: (k,k,2*Cin) float32, gb: (2*Cin) float32 or NULL; workspace: rcx_dwconv2d_bwd_workspace_bytes(2*Cin, k) bytes.
+ *   k in {3,5,7}, Cin even.  Deterministic.
+ */
+int rcx_dwconv2d_mult2_bwd(const void* x, const float* gy, const float* w_kkc, void* gx, float* gw, float* gb,
+                           void* workspace, size_t workspace_bytes, int N, int Cin, int H, int W, int k, int dtype, void* stream);
+
+/*
  * Linear-attention core of RecAttn2d's coarse level: everything after the grouped 1x1 `qk` conv of
  * LinearAttention1.forward (model/recattn.py:21-28) / LinearAttention2.forward (:44-51; the same function):
  *     q = elu(qpre)+1, k = elu(kpre)+1; out = q^T (k v^T) / (n * (q^T mean_n(k) + 1e-6)) + pe

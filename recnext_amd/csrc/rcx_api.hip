@@ -422,6 +422,52 @@ int rcx_upadd_dwconv_fwd(const void* x, const void* coarse, void* y, const float
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_upadd_dwconv_fwd");
 }
 
+size_t rcx_dwconv2d_bwd_workspace_bytes(int C, int k)
+{
+    if (C <= 0 || k <= 0 || (k & 1) == 0) return 0;
+    return align256(rcx::wgrad_partial_bytes(C, k));
+}
+
+int rcx_dwconv2d_bwd(const void* x, const float* gy, const float* w_kkc, const float* w_flipped_kkc,
+                     void* gx, float* gw, float* gb, void* workspace, size_t workspace_bytes,
+                     int N, int C, int H, int W, int k, int stride, int x_dtype, void* stream)
+{
+    if (!x || !gy || !gw) return fail(RCX_ERR_BAD_ARG, "rcx_dwconv2d_bwd: null pointer");
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive extent N=%d C=%d H=%d W=%d", N, C, H, W);
+    if (k <= 0 || (k & 1) == 0) return fail(RCX_ERR_BAD_ARG, "kernel_size must be odd and positive, got %d", k);
+    if (x_dtype != RCX_DTYPE_F32 && x_dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", x_dtype);
+    if (stride != 1 && stride != 2) return fail(RCX_ERR_UNSUPPORTED, "stride %d not supported (1 or 2)", stride);
+    if (C % 4) return fail(RCX_ERR_UNSUPPORTED, "the backward kernels need C %% 4 == 0, got C=%d", C);
+    if (gx && (!w_kkc || !w_flipped_kkc)) return fail(RCX_ERR_BAD_ARG, "rcx_dwconv2d_bwd: weights are needed for the input gradient");
+    const size_t need = rcx_dwconv2d_bwd_workspace_bytes(C, k);
+    if (!workspace || workspace_bytes < need) return fail(RCX_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int p = k / 2, Ho = (H + 2 * p - k) / stride + 1, Wo = (W + 2 * p - k) / stride + 1;
+    hipError_t e;
+    if (gx) {
+        if (stride == 1) e = step_dwconv(gy, gx, w_flipped_kkc, nullptr, N, C, H, W, k, 1, RCX_DTYPE_F32, x_dtype, s);
+        else e = rcx::bwd_down_input(nullptr, gy, gx, x_dtype, w_kkc, N, C, H, W, Ho, Wo, k, s);
+        if (e != hipSuccess) return hip_fail(e, "rcx_dwconv2d_bwd: input gradient");
+    }
+    e = rcx::bwd_wgrad(x, x_dtype, nullptr, gy, (float*)workspace, gw, gb, N, C, H, W, 0, 0, Ho, Wo, k, stride, 0, 0, s);
+    return e == hipSuccess ? 0 : hip_fail(e, "rcx_dwconv2d_bwd: weight gradient");
+}
+
+int rcx_dwconv2d_mult2_bwd(const void* x, const float* gy, const float* w_kkc, void* gx, float* gw, float* gb,
+                           void* workspace, size_t workspace_bytes, int N, int Cin, int H, int W, int k, int dtype, void* stream)
+{
+    if (!x || !gy || !gw) return fail(RCX_ERR_BAD_ARG, "rcx_dwconv2d_mult2_bwd: null pointer");
+    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive extent N=%d C=%d H=%d W=%d", N, Cin, H, W);
+    if (dtype != RCX_DTYPE_F32 && dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
+    if (k != 3 && k != 5 && k != 7) return fail(RCX_ERR_UNSUPPORTED, "kernel_size %d not supported by the multiplier-2 backward (3, 5, 7)", k);
+    if (Cin % 2) return fail(RCX_ERR_UNSUPPORTED, "the multiplier-2 backward needs an even channel count, got %d", Cin);
+    if (gx && !w_kkc) return fail(RCX_ERR_BAD_ARG, "rcx_dwconv2d_mult2_bwd: weights are needed for the input gradient");
+    const size_t need = rcx_dwconv2d_bwd_workspace_bytes(2 * Cin, k);
+    if (!workspace || workspace_bytes < need) return fail(RCX_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    hipError_t e = rcx::bwd_mult2(x, dtype, gy, w_kkc, gx, (float*)workspace, gw, gb, N, Cin, H, W, k, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "rcx_dwconv2d_mult2_bwd");
+}
+
 int rcx_linear_attention_fwd(const void* qpre, const void* kpre, const void* v, const void* pe, void* out,
                              int B, int n, int C, int heads, int dtype, void* stream)
 {

@@ -11,7 +11,7 @@
 //
 // K^T is the forward depthwise kernel with the taps flipped (the host passes a flipped pack); D^T (stride-2 adjoint)
 // and R^T (resize adjoint) are gathers, so every result is deterministic; weight gradients are reduced in two stages
-// (per-block partials, then a fixed-order sum).  The k = 5 weight-gradient kernel (k_wgrad_rows5) is the tuned one; the
+// (per-block partials, then a fixed-order sum).  The k = 5 weight-gradient kernel (k_wgrad_rows) is the tuned one; the
 // rest favour clarity over speed.
 #include "rcx_common.h"
 #include "rcx_launch.h"
@@ -42,8 +42,8 @@ k_down_bwd_input(const float* __restrict__ base, const float* __restrict__ g, TO
         const int ix = (int)(r % q.W); r /= q.W;
         const int iy = (int)(r % q.H);
         const int n = (int)(r / q.H);
-        float acc[BW_V];
-        load_vec<BW_V>(base + (((size_t)n * q.H + iy) * q.W + ix) * q.C + c, acc);
+        float acc[BW_V] = {0.f, 0.f, 0.f, 0.f};
+        if (base) load_vec<BW_V>(base + (((size_t)n * q.H + iy) * q.W + ix) * q.C + c, acc);
         for (int u = 0; u < q.k; ++u) {
             const int ty = iy + p - u;
             if (ty < 0 || (ty & 1)) continue;
@@ -110,6 +110,42 @@ k_resize_bwd(const float* __restrict__ gfine, float* __restrict__ gcoarse, BwGeo
             }
         }
         store_vec<BW_V>(gcoarse + (((size_t)n * q.Hc + cy) * q.Wc + cx) * q.C + c, acc);
+    }
+}
+
+// ---- D^T for nn.Conv2d(C, 2C, k, stride 2, groups=C): gx(n,iy,ix,c) = sum_m sum_{u,v} W[2c+m,u,v] * g(n,oy,ox,2c+m) ----
+template <typename TO>
+__global__ void __launch_bounds__(256)
+k_down_bwd_input_mult2(const float* __restrict__ g, TO* __restrict__ out, const float* __restrict__ w, BwGeom q)
+{
+    // q.C = input channels, q.Hc/q.Wc = output extent; g and w have 2*q.C channels
+    const int p = q.k / 2, Co = 2 * q.C;
+    const long long total = (long long)q.N * q.H * q.W * (q.C / 2);
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        long long r = t;
+        const int c = (int)(r % (q.C / 2)) * 2; r /= (q.C / 2);            // two input channels = four output channels
+        const int ix = (int)(r % q.W); r /= q.W;
+        const int iy = (int)(r % q.H);
+        const int n = (int)(r / q.H);
+        float acc[2] = {0.f, 0.f};
+        for (int u = 0; u < q.k; ++u) {
+            const int ty = iy + p - u;
+            if (ty < 0 || (ty & 1)) continue;
+            const int oy = ty >> 1;
+            if (oy >= q.Hc) continue;
+            for (int v = 0; v < q.k; ++v) {
+                const int tx = ix + p - v;
+                if (tx < 0 || (tx & 1)) continue;
+                const int ox = tx >> 1;
+                if (ox >= q.Wc) continue;
+                float gv[4], wv[4];
+                load_vec<4>(g + (((size_t)n * q.Hc + oy) * q.Wc + ox) * Co + 2 * c, gv);
+                load_vec<4>(w + ((size_t)u * q.k + v) * Co + 2 * c, wv);
+                acc[0] = fmaf(wv[0], gv[0], fmaf(wv[1], gv[1], acc[0]));
+                acc[1] = fmaf(wv[2], gv[2], fmaf(wv[3], gv[3], acc[1]));
+            }
+        }
+        store_vec<2>(out + (((size_t)n * q.H + iy) * q.W + ix) * q.C + c, acc);
     }
 }
 
@@ -195,27 +231,38 @@ __device__ __forceinline__ void ld2(const bf16_t* p, float (&o)[2])
     o[0] = __uint_as_float(t << 16); o[1] = __uint_as_float(t & 0xffff0000u);
 }
 
-template <typename TA, int S, bool HAS_COARSE>
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return bf16_to_f32(*p); }
+
+// K = 3, 5, 7.  MULT = 2: nn.Conv2d(C, 2C, groups=C) -- the thread's two OUTPUT channels (2cp, 2cp+1) share input channel cp
+// (q.C is the number of output channels, `a` has q.C / MULT).
+template <typename TA, int S, bool HAS_COARSE, int K, int MULT>
 __global__ void __launch_bounds__(WR_LANES * WR_SLOTS)
-k_wgrad_rows5(const TA* __restrict__ a, const float* __restrict__ coarse, const float* __restrict__ g,
-              float* __restrict__ partial, BwGeom q, int Ho, int Wo)
+k_wgrad_rows(const TA* __restrict__ a, const float* __restrict__ coarse, const float* __restrict__ g,
+             float* __restrict__ partial, BwGeom q, int Ho, int Wo)
 {
-    constexpr int K = 5, P = 2, KK = 25;
-    __shared__ float red[WR_SLOTS][13][WR_LANES * 2];
+    constexpr int P = K / 2, KK = K * K, AV = MULT == 2 ? 1 : 2, RP = 13, NP = (KK + 1 + RP - 1) / RP;
+    static_assert(!(HAS_COARSE && MULT == 2), "the coarse operand only exists for the plain depthwise conv");
+    __shared__ float red[WR_SLOTS][RP][WR_LANES * 2];
     const int cp = blockIdx.x * WR_LANES + threadIdx.x;
     const bool ok = cp < q.C / 2;
-    const int c = (ok ? cp : 0) * 2;
+    const int c = (ok ? cp : 0) * 2;                 // first of the thread's two output channels
+    const int ca = MULT == 2 ? c / 2 : c;            // its (first) input channel
+    const int Ca = q.C / MULT;                       // channels of `a`
     const int slot = blockIdx.y * WR_SLOTS + threadIdx.y, nslots = gridDim.y * WR_SLOTS;
     float acc[KK][2], accb[2] = {0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < KK; ++t) acc[t][0] = acc[t][1] = 0.f;
+    auto lda = [&](const TA* p, float (&o)[AV]) __attribute__((always_inline)) {
+        if constexpr (AV == 2) ld2(p, o); else o[0] = ld1(p);
+    };
 
     if (ok) {
         if constexpr (S == 1) {
             const int rows = q.N * q.H;
             for (int row = slot; row < rows; row += nslots) {
                 const int n = row / q.H, iy = row - n * q.H;
-                const TA* arow = a + ((size_t)n * q.H + iy) * q.W * q.C + c;
+                const TA* arow = a + ((size_t)n * q.H + iy) * q.W * Ca + ca;
                 const float* gimg = g + (size_t)n * Ho * Wo * q.C + c;
                 const float* cimg = HAS_COARSE ? coarse + (size_t)n * q.Hc * q.Wc * q.C + c : nullptr;
                 Lerp ly{0, 0, 0.f};
@@ -224,7 +271,7 @@ k_wgrad_rows5(const TA* __restrict__ a, const float* __restrict__ coarse, const 
                     if (q.mode == 1) ny = nearest_src(iy, q.Hc, q.sy);
                     else ly = bilinear_src(iy, q.Hc, q.sy);
                 }
-                // gw[u][d] = g(oy_u, ix - 2 + d), oy_u = iy - u + 2; rows outside the image contribute nothing
+                // gw[u][d] = g(oy_u, ix - P + d), oy_u = iy - u + P; rows outside the image contribute nothing
                 float gw[K][K][2];
                 const float* grow[K];
                 bool gok[K];
@@ -241,8 +288,9 @@ k_wgrad_rows5(const TA* __restrict__ a, const float* __restrict__ coarse, const 
                     }
                 }
                 for (int ix = 0; ix < q.W; ++ix) {
-                    float t[2];
-                    ld2(arow + (size_t)ix * q.C, t);
+                    float tv[AV], t[2];
+                    lda(arow + (size_t)ix * Ca, tv);
+                    t[0] = tv[0]; t[1] = tv[AV - 1];
                     if constexpr (HAS_COARSE) {
                         if (q.mode == 1) {
                             float cv[2];
@@ -260,7 +308,7 @@ k_wgrad_rows5(const TA* __restrict__ a, const float* __restrict__ coarse, const 
                             for (int i = 0; i < 2; ++i) t[i] += wy0 * (wx0 * a00[i] + wx1 * a01[i]) + wy1 * (wx0 * a10[i] + wx1 * a11[i]);
                         }
                     }
-                    // tap (u, v) pairs input column ix with output column ix - v + 2, i.e. window slot d = 4 - v
+                    // tap (u, v) pairs input column ix with output column ix - v + P, i.e. window slot d = K - 1 - v
 #pragma unroll
                     for (int u = 0; u < K; ++u)
 #pragma unroll
@@ -269,7 +317,6 @@ k_wgrad_rows5(const TA* __restrict__ a, const float* __restrict__ coarse, const 
                             acc[u * K + v][1] = fmaf(t[1], gw[u][K - 1 - v][1], acc[u * K + v][1]);
                         }
                     accb[0] += gw[P][P][0]; accb[1] += gw[P][P][1];       // g(iy, ix): every output pixel exactly once
-                    // slide the windows one column
 #pragma unroll
                     for (int u = 0; u < K; ++u) {
 #pragma unroll
@@ -285,21 +332,22 @@ k_wgrad_rows5(const TA* __restrict__ a, const float* __restrict__ coarse, const 
             for (int row = slot; row < rows; row += nslots) {
                 const int n = row / Ho, oy = row - n * Ho;
                 const float* grow = g + ((size_t)n * Ho + oy) * Wo * q.C + c;
-                const TA* aimg = a + (size_t)n * q.H * q.W * q.C + c;
-                // aw[u][d] = a(2*oy + u - 2, 2*ox - 2 + d)
-                float aw[K][K][2];
+                const TA* aimg = a + (size_t)n * q.H * q.W * Ca + ca;
+                // aw[u][d] = a(2*oy + u - P, 2*ox - P + d)
+                float aw[K][K][AV];
                 const TA* arow[K];
                 bool aok[K];
 #pragma unroll
                 for (int u = 0; u < K; ++u) {
                     const int iy = 2 * oy + u - P;
                     aok[u] = iy >= 0 && iy < q.H;
-                    arow[u] = aimg + (size_t)(aok[u] ? iy : 0) * q.W * q.C;
+                    arow[u] = aimg + (size_t)(aok[u] ? iy : 0) * q.W * Ca;
 #pragma unroll
                     for (int d = 0; d < K; ++d) {
                         const int ix = d - P;
-                        aw[u][d][0] = aw[u][d][1] = 0.f;
-                        if (aok[u] && ix >= 0 && ix < q.W) ld2(arow[u] + (size_t)ix * q.C, aw[u][d]);
+#pragma unroll
+                        for (int i = 0; i < AV; ++i) aw[u][d][i] = 0.f;
+                        if (aok[u] && ix >= 0 && ix < q.W) lda(arow[u] + (size_t)ix * Ca, aw[u][d]);
                     }
                 }
                 for (int ox = 0; ox < Wo; ++ox) {
@@ -311,46 +359,46 @@ k_wgrad_rows5(const TA* __restrict__ a, const float* __restrict__ coarse, const 
 #pragma unroll
                         for (int v = 0; v < K; ++v) {
                             acc[u * K + v][0] = fmaf(aw[u][v][0], gv[0], acc[u * K + v][0]);
-                            acc[u * K + v][1] = fmaf(aw[u][v][1], gv[1], acc[u * K + v][1]);
+                            acc[u * K + v][1] = fmaf(aw[u][v][AV - 1], gv[1], acc[u * K + v][1]);
                         }
 #pragma unroll
                     for (int u = 0; u < K; ++u) {
 #pragma unroll
-                        for (int d = 0; d < K - 2; ++d) { aw[u][d][0] = aw[u][d + 2][0]; aw[u][d][1] = aw[u][d + 2][1]; }
+                        for (int d = 0; d < K - 2; ++d)
+#pragma unroll
+                            for (int i = 0; i < AV; ++i) aw[u][d][i] = aw[u][d + 2][i];
 #pragma unroll
                         for (int d = K - 2; d < K; ++d) {
                             const int ix = 2 * (ox + 1) - P + d;
-                            aw[u][d][0] = aw[u][d][1] = 0.f;
-                            if (aok[u] && ix < q.W) ld2(arow[u] + (size_t)ix * q.C, aw[u][d]);
+#pragma unroll
+                            for (int i = 0; i < AV; ++i) aw[u][d][i] = 0.f;
+                            if (aok[u] && ix < q.W) lda(arow[u] + (size_t)ix * Ca, aw[u][d]);
                         }
                     }
                 }
             }
         }
     }
-    // block reduction over the row slots, 13 tap rows at a time (26 = 25 taps + bias), fixed order
-    float* prow = partial + (size_t)blockIdx.y * (KK + 1) * q.C + c;
+    // block reduction over the row slots, RP tap rows at a time (KK taps + the bias row), fixed order
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int pass = 0; pass < NP; ++pass) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 13; ++i) {
-            const int t = half * 13 + i;
+        for (int i = 0; i < RP; ++i) {
+            const int t = pass * RP + i;
             red[threadIdx.y][i][threadIdx.x * 2 + 0] = t < KK ? acc[t < KK ? t : 0][0] : accb[0];
             red[threadIdx.y][i][threadIdx.x * 2 + 1] = t < KK ? acc[t < KK ? t : 0][1] : accb[1];
         }
         __syncthreads();
-        // 13 * 64 sums, 256 threads
-        for (int e = threadIdx.y * WR_LANES + threadIdx.x; e < 13 * WR_LANES * 2; e += WR_LANES * WR_SLOTS) {
+        for (int e = threadIdx.y * WR_LANES + threadIdx.x; e < RP * WR_LANES * 2; e += WR_LANES * WR_SLOTS) {
             const int i = e / (WR_LANES * 2), l = e - i * (WR_LANES * 2);
             float sum = 0.f;
 #pragma unroll
             for (int r = 0; r < WR_SLOTS; ++r) sum += red[r][i][l];
-            const int ch = blockIdx.x * WR_LANES * 2 + l;
-            if (ch < q.C) partial[((size_t)blockIdx.y * (KK + 1) + half * 13 + i) * q.C + ch] = sum;
+            const int ch = blockIdx.x * WR_LANES * 2 + l, t = pass * RP + i;
+            if (ch < q.C && t <= KK) partial[((size_t)blockIdx.y * (KK + 1) + t) * q.C + ch] = sum;
         }
     }
-    (void)prow;
 }
 
 // stage 2, parallel form: 8 threads share one output (rows r = j mod 8 each), fixed-order combine through LDS
@@ -407,7 +455,7 @@ static int wr_grid_y(int C)
 size_t wgrad_partial_bytes(int C, int k)
 {
     const size_t old = sizeof(float) * (size_t)WG_ROWS_Y * WG_BLOCKS_Y * (k * k + 1) * C;
-    const size_t fast = sizeof(float) * (size_t)wr_grid_y(C) * 26 * C;
+    const size_t fast = sizeof(float) * (size_t)wr_grid_y(C) * (k * k + 1) * C;
     return old > fast ? old : fast;
 }
 
@@ -415,19 +463,21 @@ template <typename TA>
 static hipError_t wgrad_launch(const void* a, const float* coarse, const float* g, float* partial, float* gw, float* gb,
                                BwGeom q, int Ho, int Wo, int stride, int accumulate, hipStream_t s)
 {
-    if (q.k == 5 && (q.C % 2) == 0) {
+    if ((q.k == 3 || q.k == 5 || q.k == 7) && (q.C % 2) == 0 && !(coarse && q.k != 5)) {
         const int rows_total = stride == 2 ? q.N * Ho : q.N * q.H;
         int gy = wr_grid_y(q.C);
         const int need = (rows_total + WR_SLOTS - 1) / WR_SLOTS;
         if (gy > need) gy = need < 1 ? 1 : need;
         dim3 block(WR_LANES, WR_SLOTS), grid((q.C / 2 + WR_LANES - 1) / WR_LANES, gy);
-        if (stride == 2) hipLaunchKernelGGL((k_wgrad_rows5<TA, 2, false>), grid, block, 0, s, (const TA*)a, coarse, g, partial, q, Ho, Wo);
-        else if (coarse) hipLaunchKernelGGL((k_wgrad_rows5<TA, 1, true>), grid, block, 0, s, (const TA*)a, coarse, g, partial, q, Ho, Wo);
-        else hipLaunchKernelGGL((k_wgrad_rows5<TA, 1, false>), grid, block, 0, s, (const TA*)a, coarse, g, partial, q, Ho, Wo);
+#define RCX_WG(S_, HC_, K_) hipLaunchKernelGGL((k_wgrad_rows<TA, S_, HC_, K_, 1>), grid, block, 0, s, (const TA*)a, coarse, g, partial, q, Ho, Wo)
+        if (q.k == 5) { if (stride == 2) RCX_WG(2, false, 5); else if (coarse) RCX_WG(1, true, 5); else RCX_WG(1, false, 5); }
+        else if (q.k == 3) { if (stride == 2) RCX_WG(2, false, 3); else RCX_WG(1, false, 3); }
+        else { if (stride == 2) RCX_WG(2, false, 7); else RCX_WG(1, false, 7); }
+#undef RCX_WG
         hipError_t e5 = hipGetLastError();
         if (e5 != hipSuccess) return e5;
-        const int n5 = 26 * q.C;
-        hipLaunchKernelGGL(k_wgrad_reduce8, dim3((n5 + 31) / 32), dim3(32, 8), 0, s, partial, gw, gb, gy, 25, q.C, accumulate);
+        const int kk = q.k * q.k, n5 = (kk + 1) * q.C;
+        hipLaunchKernelGGL(k_wgrad_reduce8, dim3((n5 + 31) / 32), dim3(32, 8), 0, s, partial, gw, gb, gy, kk, q.C, accumulate);
         return hipGetLastError();
     }
     const int cvecs = q.C / BW_V;
@@ -451,6 +501,37 @@ hipError_t bwd_wgrad(const void* a, int a_dt, const float* coarse, const float* 
     q.sx = Wc > 0 ? (float)Wc / (float)W : 0.f;
     if (a_dt == 1) return wgrad_launch<bf16_t>(a, coarse, g, partial, gw, gb, q, Ho, Wo, stride, accumulate, s);
     return wgrad_launch<float>(a, coarse, g, partial, gw, gb, q, Ho, Wo, stride, accumulate, s);
+}
+
+// Downsample conv (channel multiplier 2, stride 2): input gradient and weight/bias gradients; Cin % 2 == 0
+hipError_t bwd_mult2(const void* x, int x_dt, const float* g, const float* w, void* gx, float* partial, float* gw, float* gb,
+                     int N, int Cin, int H, int W, int k, hipStream_t s)
+{
+    if (k != 3 && k != 5 && k != 7) return hipErrorInvalidConfiguration;
+    const int p = k / 2, Ho = (H + 2 * p - k) / 2 + 1, Wo = (W + 2 * p - k) / 2 + 1;
+    BwGeom q{};
+    q.N = N; q.C = Cin; q.H = H; q.W = W; q.Hc = Ho; q.Wc = Wo; q.k = k;
+    if (gx) {
+        const unsigned grid = grid_for((long long)N * H * W * (Cin / 2));
+        if (x_dt == 1) hipLaunchKernelGGL(k_down_bwd_input_mult2<bf16_t>, dim3(grid), dim3(256), 0, s, g, (bf16_t*)gx, w, q);
+        else hipLaunchKernelGGL(k_down_bwd_input_mult2<float>, dim3(grid), dim3(256), 0, s, g, (float*)gx, w, q);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    q.C = 2 * Cin;                                     // the weight-gradient kernel counts output channels
+    int gy = wr_grid_y(q.C);
+    const int need = (N * Ho + WR_SLOTS - 1) / WR_SLOTS;
+    if (gy > need) gy = need < 1 ? 1 : need;
+    dim3 block(WR_LANES, WR_SLOTS), grid((q.C / 2 + WR_LANES - 1) / WR_LANES, gy);
+#define RCX_WGM(TA_, K_) hipLaunchKernelGGL((k_wgrad_rows<TA_, 2, false, K_, 2>), grid, block, 0, s, (const TA_*)x, (const float*)nullptr, g, partial, q, Ho, Wo)
+    if (x_dt == 1) { if (k == 3) RCX_WGM(bf16_t, 3); else if (k == 5) RCX_WGM(bf16_t, 5); else RCX_WGM(bf16_t, 7); }
+    else { if (k == 3) RCX_WGM(float, 3); else if (k == 5) RCX_WGM(float, 5); else RCX_WGM(float, 7); }
+#undef RCX_WGM
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int kk = k * k, n5 = (kk + 1) * q.C;
+    hipLaunchKernelGGL(k_wgrad_reduce8, dim3((n5 + 31) / 32), dim3(32, 8), 0, s, partial, gw, gb, gy, kk, q.C, 0);
+    return hipGetLastError();
 }
 
 hipError_t bwd_down_input(const float* base, const float* g, void* out, int out_dt, const float* w,

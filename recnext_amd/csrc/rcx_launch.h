@@ -53,6 +53,8 @@ hipError_t linattn_core(const void* qpre, const void* kpre, const void* v, const
 size_t wgrad_partial_bytes(int C, int k);
 hipError_t bwd_wgrad(const void* a, int a_dt, const float* coarse, const float* g, float* partial, float* gw, float* gb,
                      int N, int C, int H, int W, int Hc, int Wc, int Ho, int Wo, int k, int stride, int mode, int accumulate, hipStream_t s);
+hipError_t bwd_mult2(const void* x, int x_dt, const float* g, const float* w, void* gx, float* partial, float* gw, float* gb,
+                     int N, int Cin, int H, int W, int k, hipStream_t s);
 hipError_t bwd_down_input(const float* base, const float* g, void* out, int out_dt, const float* w,
                           int N, int C, int H, int W, int Hc, int Wc, int k, hipStream_t s);
 hipError_t bwd_resize(const float* gfine, float* gcoarse, int N, int C, int H, int W, int Hc, int Wc, int mode, hipStream_t s);

@@ -1,12 +1,56 @@
 """HIP stand-in for ``Downsample.token_mixer`` + ``Downsample.norm`` (model/recnext.py:165-166, :170):
 a depthwise k x k stride-2 conv with channel multiplier 2 (``nn.Conv2d(C, 2C, 7, padding=3, groups=C, stride=2)``)
 followed by an eval-mode BatchNorm, which is a per-channel affine and is folded into the packed weights.
-Inference only; parameters stay in the wrapped modules, so state_dict keys do not change.
+In a training step the BatchNorm works on batch statistics and is not folded: the conv (forward and backward) runs on HIP
+through ``DwConvMult2Fn`` and the norm stays a PyTorch module.  Parameters stay in the wrapped modules, so state_dict keys do
+not change.  ``DwConvFn`` is the plain depthwise conv (stride 1|2) with HIP forward and backward, used by RecAttn2d.
 """
 import torch
 import torch.nn as nn
 
 from . import ops
+
+
+class DwConvFn(torch.autograd.Function):
+    """Depthwise k x k conv (pad k//2, stride 1|2): rcx_dwconv2d_fwd / rcx_dwconv2d_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride):
+        k = weight.shape[-1]
+        wp = ops.pack_dw_weight(weight.float())
+        bp = ops.pack_bias(bias.float()) if bias is not None else None
+        ctx.save_for_backward(x, wp)
+        ctx.k, ctx.stride, ctx.has_bias, ctx.wdtype = k, stride, bias is not None, weight.dtype
+        return ops.dwconv2d(x, wp, bp, k=k, stride=stride)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wp = ctx.saved_tensors
+        k, c = ctx.k, x.shape[1]
+        gx, gw, gb = ops.dwconv2d_backward(x, gy, wp, k, ctx.stride, need_input_grad=ctx.needs_input_grad[0], need_bias=ctx.has_bias)
+        gw = gw.view(k, k, c).permute(2, 0, 1).unsqueeze(1).to(ctx.wdtype)
+        return gx, gw, (gb.to(ctx.wdtype) if gb is not None else None), None
+
+
+class DwConvMult2Fn(torch.autograd.Function):
+    """nn.Conv2d(C, 2C, k, stride=2, padding=k//2, groups=C): rcx_dwconv2d_mult2_fwd / rcx_dwconv2d_mult2_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        k = weight.shape[-1]
+        wp = ops.pack_dw_weight(weight.float())
+        bp = ops.pack_bias(bias.float()) if bias is not None else None
+        ctx.save_for_backward(x, wp)
+        ctx.k, ctx.has_bias, ctx.wdtype = k, bias is not None, weight.dtype
+        return ops.dwconv2d_mult2(x, wp, bp, k=k, stride=2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wp = ctx.saved_tensors
+        k, c = ctx.k, x.shape[1]
+        gx, gw, gb = ops.dwconv2d_mult2_backward(x, gy, wp, k, need_input_grad=ctx.needs_input_grad[0], need_bias=ctx.has_bias)
+        gw = gw.view(k, k, 2 * c).permute(2, 0, 1).unsqueeze(1).to(ctx.wdtype)
+        return gx, gw, (gb.to(ctx.wdtype) if gb is not None else None)
 
 
 class DownsampleDwConv(nn.Module):
@@ -43,8 +87,13 @@ class DownsampleDwConv(nn.Module):
         return self._pack
 
     def forward(self, x):
-        if self.training or (torch.is_grad_enabled() and x.requires_grad):
-            raise NotImplementedError("DownsampleDwConv is inference-only (eval mode, no autograd)")
+        conv = self.token_mixer
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if self.training or needs_grad:
+            if conv.stride[0] != 2 or conv.kernel_size[0] not in (3, 5, 7) or x.shape[1] % 2:
+                raise NotImplementedError("the HIP backward of the multiplier-2 conv covers stride 2, k in {3,5,7}, even channel counts")
+            y = DwConvMult2Fn.apply(x, conv.weight, conv.bias)
+            return self.norm(y) if self.norm is not None else y
         w, b = self.packed_params()
         k, stride = self.token_mixer.kernel_size[0], self.token_mixer.stride[0]
         return ops.dwconv2d_mult2(x, w, b, k=k, stride=stride)

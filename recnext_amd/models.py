@@ -206,15 +206,16 @@ def fold_token_mixer_norms(net):
 
 @torch.no_grad()
 def use_hip_downsample(net):
-    """Inference-only: run each Downsample's depthwise 7x7 stride-2 conv (C -> 2C) and the eval-mode BatchNorm
-    after it as one HIP kernel.  Returns the number of layers replaced."""
+    """Run each Downsample's depthwise 7x7 stride-2 conv (C -> 2C) on HIP: in eval mode fused with
+    the BatchNorm after it into one kernel, in a training step with a HIP backward and the norm on batch statistics.
+    Returns the number of layers replaced."""
     from .dwconv import DownsampleDwConv
     n = 0
     for m in net.modules():
         if isinstance(m, Downsample) and isinstance(m.token_mixer, nn.Conv2d) and isinstance(m.norm, nn.BatchNorm2d):
-            if m.norm.training:
-                raise RuntimeError("use_hip_downsample needs eval mode (running statistics)")
-            m.token_mixer = DownsampleDwConv(m.token_mixer, m.norm).eval()
+            training = m.norm.training
+            m.token_mixer = DownsampleDwConv(m.token_mixer, m.norm)
+            m.token_mixer.train(training)
             m.norm = nn.Identity()
             n += 1
     return n

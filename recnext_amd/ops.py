@@ -172,6 +172,45 @@ def dwconv2d_mult2(x, w_kkc, bias=None, k=7, stride=2):
     return y
 
 
+def dwconv2d_backward(x, gy, w_kkc, k, stride, need_input_grad=True, need_bias=False):
+    """Backward of dwconv2d: -> (gx like x | None, gw (k,k,C) float32, gb (C) float32 | None). Deterministic."""
+    x = _nhwc(x)
+    n, c, h, w = x.shape
+    gy = _nhwc(gy.to(torch.float32), "grad_output")
+    lib = _lib.load()
+    wflip = w_kkc.view(k, k, c).flip(0, 1).contiguous()
+    gx = _empty_nhwc(n, c, h, w, x.dtype, x.device) if need_input_grad else None
+    gw = torch.empty(k * k * c, dtype=torch.float32, device=x.device)
+    gb = torch.empty(c, dtype=torch.float32, device=x.device) if need_bias else None
+    nbytes = lib.rcx_dwconv2d_bwd_workspace_bytes(c, k)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.rcx_dwconv2d_bwd(x.data_ptr(), gy.data_ptr(), w_kkc.data_ptr(), wflip.data_ptr(),
+                                  gx.data_ptr() if gx is not None else None, gw.data_ptr(), gb.data_ptr() if gb is not None else None,
+                                  ws.data_ptr(), nbytes, n, c, h, w, k, stride, _dt(x), _stream(x.device))
+    _lib.check(rc, "rcx_dwconv2d_bwd")
+    return gx, gw, gb
+
+
+def dwconv2d_mult2_backward(x, gy, w_kkc, k, need_input_grad=True, need_bias=False):
+    """Backward of dwconv2d_mult2 (stride 2): -> (gx like x | None, gw (k,k,2C) float32, gb (2C) float32 | None)."""
+    x = _nhwc(x)
+    n, c, h, w = x.shape
+    gy = _nhwc(gy.to(torch.float32), "grad_output")
+    lib = _lib.load()
+    gx = _empty_nhwc(n, c, h, w, x.dtype, x.device) if need_input_grad else None
+    gw = torch.empty(k * k * 2 * c, dtype=torch.float32, device=x.device)
+    gb = torch.empty(2 * c, dtype=torch.float32, device=x.device) if need_bias else None
+    nbytes = lib.rcx_dwconv2d_bwd_workspace_bytes(2 * c, k)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.rcx_dwconv2d_mult2_bwd(x.data_ptr(), gy.data_ptr(), w_kkc.data_ptr(), gx.data_ptr() if gx is not None else None,
+                                        gw.data_ptr(), gb.data_ptr() if gb is not None else None, ws.data_ptr(), nbytes,
+                                        n, c, h, w, k, _dt(x), _stream(x.device))
+    _lib.check(rc, "rcx_dwconv2d_mult2_bwd")
+    return gx, gw, gb
+
+
 def linear_attention_core(qpre, kpre, v, pe, heads):
     """Everything after the qk projection of LinearAttention1/2 (model/recattn.py:21-28, :44-51).
 

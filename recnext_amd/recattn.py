@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .dwconv import DwConvFn as _DwConvFn
 from .layers import ConvNorm
 
 
@@ -38,7 +39,10 @@ class LinearAttention(nn.Module):
         b, c, h, w = x.shape
         n = h * w
         s = n ** -0.5
-        qk = F.elu(self.qk(x)) + 1.0
+        if x.is_cuda:
+            qk = F.elu(self._qk_gpu(x)) + 1.0
+        else:
+            qk = F.elu(self.qk(x)) + 1.0
         q, k = qk.reshape(b, 2, self.num_heads, self.head_dim, n).unbind(dim=1)
         v = x.reshape(b, self.num_heads, self.head_dim, n)
         q_t, v_t = q.transpose(-1, -2), v.transpose(-1, -2)
@@ -49,7 +53,29 @@ class LinearAttention(nn.Module):
             a = q_t @ k
             a = a / (a.mean(dim=-1, keepdim=True) + 1e-6)
             out = (a * s) @ (v_t * s)
-        return out.transpose(-1, -2).reshape(b, c, h, w) + self.pe(x)
+        pe = _conv_norm_train(self.pe, x, 1) if (x.is_cuda and c % 4 == 0) else self.pe(x)
+        return out.transpose(-1, -2).reshape(b, c, h, w) + pe
+
+    def _qk_gpu(self, x):
+        """The grouped 1x1 `qk` conv as two GEMMs on the token-major view (same function; the GEMM library's forward and
+        backward are far faster than the grouped-conv path), then the module's own BatchNorm if it has not been fused."""
+        b, c, h, w = x.shape
+        m = self.qk
+        conv = m if isinstance(m, nn.Conv2d) else m.conv
+        tok = x.permute(0, 2, 3, 1).reshape(b * h * w, c)
+        wq, wk = conv.weight[:c, :, 0, 0], conv.weight[c:, :, 0, 0]
+        bq = None if conv.bias is None else conv.bias[:c]
+        bk = None if conv.bias is None else conv.bias[c:]
+        y = torch.cat((F.linear(tok[:, :c // 2], wq, bq), F.linear(tok[:, c // 2:], wk, bk)), dim=1)
+        y = y.view(b, h, w, 2 * c).permute(0, 3, 1, 2)
+        return y if isinstance(m, nn.Conv2d) else m.norm(y)
+
+
+def _conv_norm_train(m, x, stride):
+    """ConvNorm in a training step: HIP depthwise conv (+ autograd), then the module's own BatchNorm (batch statistics)."""
+    if isinstance(m, nn.Conv2d):
+        return _DwConvFn.apply(x, m.weight, m.bias, stride)
+    return m.norm(_DwConvFn.apply(x, m.conv.weight, m.conv.bias, stride))
 
 
 def _folded(m):
@@ -106,11 +132,14 @@ class RecAttn2d(nn.Module):
         return self._pack
 
     def forward(self, x):
-        if self.training:
-            raise NotImplementedError("recnext_amd.RecAttn2d runs in eval mode only (BatchNorm is folded into the "
-                                      "HIP depthwise kernels); call .eval()")
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("recnext_amd.RecAttn2d has no backward yet; run under torch.no_grad()")
+        if self.training or (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            # training step (engine.py:48-64): BatchNorm uses batch statistics, so nothing is folded; the depthwise convs and
+            # their gradients run on HIP, the linear attention and the norms on PyTorch-ROCm operators (autograd)
+            if x.shape[1] % 4:
+                raise NotImplementedError("the HIP depthwise backward needs a channel count that is a multiple of 4")
+            d = _conv_norm_train(self.down[0], x, 2)
+            a = self.down[1](d)
+            return _conv_norm_train(self.conv, x + F.interpolate(a, size=x.shape[2:], mode=self.mode), 1)
         wd, bd, wc, bc, wq, bq, wk, bk, wpe, bpe = self.packed_params()
         k = self.kernel_size
         la = self.down[1]

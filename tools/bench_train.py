@@ -26,6 +26,8 @@ for which in args.which.split(","):
     fam = models.CONFIGS[args.model]["family"]
     net = models.create_model(args.model, token_mixer=None if which == "hip" else eager_token_mixer(fam))
     net = net.to(dev).to(memory_format=torch.channels_last).train()
+    if which == "hip":
+        models.use_hip_downsample(net)                         # Downsample depthwise conv: HIP forward + backward
     opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
     x = torch.randn(args.batch, 3, 224, 224, device=dev).contiguous(memory_format=torch.channels_last)
     y = torch.randint(0, 1000, (args.batch,), device=dev)
