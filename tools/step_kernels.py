@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Per-kernel time of the LAST step of a rocprofv3 --kernel-trace run (warm-up and library autotuning excluded):
+    rocprofv3 --kernel-trace --output-format csv -d OUT -- python3 <bench script>;  python3 tools/step_kernels.py OUT STEPS out.csv
+STEPS = number of equal steps the run executed (warm-up included); the last 1/STEPS of the dispatches is summarised."""
+import collections
+import csv
+import glob
+import sys
+
+root, steps, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+f = glob.glob(root + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+last = rows[int(len(rows) * (steps - 1) / steps):]
+tot, cnt = collections.Counter(), collections.Counter()
+for r in last:
+    name = r["Kernel_Name"].replace("void ", "")
+    name = name[:name.find("(")] if "(" in name else name
+    tot[name[:150]] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    cnt[name[:150]] += 1
+total = sum(tot.values())
+with open(out, "w", newline="") as fh:
+    w = csv.writer(fh)
+    w.writerow(["Name", "Calls", "TotalNs", "AverageNs", "Percentage"])
+    for k, v in tot.most_common(40):
+        w.writerow([k, cnt[k], v, round(v / cnt[k], 1), round(100.0 * v / total, 2)])
+print(f"{len(last)} dispatches, {total / 1e6:.2f} ms of kernels, wall span {(int(last[-1]['End_Timestamp']) - int(last[0]['Start_Timestamp'])) / 1e6:.2f} ms -> {out}")
