@@ -34,4 +34,27 @@ for dtype in (torch.bfloat16, torch.float32):
         diffs = sum(0 if torch.equal(ops.dwconv2d_mult2(x, w, b, k=7, stride=2), y0) else 1 for _ in range(reps))
         print(f"down {n}x{c}x{h}x{h} {dtype}: {diffs} / {reps} runs differ", flush=True)
         bad += diffs
+# single-step kernels and the linear-attention core
+for dtype in (torch.bfloat16, torch.float32):
+    for n, c, h in [(256, 64, 56), (256, 128, 28), (256, 256, 14), (32, 128, 64), (32, 64, 128)]:
+        x = torch.randn(n, c, h, h, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+        cs = torch.randn(n, c, h // 2, h // 2, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+        w = ops.pack_dw_weight(torch.randn(c, 1, 5, 5, device=dev) * 0.1)
+        b = ops.pack_bias(torch.randn(c, device=dev))
+        for name, fn in (("upadd", lambda: ops.upadd_dwconv(x, cs, w, b, k=5, mode="nearest")),
+                         ("down5", lambda: ops.dwconv2d(x, w, b, k=5, stride=2)),
+                         ("conv5", lambda: ops.dwconv2d(x, w, b, k=5, stride=1))):
+            y0 = fn().clone()
+            diffs = sum(0 if torch.equal(fn(), y0) else 1 for _ in range(reps))
+            print(f"{name} {n}x{c}x{h}x{h} {dtype}: {diffs} / {reps} runs differ", flush=True)
+            bad += diffs
+for b_, c, heads, h in [(256, 64, 2, 28), (256, 128, 4, 14), (256, 512, 16, 4)]:
+    d = torch.randn(b_, c, h, h, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    pe = torch.randn_like(d)
+    q = torch.randn(b_, h * h, c, device=dev).bfloat16()
+    k = torch.randn(b_, h * h, c, device=dev).bfloat16()
+    y0 = ops.linear_attention_core(q, k, d, pe, heads).clone()
+    diffs = sum(0 if torch.equal(ops.linear_attention_core(q, k, d, pe, heads), y0) else 1 for _ in range(reps))
+    print(f"linattn {b_}x{c}x{h}x{h}: {diffs} / {reps} runs differ", flush=True)
+    bad += diffs
 print("TOTAL differing runs:", bad)
