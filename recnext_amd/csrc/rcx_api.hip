@@ -81,7 +81,8 @@ bool use_split(int N, int C, int H, int W, int level, int k, int dtype)
     const char* f = getenv("RCX_FORCE_GENERIC");
     if (f && *f && *f != '0') return false;
     if (level < 1 || k != 5 || H != W || (H & 1)) return false;
-    if (rcx::lanes_applicable(N, C, H, W, level, k, dtype)) return false;
+    const char* force = getenv("RCX_FORCE_SPLIT");                  // A/B knob: three launches even where one fused kernel exists
+    if (rcx::lanes_applicable(N, C, H, W, level, k, dtype) && !(force && *force == '1')) return false;
     return rcx::down5_lanes_applicable(N, C, H, W, k, 2, dtype, RCX_DTYPE_F32) &&
            rcx::lanes_applicable(N, C, H / 2, W / 2, level - 1, k, RCX_DTYPE_F32) &&
            rcx::upadd_lanes_applicable(N, C, H, W, H / 2, W / 2, k, dtype, RCX_DTYPE_F32, dtype);
@@ -140,7 +141,7 @@ const char* rcx_recconv2d_fwd_plan(int N, int C, int H, int W, int level, int k,
 {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0) return "invalid";
     static thread_local char desc[256];
-    if (use_lanes(N, C, H, W, level, k, dtype) && rcx::lanes_describe(N, C, H, W, level, k, mode == RCX_MODE_NEAREST ? 1 : 0, dtype, desc, (int)sizeof(desc)) > 0) return desc;
+    if (!(getenv("RCX_FORCE_SPLIT") && use_split(N, C, H, W, level, k, dtype)) && use_lanes(N, C, H, W, level, k, dtype) && rcx::lanes_describe(N, C, H, W, level, k, mode == RCX_MODE_NEAREST ? 1 : 0, dtype, desc, (int)sizeof(desc)) > 0) return desc;
     if (use_split(N, C, H, W, level, k, dtype)) {
         char inner[128];
         rcx::lanes_describe(N, C, H / 2, W / 2, level - 1, k, mode == RCX_MODE_NEAREST ? 1 : 0, RCX_DTYPE_F32, inner, (int)sizeof(inner));
@@ -171,6 +172,7 @@ int rcx_pack_bias(const void* b, float* dst, int C, int dtype, void* stream)
 size_t rcx_recconv2d_fwd_workspace_bytes(int N, int C, int H, int W, int level, int k, int dtype)
 {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0) return 0;
+    if (getenv("RCX_FORCE_SPLIT") && use_split(N, C, H, W, level, k, dtype)) return split_bytes(N, C, H, W);
     if (use_lanes(N, C, H, W, level, k, dtype)) return 0;          // registers only
     if (use_split(N, C, H, W, level, k, dtype)) return split_bytes(N, C, H, W);
     if (use_plane(N, C, H, W, level, k, dtype)) return 0;          // the fused schedule keeps every intermediate in LDS
@@ -186,7 +188,7 @@ int rcx_recconv2d_fwd(const void* x, void* y, const float* wpack, const float* b
     if (x == y) return fail(RCX_ERR_BAD_ARG, "y must not alias x");
     if (level < 0 || level > RCX_MAX_LEVEL) return fail(RCX_ERR_BAD_ARG, "level %d outside [0,%d]", level, RCX_MAX_LEVEL);
     if (mode != RCX_MODE_BILINEAR && mode != RCX_MODE_NEAREST) return fail(RCX_ERR_BAD_ARG, "unknown mode %d", mode);
-    if (use_lanes(N, C, H, W, level, k, dtype)) {
+    if (!(getenv("RCX_FORCE_SPLIT") && use_split(N, C, H, W, level, k, dtype)) && use_lanes(N, C, H, W, level, k, dtype)) {
         hipError_t le = rcx::lanes_recconv(x, y, wpack, bpack, N, C, H, W, level, k, mode, dtype, (hipStream_t)stream);
         return le == hipSuccess ? 0 : hip_fail(le, "lanes schedule");
     }
