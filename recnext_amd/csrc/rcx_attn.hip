@@ -10,6 +10,8 @@
 // (the reference asserts it to 1e-4, lsnet/model/recattn.py:481-501), so both variants run this O(n d^2) form in fp32.
 // Layout: all five tensors are (B, n, C) = NHWC; head h owns channels [h*D, (h+1)*D), D = C / heads.  G = 4 output columns per
 // thread when D % 4 == 0 (D <= 64), else G = 1 (D <= 32).
+#include <stdlib.h>
+
 #include "rcx_common.h"
 #include "rcx_launch.h"
 
@@ -24,7 +26,8 @@ __device__ __forceinline__ float la_ld(const float* p) { return *p; }
 __device__ __forceinline__ float la_ld(const bf16_t* p) { return bf16_to_f32(*p); }
 __device__ __forceinline__ void la_st(float* p, float v) { *p = v; }
 __device__ __forceinline__ void la_st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
-__device__ __forceinline__ float elu1(float x) { return (x > 0.f ? x : expm1f(x)) + 1.f; }
+// elu(x) + 1 = x + 1 (x > 0) | exp(x) (x <= 0): no expm1 needed, and none of its cancellation
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.f : __expf(x); }
 
 // G consecutive channels in one access (G = 4: 8 bytes of bf16 / 16 bytes of float32)
 template <int G> __device__ __forceinline__ void la_ldv(const float* p, float (&o)[G]) { load_vec<G>(p, o); }
@@ -149,6 +152,148 @@ k_linattn_core(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* 
     }
 }
 
+
+// Register-tiled form for head dimensions that are multiples of 4 (every A-series model): phase 1 gives each thread a 4x4
+// block of k v^T over a 1/TG share of the tokens (two 16-byte LDS reads per 16 FMAs; the TG partial blocks are then summed in
+// a fixed order), phase 2 a (two tokens) x (four columns) block of the output (six 16-byte reads per 32 FMAs).
+
+// DM = 32 or 64: capacity of the LDS tiles (head dimensions up to 32 take 21 KB instead of 50 KB: 7 blocks per CU instead of 3)
+template <typename T, int DM>
+__global__ void __launch_bounds__(LA_NT)
+k_linattn_core4(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* __restrict__ v, const T* __restrict__ pe,
+                T* __restrict__ out, int n, int C, int heads)
+{
+    __shared__ __attribute__((aligned(16))) float a_s[LA_TT][DM + 4];      // + 4: rows stay 16-byte aligned, odd multiple of 16 B
+    __shared__ __attribute__((aligned(16))) float v_s[LA_TT][DM];
+    __shared__ __attribute__((aligned(16))) float kv_s[DM][DM];
+    __shared__ float kbar_s[DM];
+    __shared__ float den_s[LA_TT];
+    const int D = C / heads, Q = D / 4;
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+    const size_t base = (size_t)b * n * C + (size_t)h * D;
+    const int tid = threadIdx.x;
+    const float s2 = 1.f / (float)n;
+    const int NI = Q * Q;                                         // 4x4 blocks of kv (<= 256)
+    int TG = 1;                                                   // token groups: power of two, <= 8, NI * TG <= 256
+    while (TG < 8 && NI * TG * 2 <= LA_NT) TG *= 2;
+    const int tg = tid / NI, blk = tid - tg * NI;
+    const bool p1 = tid < NI * TG;
+    const int e1q = blk / Q, e2q = blk - e1q * Q;
+
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    float ksum = 0.f;
+    for (int t0 = 0; t0 < n; t0 += LA_TT) {
+        const int tt = n - t0 < LA_TT ? n - t0 : LA_TT;
+        const int tt8 = (tt + 7) & ~7;
+        __syncthreads();
+        for (int i = tid; i < tt8 * Q; i += LA_NT) {
+            const int t = i / Q, e = (i - t * Q) * 4;
+            float kk[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (t < tt) {
+                const size_t g = base + (size_t)(t0 + t) * C + e;
+                la_ldv<4>(kpre + g, kk);
+                la_ldv<4>(v + g, vv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) kk[j] = elu1(kk[j]);
+            }
+            *reinterpret_cast<float4*>(&a_s[t][e]) = make_float4(kk[0], kk[1], kk[2], kk[3]);   // rows past tt are zero
+            *reinterpret_cast<float4*>(&v_s[t][e]) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        }
+        __syncthreads();
+        if (p1) {
+            for (int t = tg; t < tt8; t += TG) {
+                const float4 k4 = *reinterpret_cast<const float4*>(&a_s[t][e1q * 4]);
+                const float4 v4 = *reinterpret_cast<const float4*>(&v_s[t][e2q * 4]);
+                const float kk[4] = {k4.x, k4.y, k4.z, k4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(kk[i], vv[j], acc[i][j]);
+            }
+        }
+        if (tid < D) {
+            for (int t8 = 0; t8 < tt8; t8 += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ksum += a_s[t8 + u][tid];
+            }
+        }
+    }
+    // sum the TG partial blocks in a fixed order
+    for (int g = 0; g < TG; ++g) {
+        __syncthreads();
+        if (p1 && tg == g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4* dst = reinterpret_cast<float4*>(&kv_s[e1q * 4 + i][e2q * 4]);
+                float4 cur = g == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : *dst;
+                cur.x += acc[i][0] * s2; cur.y += acc[i][1] * s2; cur.z += acc[i][2] * s2; cur.w += acc[i][3] * s2;
+                *dst = cur;
+            }
+        }
+    }
+    if (tid < D) kbar_s[tid] = ksum / (float)n;
+
+    for (int t0 = 0; t0 < n; t0 += LA_TT) {
+        const int tt = n - t0 < LA_TT ? n - t0 : LA_TT;
+        const int tt2 = (tt + 1) & ~1;
+        __syncthreads();
+        for (int i = tid; i < tt2 * Q; i += LA_NT) {
+            const int t = i / Q, e = (i - t * Q) * 4;
+            float qq[4] = {0.f, 0.f, 0.f, 0.f};
+            if (t < tt) {
+                la_ldv<4>(qpre + base + (size_t)(t0 + t) * C + e, qq);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qq[j] = elu1(qq[j]);
+            }
+            *reinterpret_cast<float4*>(&a_s[t][e]) = make_float4(qq[0], qq[1], qq[2], qq[3]);
+        }
+        __syncthreads();
+        if (tid < tt) {
+            float d = 0.f;
+#pragma unroll 4
+            for (int e = 0; e < D; ++e) d = fmaf(a_s[tid][e], kbar_s[e], d);
+            den_s[tid] = d + 1e-6f;
+        }
+        __syncthreads();
+        for (int it = tid; it < (tt2 / 2) * Q; it += LA_NT) {
+            const int tp = it / Q, e2 = (it - tp * Q) * 4, ta = 2 * tp, tb = ta + 1;
+            float o[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[0][j] = o[1][j] = 0.f;
+            for (int eq = 0; eq < Q; ++eq) {
+                const float4 qa4 = *reinterpret_cast<const float4*>(&a_s[ta][eq * 4]);
+                const float4 qb4 = *reinterpret_cast<const float4*>(&a_s[tb][eq * 4]);
+                const float qa[4] = {qa4.x, qa4.y, qa4.z, qa4.w}, qb[4] = {qb4.x, qb4.y, qb4.z, qb4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 r = *reinterpret_cast<const float4*>(&kv_s[eq * 4 + i][e2]);
+                    o[0][0] = fmaf(qa[i], r.x, o[0][0]); o[0][1] = fmaf(qa[i], r.y, o[0][1]);
+                    o[0][2] = fmaf(qa[i], r.z, o[0][2]); o[0][3] = fmaf(qa[i], r.w, o[0][3]);
+                    o[1][0] = fmaf(qb[i], r.x, o[1][0]); o[1][1] = fmaf(qb[i], r.y, o[1][1]);
+                    o[1][2] = fmaf(qb[i], r.z, o[1][2]); o[1][3] = fmaf(qb[i], r.w, o[1][3]);
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const int t = ta + w;
+                if (t < tt) {
+                    const float inv = 1.f / den_s[t];
+                    const size_t gi = base + (size_t)(t0 + t) * C + e2;
+                    float pp[4], r[4];
+                    la_ldv<4>(pe + gi, pp);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) r[j] = fmaf(o[w][j], inv, pp[j]);
+                    la_stv<4>(out + gi, r);
+                }
+            }
+        }
+    }
+}
+
 hipError_t linattn_core(const void* qpre, const void* kpre, const void* v, const void* pe, void* out,
                         int B, int n, int C, int heads, int dtype, hipStream_t s)
 {
@@ -156,7 +301,16 @@ hipError_t linattn_core(const void* qpre, const void* kpre, const void* v, const
     const bool wide = ((C / heads) % 4) == 0;
 #define RCX_LA_LAUNCH(T, G) hipLaunchKernelGGL((k_linattn_core<T, G>), grid, block, 0, s, (const T*)qpre, (const T*)kpre, (const T*)v, \
                                                (const T*)pe, (T*)out, n, C, heads)
-    if (dtype == 1) { if (wide) RCX_LA_LAUNCH(bf16_t, 4); else RCX_LA_LAUNCH(bf16_t, 1); }
+    const char* old = getenv("RCX_ATTN_SCALAR");                 // A/B knob: the untiled kernel for every head dimension
+    const bool tiled = wide && !(old && *old == '1');
+    if (tiled) {
+#define RCX_LA4(T, DM) hipLaunchKernelGGL((k_linattn_core4<T, DM>), grid, block, 0, s, (const T*)qpre, (const T*)kpre, (const T*)v, (const T*)pe, (T*)out, n, C, heads)
+        const bool small = C / heads <= 32;
+        if (dtype == 1) { if (small) RCX_LA4(bf16_t, 32); else RCX_LA4(bf16_t, 64); }
+        else { if (small) RCX_LA4(float, 32); else RCX_LA4(float, 64); }
+#undef RCX_LA4
+    }
+    else if (dtype == 1) { if (wide) RCX_LA_LAUNCH(bf16_t, 4); else RCX_LA_LAUNCH(bf16_t, 1); }
     else { if (wide) RCX_LA_LAUNCH(float, 4); else RCX_LA_LAUNCH(float, 1); }
 #undef RCX_LA_LAUNCH
     return hipGetLastError();
