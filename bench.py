@@ -43,7 +43,8 @@ def parse_args():
 
 
 class MixerTimers:
-    """HIP events around every RecConv2d call (recorded on the stream the kernels are launched on)."""
+    """HIP events around every token-mixer call (recorded on the stream the kernels are launched on): RecConv2d is one kernel
+    launch; RecAttn2d (A family) is a unit of four HIP kernels and two GEMMs and is reported as such."""
 
     def __init__(self, net, torch, RecConv2d):
         self.torch = torch
@@ -75,16 +76,20 @@ class MixerTimers:
         by_shape = {}
         for m, shape, s, e in self.records:
             n, c, h, w = shape
-            key = (c, h, w, m.level, m.kernel_size)
+            key = (c, h, w, getattr(m, "level", None), m.kernel_size)
             ent = by_shape.setdefault(key, {"ms": 0.0, "calls": 0, "N": n})
             ent["ms"] += s.elapsed_time(e)
             ent["calls"] += 1
         shapes, kernels = [], {}
         for (c, h, w, level, k), ent in by_shape.items():
             n = ent["N"]
-            alg = 2 * n * c * h * w * elem_bytes + (level + 2) * c * k * k * elem_bytes
             avg_ms = ent["ms"] / ent["calls"]
-            plan = plan_of(n, c, h, w, level, k)
+            if level is None:                 # RecAttn2d: compulsory bytes of its depthwise pieces, 3.5 * S per block
+                alg = int(3.5 * n * c * h * w * elem_bytes)
+                plan = "recattn2d(k_down5_lanes + qk GEMMs + pe conv + k_linattn_core4 + k_upadd_lanes)"
+            else:
+                alg = 2 * n * c * h * w * elem_bytes + (level + 2) * c * k * k * elem_bytes
+                plan = plan_of(n, c, h, w, level, k)
             shapes.append({"C": c, "H": h, "W": w, "level": level, "k": k, "N": n, "calls": ent["calls"], "plan": plan,
                            "total_ms": ent["ms"], "avg_ms": avg_ms, "algorithmic_bytes": alg,
                            "achieved_GBs": alg / (avg_ms * 1e-3) / 1e9})
@@ -93,7 +98,7 @@ class MixerTimers:
             kk["total_ms"] += ent["ms"]
             kk["launches"] += ent["calls"]
             kk["algorithmic_bytes"] += alg * ent["calls"]
-            kk["shapes"].append(f"{n}x{c}x{h}x{w}_L{level}")
+            kk["shapes"].append(f"{n}x{c}x{h}x{w}_L{level}" if level is not None else f"{n}x{c}x{h}x{w}_attn")
         shapes.sort(key=lambda r: -r["total_ms"])
         kernels = sorted(kernels.values(), key=lambda r: -r["total_ms"])
         for kk in kernels:
@@ -109,6 +114,10 @@ def kernel_name(plan, elem_bytes):
         lpp = int(plan[len("plane(cb="):].split(",")[0]) // 2
         kern = "k_recconv_whole" if "whole-plane" in plan else "k_recconv_plane"
         return f"rcx::{kern}<{lpp}, {t}>"
+    if plan.startswith("recattn2d("):
+        return "RecAttn2d token mixer: " + plan[len("recattn2d("):-1] + " (one unit, several launches)"
+    if plan.startswith("split("):
+        return "rcx split schedule: " + plan[len("split("):-1]
     if plan.startswith("lanes(k_recconv_lanes"):
         kern = plan[len("lanes("):plan.index(">")]
         return f"rcx::lanes::{kern}, {t}>"
@@ -174,7 +183,8 @@ def main():
     torch.backends.cudnn.benchmark = True
     net = build_inference_model(args.model, device, dtype, seed=0)       # identical weights on every rank
     x = synthetic_batch(args.batch, args.resolution, device, dtype, seed=rank)   # this rank's shard of the global batch
-    timers = MixerTimers(net, torch, recnext_amd.RecConv2d)
+    from recnext_amd.recattn import RecAttn2d
+    timers = MixerTimers(net, torch, (recnext_amd.RecConv2d, RecAttn2d))
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -205,7 +215,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.model} forward, BN-folded, channels_last, {args.resolution}x{args.resolution}, "
-                                   f"batch {args.batch}/GPU, random-init weights, HIP RecConv2d token mixers",
+                                   f"batch {args.batch}/GPU, random-init weights, HIP token mixers",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world} (batch-sharded replicas, no collective in the timed region)"},
             "roofline": {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
