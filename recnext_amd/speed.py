@@ -9,6 +9,7 @@ Additions: ``--dtype`` (the reference runs fp32 only) and channels_last storage,
 token mixers consume zero-copy.  There is no CPU mode here: the product path is GPU-only.
 """
 import argparse
+import os
 import time
 
 import torch
@@ -52,9 +53,35 @@ def synthetic_batch(batch_size, resolution, device, dtype=torch.bfloat16, seed=0
 
 
 @torch.no_grad()
+def tune_gemms(model, inputs):
+    """PyTorch-ROCm plumbing, the GEMM counterpart of ``cudnn.benchmark``: let TunableOp pick the GEMM-library solution for
+    every 1x1-conv / linear shape of the skeleton during one forward pass, then freeze the choices (same GEMMs, faster tiles;
+    about 5 s).  Returns True if tuning ran."""
+    try:
+        import tempfile
+        import torch.cuda.tunable as tn
+    except ImportError:        # an older PyTorch without TunableOp: keep the default selection
+        return False
+    tn.enable(True)
+    try:
+        tn.set_filename(os.path.join(tempfile.gettempdir(), "recnext_amd_tunableop.csv"), True)   # results file: not the cwd
+        tn.set_max_tuning_duration(20)
+        tn.set_max_tuning_iterations(10)
+        tn.tuning_enable(True)
+        with torch.no_grad():
+            model(inputs)
+        torch.cuda.synchronize()
+        return True
+    except Exception:
+        return False
+    finally:
+        tn.tuning_enable(False)
+
+
 def throughput(name, model, device, batch_size, resolution=224, dtype=torch.bfloat16, t0=T0, t1=T1):
     inputs = synthetic_batch(batch_size, resolution, device, dtype)
     torch.cuda.empty_cache()
+    tune_gemms(model, inputs)
     torch.cuda.synchronize()
     start = time.time()
     while time.time() - start < t0:
