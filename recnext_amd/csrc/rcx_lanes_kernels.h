@@ -7,11 +7,17 @@
 #ifndef RCX_LSTAMP
 #define RCX_LSTAMP(id) do { } while (0)
 #endif
+#ifdef RCX_STAMPS
+#define RCX_LABLATE(a, bit) ((a).ablate & (bit))
+#else
+#define RCX_LABLATE(a, bit) 0
+#endif
 
 namespace rcx {
 namespace lanes {
 
 struct LanesArgs {
+    int ablate;        // diagnostic build only (RCX_LANES_ABLATE): 1 = skip the arithmetic, 2 = skip the global loads, 4 = skip the stores
     int N, C;
     int nblk;          // channel blocks per image (C / CBW)
     int ni;            // images per workgroup (consecutive)
@@ -65,9 +71,11 @@ void k_recconv_lanes(const TIO* __restrict__ x, TIO* __restrict__ y, const float
         g_off[i] = p * a.C * ESZ + part * 16;
         l_off[i] = lds_slot<W0, B0, LA>(p) * PITCH + part * 16;
     });
+    RCX_LSTAMP(32);
     u32x4 v[STAGE];
     auto prefetch = [&](int n) RCX_INL {
         const unsigned char* xg = reinterpret_cast<const unsigned char*>(x + (size_t)n * img_stride + c0);
+        if (RCX_LABLATE(a, 2)) { sfor<STAGE>([&](auto I) RCX_INL { v[decltype(I)::value] = u32x4{0u, 0u, 0u, 0u}; }); return; }
         sfor<STAGE>([&](auto I) RCX_INL { v[decltype(I)::value] = *reinterpret_cast<const u32x4*>(xg + g_off[decltype(I)::value]); });
     };
     if (n0 < n1) prefetch(n0);
@@ -110,10 +118,12 @@ void k_recconv_lanes(const TIO* __restrict__ x, TIO* __restrict__ y, const float
             constexpr int i = decltype(I)::value;
             if (have[i]) *reinterpret_cast<u32x4*>(img + l_off[i]) = v[i];
         });
+        if (n == n0) RCX_LSTAMP(33);
         __syncthreads();
+        if (n == n0) RCX_LSTAMP(34);
         if (n + 1 < n1) prefetch(n + 1);
         // ---- the whole block in registers; every output row overwrites the lane's own (already consumed) x bytes
-        if (active) {
+        if (active && !RCX_LABLATE(a, 1)) {
             Level<LPC, MODE, 0, LEVEL, W0, B0, 1, CBW>::run_io(
                 [&](auto R, float (&row)[B0]) RCX_INL {
 #pragma unroll
@@ -125,14 +135,17 @@ void k_recconv_lanes(const TIO* __restrict__ x, TIO* __restrict__ y, const float
                 },
                 my_taps, c);
         }
+        if (n == n0) RCX_LSTAMP(35);
         __syncthreads();
+        if (n == n0) RCX_LSTAMP(36);
         // ---- y: raw LDS image -> coalesced 16-byte stores (same thread <-> chunk mapping as the loads, so the next
         //      image's LDS writes need no barrier after these reads)
         unsigned char* yg = reinterpret_cast<unsigned char*>(y + (size_t)n * img_stride + c0);
-        sfor<STAGE>([&](auto I) RCX_INL {
+        if (!RCX_LABLATE(a, 4)) sfor<STAGE>([&](auto I) RCX_INL {
             constexpr int i = decltype(I)::value;
             if (have[i]) *reinterpret_cast<u32x4*>(yg + g_off[i]) = *reinterpret_cast<const u32x4*>(img + l_off[i]);
         });
+        if (n == n0) RCX_LSTAMP(37);
     }
 }
 
@@ -516,6 +529,7 @@ static hipError_t launch_w(const void* x, void* y, const float* wpack, const flo
     }
     LanesArgs a = p.args;
     a.has_bias = bpack != nullptr;
+    a.ablate = env_int("RCX_LANES_ABLATE", 0);
     const unsigned grid = (unsigned)(a.nblk * (((a.N + a.ni - 1) / a.ni + 7) / 8 * 8));
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), p.lds, s, (const TIO*)x, (TIO*)y, wpack, bpack, a);
     return hipGetLastError();

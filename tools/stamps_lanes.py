@@ -46,6 +46,12 @@ for s in range(4):
     names[25 + 4 * s] = f"p2 band{s} barrier passed"
     names[26 + 4 * s] = f"p2 band{s} y(b-2) stored"
     names[27 + 4 * s] = f"p2 band{s} computed"
+names.update({32: "whole: start", 33: "whole: taps + x written to LDS", 34: "whole: barrier passed", 35: "whole: computed", 36: "whole: 2nd barrier", 37: "whole: y stored"})
+if (st[:, 32] > 0).any():                      # whole-plane kernel: relative to the earliest workgroup's start
+    t_first = st[st[:, 32] > 0, 32].min()
+    print("workgroup starts after the first one (kilo-ticks): median %.3f  p90 %.3f  max %.3f" % tuple(
+        np.percentile((st[st[:, 32] > 0, 32] - t_first) / 1000.0, q) for q in (50, 90, 100)))
+    st[:, 0] = st[:, 32]
 valid = st[:, 0] > 0
 rel = (st[valid] - st[valid, 0:1]) / 1000.0
 print("workgroups sampled:", int(valid.sum()), "(kilo-ticks of the 100 MHz-class s_memtime counter since the kernel-local start; median over workgroups)")
