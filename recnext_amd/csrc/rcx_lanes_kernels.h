@@ -49,6 +49,8 @@ void k_recconv_lanes(const TIO* __restrict__ x, TIO* __restrict__ y, const float
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* taps = reinterpret_cast<float*>(smem);                 // [NCONV][26][CBW]
     unsigned char* img = smem + TAPS_BYTES;                        // [HW][PITCH]
+    float* xarea = reinterpret_cast<float*>(img + HW * PITCH);     // [CBW][xch_stride]: neighbour-exchange lines (rcx_lanes.h)
+    constexpr int XFLOATS = RCX_XCH_LDS ? CBW * xch_stride(LPC, B0) : 0;
 
     const int tid = threadIdx.x;
     // workgroup -> (channel block, image group): the channel blocks of one image group get ids that are equal mod 8,
@@ -103,11 +105,14 @@ void k_recconv_lanes(const TIO* __restrict__ x, TIO* __restrict__ y, const float
         });
     }
 
+    for (int i = tid; i < XFLOATS; i += NT) xarea[i] = 0.f;           // the zeros are the horizontal padding; ordered by the first barrier below
+
     const int lane = tid & 63, wave = tid >> 6;
     Ctx c;
     c.lane_in_group = lane % LPC;
     c.mode = MODE;
     const int ch = wave * CPW + lane / LPC;
+    xch_setup<LPC>(c, xarea, ch, B0);
     const bool active = c.lane_in_group < LA;
     unsigned char* mine = img + c.lane_in_group * PITCH + ch * ESZ;   // + (row * W0 + j * LA) * PITCH for column j of the lane
     const float* my_taps = taps + ch;
@@ -124,10 +129,22 @@ void k_recconv_lanes(const TIO* __restrict__ x, TIO* __restrict__ y, const float
         if (n + 1 < n1) prefetch(n + 1);
         // ---- the whole block in registers; every output row overwrites the lane's own (already consumed) x bytes
         if (active && !RCX_LABLATE(a, 1)) {
+            // x rows are read one row ahead (raw bits; converted when the row is consumed), so that the LDS round trip of
+            // row r+1 runs under the FMAs of row r.  Output rows trail the input by two rows, so the bytes are still x.
+            typename Raw<TIO>::raw_t ahead[B0];
             Level<LPC, MODE, 0, LEVEL, W0, B0, 1, CBW>::run_io(
                 [&](auto R, float (&row)[B0]) RCX_INL {
+                    constexpr int r = decltype(R)::value;
+                    if constexpr (r == 0) {
 #pragma unroll
-                    for (int j = 0; j < B0; ++j) row[j] = Raw<TIO>::ld(mine + (decltype(R)::value * W0 + j * LA) * PITCH);
+                        for (int j = 0; j < B0; ++j) ahead[j] = Raw<TIO>::ldr(mine + (j * LA) * PITCH);
+                    }
+#pragma unroll
+                    for (int j = 0; j < B0; ++j) row[j] = Raw<TIO>::cvt(ahead[j]);
+                    if constexpr (r + 1 < W0) {
+#pragma unroll
+                        for (int j = 0; j < B0; ++j) ahead[j] = Raw<TIO>::ldr(mine + ((r + 1) * W0 + j * LA) * PITCH);
+                    }
                 },
                 [&](auto O, const float (&acc)[B0]) RCX_INL {
 #pragma unroll
@@ -177,6 +194,8 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* taps = reinterpret_cast<float*>(smem);
     unsigned char* ring = smem + TAPS_BYTES;      // [3][BAND_PX][PITCH]
+    float* xarea = reinterpret_cast<float*>(ring + 3 * BAND_BYTES);   // [CBW][xch_stride]: neighbour-exchange lines (rcx_lanes.h)
+    constexpr int XFLOATS = RCX_XCH_LDS ? CBW * xch_stride(LPC, B0) : 0;
 
     const int tid = threadIdx.x;
     // workgroup -> (channel block, image group): the channel blocks of one image group get ids that are equal mod 8,
@@ -252,11 +271,14 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
         });
     }
 
+    for (int i = tid; i < XFLOATS; i += NT) xarea[i] = 0.f;           // the zeros are the horizontal padding; ordered by the barrier below
+
     const int lane = tid & 63, wave = tid >> 6;
     Ctx c;
     c.lane_in_group = lane % LPC;
     c.mode = MODE;
     const int ch = wave * CPW + lane / LPC;
+    xch_setup<LPC>(c, xarea, ch, B0);
     const bool active = c.lane_in_group < LA;
     const int mine = c.lane_in_group * PITCH + ch * ESZ;              // + (row * W0 + j * LA) * PITCH for column j of the lane
     const float* my_taps = taps + ch;
@@ -272,8 +294,9 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
         // ================= pass 1: F_1 = down(x) =================
         {
             float A[2][B1];
-            float w[25], bias;
-            if (active) load_taps<CBW>(my_taps, w, bias);            // stays in registers for the whole pass
+            Taps w;
+            if (active) load_taps<CBW>(my_taps, w);                  // stays in registers for the whole pass
+            const float bias = w.bias();
 #pragma unroll 1
             for (int s = 0; s < NS; ++s) {
                 unsigned char* cur = slot_ptr(0);
@@ -299,7 +322,7 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
 #pragma unroll
                             for (int j = 0; j < B0; ++j) nxt[j] = Raw<TIO>::ld(xb + ((i + 1) * W0 + j * LA) * PITCH);
                         }
-                        make_ext<LPC, B0, 1>(row, ext);
+                        make_ext<LPC, B0, 1>(row, ext, c);
                         sfor<5>([&](auto U) RCX_INL {
                             constexpr int u = decltype(U)::value;
                             constexpr int t = i + 2 - u;
@@ -310,7 +333,7 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
                                 for (int q = 0; q < B1; ++q) {
                                     float acc = is_first ? bias : L[orel + 1][q];
 #pragma unroll
-                                    for (int vv = 0; vv < 5; ++vv) acc = fmaf(ext[2 * q + vv], w[u * 5 + vv], acc);
+                                    for (int vv = 0; vv < 5; ++vv) acc = fmaf(ext[2 * q + vv], w.get(u * 5 + vv), acc);
                                     L[orel + 1][q] = acc;
                                 }
                             }
@@ -357,8 +380,9 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
         if (n == n0) RCX_LSTAMP(2);
         {
             float Cy[4][B0];
-            float w[25], bias;
-            if (active) load_taps<CBW>(my_taps + (1 + LEVEL) * 26 * CBW, w, bias);
+            Taps w;
+            if (active) load_taps<CBW>(my_taps + (1 + LEVEL) * 26 * CBW, w);
+            const float bias = w.bias();
 #pragma unroll 1
             for (int s = 0; s < NS; ++s) {
                 unsigned char* cur = slot_ptr(0);
@@ -389,7 +413,7 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
                     sfor<HS + 2>([&](auto K) RCX_INL {
 #pragma unroll
                         for (int q = 0; q < B1; ++q) asm volatile("" : "+v"(cw[decltype(K)::value][q]));
-                        hresize_row<LPC, B1, B0>(cw[decltype(K)::value], wt, hw[decltype(K)::value]);
+                        hresize_row<LPC, B1, B0>(cw[decltype(K)::value], wt, hw[decltype(K)::value], c);
                     });
                     float L[SR + 4][B0];
 #pragma unroll
@@ -416,16 +440,28 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
 #pragma unroll
                             for (int j = 0; j < B0; ++j) nxt[j] = Raw<TIO>::ld(xb + ((i + 1) * W0 + j * LA) * PITCH);
                         }
-                        make_ext<LPC, B0, 1>(row, ext);
+                        make_ext<LPC, B0, 1>(row, ext, c);
                         sfor<5>([&](auto U) RCX_INL {
                             constexpr int u = decltype(U)::value;
                             constexpr int idx = i + 2 - u + 2;                           // output row (i + 2 - u) relative to the band, + 2
+                            if constexpr (RCX_PK_FMA) {                                  // two columns per v_pk_fma_f32, see conv5_s1
 #pragma unroll
-                            for (int j = 0; j < B0; ++j) {
-                                float acc = u == 0 ? bias : L[idx][j];
+                                for (int q = 0; q < B0 / 2; ++q) {
+                                    f32x2 acc = u == 0 ? f32x2{bias, bias} : f32x2{L[idx][2 * q], L[idx][2 * q + 1]};
 #pragma unroll
-                                for (int vv = 0; vv < 5; ++vv) acc = fmaf(ext[j + vv], w[u * 5 + vv], acc);
-                                L[idx][j] = acc;
+                                    for (int vv = 0; vv < 5; ++vv)
+                                        acc = __builtin_elementwise_fma(f32x2{ext[2 * q + vv], ext[2 * q + vv + 1]}, w.splat(u * 5 + vv), acc);
+                                    L[idx][2 * q] = acc.x;
+                                    L[idx][2 * q + 1] = acc.y;
+                                }
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < B0; ++j) {
+                                    float acc = u == 0 ? bias : L[idx][j];
+#pragma unroll
+                                    for (int vv = 0; vv < 5; ++vv) acc = fmaf(ext[j + vv], w.get(u * 5 + vv), acc);
+                                    L[idx][j] = acc;
+                                }
                             }
                         });
                         // output row i - 2 (relative) is complete
@@ -504,6 +540,7 @@ static inline LanesPlan plan(int N, int C, int H, int W, int level, int k, int d
     const int cbw = waves * cpw;
     if (C % cbw != 0 || (cbw * esz) % 16 != 0) return p;
     p.lds = (size_t)(level + 2) * 26 * cbw * 4 + (size_t)(banded ? 3 * sr : H) * W * (cbw * esz + 16);
+    if (RCX_XCH_LDS) p.lds += (size_t)cbw * xch_stride(lpc, W / lanes_active(W, lpc)) * 4;
     if (p.lds > 160 * 1024) return p;
     p.banded = banded; p.sr = sr;
     p.w0 = W; p.level = level; p.lpc = lpc; p.waves = waves;
