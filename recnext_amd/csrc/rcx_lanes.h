@@ -58,7 +58,10 @@ constexpr int lanes_active(int w0, int lpc) { return (w0 % 16 == 0) ? 16 : (lpc 
 
 // ------------------------------------------------------------------------------------------------
 template <typename TIO> struct Raw;
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 template <> struct Raw<float> {
+    // x element into a register that is only ever loaded this way (see the bf16 form)
+    static __device__ __forceinline__ void ld_into(const unsigned char* p, float& v) { v = *reinterpret_cast<const float*>(p); }
     typedef float raw_t;
     static __device__ __forceinline__ raw_t ldr(const unsigned char* p) { return *reinterpret_cast<const float*>(p); }
     static __device__ __forceinline__ float cvt(raw_t r) { return r; }
@@ -66,6 +69,14 @@ template <> struct Raw<float> {
     static __device__ __forceinline__ void st(unsigned char* p, float v) { *reinterpret_cast<float*>(p) = v; }
 };
 template <> struct Raw<bf16_t> {
+    // bf16 -> f32 without a VALU instruction: the 16 bits land in the upper half of v (ds_read_u16_d16_hi), whose lower
+    // half must already be zero -- true for a register that was zeroed once and is only ever loaded through here
+    static __device__ __forceinline__ void ld_into(const unsigned char* p, float& v)
+    {
+        u16x2 r = __builtin_bit_cast(u16x2, v);
+        r.y = *reinterpret_cast<const bf16_t*>(p);
+        v = __builtin_bit_cast(float, r);
+    }
     typedef bf16_t raw_t;
     static __device__ __forceinline__ raw_t ldr(const unsigned char* p) { return *reinterpret_cast<const bf16_t*>(p); }
     static __device__ __forceinline__ float cvt(raw_t r) { return bf16_to_f32(r); }
@@ -183,6 +194,7 @@ template <int LPC, int B, int D>
 __device__ __forceinline__ void make_ext(const float (&row)[B], float (&ext)[B + 4], const Ctx& c)
 {
 #if RCX_XCH_LDS
+    if constexpr (RCX_XCH_LDS == 2 && B == 1) { make_ext<LPC, B, D>(row, ext); return; }   // hybrid: DPP below the B >= 2 levels
     static_assert(B == 1 || B == 2 || B == 4, "exchange lines exist for 1, 2 and 4 columns per lane");
     constexpr int PL = xch_pl(LPC);
 #pragma unroll
@@ -235,7 +247,7 @@ __device__ __forceinline__ void load_taps(const float* __restrict__ tl, Taps& w)
 
 // 5x5 depthwise, stride 1, pad 2.  in_row(IC<r>, float(&)[B]) yields input row r (called once per row, in
 // order); out_row(IC<o>, const float(&)[B]) receives output row o as soon as it is complete.
-template <int LPC, int H, int B, int D, class InRow, class OutRow>
+template <int LPC, int H, int B, int D, bool PK = true, class InRow, class OutRow>
 __device__ __forceinline__ void conv5_s1(const Taps& w, InRow&& in_row, OutRow&& out_row, const Ctx& c)
 {
     const float bias = w.bias();
@@ -269,7 +281,7 @@ __device__ __forceinline__ void conv5_s1(const Taps& w, InRow&& in_row, OutRow&&
             constexpr int o = r + 2 - u;
             if constexpr (o >= 0 && o < H) {
                 constexpr bool first = (u == 0) || (r == 0);             // input row max(o-2, 0) is the first to reach output row o
-                if constexpr (RCX_PK_FMA && B % 2 == 0 && H <= 16) {            // (taller planes: the pairs cost too many registers)
+                if constexpr (RCX_PK_FMA && PK && B % 2 == 0) {
                     // two adjacent columns per v_pk_fma_f32 (the tap is splat through op_sel): same products, same order of
                     // summation as the scalar form, half the instructions -- and a packed FMA costs the same 4 cycles as
                     // any other VALU instruction once a DPP move has put the SIMD into its slow issue mode
@@ -423,6 +435,7 @@ template <int LPC, int BC, int BF>
 __device__ __forceinline__ void hresize_row(const float (&cr)[BC], const float (&wt)[BF][2], float (&out)[BF], const Ctx& c)
 {
 #if RCX_XCH_LDS
+    if constexpr (RCX_XCH_LDS == 2 && BF == 1) { hresize_row<LPC, BC, BF>(cr, wt, out); return; }
     static_assert(BC == 1 || BC == 2 || BC == 4, "exchange lines exist for 1, 2 and 4 columns per lane");
     constexpr int PL = xch_pl(LPC);
     float cext[BC + 2];
@@ -451,7 +464,7 @@ __device__ __forceinline__ void hresize_row(const float (&cr)[BC], const float (
 // TWICE per row when l < LEVEL: once for the stride-2 conv, once to build T_l = F_l + resize(C_{l+1})), and
 // out_row(IC<o>, row) receives C_l = conv_{LEVEL-l}(T_l) row by row.  run() is the all-in-registers wrapper
 // used below level 0.  W is this level's width, (B, D) its lane layout.
-template <int LPC, int MODE, int LVL, int LEVEL, int W, int B, int D, int CBW>
+template <int LPC, int MODE, int LVL, int LEVEL, int W, int B, int D, int CBW, bool PK = true>
 struct Level {
     static constexpr int H = W;
     static constexpr int WN = down_size5(W);
@@ -468,12 +481,12 @@ struct Level {
                 float Fn[WN][BN];
                 load_taps<CBW>(taps, w);                                   // conv 0 of the pack = the shared `down`
                 conv5_s2<LPC, H, B, D, WN, BN>(w, in_row, Fn, c);
-                Level<LPC, MODE, LVL + 1, LEVEL, WN, BN, DN, CBW>::run(Fn, Cn, taps, c);
+                Level<LPC, MODE, LVL + 1, LEVEL, WN, BN, DN, CBW, PK>::run(Fn, Cn, taps, c);
             }
             float hrow[WN][B];
             hresize(Cn, hrow, c);
             load_taps<CBW>(taps + (1 + LEVEL - LVL) * 26 * CBW, w);
-            conv5_s1<LPC, H, B, D>(w,
+            conv5_s1<LPC, H, B, D, PK>(w,
                 [&](auto R, float (&row)[B]) RCX_INL {
                     in_row(R, row);
                     constexpr VT t = vtab(MODE, WN, H, decltype(R)::value);
@@ -486,7 +499,7 @@ struct Level {
                 out_row, c);
         } else {
             load_taps<CBW>(taps + (1 + LEVEL - LVL) * 26 * CBW, w);
-            conv5_s1<LPC, H, B, D>(w, in_row, out_row, c);
+            conv5_s1<LPC, H, B, D, PK>(w, in_row, out_row, c);
         }
     }
 
@@ -517,7 +530,7 @@ struct Level {
             sfor<WN>([&](auto R) RCX_INL {
                 constexpr int r = decltype(R)::value;
                 const float v = Cn[r][0];
-#if RCX_XCH_LDS
+#if RCX_XCH_LDS == 1
                 static_assert(2 * D <= XCH_PAD, "lane stride beyond the exchange line's padding");
                 lds_float* p = c.xl[0] + XCH_PAD;
                 xch_put(p, v);

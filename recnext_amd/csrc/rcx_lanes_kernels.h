@@ -117,6 +117,10 @@ void k_recconv_lanes(const TIO* __restrict__ x, TIO* __restrict__ y, const float
     unsigned char* mine = img + c.lane_in_group * PITCH + ch * ESZ;   // + (row * W0 + j * LA) * PITCH for column j of the lane
     const float* my_taps = taps + ch;
 
+    float xr[2][B0];                                                  // x rows in flight (lower halves stay zero, Raw::ld_into)
+#pragma unroll
+    for (int j = 0; j < B0; ++j) { xr[0][j] = 0.f; xr[1][j] = 0.f; asm volatile("" : "+v"(xr[0][j]), "+v"(xr[1][j])); }
+
     for (int n = n0; n < n1; ++n) {
         // ---- this image's chunks (already in registers) -> raw LDS image
         sfor<STAGE>([&](auto I) RCX_INL {
@@ -129,22 +133,22 @@ void k_recconv_lanes(const TIO* __restrict__ x, TIO* __restrict__ y, const float
         if (n + 1 < n1) prefetch(n + 1);
         // ---- the whole block in registers; every output row overwrites the lane's own (already consumed) x bytes
         if (active && !RCX_LABLATE(a, 1)) {
-            // x rows are read one row ahead (raw bits; converted when the row is consumed), so that the LDS round trip of
-            // row r+1 runs under the FMAs of row r.  Output rows trail the input by two rows, so the bytes are still x.
-            typename Raw<TIO>::raw_t ahead[B0];
+            // x rows are read one row ahead into two alternating register sets (even / odd rows), so that the LDS round trip
+            // of row r+1 runs under the FMAs of row r.  bf16 lands in the upper half of a register whose lower half stays zero
+            // (Raw::ld_into), which is the f32 value.  Output rows trail the input by two rows, so the bytes are still x.
             Level<LPC, MODE, 0, LEVEL, W0, B0, 1, CBW>::run_io(
                 [&](auto R, float (&row)[B0]) RCX_INL {
                     constexpr int r = decltype(R)::value;
                     if constexpr (r == 0) {
 #pragma unroll
-                        for (int j = 0; j < B0; ++j) ahead[j] = Raw<TIO>::ldr(mine + (j * LA) * PITCH);
+                        for (int j = 0; j < B0; ++j) Raw<TIO>::ld_into(mine + (j * LA) * PITCH, xr[0][j]);
                     }
-#pragma unroll
-                    for (int j = 0; j < B0; ++j) row[j] = Raw<TIO>::cvt(ahead[j]);
                     if constexpr (r + 1 < W0) {
 #pragma unroll
-                        for (int j = 0; j < B0; ++j) ahead[j] = Raw<TIO>::ldr(mine + ((r + 1) * W0 + j * LA) * PITCH);
+                        for (int j = 0; j < B0; ++j) Raw<TIO>::ld_into(mine + ((r + 1) * W0 + j * LA) * PITCH, xr[(r + 1) & 1][j]);
                     }
+#pragma unroll
+                    for (int j = 0; j < B0; ++j) row[j] = xr[r & 1][j];
                 },
                 [&](auto O, const float (&acc)[B0]) RCX_INL {
 #pragma unroll
@@ -283,6 +287,8 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
     const int mine = c.lane_in_group * PITCH + ch * ESZ;              // + (row * W0 + j * LA) * PITCH for column j of the lane
     const float* my_taps = taps + ch;
     constexpr VT te = vtab(MODE, H1, H0, 2), to = vtab(MODE, H1, H0, 3);   // vertical weights of an interior even / odd row
+    // packed FMAs in pass 2 only where the register pairs still leave two waves per SIMD (float32 I/O stages twice the bytes)
+    constexpr bool PK2 = RCX_PK_FMA && sizeof(TIO) == 2;
 
     RCX_LSTAMP(0);
     __syncthreads();                               // taps are read (pass 1 keeps them in registers) before the first band barrier
@@ -369,7 +375,7 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
         float wt[B0][2];
         if (active) {
             float Q[H1][B1];
-            Level<LPC, MODE, 1, LEVEL, W1, B1, 1, CBW>::run(P, Q, my_taps, c);
+            Level<LPC, MODE, 1, LEVEL, W1, B1, 1, CBW, PK2>::run(P, Q, my_taps, c);
             sfor<H1>([&](auto R) RCX_INL {
 #pragma unroll
                 for (int q = 0; q < B1; ++q) P[decltype(R)::value][q] = Q[decltype(R)::value][q];
@@ -379,7 +385,7 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
         // ================= pass 2: y = conv_L(x + resize(C_1)) =================
         if (n == n0) RCX_LSTAMP(2);
         {
-            float Cy[4][B0];
+            f32x2 Cy[4][B0 / 2];
             Taps w;
             if (active) load_taps<CBW>(my_taps + (1 + LEVEL) * 26 * CBW, w);
             const float bias = w.bias();
@@ -415,11 +421,13 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
                         for (int q = 0; q < B1; ++q) asm volatile("" : "+v"(cw[decltype(K)::value][q]));
                         hresize_row<LPC, B1, B0>(cw[decltype(K)::value], wt, hw[decltype(K)::value], c);
                     });
-                    float L[SR + 4][B0];
+                    // partial sums of the band's rows as column pairs (v_pk_fma_f32: two columns per instruction, the tap
+                    // splat through op_sel; same products and order of summation as the scalar form)
+                    f32x2 L[SR + 4][B0 / 2];
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
 #pragma unroll
-                        for (int j = 0; j < B0; ++j) L[k][j] = s == 0 ? bias : Cy[k][j];
+                        for (int q = 0; q < B0 / 2; ++q) L[k][q] = s == 0 ? f32x2{bias, bias} : Cy[k][q];
                     unsigned char* xb = cur + mine;
                     unsigned char* pb = prev + mine;
                     float nxt[B0];                                      // next row's x, loaded one row ahead of its use
@@ -441,45 +449,52 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
                             for (int j = 0; j < B0; ++j) nxt[j] = Raw<TIO>::ld(xb + ((i + 1) * W0 + j * LA) * PITCH);
                         }
                         make_ext<LPC, B0, 1>(row, ext, c);
+                        // the row as aligned pairs E[k] = (ext[2k], ext[2k+1]) and the odd ones O[k] = (ext[2k+1], ext[2k+2])
+                        f32x2 E[B0 / 2 + 2], O[B0 / 2 + 1];
+                        if constexpr (PK2) {
+#pragma unroll
+                            for (int k = 0; k < B0 / 2 + 2; ++k) E[k] = f32x2{ext[2 * k], ext[2 * k + 1]};
+#pragma unroll
+                            for (int k = 0; k < B0 / 2 + 1; ++k) O[k] = f32x2{ext[2 * k + 1], ext[2 * k + 2]};
+                        }
                         sfor<5>([&](auto U) RCX_INL {
                             constexpr int u = decltype(U)::value;
                             constexpr int idx = i + 2 - u + 2;                           // output row (i + 2 - u) relative to the band, + 2
-                            if constexpr (RCX_PK_FMA) {                                  // two columns per v_pk_fma_f32, see conv5_s1
 #pragma unroll
-                                for (int q = 0; q < B0 / 2; ++q) {
-                                    f32x2 acc = u == 0 ? f32x2{bias, bias} : f32x2{L[idx][2 * q], L[idx][2 * q + 1]};
+                            for (int q = 0; q < B0 / 2; ++q) {
+                                f32x2 acc = u == 0 ? f32x2{bias, bias} : L[idx][q];
+                                if constexpr (PK2) {
+                                    acc = __builtin_elementwise_fma(E[q], w.splat(u * 5 + 0), acc);
+                                    acc = __builtin_elementwise_fma(O[q], w.splat(u * 5 + 1), acc);
+                                    acc = __builtin_elementwise_fma(E[q + 1], w.splat(u * 5 + 2), acc);
+                                    acc = __builtin_elementwise_fma(O[q + 1], w.splat(u * 5 + 3), acc);
+                                    acc = __builtin_elementwise_fma(E[q + 2], w.splat(u * 5 + 4), acc);
+                                } else {
 #pragma unroll
-                                    for (int vv = 0; vv < 5; ++vv)
-                                        acc = __builtin_elementwise_fma(f32x2{ext[2 * q + vv], ext[2 * q + vv + 1]}, w.splat(u * 5 + vv), acc);
-                                    L[idx][2 * q] = acc.x;
-                                    L[idx][2 * q + 1] = acc.y;
+                                    for (int vv = 0; vv < 5; ++vv) {
+                                        acc.x = fmaf(ext[2 * q + vv], w.get(u * 5 + vv), acc.x);
+                                        acc.y = fmaf(ext[2 * q + vv + 1], w.get(u * 5 + vv), acc.y);
+                                    }
                                 }
-                            } else {
-#pragma unroll
-                                for (int j = 0; j < B0; ++j) {
-                                    float acc = u == 0 ? bias : L[idx][j];
-#pragma unroll
-                                    for (int vv = 0; vv < 5; ++vv) acc = fmaf(ext[j + vv], w.get(u * 5 + vv), acc);
-                                    L[idx][j] = acc;
-                                }
+                                L[idx][q] = acc;
                             }
                         });
                         // output row i - 2 (relative) is complete
                         if constexpr (i < 2) {
                             if (s > 0) {
 #pragma unroll
-                                for (int j = 0; j < B0; ++j) Raw<TIO>::st(pb + ((SR + i - 2) * W0 + j * LA) * PITCH, L[i][j]);
+                                for (int j = 0; j < B0; ++j) Raw<TIO>::st(pb + ((SR + i - 2) * W0 + j * LA) * PITCH, (j & 1) ? L[i][j / 2].y : L[i][j / 2].x);
                             }
                         } else {
 #pragma unroll
-                            for (int j = 0; j < B0; ++j) Raw<TIO>::st(xb + ((i - 2) * W0 + j * LA) * PITCH, L[i][j]);
+                            for (int j = 0; j < B0; ++j) Raw<TIO>::st(xb + ((i - 2) * W0 + j * LA) * PITCH, (j & 1) ? L[i][j / 2].y : L[i][j / 2].x);
                         }
                         RCX_ROW_FENCE;
                     });
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
 #pragma unroll
-                        for (int j = 0; j < B0; ++j) Cy[k][j] = L[SR + k][j];
+                        for (int q = 0; q < B0 / 2; ++q) Cy[k][q] = L[SR + k][q];
                 }
                 if (s >= 2) drop_band(n, s - 2);
                 if (n == n0 && s < 4) RCX_LSTAMP(27 + 4 * s);
@@ -491,7 +506,7 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
 #pragma unroll
-                    for (int j = 0; j < B0; ++j) Raw<TIO>::st(pb + ((SR - 2 + k) * W0 + j * LA) * PITCH, Cy[k][j]);
+                    for (int j = 0; j < B0; ++j) Raw<TIO>::st(pb + ((SR - 2 + k) * W0 + j * LA) * PITCH, (j & 1) ? Cy[k][j / 2].y : Cy[k][j / 2].x);
             }
             __syncthreads();
             if (NS >= 2) store_band(n, NS - 2, slot_ptr(1));
