@@ -221,16 +221,19 @@ __device__ __forceinline__ void make_ext(const float (&row)[B], float (&ext)[B +
 #endif
 }
 
-// The 25 taps + bias of one conv as 13 aligned register pairs: v_pk_fma_f32 takes a tap splat out of either half of a
-// pair through op_sel, so nothing is duplicated; the scalar FMAs read the halves as plain registers.
+// The 25 taps + bias of one conv as 15 aligned register pairs, three per tap row: (w0,w1) (w2,w3) (w4,-), the bias in the
+// spare half of the last one.  v_pk_fma_f32 takes a tap splat out of either half of a pair through op_sel (two columns
+// per instruction) or a whole pair (two taps per instruction); the scalar FMAs read the halves as plain registers.
 struct Taps {
-    f32x2 p[13];
-    __device__ __forceinline__ float get(int t) const { return (t & 1) ? p[t >> 1].y : p[t >> 1].x; }
-    __device__ __forceinline__ f32x2 splat(int t) const
+    f32x2 p[15];
+    __device__ __forceinline__ float get(int u, int v) const { return (v & 1) ? p[3 * u + (v >> 1)].y : p[3 * u + (v >> 1)].x; }
+    __device__ __forceinline__ f32x2 splat(int u, int v) const
     {
-        return (t & 1) ? __builtin_shufflevector(p[t >> 1], p[t >> 1], 1, 1) : __builtin_shufflevector(p[t >> 1], p[t >> 1], 0, 0);
+        const f32x2 q = p[3 * u + (v >> 1)];
+        return (v & 1) ? __builtin_shufflevector(q, q, 1, 1) : __builtin_shufflevector(q, q, 0, 0);
     }
-    __device__ __forceinline__ float bias() const { return p[12].y; }
+    __device__ __forceinline__ f32x2 pair(int u, int k) const { return p[3 * u + k]; }     // taps 2k, 2k+1 of row u (k = 0, 1)
+    __device__ __forceinline__ float bias() const { return p[14].y; }
 };
 
 // taps of one conv from the workgroup's LDS copy [26][CBW] (25 taps + bias row); tl already points at the lane's channel.
@@ -240,9 +243,13 @@ template <int CBW>
 __device__ __forceinline__ void load_taps(const float* __restrict__ tl, Taps& w)
 {
 #pragma unroll
-    for (int k = 0; k < 13; ++k) w.p[k] = f32x2{tl[(2 * k) * CBW], tl[(2 * k + 1) * CBW]};
+    for (int u = 0; u < 5; ++u) {
+        w.p[3 * u] = f32x2{tl[(5 * u) * CBW], tl[(5 * u + 1) * CBW]};
+        w.p[3 * u + 1] = f32x2{tl[(5 * u + 2) * CBW], tl[(5 * u + 3) * CBW]};
+        w.p[3 * u + 2] = f32x2{tl[(5 * u + 4) * CBW], u == 4 ? tl[25 * CBW] : 0.f};
+    }
 #pragma unroll
-    for (int k = 0; k < 13; ++k) asm volatile("" : "+v"(w.p[k]));
+    for (int k = 0; k < 15; ++k) asm volatile("" : "+v"(w.p[k]));
 }
 
 // 5x5 depthwise, stride 1, pad 2.  in_row(IC<r>, float(&)[B]) yields input row r (called once per row, in
@@ -251,7 +258,21 @@ template <int LPC, int H, int B, int D, bool PK = true, class InRow, class OutRo
 __device__ __forceinline__ void conv5_s1(const Taps& w, InRow&& in_row, OutRow&& out_row, const Ctx& c)
 {
     const float bias = w.bias();
+    // B odd: two taps per v_pk_fma_f32 into two partial sums per output (taps 0,2,4 / 1,3), added when the row is complete
+    constexpr bool TP = RCX_PK_FMA && PK && (B % 2) == 1;
     float acc[H][B];
+    f32x2 acc2[TP ? H : 1][B];
+    auto emit = [&](auto O) RCX_INL {
+        constexpr int o = decltype(O)::value;
+        if constexpr (TP) {
+            float done[B];
+#pragma unroll
+            for (int j = 0; j < B; ++j) done[j] = acc2[o][j].x + acc2[o][j].y;
+            out_row(O, done);
+        } else {
+            out_row(O, acc[o]);
+        }
+    };
 #if RCX_XCH_LDS
     float ahead[B + 4];                                               // row r+1 goes through the exchange under row r's FMAs
     {
@@ -290,36 +311,48 @@ __device__ __forceinline__ void conv5_s1(const Taps& w, InRow&& in_row, OutRow&&
                         f32x2 a = first ? f32x2{bias, bias} : f32x2{acc[o][2 * q], acc[o][2 * q + 1]};
 #pragma unroll
                         for (int v = 0; v < 5; ++v)
-                            a = __builtin_elementwise_fma(f32x2{ext[2 * q + v], ext[2 * q + v + 1]}, w.splat(u * 5 + v), a);
+                            a = __builtin_elementwise_fma(f32x2{ext[2 * q + v], ext[2 * q + v + 1]}, w.splat(u, v), a);
                         acc[o][2 * q] = a.x;
                         acc[o][2 * q + 1] = a.y;
+                    }
+                } else if constexpr (TP) {
+#pragma unroll
+                    for (int j = 0; j < B; ++j) {
+                        f32x2 a = first ? f32x2{bias, 0.f} : acc2[o][j];
+                        a = __builtin_elementwise_fma(f32x2{ext[j], ext[j + 1]}, w.pair(u, 0), a);
+                        a = __builtin_elementwise_fma(f32x2{ext[j + 2], ext[j + 3]}, w.pair(u, 1), a);
+                        a.x = fmaf(ext[j + 4], w.get(u, 4), a.x);
+                        acc2[o][j] = a;
                     }
                 } else {
 #pragma unroll
                     for (int j = 0; j < B; ++j) {
                         float a = first ? bias : acc[o][j];
 #pragma unroll
-                        for (int v = 0; v < 5; ++v) a = fmaf(ext[j + v], w.get(u * 5 + v), a);
+                        for (int v = 0; v < 5; ++v) a = fmaf(ext[j + v], w.get(u, v), a);
                         acc[o][j] = a;
                     }
                 }
             }
         });
-        if constexpr (r >= 2) out_row(IC<r - 2>{}, acc[r - 2]);
+        if constexpr (r >= 2) emit(IC<r - 2>{});
         RCX_ROW_FENCE;
         if constexpr (r == H - 1) {
-            if constexpr (H >= 2) out_row(IC<H - 2>{}, acc[H - 2]);
-            out_row(IC<H - 1>{}, acc[H - 1]);
+            if constexpr (H >= 2) emit(IC<H - 2>{});
+            emit(IC<H - 1>{});
         }
     });
 }
 
 // 5x5 depthwise, stride 2, pad 2: (HI, BI) -> (HO, BO).  BI >= 2: BO = BI/2, same lanes.  BI == 1: the result is
 // valid in the lanes that are multiples of 2*D (horizontal stride-1 evaluation, every other lane is unused).
-template <int LPC, int HI, int BI, int D, int HO, int BO, class InRow>
+template <int LPC, int HI, int BI, int D, int HO, int BO, bool PK = true, class InRow>
 __device__ __forceinline__ void conv5_s2(const Taps& w, InRow&& in_row, float (&out)[HO][BO], const Ctx& c)
 {
     const float bias = w.bias();
+    // two taps per v_pk_fma_f32 into two partial sums per output (taps 0,2,4 / 1,3), added when the output row is complete
+    constexpr bool TP = RCX_PK_FMA && PK;
+    f32x2 out2[TP ? HO : 1][BO];
 #if RCX_XCH_LDS
     float ahead[BI + 4];
     {
@@ -350,12 +383,23 @@ __device__ __forceinline__ void conv5_s2(const Taps& w, InRow&& in_row, float (&
             if constexpr (t >= 0 && (t % 2) == 0 && (t / 2) < HO) {
                 constexpr int o = t / 2;
                 constexpr bool is_first = (r == (2 * o - 2 > 0 ? 2 * o - 2 : 0));   // first input row that reaches output row o
+                constexpr bool is_last = (r == (2 * o + 2 < HI - 1 ? 2 * o + 2 : HI - 1));
 #pragma unroll
                 for (int i = 0; i < BO; ++i) {
-                    float a = is_first ? bias : out[o][i];
+                    const int e0 = BI >= 2 ? 2 * i : 0;
+                    if constexpr (TP) {
+                        f32x2 a = is_first ? f32x2{bias, 0.f} : out2[o][i];
+                        a = __builtin_elementwise_fma(f32x2{ext[e0], ext[e0 + 1]}, w.pair(u, 0), a);
+                        a = __builtin_elementwise_fma(f32x2{ext[e0 + 2], ext[e0 + 3]}, w.pair(u, 1), a);
+                        a.x = fmaf(ext[e0 + 4], w.get(u, 4), a.x);
+                        out2[o][i] = a;
+                        if constexpr (is_last) out[o][i] = a.x + a.y;
+                    } else {
+                        float a = is_first ? bias : out[o][i];
 #pragma unroll
-                    for (int v = 0; v < 5; ++v) a = fmaf(ext[(BI >= 2 ? 2 * i : 0) + v], w.get(u * 5 + v), a);
-                    out[o][i] = a;
+                        for (int v = 0; v < 5; ++v) a = fmaf(ext[e0 + v], w.get(u, v), a);
+                        out[o][i] = a;
+                    }
                 }
             }
         });
@@ -480,7 +524,7 @@ struct Level {
             {
                 float Fn[WN][BN];
                 load_taps<CBW>(taps, w);                                   // conv 0 of the pack = the shared `down`
-                conv5_s2<LPC, H, B, D, WN, BN>(w, in_row, Fn, c);
+                conv5_s2<LPC, H, B, D, WN, BN, PK>(w, in_row, Fn, c);
                 Level<LPC, MODE, LVL + 1, LEVEL, WN, BN, DN, CBW, PK>::run(Fn, Cn, taps, c);
             }
             float hrow[WN][B];

@@ -339,7 +339,7 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
                                 for (int q = 0; q < B1; ++q) {
                                     float acc = is_first ? bias : L[orel + 1][q];
 #pragma unroll
-                                    for (int vv = 0; vv < 5; ++vv) acc = fmaf(ext[2 * q + vv], w.get(u * 5 + vv), acc);
+                                    for (int vv = 0; vv < 5; ++vv) acc = fmaf(ext[2 * q + vv], w.get(u, vv), acc);
                                     L[orel + 1][q] = acc;
                                 }
                             }
@@ -464,16 +464,16 @@ void k_recconv_lanes_banded(const TIO* __restrict__ x, TIO* __restrict__ y, cons
                             for (int q = 0; q < B0 / 2; ++q) {
                                 f32x2 acc = u == 0 ? f32x2{bias, bias} : L[idx][q];
                                 if constexpr (PK2) {
-                                    acc = __builtin_elementwise_fma(E[q], w.splat(u * 5 + 0), acc);
-                                    acc = __builtin_elementwise_fma(O[q], w.splat(u * 5 + 1), acc);
-                                    acc = __builtin_elementwise_fma(E[q + 1], w.splat(u * 5 + 2), acc);
-                                    acc = __builtin_elementwise_fma(O[q + 1], w.splat(u * 5 + 3), acc);
-                                    acc = __builtin_elementwise_fma(E[q + 2], w.splat(u * 5 + 4), acc);
+                                    acc = __builtin_elementwise_fma(E[q], w.splat(u, 0), acc);
+                                    acc = __builtin_elementwise_fma(O[q], w.splat(u, 1), acc);
+                                    acc = __builtin_elementwise_fma(E[q + 1], w.splat(u, 2), acc);
+                                    acc = __builtin_elementwise_fma(O[q + 1], w.splat(u, 3), acc);
+                                    acc = __builtin_elementwise_fma(E[q + 2], w.splat(u, 4), acc);
                                 } else {
 #pragma unroll
                                     for (int vv = 0; vv < 5; ++vv) {
-                                        acc.x = fmaf(ext[2 * q + vv], w.get(u * 5 + vv), acc.x);
-                                        acc.y = fmaf(ext[2 * q + vv + 1], w.get(u * 5 + vv), acc.y);
+                                        acc.x = fmaf(ext[2 * q + vv], w.get(u, vv), acc.x);
+                                        acc.y = fmaf(ext[2 * q + vv + 1], w.get(u, vv), acc.y);
                                     }
                                 }
                                 L[idx][q] = acc;
