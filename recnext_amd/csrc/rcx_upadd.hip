@@ -201,12 +201,24 @@ void k_upadd_lanes(const TX* __restrict__ x, const TC* __restrict__ coarse, TX* 
                     sfor<5>([&](auto U) RCX_INL {
                         constexpr int u = decltype(U)::value;
                         constexpr int idx = i + 2 - u + 2;
+                        if constexpr (RCX_PK_FMA && sizeof(TX) == 2) {           // two columns per v_pk_fma_f32 (rcx_lanes.h, conv5_s1)
 #pragma unroll
-                        for (int j = 0; j < B0; ++j) {
-                            float acc = u == 0 ? bias : L[idx][j];
+                            for (int q = 0; q < B0 / 2; ++q) {
+                                f32x2 acc = u == 0 ? f32x2{bias, bias} : f32x2{L[idx][2 * q], L[idx][2 * q + 1]};
 #pragma unroll
-                            for (int vv = 0; vv < 5; ++vv) acc = fmaf(ext[j + vv], w[u * 5 + vv], acc);
-                            L[idx][j] = acc;
+                                for (int vv = 0; vv < 5; ++vv)
+                                    acc = __builtin_elementwise_fma(f32x2{ext[2 * q + vv], ext[2 * q + vv + 1]}, f32x2{w[u * 5 + vv], w[u * 5 + vv]}, acc);
+                                L[idx][2 * q] = acc.x;
+                                L[idx][2 * q + 1] = acc.y;
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < B0; ++j) {
+                                float acc = u == 0 ? bias : L[idx][j];
+#pragma unroll
+                                for (int vv = 0; vv < 5; ++vv) acc = fmaf(ext[j + vv], w[u * 5 + vv], acc);
+                                L[idx][j] = acc;
+                            }
                         }
                     });
                     if constexpr (i < 2) {
