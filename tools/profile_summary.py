@@ -30,7 +30,8 @@ if stats:
     with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
-        for r in rows[:40]:
+        keep = rows[:40] + [r for r in rows[40:] if "rcx::" in r["Name"]]      # the top of the list plus every kernel of this library
+        for r in keep:
             w.writerow([short(r["Name"])[:160], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
 
 pmc = defaultdict(lambda: defaultdict(list))
