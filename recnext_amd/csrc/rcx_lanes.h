@@ -62,6 +62,8 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 template <> struct Raw<float> {
     // x element into a register that is only ever loaded this way (see the bf16 form)
     static __device__ __forceinline__ void ld_into(const unsigned char* p, float& v) { v = *reinterpret_cast<const float*>(p); }
+    template <int OFF> static __device__ __forceinline__ void ld_hi(const unsigned char* base, float& v) { v = *reinterpret_cast<const float*>(base + OFF); }
+    template <int N> static __device__ __forceinline__ void settle(float (&)[N]) {}
     typedef float raw_t;
     static __device__ __forceinline__ raw_t ldr(const unsigned char* p) { return *reinterpret_cast<const float*>(p); }
     static __device__ __forceinline__ float cvt(raw_t r) { return r; }
@@ -76,6 +78,22 @@ template <> struct Raw<bf16_t> {
         u16x2 r = __builtin_bit_cast(u16x2, v);
         r.y = *reinterpret_cast<const bf16_t*>(p);
         v = __builtin_bit_cast(float, r);
+    }
+    // The same as one instruction the compiler does not select on gfx950 (its D16 loads do not preserve the other half under
+    // SRAM-ECC; with the lower half already zero either behaviour gives the f32 value).  The compiler does not count an
+    // LDS operation issued from inline asm, so settle() waits for it explicitly before the row is used; its own counts stay
+    // safe because LDS operations complete in order (it can only wait longer than it thinks).
+    template <int OFF> static __device__ __forceinline__ void ld_hi(const unsigned char* base, float& v)
+    {
+        static_assert(OFF >= 0 && OFF < 65536, "LDS instruction offset field");
+        const unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)base;
+        asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "+v"(v) : "v"(addr), "n"(OFF));
+    }
+    template <int N> static __device__ __forceinline__ void settle(float (&v)[N])
+    {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < N; ++j) asm volatile("" : "+v"(v[j]));
     }
     typedef bf16_t raw_t;
     static __device__ __forceinline__ raw_t ldr(const unsigned char* p) { return *reinterpret_cast<const bf16_t*>(p); }

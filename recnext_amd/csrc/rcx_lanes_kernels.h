@@ -117,7 +117,7 @@ void k_recconv_lanes(const TIO* __restrict__ x, TIO* __restrict__ y, const float
     unsigned char* mine = img + c.lane_in_group * PITCH + ch * ESZ;   // + (row * W0 + j * LA) * PITCH for column j of the lane
     const float* my_taps = taps + ch;
 
-    float xr[2][B0];                                                  // x rows in flight (lower halves stay zero, Raw::ld_into)
+    float xr[2][B0];                                                  // x rows in flight (lower halves stay zero, Raw::ld_hi)
 #pragma unroll
     for (int j = 0; j < B0; ++j) { xr[0][j] = 0.f; xr[1][j] = 0.f; asm volatile("" : "+v"(xr[0][j]), "+v"(xr[1][j])); }
 
@@ -135,17 +135,18 @@ void k_recconv_lanes(const TIO* __restrict__ x, TIO* __restrict__ y, const float
         if (active && !RCX_LABLATE(a, 1)) {
             // x rows are read one row ahead into two alternating register sets (even / odd rows), so that the LDS round trip
             // of row r+1 runs under the FMAs of row r.  bf16 lands in the upper half of a register whose lower half stays zero
-            // (Raw::ld_into), which is the f32 value.  Output rows trail the input by two rows, so the bytes are still x.
+            // (Raw::ld_hi), which is the f32 value.  Output rows trail the input by two rows, so the bytes are still x.
             Level<LPC, MODE, 0, LEVEL, W0, B0, 1, CBW>::run_io(
                 [&](auto R, float (&row)[B0]) RCX_INL {
                     constexpr int r = decltype(R)::value;
                     if constexpr (r == 0) {
-#pragma unroll
-                        for (int j = 0; j < B0; ++j) Raw<TIO>::ld_into(mine + (j * LA) * PITCH, xr[0][j]);
+                        sfor<B0>([&](auto J) RCX_INL { Raw<TIO>::template ld_hi<(decltype(J)::value * LA) * PITCH>(mine, xr[0][decltype(J)::value]); });
                     }
+                    Raw<TIO>::settle(xr[r & 1]);                             // row r was requested one row ago
                     if constexpr (r + 1 < W0) {
-#pragma unroll
-                        for (int j = 0; j < B0; ++j) Raw<TIO>::ld_into(mine + ((r + 1) * W0 + j * LA) * PITCH, xr[(r + 1) & 1][j]);
+                        sfor<B0>([&](auto J) RCX_INL {
+                            Raw<TIO>::template ld_hi<((r + 1) * W0 + decltype(J)::value * LA) * PITCH>(mine, xr[(r + 1) & 1][decltype(J)::value]);
+                        });
                     }
 #pragma unroll
                     for (int j = 0; j < B0; ++j) row[j] = xr[r & 1][j];
