@@ -121,6 +121,9 @@ def kernel_name(plan, elem_bytes):
     if plan.startswith("lanes(k_recconv_lanes"):
         kern = plan[len("lanes("):plan.index(">")]
         return f"rcx::lanes::{kern}, {t}>"
+    if plan.startswith("cpl(k_recconv_cpl"):
+        kern = plan[len("cpl("):plan.index(">")]
+        return f"rcx::cpl::{kern}, {t}>"
     return "rcx::k_conv_generic<...> (one launch per ladder step)"
 
 
