@@ -126,6 +126,30 @@ def test_sweep_against_c_oracle(case):
     assert np.allclose(gotb, refb, atol=BF16_ATOL, rtol=BF16_RTOL)
 
 
+@pytest.mark.parametrize("mode", ["bilinear", "nearest"])
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_channel_per_lane_kernel_against_oracle_and_lanes_kernel(mode, bias, dtype, monkeypatch):
+    """The 7x7 / level 1 block has two register-resident kernels (rcx_cpl.hip, rcx_lanes.hip): both against the oracle and
+    against each other (the lanes kernel pairs taps in another order: float32 rounding differences only)."""
+    n, c, level, k = 5, 128, 1, 5
+    rng = np.random.default_rng(zlib.crc32(repr((mode, bias, str(dtype))).encode()))
+    x, wd, wc, bd, bc = _rand_case(rng, n, c, 7, 7, level, k, bias)
+    if dtype == torch.bfloat16:
+        x = bf16_round_np(x)
+    ref = c_oracle.recconv2d(x, wd, wc, bd, bc, level, mode)
+    assert ops.recconv2d_plan(n, c, 7, 7, level, k, mode, dtype).startswith("cpl(")
+    got = _run_hip(x, wd, wc, bd, bc, level, k, mode, dtype)
+    monkeypatch.setenv("RCX_CPL", "0")
+    assert ops.recconv2d_plan(n, c, 7, 7, level, k, mode, dtype).startswith("lanes(")
+    other = _run_hip(x, wd, wc, bd, bc, level, k, mode, dtype)
+    if dtype == torch.float32:
+        assert np.abs(got - ref).max() < F32_TIGHT and np.abs(other - ref).max() < F32_TIGHT
+        assert np.abs(got - other).max() < 1e-5
+    else:
+        assert np.allclose(got, ref, atol=BF16_ATOL, rtol=BF16_RTOL) and np.allclose(other, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
+
+
 @pytest.mark.parametrize("stride", [1, 2])
 @pytest.mark.parametrize("k", [3, 5, 7])
 @pytest.mark.parametrize("dtypes", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32),
