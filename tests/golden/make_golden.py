@@ -144,6 +144,40 @@ def gen_recconv(ref, out):
         print("recconv", name, tuple(y.shape), f"bf16-vs-f32 maxabs={float((y_bf - y).abs().max()):.4f}")
 
 
+# gradients of the reference block itself (autograd through model/recnext.py:24-34): (name, N, C, H, W, level, k, mode, bias, seed)
+RECCONV_GRAD_CASES = [
+    ("l1_7x7", 2, 8, 7, 7, 1, 5, "bilinear", False, 40),
+    ("l2_14x14", 2, 8, 14, 14, 2, 5, "bilinear", False, 41),
+    ("l3_28x28", 1, 8, 28, 28, 3, 5, "bilinear", False, 42),
+    ("l2_25x13_nearest_bias", 1, 8, 25, 13, 2, 5, "nearest", True, 43),
+    ("l4_56x56_c16", 1, 16, 56, 56, 4, 5, "bilinear", False, 44),
+]
+
+
+def gen_recconv_grads(ref, out):
+    for (name, n, c, h, w, level, k, mode, bias, seed) in RECCONV_GRAD_CASES:
+        torch.manual_seed(seed)
+        mod = ref.RecConv2d(c, kernel_size=k, bias=bias, level=level, mode=mode).train()
+        x = torch.randn(n, c, h, w, requires_grad=True)
+        gy = torch.randn(n, c, h, w)
+        with torch.enable_grad():
+            y = mod(x)
+            y.backward(gy)
+        rec = {
+            "x": np32(x), "gy": np32(gy), "y": np32(y), "gx": np32(x.grad),
+            "w_down": np32(mod.down.weight), "gw_down": np32(mod.down.weight.grad),
+            "w_convs": np.stack([np32(cv.weight) for cv in mod.convs]),
+            "gw_convs": np.stack([np32(cv.weight.grad) for cv in mod.convs]),
+            "meta": np.array(json.dumps(dict(N=n, C=c, H=h, W=w, level=level, k=k, mode=mode, bias=bias, seed=seed))),
+        }
+        if bias:
+            rec.update({"b_down": np32(mod.down.bias), "gb_down": np32(mod.down.bias.grad),
+                        "b_convs": np.stack([np32(cv.bias) for cv in mod.convs]),
+                        "gb_convs": np.stack([np32(cv.bias.grad) for cv in mod.convs])})
+        np.savez(os.path.join(out, f"grad_recconv_{name}.npz"), **rec)
+        print("recconv grads", name, f"|gx|max={float(x.grad.abs().max()):.3f} |gw_down|max={float(mod.down.weight.grad.abs().max()):.3f}")
+
+
 def randomize_bn(module, gen):
     for m in module.modules():
         if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
@@ -155,14 +189,17 @@ def randomize_bn(module, gen):
 
 def gen_recattn(refa, utils, out):
     # (name, dim, stage, H, W, seed) ; num_heads = 2**(stage+1) as at model/recattn.py:166
-    for (name, dim, stage, h, w, seed) in [("la1_14x14", 16, 1, 14, 14, 20), ("la2_7x7", 32, 3, 7, 7, 21),
-                                           ("la1_9x12", 16, 0, 9, 12, 22)]:
+    # the last four are the token mixers of RecNeXt-A3 at 224x224 (BASELINE config 4): dim / stage / plane of model/recattn.py:403
+    for (name, dim, stage, h, w, seed, n) in [("la1_14x14", 16, 1, 14, 14, 20, 2), ("la2_7x7", 32, 3, 7, 7, 21, 2),
+                                              ("la1_9x12", 16, 0, 9, 12, 22, 2),
+                                              ("a3s0_56x56", 64, 0, 56, 56, 23, 1), ("a3s1_28x28", 128, 1, 28, 28, 24, 1),
+                                              ("a3s2_14x14", 256, 2, 14, 14, 25, 2), ("a3s3_7x7", 512, 3, 7, 7, 26, 2)]:
         torch.manual_seed(seed)
         gen = torch.Generator().manual_seed(seed)
         heads = 2 ** (stage + 1)
         mod = refa.RecAttn2d(dim, num_heads=heads, stage=stage).eval()
         randomize_bn(mod, gen)
-        x = torch.randn(2, dim, h, w)
+        x = torch.randn(n, dim, h, w)
         with torch.no_grad():
             y_unfused = mod(x)
             utils.replace_batchnorm(mod)
@@ -240,6 +277,7 @@ def main():
     utils = load_by_path("ref_utils", os.path.join(args.reference, "utils.py"))
     gen_interp_tables(args.out)
     gen_recconv(ref, args.out)
+    gen_recconv_grads(ref, args.out)
     gen_recattn(refa, utils, args.out)
     gen_tiny_model(ref, refa, utils, args.out)
     gen_kats(registry, utils, args.out)

@@ -63,6 +63,33 @@ def test_fp32_gradients_match_aten_autograd(case):
             assert _rel(po.grad, pr.grad) < 1e-4, name
 
 
+@pytest.mark.parametrize("name", __import__("tests.util", fromlist=["grad_cases"]).grad_cases())
+def test_fp32_gradients_match_pinned_reference_fixtures(name):
+    """HIP backward against gradients produced by the imported reference block (tests/golden/grad_recconv_*.npz)."""
+    from tests.util import load_grad
+    d, m = load_grad(name)
+    dev = torch.device("cuda:0")
+    mod = recnext_amd.RecConv2d(m["C"], m["k"], m["bias"], m["level"], m["mode"])
+    sd = {"down.weight": d["w_down"], **{f"convs.{i}.weight": w for i, w in enumerate(d["w_convs"])}}
+    if m["bias"]:
+        sd.update({"down.bias": d["b_down"], **{f"convs.{i}.bias": b for i, b in enumerate(d["b_convs"])}})
+    mod.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+    mod = mod.to(dev).train()
+    x = torch.from_numpy(d["x"]).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = mod(x)
+    assert float((y.detach().cpu() - torch.from_numpy(d["y"])).abs().max()) < 1e-4
+    y.backward(torch.from_numpy(d["gy"]).to(dev))
+    rel = lambda a, b: float(np.abs(a.detach().cpu().numpy() - b).max() / (np.abs(b).max() + 1e-12))
+    assert rel(x.grad, d["gx"]) < 1e-4
+    assert rel(mod.down.weight.grad, d["gw_down"]) < 1e-4
+    for j, cv in enumerate(mod.convs):
+        assert rel(cv.weight.grad, d["gw_convs"][j]) < 1e-4, j
+    if m["bias"]:
+        assert rel(mod.down.bias.grad, d["gb_down"]) < 1e-4
+        for j, cv in enumerate(mod.convs):
+            assert rel(cv.bias.grad, d["gb_convs"][j]) < 1e-4, j
+
+
 def test_bf16_input_gradients():
     dev = torch.device("cuda:0")
     ref, ours = _pair(16, 2, "bilinear", False, dev)

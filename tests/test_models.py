@@ -85,9 +85,10 @@ def test_tiny_model_logits_gpu_with_hip_token_mixers(fam):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["recnext_m0", "recnext_a0"])
-def test_full_model_hip_vs_eager_gpu(name):
-    """Whole registered model at 224: HIP token mixers vs the ATen restatement, same weights, fp32 and bf16."""
+@pytest.mark.parametrize("name,batch", [("recnext_m0", 2), ("recnext_a0", 2), ("recnext_a3", 4), ("recnext_m3", 2)])
+def test_full_model_hip_vs_eager_gpu(name, batch):
+    """Whole registered model at 224: HIP token mixers vs the ATen restatement, same weights, fp32 and bf16.
+    recnext_a3 is BASELINE config 4, recnext_m3 the headline model."""
     dev = torch.device("cuda:0")
     fam = models.CONFIGS[name]["family"]
     torch.manual_seed(0)
@@ -101,7 +102,7 @@ def test_full_model_hip_vs_eager_gpu(name):
     models.replace_batchnorm(ref)
     models.replace_batchnorm(net)
     ref, net = ref.to(dev), net.to(dev).to(memory_format=torch.channels_last)
-    x = torch.randn(2, 3, 224, 224, device=dev)
+    x = torch.randn(batch, 3, 224, 224, device=dev)
     with torch.no_grad():
         a, b = ref(x), net(x.contiguous(memory_format=torch.channels_last))
         assert (a - b).abs().max() < 1e-3 * max(1.0, float(a.abs().max()))

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import c_oracle, recconv_np, torch_eager
-from tests.util import GOLDEN, load_recattn, load_recconv, recattn_cases, recconv_cases
+from tests.util import GOLDEN, grad_cases, load_grad, load_recattn, load_recconv, recattn_cases, recconv_cases
 
 import os
 
@@ -120,3 +120,57 @@ def test_channel_multiplier_dwconv_matches_aten():
         ref = conv(x).numpy()
     got = recconv_np.dwconv2d_mult(x.numpy().astype(np.float64), conv.weight.detach().numpy(), conv.bias.detach().numpy(), stride=2)
     assert np.abs(got - ref).max() < TOL
+
+
+def _load_eager_recattn(d, m):
+    """EagerRecAttn2d (oracle/torch_eager.py) carrying a fixture's fused weights: identity BatchNorm with the fused bias as beta."""
+    from oracle.torch_eager import EagerRecAttn2d
+    mod = EagerRecAttn2d(m["dim"], num_heads=m["heads"], stage=m["stage"]).eval()
+    with torch.no_grad():
+        for cn, wk_, bk_ in ((mod.down[0], "w_down", "b_down"), (mod.conv, "w_conv", "b_conv"),
+                             (mod.down[1].qk, "w_qk", "b_qk"), (mod.down[1].pe, "w_pe", "b_pe")):
+            cn.conv.weight.copy_(torch.from_numpy(d[wk_]))
+            cn.norm.weight.fill_(1.0); cn.norm.bias.copy_(torch.from_numpy(d[bk_]))
+            cn.norm.running_mean.zero_(); cn.norm.running_var.fill_(1.0 - cn.norm.eps)
+    return mod
+
+
+@pytest.mark.parametrize("name", recattn_cases())
+def test_eager_recattn_restatement_matches_reference(name):
+    """oracle/torch_eager.py's own ConvNorm / LinearAttention / RecAttn2d (nothing imported from the product) against the
+    imported reference's outputs, unfused and after fuse(); includes the four RecNeXt-A3 token-mixer shapes (config 4)."""
+    from recnext_amd.models import replace_batchnorm
+    d, m = load_recattn(name)
+    mod = _load_eager_recattn(d, m)
+    assert not any(type(s).__module__.startswith("recnext_amd") for s in mod.modules())
+    x = torch.from_numpy(d["x"])
+    with torch.no_grad():
+        assert float((mod(x) - torch.from_numpy(d["y"])).abs().max()) < 2e-5
+        assert float((mod.down(x) - torch.from_numpy(d["attn_out"])).abs().max()) < 2e-5
+        replace_batchnorm(mod)                                    # utils.py:227-234 through EagerConvNorm.fuse
+        assert isinstance(mod.conv, torch.nn.Conv2d)
+        assert float((mod(x) - torch.from_numpy(d["y"])).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("name", grad_cases())
+def test_eager_recconv_autograd_matches_reference_gradients(name):
+    """Autograd through the ATen restatement reproduces the gradients the imported reference block produced
+    (tests/golden/make_golden.py::gen_recconv_grads): this is what the HIP backward is compared with on the GPU."""
+    from oracle.torch_eager import recconv2d_eager
+    d, m = load_grad(name)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).requires_grad_(True)
+    x, wd, wc = t(d["x"]), t(d["w_down"]), [t(w) for w in d["w_convs"]]
+    bd = t(d["b_down"]) if m["bias"] else None
+    bc = [t(b) for b in d["b_convs"]] if m["bias"] else None
+    y = recconv2d_eager(x, wd, wc, bd, bc, m["mode"])
+    assert float((y.detach() - torch.from_numpy(d["y"])).abs().max()) < 1e-5
+    y.backward(torch.from_numpy(d["gy"]))
+    rel = lambda a, b: float(np.abs(a.numpy() - b).max() / (np.abs(b).max() + 1e-12))
+    assert rel(x.grad, d["gx"]) < 1e-5
+    assert rel(wd.grad, d["gw_down"]) < 1e-5
+    for j, w in enumerate(wc):
+        assert rel(w.grad, d["gw_convs"][j]) < 1e-5
+    if m["bias"]:
+        assert rel(bd.grad, d["gb_down"]) < 1e-5
+        for j, b in enumerate(bc):
+            assert rel(b.grad, d["gb_convs"][j]) < 1e-5

@@ -359,6 +359,54 @@ def test_recattn2d_module_matches_reference_golden(name):
     assert float((y.cpu() - torch.from_numpy(d["y"])).abs().max()) < 2e-4
 
 
+# ---- BASELINE config 4: the four token mixers of RecNeXt-A3 at 224x224, batch 256 (model/recattn.py:403, :163-171) ----
+A3_FULL = [("A3 stage0", 256, 64, 0, 56), ("A3 stage1", 256, 128, 1, 28), ("A3 stage2", 256, 256, 2, 14), ("A3 stage3", 256, 512, 3, 7)]
+
+
+@pytest.mark.parametrize("case", A3_FULL, ids=lambda c: c[0])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_recattn2d_full_size_properties(case, dtype):
+    """RecAttn2d at config-4 sizes: determinism, batch-shard == full batch bit for bit, and three images against the
+    oracle's ATen restatement (oracle/torch_eager.py, pinned by the recattn_a3s* fixtures) evaluated in float32 on the CPU."""
+    from oracle.torch_eager import EagerRecAttn2d
+    from recnext_amd.models import replace_batchnorm
+    from recnext_amd.recattn import RecAttn2d
+    _, n, dim, stage, hw = case
+    torch.manual_seed(stage)
+    ref = EagerRecAttn2d(dim, num_heads=2 ** (stage + 1), stage=stage).eval()
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.6, 1.4); m.bias.data.normal_(0, 0.2)
+    mod = RecAttn2d(dim, num_heads=2 ** (stage + 1), stage=stage).eval()
+    mod.load_state_dict(ref.state_dict(), strict=True)
+    mod = mod.to(dev())
+    x = torch.randn(n, dim, hw, hw, device=dev()).to(dtype).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        mm = mod.to(dtype)
+        y = mm(x)
+        assert torch.equal(mm(x), y), "not deterministic"
+        lo = n // 3
+        ys = mm(x[lo:lo + 5])
+    assert y.dtype == dtype and torch.isfinite(y.float()).all()
+    if dtype == torch.float32:
+        assert torch.equal(ys, y[lo:lo + 5]), "batch shard differs from full batch"
+    else:       # the qk projection is a library GEMM whose bf16 tiling may depend on the row count
+        assert (ys.float() - y[lo:lo + 5].float()).abs().max() <= 2e-2 * float(y.float().abs().max())
+    idx = [0, n // 2, n - 1]
+    with torch.no_grad():
+        want = ref(x[idx].float().cpu().contiguous())
+        replace_batchnorm(ref)
+        want_fused = ref(x[idx].float().cpu().contiguous())
+    assert float((want - want_fused).abs().max()) < 1e-4
+    got = y[idx].float().cpu()
+    scale = float(want.abs().max())
+    if dtype == torch.float32:
+        assert float((got - want).abs().max()) < 1e-3 * max(1.0, scale)
+    else:       # bf16: the qk GEMM, pe and the attention output are rounded to bf16 between the kernels (as in the reference)
+        assert float((got - want).abs().max()) < 3e-2 * max(1.0, scale)
+        assert float((got - want).abs().mean()) < 3e-3 * max(1.0, scale)
+
+
 # ---- register-resident single-step kernels (rcx_upadd.hip) on the 7*2^k planes ----
 @pytest.mark.parametrize("mode", ["bilinear", "nearest"])
 @pytest.mark.parametrize("case", [(3, 64, 56), (2, 48, 56), (3, 96, 28), (5, 32, 28), (3, 256, 14), (2, 80, 14), (2, 64, 64), (2, 32, 32)],

@@ -16,6 +16,15 @@ def recattn_cases():
     return sorted(os.path.basename(p)[len("recattn_"):-4] for p in glob.glob(os.path.join(GOLDEN, "recattn_*.npz")))
 
 
+def grad_cases():
+    return sorted(os.path.basename(p)[len("grad_recconv_"):-4] for p in glob.glob(os.path.join(GOLDEN, "grad_recconv_*.npz")))
+
+
+def load_grad(name):
+    d = np.load(os.path.join(GOLDEN, f"grad_recconv_{name}.npz"))
+    return d, json.loads(str(d["meta"]))
+
+
 def load_recconv(name):
     d = np.load(os.path.join(GOLDEN, f"recconv_{name}.npz"))
     meta = json.loads(str(d["meta"]))
