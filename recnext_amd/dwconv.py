@@ -2,8 +2,9 @@
 a depthwise k x k stride-2 conv with channel multiplier 2 (``nn.Conv2d(C, 2C, 7, padding=3, groups=C, stride=2)``)
 followed by an eval-mode BatchNorm, which is a per-channel affine and is folded into the packed weights.
 In a training step the BatchNorm works on batch statistics and is not folded: the conv (forward and backward) runs on HIP
-through ``DwConvMult2Fn`` and the norm stays a PyTorch module.  Parameters stay in the wrapped modules, so state_dict keys do
-not change.  ``DwConvFn`` is the plain depthwise conv (stride 1|2) with HIP forward and backward, used by RecAttn2d.
+through ``DwConvMult2Fn`` and the norm stays a PyTorch module.  ``models.use_hip_downsample`` attaches the wrapper to a
+``Downsample`` WITHOUT registering it as a child module: ``token_mixer`` and ``norm`` stay the Downsample's own direct children,
+so the state_dict keys are the reference's (``downsample.token_mixer.weight``, ``downsample.norm.*``) before and after.  ``DwConvFn`` is the plain depthwise conv (stride 1|2) with HIP forward and backward, used by RecAttn2d.
 """
 import torch
 import torch.nn as nn
@@ -89,7 +90,8 @@ class DownsampleDwConv(nn.Module):
     def forward(self, x):
         conv = self.token_mixer
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if self.training or needs_grad:
+        training = self.norm.training if self.norm is not None else conv.training     # the flags of the modules that own the state
+        if training or needs_grad:
             if conv.stride[0] != 2 or conv.kernel_size[0] not in (3, 5, 7) or x.shape[1] % 2:
                 raise NotImplementedError("the HIP backward of the multiplier-2 conv covers stride 2, k in {3,5,7}, even channel counts")
             y = DwConvMult2Fn.apply(x, conv.weight, conv.bias)

@@ -81,9 +81,10 @@ class Downsample(nn.Module):
         self.token_mixer = nn.Conv2d(in_channels, out_channels, kernel_size=7, padding=3, groups=in_channels, stride=2)
         self.norm = nn.BatchNorm2d(out_channels)
         self.channel_mixer = channel_mlp(out_channels, out_channels * mlp_ratio, act_layer)
+        object.__setattr__(self, "_hip", None)          # set by use_hip_downsample; never a registered child (state_dict keys stay)
 
     def forward(self, x):
-        x = self.norm(self.token_mixer(x))
+        x = self._hip(x) if self._hip is not None else self.norm(self.token_mixer(x))
         return x + self.channel_mixer(x)
 
 
@@ -208,15 +209,13 @@ def fold_token_mixer_norms(net):
 def use_hip_downsample(net):
     """Run each Downsample's depthwise 7x7 stride-2 conv (C -> 2C) on HIP: in eval mode fused with
     the BatchNorm after it into one kernel, in a training step with a HIP backward and the norm on batch statistics.
-    Returns the number of layers replaced."""
+    ``token_mixer`` and ``norm`` remain the Downsample's direct children (same state_dict keys as the reference, so checkpoints
+    load and save unchanged in either order); only the forward is rerouted.  Returns the number of layers rerouted."""
     from .dwconv import DownsampleDwConv
     n = 0
     for m in net.modules():
-        if isinstance(m, Downsample) and isinstance(m.token_mixer, nn.Conv2d) and isinstance(m.norm, nn.BatchNorm2d):
-            training = m.norm.training
-            m.token_mixer = DownsampleDwConv(m.token_mixer, m.norm)
-            m.token_mixer.train(training)
-            m.norm = nn.Identity()
+        if isinstance(m, Downsample) and m._hip is None and isinstance(m.token_mixer, nn.Conv2d) and isinstance(m.norm, nn.BatchNorm2d):
+            object.__setattr__(m, "_hip", DownsampleDwConv(m.token_mixer, m.norm))
             n += 1
     return n
 

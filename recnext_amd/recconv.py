@@ -81,7 +81,19 @@ class RecConv2d(nn.Module):
         return self._pack
 
     def forward(self, x):
+        # Schedule choice.  Autograd needs the per-level schedule (it keeps the float32 pyramid for the backward), so ANY call
+        # with grad mode on and something that requires grad takes it -- including a model in eval() called outside
+        # torch.no_grad(), which is legal (the block has no train/eval distinction) but several times slower than the fused
+        # inference kernels: warn once so that a forgotten no_grad() does not pass for a slow kernel.
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            if self.fold_scale is not None:
+                raise RuntimeError("this RecConv2d carries a folded output affine (fold_token_mixer_norms / fold_output_affine), an "
+                                   "inference-only transform: wrap the call in torch.no_grad() (or torch.inference_mode())")
+            if self.in_channels % 4:
+                raise NotImplementedError(f"the HIP backward of RecConv2d needs a channel count that is a multiple of 4, got "
+                                          f"{self.in_channels}; run inference under torch.no_grad()")
+            if not self.training and not x.requires_grad:
+                _warn_eval_with_grad()
             return _RecConv2dFn.apply(x, self, *self.parameters())
         wpack, bpack = self.packed_params()
         return ops.recconv2d_forward(x, wpack, bpack, self.level, self.kernel_size, self.mode)
@@ -89,6 +101,19 @@ class RecConv2d(nn.Module):
     def extra_repr(self):
         return (f"{self.in_channels}, kernel_size={self.kernel_size}, level={self.level}, mode={self.mode!r}, "
                 f"bias={self.down.bias is not None}")
+
+
+_warned = False
+
+
+def _warn_eval_with_grad():
+    global _warned
+    if not _warned:
+        _warned = True
+        import warnings
+        warnings.warn("recnext_amd.RecConv2d: module is in eval() but grad mode is on and its parameters require grad, so the "
+                      "training schedule (saved float32 pyramid, one launch per level) runs instead of the fused inference "
+                      "kernel; wrap inference in torch.no_grad()", stacklevel=3)
 
 
 class _RecConv2dFn(torch.autograd.Function):

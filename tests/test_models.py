@@ -159,3 +159,26 @@ def test_linear_pointwise_is_the_same_function_cpu():
         assert models.use_linear_pointwise(net) == 2 * (14 + 3)
         assert set(net.state_dict()) == keys                      # same parameter names
         assert (net(x) - ref).abs().max() < 1e-5
+
+
+def test_hip_downsample_keeps_the_reference_state_dict_keys():
+    """use_hip_downsample reroutes the forward only: keys equal the reference's and strict loads work in both orders."""
+    _, sd = _load_tiny("m")
+    a = _tiny("m")
+    before = dict(a.state_dict())
+    assert models.use_hip_downsample(a) == 3
+    assert list(a.state_dict()) == list(before)
+    assert {k for k in a.state_dict() if not k.endswith("num_batches_tracked")} == set(sd)
+    assert "stages.1.downsample.token_mixer.weight" in a.state_dict() and "stages.1.downsample.norm.running_var" in a.state_dict()
+    b = _tiny("m")
+    b.load_state_dict(a.state_dict(), strict=True)                # transformed -> plain
+    c = _tiny("m")
+    models.use_hip_downsample(c)
+    c.load_state_dict(b.state_dict(), strict=True)                # plain -> transformed
+    assert models.use_hip_downsample(c) == 0                      # idempotent
+    # the rerouted forward reads the very modules the state_dict names
+    ds = c.stages[1].downsample
+    assert ds._hip.token_mixer is ds.token_mixer and ds._hip.norm is ds.norm
+    import copy
+    d = copy.deepcopy(c).stages[1].downsample
+    assert d._hip.token_mixer is d.token_mixer and d._hip.norm is d.norm
