@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/sec of RecNeXt-M3 224x224 bf16 with the HIP RecConv2d token mixers.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: starts its own N ranks, see below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Called with --gpus N > 1 and no WORLD_SIZE in the environment, the still GPU-free parent starts N child ranks with
+torch.distributed.run (fresh processes) and exits with their return code.
 
 One "step" = one forward pass of the BN-folded, channels_last RecNeXt-M3 over one synthetic batch of
 256 images per GPU (weak scaling: batch-sharded, no collective in the timed region -- SURVEY 8e).
@@ -13,7 +16,9 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
                 events on the launch stream inside the timed region, against the 8 TB/s HBM peak.
   token_mixers  the same accounting summed over all 21 RecConv2d calls of the model.
   cpu_baseline  the reference's CPU path (oracle/torch_eager.py: the same ATen operators on the host
-                cores) timed on a bounded sample of the same workload; rank 0, N=1 only.
+                cores) timed on a bounded sample of the same workload at 1 / 8 / 32 / all-physical-core
+                threads, best reported with its thread count; plus BASELINE config 1 (RecNeXt-M0, batch 1,
+                fp32); rank 0, N=1 only.
 """
 import argparse
 import json
@@ -38,7 +43,7 @@ def parse_args():
     ap.add_argument("--resolution", type=int, default=224)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="total budget of the cpu_baseline leg")
     return ap.parse_args()
 
 
@@ -127,45 +132,108 @@ def kernel_name(plan, elem_bytes):
     return "rcx::k_conv_generic<...> (one launch per ladder step)"
 
 
-def cpu_baseline(model_name, resolution, seconds, torch):
-    """Reference CPU path on the host cores: same skeleton, ATen token mixers (oracle/torch_eager.py), fp32."""
-    from oracle.torch_eager import eager_token_mixer
-    from recnext_amd import models
-    from recnext_amd.speed import build_inference_model, synthetic_batch
-    fam = models.CONFIGS[model_name]["family"]
-    bs = 8
-    net = build_inference_model(model_name, "cpu", torch.float32, token_mixer=eager_token_mixer(fam))
-    x = synthetic_batch(bs, resolution, "cpu", torch.float32)
+def _physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False) or 0
+    except Exception:
+        n = 0
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n or avail, avail))
+
+
+def _cpu_rate(net, x, seconds, torch, max_iters=200):
     with torch.no_grad():
-        net(x)                                                   # warm-up (mkldnn primitive creation)
+        net(x)                                                   # warm-up (mkldnn primitive creation for this thread count)
         t0 = time.perf_counter()
         iters = 0
-        while time.perf_counter() - t0 < seconds and iters < 200:
+        while iters < 1 or (time.perf_counter() - t0 < seconds and iters < max_iters):
             net(x)
             iters += 1
-        dt = time.perf_counter() - t0
-    return {"value": bs * iters / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "host_cpus": os.cpu_count(),
-            "sample": f"{iters} forward passes of {model_name} {resolution}x{resolution}, batch {bs}, fp32 (BN-folded), "
-                      f"token mixers = reference ATen ops (depthwise conv2d + interpolate + add) restated in "
-                      f"oracle/torch_eager.py, {dt:.1f} s wall"}
+        return x.shape[0] * iters / (time.perf_counter() - t0), iters
+
+
+def reference_model(model_name, device, dtype):
+    """The model with the REFERENCE's token mixers (ATen depthwise conv2d + interpolate + add, oracle/torch_eager.py), BN-folded,
+    eval: what the cpu_baseline leg times, and what `python -m recnext_amd.speed --impl ref` times."""
+    from oracle.torch_eager import eager_token_mixer
+    from recnext_amd import models
+    from recnext_amd.speed import build_inference_model
+    return build_inference_model(model_name, device, dtype, token_mixer=eager_token_mixer(models.CONFIGS[model_name]["family"]))
+
+
+def cpu_baseline(model_name, resolution, seconds, torch):
+    """Reference CPU path on the host cores: same skeleton, ATen token mixers (oracle/torch_eager.py), fp32, the loop of
+    speed_gpu.py:11-27.  torch's default thread count (= every logical CPU of a shared host) oversubscribes badly, so the
+    thread count is swept and the best is reported."""
+    from recnext_amd.speed import synthetic_batch
+    bs = 8
+    phys = _physical_cores()
+    counts = sorted({c for c in (1, 8, 32, phys) if c <= phys})
+    default_threads = torch.get_num_threads()
+    net = reference_model(model_name, "cpu", torch.float32)
+    x = synthetic_batch(bs, resolution, "cpu", torch.float32)
+    share = seconds * 0.7 / len(counts)
+    sweep = {}
+    for c in counts:
+        torch.set_num_threads(c)
+        sweep[c], _ = _cpu_rate(net, x, share, torch)
+    best = max(sweep, key=sweep.get)
+    # BASELINE config 1: RecNeXt-M0 forward, 224x224, batch 1, fp32 (SURVEY 8d "Config 1")
+    m0 = reference_model("recnext_m0", "cpu", torch.float32)
+    x1 = synthetic_batch(1, 224, "cpu", torch.float32)
+    cfg1 = {}
+    for c in sorted({1, min(8, phys)}):
+        torch.set_num_threads(c)
+        rate, _ = _cpu_rate(m0, x1, seconds * 0.15, torch, max_iters=60)
+        cfg1[c] = {"images_per_s": round(rate, 2), "ms_per_image": round(1e3 / rate, 2)}
+    torch.set_num_threads(default_threads)
+    return {"value": sweep[best], "unit": "images/s", "cores": best, "kind": "port",
+            "host_cpus": os.cpu_count(), "physical_cores": phys,
+            "thread_sweep_images_per_s": {str(c): round(v, 2) for c, v in sweep.items()},
+            "config1_recnext_m0_batch1_fp32": {str(c): v for c, v in cfg1.items()},
+            "sample": f"forward passes of {model_name} {resolution}x{resolution}, batch {bs}, fp32 (BN-folded), token mixers = "
+                      f"reference ATen ops (depthwise conv2d + interpolate + add) restated in oracle/torch_eager.py; "
+                      f"{share:.1f} s per thread count in {counts}, best = {best} threads; config 1 (M0, batch 1) timed beside it"}
 
 
 def load_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC profile (profiles/*traffic*.json), or None."""
+    """(HBM bytes per launch of `kernel`, source file) from the committed PMC profiles (profiles/*traffic*.json; the newest
+    round that lists the kernel), or (None, None).  Not measured in this run: PMC collection needs rocprofv3 around the process."""
     import glob
-    best = None
+    best = (None, None)
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
         try:
             for rec in json.load(open(p)).get("kernels", []):
-                if rec.get("kernel") == kernel:
-                    best = rec.get("hbm_bytes_per_launch")
+                if rec.get("kernel") == kernel and rec.get("hbm_bytes_per_launch") is not None:
+                    best = (rec["hbm_bytes_per_launch"], os.path.relpath(p, ROOT))
         except (OSError, ValueError):
             pass
     return best
 
 
+def maybe_spawn_ranks(argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves.  Runs before torch is
+    imported, so this process never touches the GPU; the ranks are fresh children, and we exit with their return code."""
+    if "WORLD_SIZE" in os.environ:
+        return
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_rcx_launch", os.path.join(ROOT, "recnext_amd", "launch.py"))   # torch-free
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sys.exit(mod.spawn_ranks(n, os.path.abspath(__file__), argv))
+
+
 def main():
+    maybe_spawn_ranks(sys.argv[1:])
     args = parse_args()
     import torch
     import recnext_amd
@@ -175,9 +243,9 @@ def main():
     from recnext_amd import dist as rdist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus > 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 bench.py --gpus N ...")
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: launch with "
+                         "`python bench.py --gpus N` or torch.distributed.run --nproc-per-node N")
     r = rdist.init("cuda")                                  # backend "nccl" == RCCL over xGMI
     world, rank, device = r.world, r.rank, r.device
 
@@ -200,8 +268,11 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             net(x)
+        torch.cuda.synchronize(device)
+        own = time.perf_counter() - t0                        # this rank's K steps, before waiting for the others
         rdist.barrier(r)
         elapsed = rdist.max_over_ranks(r, time.perf_counter() - t0)
+        per_rank = [args.batch * args.steps / t for t in rdist.gather_over_ranks(r, own)]
         timers.enabled = False
 
     if rank == 0:
@@ -210,6 +281,7 @@ def main():
         plan_of = lambda n, c, h, w, level, k: ops.recconv2d_plan(n, c, h, w, level, k, "bilinear", dtype)
         per_shape, per_kernel = timers.summarize(elem, plan_of)
         dom = per_kernel[0]                                   # the kernel instantiation with the most time in the step
+        traffic, traffic_source = load_traffic(dom["kernel"])
         mixer_ms_per_step = sum(rr["total_ms"] for rr in per_shape) / args.steps
         mixer_bytes = models.token_mixer_algorithmic_bytes(args.model, args.resolution, elem) * args.batch \
             if models.CONFIGS[args.model]["family"] == "m" else None
@@ -219,13 +291,14 @@ def main():
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "rccl_ranks": world, "per_rank_images_per_s": [round(v, 1) for v in per_rank],
             "config": {"workload": f"{args.model} forward, BN-folded, channels_last, {args.resolution}x{args.resolution}, "
                                    f"batch {args.batch}/GPU, random-init weights, HIP token mixers"
                                    + (", GEMM solutions picked by TunableOp" if gemm_tuned else ""),
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world} (batch-sharded replicas, no collective in the timed region)"},
             "roofline": {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": load_traffic(dom["kernel"]),
+                         "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": dom["kernel"], "shapes": dom["shapes"], "avg_launch_ms": dom["avg_launch_ms"],
                          "algorithmic_bytes_per_launch": dom["algorithmic_bytes"] / dom["launches"],
                          "launches_timed": dom["launches"],

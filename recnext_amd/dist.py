@@ -65,6 +65,19 @@ def sum_over_ranks(r, value):
     return float(t.item())
 
 
+def gather_over_ranks(r, value):
+    """[value of rank 0, ..., value of rank world-1] on every rank (one small all-gather)."""
+    if r.world == 1:
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=r.device)
+    out = [torch.empty_like(t) for _ in range(r.world)]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+from .launch import free_port, launcher_command, spawn_ranks  # noqa: E402,F401  (torch-free; bench.py loads it by path)
+
+
 def shard_bounds(n_global, rank, world):
     """Contiguous shard [lo, hi) of a global batch, sizes differing by at most one (as DistributedSampler pads)."""
     base, rem = divmod(n_global, world)

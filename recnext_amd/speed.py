@@ -6,7 +6,10 @@ Same procedure: build the registered model, fold BatchNorm (utils.replace_batchn
 input created once on the device, T0 seconds of warm-up, then iterate with a device synchronise per
 iteration until T1 seconds have accumulated; print ``name device images/s @ batch size B``.
 Additions: ``--dtype`` (the reference runs fp32 only) and channels_last storage, which is what the HIP
-token mixers consume zero-copy.  There is no CPU mode here: the product path is GPU-only.
+token mixers consume zero-copy; ``--gpus N`` (one rank per GPU on batch shards, whole-job images/s;
+recnext_amd.launch starts the ranks); ``--impl ref`` / ``--device cpu`` time the REFERENCE's operator chain
+instead (the baseline leg of bench.py -- measurement only; the product path itself has no CPU mode and
+``--impl hip --device cpu`` is an error).
 """
 import argparse
 import os
@@ -78,24 +81,47 @@ def tune_gemms(model, inputs):
         tn.tuning_enable(False)
 
 
-def throughput(name, model, device, batch_size, resolution=224, dtype=torch.bfloat16, t0=T0, t1=T1):
-    inputs = synthetic_batch(batch_size, resolution, device, dtype)
-    torch.cuda.empty_cache()
-    tune_gemms(model, inputs)
-    torch.cuda.synchronize()
+def throughput(name, model, device, batch_size, resolution=224, dtype=torch.bfloat16, t0=T0, t1=T1, ranks=None, quiet=False):
+    """speed_gpu.py:11-27.  With `ranks` (recnext_amd.dist.Ranks, world > 1) every rank runs the loop on its own shard of
+    `batch_size` images per GPU and rank 0 reports the whole-job rate (sum over ranks)."""
+    cuda = torch.device(device).type == "cuda"
+    sync = torch.cuda.synchronize if cuda else (lambda: None)
+    inputs = synthetic_batch(batch_size, resolution, device, dtype, seed=ranks.rank if ranks else 0)
+    if cuda:
+        torch.cuda.empty_cache()
+        tune_gemms(model, inputs)
+    sync()
     start = time.time()
+    model(inputs)
     while time.time() - start < t0:
         model(inputs)
     timing = []
-    torch.cuda.synchronize()
+    sync()
     while sum(timing) < t1:
         start = time.time()
         model(inputs)
-        torch.cuda.synchronize()
+        sync()
         timing.append(time.time() - start)
     rate = batch_size / (sum(timing) / len(timing))
-    print(name, device, rate, "images/s @ batch size", batch_size)
+    if ranks is not None and ranks.world > 1:
+        from . import dist as rdist
+        rate = rdist.sum_over_ranks(ranks, rate)
+        batch_size *= ranks.world
+    if not quiet and (ranks is None or ranks.is_main):
+        print(name, device if ranks is None or ranks.world == 1 else f"{ranks.world}x{torch.device(device).type}", rate,
+              "images/s @ batch size", batch_size)
     return rate
+
+
+def _reference_net(name, device, dtype):
+    """--impl ref: the reference's operator chain as the token mixers.  It lives with the benchmark's baseline leg (bench.py at
+    the repository root), not in this package: the product has exactly one implementation."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_rcx_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench.reference_model(name, device, dtype)
 
 
 def main(argv=None):
@@ -104,12 +130,39 @@ def main(argv=None):
     ap.add_argument("--resolution", default=224, type=int)
     ap.add_argument("--batch-size", default=2048, type=int)
     ap.add_argument("--dtype", default="bf16", choices=sorted(DTYPES))
+    ap.add_argument("--impl", default="hip", choices=["hip", "ref"], help="hip: this repository's kernels; ref: the reference's ATen operator chain")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"])
+    ap.add_argument("--gpus", default=1, type=int, help="ranks (one per GPU); --batch-size is per GPU")
+    ap.add_argument("--threads", default=0, type=int, help="--device cpu: torch thread count (0 = leave)")
+    ap.add_argument("--t0", default=T0, type=float)
+    ap.add_argument("--t1", default=T1, type=float)
     args = ap.parse_args(argv)
+    if args.impl == "hip" and args.device == "cpu":
+        ap.error("the HIP token mixers have no CPU path; use --impl ref --device cpu for the reference's CPU baseline")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import sys
+        from . import launch              # children are fresh processes; this parent has not touched the GPU
+        raise SystemExit(launch.spawn_ranks(args.gpus, os.path.abspath(__file__), list(argv if argv is not None else sys.argv[1:])))
     torch.autograd.set_grad_enabled(False)
-    device = "cuda:0"
-    net = build_inference_model(args.model, device, DTYPES[args.dtype])
-    throughput(args.model, net, device, args.batch_size, args.resolution, DTYPES[args.dtype])
+    from . import dist as rdist
+    ranks = rdist.init(args.device)
+    device = str(ranks.device)
+    dtype = DTYPES[args.dtype]
+    if args.device == "cpu" and args.threads:
+        torch.set_num_threads(args.threads)
+    net = _reference_net(args.model, device, dtype) if args.impl == "ref" else build_inference_model(args.model, device, dtype)
+    rdist.barrier(ranks)
+    rate = throughput(args.model if args.impl == "hip" else args.model + "[ref]", net, device, args.batch_size, args.resolution,
+                      dtype, args.t0, args.t1, ranks=ranks)
+    rdist.finish(ranks)
+    return rate
 
 
 if __name__ == "__main__":
-    main()
+    if __package__ in (None, ""):         # started by path (a child rank of --gpus N): make the package importable
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from recnext_amd.speed import main as _main
+        _main()
+    else:
+        main()

@@ -77,3 +77,55 @@ def test_single_process_is_a_noop():
     assert rdist.max_over_ranks(r, 2.5) == 2.5
     rdist.barrier(r)
     rdist.finish(r)
+
+
+def test_spawn_ranks_starts_fresh_children_under_torch_distributed_run(tmp_path):
+    """The self-launch path of `python bench.py --gpus N`: recnext_amd.launch (torch-free) starts N ranks with
+    torch.distributed.run on 127.0.0.1 and relays the exit code; here two CPU ranks over gloo."""
+    import sys
+    from recnext_amd import launch
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_worker.py")
+    cmd = launch.launcher_command(2, worker, ["gloo-sum", "x"], port=1234)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "127.0.0.1" in cmd
+    out = tmp_path / "sum.pt"
+    assert launch.spawn_ranks(2, worker, ["gloo-sum", str(out)]) == 0
+    rec = torch.load(out)
+    assert rec == {"sum": 3.0, "world": 2, "gathered": [0.0, 2.0]}
+    assert launch.spawn_ranks(2, worker, ["no-such-job", str(out)]) != 0          # a failing rank is reported
+
+
+def test_bench_parent_decides_to_spawn_before_importing_torch(monkeypatch):
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.maybe_spawn_ranks(["--gpus", "1", "--steps", "2"]) is None
+    assert bench.maybe_spawn_ranks(["--steps", "2"]) is None
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    assert bench.maybe_spawn_ranks(["--gpus", "4"]) is None                        # already under a launcher
+    monkeypatch.delenv("WORLD_SIZE")
+    calls = []
+    import recnext_amd.launch as real
+    monkeypatch.setattr(real, "spawn_ranks", lambda n, script, argv, env=None: calls.append((n, script, argv)) or 7)
+    monkeypatch.setattr(importlib.util, "spec_from_file_location",
+                        lambda name, path: type("S", (), {"loader": type("L", (), {"exec_module": staticmethod(lambda m: None)})()})())
+    monkeypatch.setattr(importlib.util, "module_from_spec", lambda spec: real)
+    with pytest.raises(SystemExit) as e:
+        bench.maybe_spawn_ranks(["--gpus=8", "--steps", "2"])
+    assert e.value.code == 7 and calls == [(8, os.path.join(root, "bench.py"), ["--gpus=8", "--steps", "2"])]
+
+
+def test_speed_harness_reference_leg_on_the_host_cores(capsys):
+    """recnext_amd.speed (speed_gpu.py:11-27, :39-51): the T0/T1 loop and the output line, on the CPU reference leg
+    (`--impl ref --device cpu`); the HIP leg refuses the CPU."""
+    from recnext_amd import speed
+    rate = speed.main(["--model", "recnext_m0", "--batch-size", "2", "--resolution", "64", "--impl", "ref", "--device", "cpu",
+                       "--dtype", "fp32", "--threads", "2", "--t0", "0.2", "--t1", "0.5"])
+    out = capsys.readouterr().out.strip().splitlines()[-1].split()
+    assert out[0] == "recnext_m0[ref]" and out[1] == "cpu" and out[3:] == ["images/s", "@", "batch", "size", "2"]
+    assert abs(float(out[2]) - rate) < 1e-6 * rate and rate > 0
+    with pytest.raises(SystemExit):
+        speed.main(["--impl", "hip", "--device", "cpu"])

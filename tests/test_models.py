@@ -182,3 +182,12 @@ def test_hip_downsample_keeps_the_reference_state_dict_keys():
     import copy
     d = copy.deepcopy(c).stages[1].downsample
     assert d._hip.token_mixer is d.token_mixer and d._hip.norm is d.norm
+
+
+@pytest.mark.gpu
+def test_speed_harness_hip_leg(capsys):
+    """recnext_amd.speed on the GPU (the reference's speed_gpu.py loop with the HIP token mixers), short T0/T1."""
+    from recnext_amd import speed
+    rate = speed.main(["--model", "recnext_m0", "--batch-size", "16", "--t0", "0.3", "--t1", "0.6"])
+    out = capsys.readouterr().out.strip().splitlines()[-1].split()
+    assert out[0] == "recnext_m0" and out[1].startswith("cuda") and out[-1] == "16" and rate > 100
