@@ -143,7 +143,6 @@ def main(argv=None):
         import sys
         from . import launch              # children are fresh processes; this parent has not touched the GPU
         raise SystemExit(launch.spawn_ranks(args.gpus, os.path.abspath(__file__), list(argv if argv is not None else sys.argv[1:])))
-    torch.autograd.set_grad_enabled(False)
     from . import dist as rdist
     ranks = rdist.init(args.device)
     device = str(ranks.device)
@@ -152,8 +151,9 @@ def main(argv=None):
         torch.set_num_threads(args.threads)
     net = _reference_net(args.model, device, dtype) if args.impl == "ref" else build_inference_model(args.model, device, dtype)
     rdist.barrier(ranks)
-    rate = throughput(args.model if args.impl == "hip" else args.model + "[ref]", net, device, args.batch_size, args.resolution,
-                      dtype, args.t0, args.t1, ranks=ranks)
+    with torch.no_grad():                 # speed_gpu.py:40 switches autograd off for the whole process; scoped here
+        rate = throughput(args.model if args.impl == "hip" else args.model + "[ref]", net, device, args.batch_size, args.resolution,
+                          dtype, args.t0, args.t1, ranks=ranks)
     rdist.finish(ranks)
     return rate
 
