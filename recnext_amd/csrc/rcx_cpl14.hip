@@ -1,0 +1,515 @@
+// Channel-per-lane RecConv2d for the 14x14 / level 2 block (model/recnext.py:24-34 at stage 2 of RecNeXt-M*: 13 of M3's 21
+// blocks).  One LANE owns a whole (image, channel) plane, a wave owns 64 consecutive channels of one image (128 contiguous
+// bytes per pixel in NHWC bf16), so nothing is ever exchanged between lanes: no DPP (rcx_lanes.h: a DPP move puts the SIMD
+// into its slow issue mode), no LDS, no barrier; the zero padding is resolved at compile time (border taps are not issued).
+//
+// Everything lives in registers as float32 PAIRS of horizontally adjacent pixels, (x[2j], x[2j+1]) in an even-aligned
+// register pair, so that every convolution is v_pk_fma_f32 on operands that already sit where the instruction wants them:
+//   * stride-1 convs (14x14, 7x7, 4x4) pair COLUMNS: acc(2j,2j+1) += in(2j+d, 2j+1+d) * splat(w); even d reads the plane's
+//     own pairs, odd d reads a second copy of the row shifted by one pixel (one v_pk_mov_b32 per pair, built once per row);
+//   * stride-2 convs (14->7, 7->4) pair TAPS: acc += in(2i-2,2i-1)*(w0,w1) + in(2i,2i+1)*(w2,w3), the two halves added at
+//     the end -- the de-interleave a strided conv needs is free in this layout;
+//   * both 14x14 passes stream x one row at a time and are input-row stationary: a row is scattered into the F1 rows (pass 1)
+//     or into a ring of five output accumulator rows (pass 2) it feeds; finished rows leave as bf16 straight from registers.
+// x is read from HBM once: between its two uses it waits in the ACCUMULATOR half of the unified 512-entry register file
+// (v_accvgpr_write / v_accvgpr_read, one move each way).  The kernel therefore runs ONE wave per SIMD by design -- 256 x 256
+// planes / 64 = 1024 waves = the chip's 1024 SIMDs -- where a lone wave issues one instruction per ~4 cycles of any kind,
+// which is exactly what a packed FMA costs: the arithmetic runs at the vector peak as long as the instruction stream is
+// (almost) nothing but packed FMAs.  All addressing is scalar: uniform base (SGPR pair) + per-lane 32-bit byte offset +
+// immediate, no vector address arithmetic.  Same arithmetic as the other schedules: float32 throughout, one rounding at the
+// final store.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "rcx_common.h"
+#include "rcx_lanes.h"
+#include "rcx_launch.h"
+
+namespace rcx {
+namespace cpl14 {
+
+using lanes::f32x2;
+using lanes::vtab;
+using lanes::VT;
+
+#define RCX_FENCE __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ f32x2 pfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat(float v) { return f32x2{v, v}; }
+// (a.y, b.x): the pair that starts one pixel to the right of a -- one v_pk_mov_b32
+__device__ __forceinline__ f32x2 shift1(f32x2 a, f32x2 b) { return __builtin_shufflevector(a, b, 1, 2); }
+
+// ---- addressing: uniform base in an SGPR pair (made opaque, so that the compiler keeps "scalar base + lane offset + immediate"
+// and does not re-associate towards one vector base plus vector adds) + this lane's byte offset
+typedef const __attribute__((address_space(1))) char* gcptr;        // explicit global address space: global_*, never flat_*
+typedef __attribute__((address_space(1))) char* gptr;
+__device__ __forceinline__ gcptr opaque(gcptr p) { asm volatile("" : "+s"(p)); return p; }
+template <typename T> __device__ __forceinline__ T gload(gcptr p) { return *reinterpret_cast<const __attribute__((address_space(1))) T*>(p); }
+// A load that stays where it is written: a relaxed wavefront-scope atomic load is the same global_load instruction (no cache
+// bits at this scope) but, being ordered, is neither sunk towards its first use nor hoisted -- the x rows must be requested
+// AHEAD rows before they are touched, and the compiler still counts it in its own s_waitcnt bookkeeping.
+template <typename T> __device__ __forceinline__ T gload_here(gcptr p)
+{
+    return __hip_atomic_load(reinterpret_cast<const __attribute__((address_space(1))) T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+template <typename T> __device__ __forceinline__ void gstore(gcptr p, T v) { *(__attribute__((address_space(1))) T*)(p) = v; }
+
+// Pins.  sched_barrier orders only what the machine scheduler sees; the instruction selector before it is free to float pure
+// arithmetic across the barrier (and it does: without pins the FMAs of all fourteen rows sink below the loads, conversions and
+// stash moves of all fourteen rows, and 196 converted values are live at once).  An empty volatile asm that reads and writes
+// a value is ordered against the barriers and ties the value's producers above it and its consumers below it: no instruction.
+__device__ __forceinline__ void pin(f32x2& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+template <int A> __device__ __forceinline__ void pin(f32x2 (&v)[A]) {
+#pragma unroll
+    for (int i = 0; i < A; ++i) pin(v[i]);
+}
+template <int A, int B> __device__ __forceinline__ void pin(f32x2 (&v)[A][B]) {
+#pragma unroll
+    for (int i = 0; i < A; ++i) pin(v[i]);
+}
+
+// first touch of a row of hand-issued loads: wait until at most PENDING younger memory operations are outstanding
+template <int PENDING>
+__device__ __forceinline__ void pin_row(uint32_t (&v)[14])
+{
+    asm volatile("s_waitcnt vmcnt(%14)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                 "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]) : "n"(PENDING));
+}
+
+// AGPR stash: the accumulator half of the unified register file holds x between its two uses (one VALU move each way)
+// (volatile: they stay in the row they are written in)
+__device__ __forceinline__ float stash(float v) { float a; asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v)); return a; }
+__device__ __forceinline__ float unstash(float a) { float v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; }
+
+// Row access.  CT > 0: the channel count is a compile-time constant, a row needs one scalar base (two for float32 I/O) and the
+// columns are immediates; CT == 0: one scalar base per row and 14 per-lane column offsets computed once.
+template <int CT, typename TIO>
+struct RowAddr {
+    static constexpr int W = 14;
+    static constexpr int PIXB = CT * (int)sizeof(TIO);
+    static constexpr int GROUP = CT > 0 ? ((8192 / (PIXB > 0 ? PIXB : 1) >= W) ? W : 8192 / (PIXB > 0 ? PIXB : 1)) : W;   // columns per base
+    unsigned col[CT > 0 ? 1 : W];                                                             // CT == 0: vo + q * pix
+    size_t pix;
+    __device__ __forceinline__ RowAddr(unsigned vo, size_t pix_) : pix(pix_)
+    {
+        if constexpr (CT > 0) {
+            static_assert(GROUP >= 2 && GROUP % 2 == 0, "channel count too large for immediate addressing");
+            col[0] = vo;
+        } else {
+#pragma unroll
+            for (int q = 0; q < W; ++q) col[q] = vo + (unsigned)q * (unsigned)pix_;
+        }
+    }
+    // f(IC<q>, base, voff, IC<imm>): element (r, q) of this lane lives at base (uniform) + voff (this lane's 32-bit offset) + imm
+    template <class F>
+    __device__ __forceinline__ void row(gcptr plane, int r, F&& f) const
+    {
+        if constexpr (CT > 0) {
+            lanes::sfor<(W + GROUP - 1) / GROUP>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                constexpr int q0 = g * GROUP, q1 = q0 + GROUP < W ? q0 + GROUP : W, mid = q0 + GROUP / 2;
+                const gcptr base = opaque(plane + (size_t)(r * W + mid) * PIXB);
+                lanes::sfor<q1 - q0>([&](auto qc) {
+                    constexpr int q = q0 + decltype(qc)::value;
+                    f(lanes::IC<q>{}, base, col[0], lanes::IC<(q - mid) * PIXB>{});
+                });
+            });
+        } else {
+            const gcptr base = opaque(plane + (size_t)(r * W) * pix);
+            lanes::sfor<W>([&](auto qc) { f(qc, base, col[decltype(qc)::value], lanes::IC<0>{}); });
+        }
+    }
+};
+
+// x loads are issued by hand (inline asm): the compiler sinks an ordinary load towards its first use and widens or converts an
+// ordered one right behind it, and either way the prefetch distance collapses; issued here they stay AHEAD rows in front, and
+// the row's first touch, pin_row(), carries the one counted wait the row needs.  The compiler does not count these loads: its own
+// waits (for the tap loads) can only come out longer than necessary, never shorter.
+template <typename TIO> struct PixLd;
+template <> struct PixLd<float> {
+    template <int IMM> static __device__ __forceinline__ void ld(uint32_t& dst, gcptr base, unsigned voff)
+    {
+        asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM));
+    }
+    static __device__ __forceinline__ float cvt(uint32_t r) { return __uint_as_float(r); }
+};
+template <> struct PixLd<bf16_t> {
+    // bf16 -> float32 without an instruction: the D16 "hi" load puts the 16 bits into the upper half of the register and, on
+    // gfx950 (SRAM-ECC: D16 loads do not preserve the other half), ZEROES the lower half -- measured, tools/ubench/d16_probe.hip
+    // (a register preset to 0xAAAAAAAA reads 0x12030000 after loading 0x1203); the compiler never selects this form itself.
+    template <int IMM> static __device__ __forceinline__ void ld(uint32_t& dst, gcptr base, unsigned voff)
+    {
+        asm volatile("global_load_short_d16_hi %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM));
+    }
+    static __device__ __forceinline__ float cvt(uint32_t r) { return __uint_as_float(r); }
+};
+
+// a pair of horizontally adjacent output pixels: converted once, stored as two elements (the lanes of a wave write 128
+// contiguous bytes per instruction)
+template <typename TIO> struct PixSt;
+template <> struct PixSt<float> {
+    typedef f32x2 packed;
+    static __device__ __forceinline__ packed prep(f32x2 v) { return v; }
+    static __device__ __forceinline__ void st(gcptr p, packed v, int half) { gstore<float>(p, half ? v.y : v.x); }
+};
+template <> struct PixSt<bf16_t> {
+    typedef uint32_t packed;
+    static __device__ __forceinline__ packed prep(f32x2 v)
+    {
+        uint32_t pk;                                                   // one conversion for the two pixels (RNE, NaN stays NaN)
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(v.x), "v"(v.y));
+        return pk;
+    }
+    static __device__ __forceinline__ void st(gcptr p, packed v, int half)
+    {
+        gstore<bf16_t>(p, half ? (bf16_t)(v >> 16) : (bf16_t)v);                    // global_store_short / global_store_short_d16_hi
+    }
+};
+
+// The 25 taps of conv `conv` of the tap-major pack for this lane's channel, as three register pairs per tap row:
+// (w0,w1) (w2,w3) (w4,-).  Stride-2 convs use the pairs as they are; stride-1 convs splat one half (an op_sel modifier).
+struct Taps {
+    f32x2 p[5][3];
+    float bias;
+    __device__ __forceinline__ float at(int u, int v) const { return (v & 1) ? p[u][v >> 1].y : p[u][v >> 1].x; }
+};
+
+// CT > 0: one scalar base per tap row, the five taps of a row are immediates (C * 4 bytes apart)
+template <int CT>
+__device__ __forceinline__ void load_taps(Taps& t, const float* __restrict__ wpack, const float* __restrict__ bpack, int conv, int C,
+                                          unsigned vow, int has_bias)
+{
+    const gcptr wb = (gcptr)(wpack + (size_t)conv * 25 * C);
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const gcptr rowb = opaque(wb + (size_t)(u * 5 + 2) * C * 4);       // the middle tap: -2C*4 .. +2C*4 fit the immediate field
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            const float w = gload<float>(rowb + (ptrdiff_t)(v - 2) * (CT > 0 ? CT : C) * 4 + vow);
+            if (v & 1) t.p[u][v >> 1].y = w;
+            else t.p[u][v >> 1].x = w;
+        }
+        t.p[u][2].y = 0.f;
+    }
+    t.bias = has_bias ? gload<float>((gcptr)(bpack + (size_t)conv * C) + vow) : 0.f;
+}
+
+// ---- stride-2 5x5 conv, pad 2: in = NI x NI plane as pairs in[NI][(NI+1)/2] (odd NI: the last pair's .y is 0), out NO x NO
+// pairs.  Tap pairs: out(o,i) = sum_u [ in[r](2i-2,2i-1).(w0,w1) + in[r](2i,2i+1).(w2,w3) + in[r](2i+2)*w4 ], r = 2o+u-2.
+template <int NI, int NO>
+__device__ __forceinline__ void down5(const f32x2 (&in)[NI][(NI + 1) / 2], f32x2 (&out)[NO][(NO + 1) / 2], const Taps& t)
+{
+    constexpr int PI = (NI + 1) / 2;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        f32x2 acc[NO];
+#pragma unroll
+        for (int i = 0; i < NO; ++i) acc[i] = f32x2{t.bias, 0.f};
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int r = 2 * o + u - 2;
+            if (r < 0 || r >= NI) continue;
+            // one tap part at a time over all outputs: consecutive instructions never touch the same accumulator (a packed
+            // FMA's result cannot be forwarded to the very next instruction; the compiler pads adjacent dependent ones with s_nop)
+#pragma unroll
+            for (int i = 1; i < NO; ++i) acc[i] = pfma(in[r][i - 1], t.p[u][0], acc[i]);
+#pragma unroll
+            for (int i = 0; i < NO; ++i) if (i < PI) acc[i] = pfma(in[r][i], t.p[u][1], acc[i]);
+#pragma unroll
+            for (int i = 0; i < NO; ++i) if (2 * i + 2 < NI) acc[i].x = fmaf(in[r][i + 1].x, t.p[u][2].x, acc[i].x);
+        }
+#pragma unroll
+        for (int i = 0; i < NO; ++i) {
+            const float v = acc[i].x + acc[i].y;
+            if (i & 1) out[o][i >> 1].y = v;
+            else out[o][i >> 1].x = v;
+        }
+        if (NO & 1) out[o][NO >> 1].y = 0.f;
+        pin(out[o]);
+        RCX_FENCE;
+    }
+}
+
+// one input row of a stride-1 5x5 conv scattered into the accumulator rows it feeds.  row = the NP pairs of an N-wide row
+// (odd N: last .y is 0); acc_of(o) gives the accumulator row of output row o.
+template <int N, class AccOf>
+__device__ __forceinline__ void conv5_row(const f32x2 (&row)[(N + 1) / 2], int t, const Taps& w, AccOf&& acc_of)
+{
+    constexpr int NP = (N + 1) / 2;
+    // the row shifted by one pixel: odd[j] = (x[2j-1], x[2j]), j = 0..NP (x[-1] = x[N] = 0)
+    f32x2 odd[NP + 1];
+    odd[0] = f32x2{0.f, row[0].x};
+#pragma unroll
+    for (int j = 1; j < NP; ++j) odd[j] = shift1(row[j - 1], row[j]);
+    odd[NP] = f32x2{row[NP - 1].y, 0.f};
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int o = t - u + 2;
+        if (o < 0 || o >= N) continue;
+        f32x2(&a)[NP] = acc_of(o);
+        // output pair (2j, 2j+1); tap v = 0..4 reads input pixels 2j+v-2, 2j+v-1.  One tap at a time over all pairs, so that
+        // consecutive instructions never touch the same accumulator (see down5)
+#pragma unroll
+        for (int j = 1; j < NP; ++j) a[j] = pfma(row[j - 1], splat(w.at(u, 0)), a[j]);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) a[j] = pfma(odd[j], splat(w.at(u, 1)), a[j]);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) a[j] = pfma(row[j], splat(w.at(u, 2)), a[j]);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) if (2 * j + 1 < N) a[j] = pfma(odd[j + 1], splat(w.at(u, 3)), a[j]);   // (x[2j+1], x[2j+2]); nothing when both are padding
+#pragma unroll
+        for (int j = 0; j + 1 < NP; ++j) a[j] = pfma(row[j + 1], splat(w.at(u, 4)), a[j]);
+    }
+}
+
+// whole stride-1 conv of a small plane (N <= 8): out = conv(in), all rows resident
+template <int N>
+__device__ __forceinline__ void conv5_plane(const f32x2 (&in)[N][(N + 1) / 2], f32x2 (&out)[N][(N + 1) / 2], const Taps& w)
+{
+    constexpr int NP = (N + 1) / 2;
+#pragma unroll
+    for (int o = 0; o < N; ++o)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) out[o][j] = f32x2{w.bias, (2 * j + 1 < N) ? w.bias : 0.f};
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        conv5_row<N>(in[t], t, w, [&](int o) -> f32x2(&)[NP] { return out[o]; });
+#pragma unroll
+        for (int o = 0; o < N; ++o) if (o >= t - 2 && o <= t + 2) pin(out[o]);
+        RCX_FENCE;
+    }
+    if (N & 1) {        // the padding column collected products of real pixels: clear it, later stages read it as zero padding
+#pragma unroll
+        for (int o = 0; o < N; ++o) out[o][NP - 1].y = 0.f;
+    }
+}
+
+// horizontal resize of one row, NI -> NO pixels (ATen index arithmetic, rcx_lanes.h vtab)
+template <int MODE, int NI, int NO>
+__device__ __forceinline__ void resize_row(const f32x2 (&in)[(NI + 1) / 2], f32x2 (&out)[(NO + 1) / 2])
+{
+    auto px = [&](int i) -> float { return (i & 1) ? in[i >> 1].y : in[i >> 1].x; };
+#pragma unroll
+    for (int q = 0; q < NO; ++q) {
+        const VT t = vtab(MODE, NI, NO, q);
+        const float v = (MODE == 1 || t.i0 == t.i1) ? px(t.i0) : fmaf(t.l, px(t.i1), (1.f - t.l) * px(t.i0));
+        if (q & 1) out[q >> 1].y = v;
+        else out[q >> 1].x = v;
+    }
+    if (NO & 1) out[NO >> 1].y = 0.f;
+}
+
+// dst += vertical resize: dst(row d of NO) += (1-l) * h[i0] + l * h[i1]
+template <int MODE, int NI, int NO, int NP>
+__device__ __forceinline__ void add_resized_row(f32x2 (&dst)[NP], const f32x2 (&h)[NI][NP], int d)
+{
+    const VT t = vtab(MODE, NI, NO, d);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        if (MODE == 1 || t.i0 == t.i1) dst[j] = dst[j] + h[t.i0][j];
+        else dst[j] = pfma(splat(t.l), h[t.i1][j], pfma(splat(1.f - t.l), h[t.i0][j], dst[j]));
+    }
+}
+
+template <int MODE, int CT, typename TIO>
+__global__ __launch_bounds__(64)
+void k_recconv_cpl14(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack,
+                     int N, int C_rt, int has_bias)
+{
+    constexpr int W = 14, P = 7, W1 = 7, P1 = 4, W2 = 4, P2 = 2;
+    const int C = CT > 0 ? CT : C_rt;
+    const int nb = (C + 63) / 64;
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so b and b+8 share an L2; give each XCD a contiguous
+    // run of (image, channel block) units -- the channel blocks of one image then stream the same 128-byte-interleaved lines
+    // through one L2 at about the same time
+    unsigned b = blockIdx.x;
+    const unsigned G = gridDim.x;
+    if ((G & 7u) == 0) b = (b & 7u) * (G >> 3) + (b >> 3);
+    const int n = (int)(b / (unsigned)nb), cb = (int)(b - (unsigned)n * (unsigned)nb);
+    if (n >= N) return;
+    const int c = cb * 64 + (int)threadIdx.x;
+    if (c >= C) return;                                     // tail lanes of a ragged last block: EXEC-masked for the whole kernel
+    const size_t pix = (size_t)C * sizeof(TIO);             // bytes between horizontally adjacent pixels (uniform)
+    const gcptr xb = (gcptr)x + (size_t)n * W * W * pix;
+    const gcptr yb = (gcptr)y + (size_t)n * W * W * pix;
+    const unsigned vo = (unsigned)c * (unsigned)sizeof(TIO), vow = (unsigned)c * 4u;
+    const RowAddr<CT, TIO> ra(vo, pix);
+
+    // ---- pass 1, one x row at a time (loads run AHEAD rows in front: a wave cannot have more than 64 memory operations in
+    // flight anyway): 14 elements straight from HBM (each load instruction moves 128 contiguous bytes per wave), kept for pass 2
+    // in the accumulator half of the register file, and scattered into the F1 = down(x) rows they feed (14 -> 7, tap pairs)
+    constexpr int AHEAD = 3;                                // 3 * 14 + 14 = 56 loads in flight at most (the counter holds 63)
+    uint32_t raw[W][W];                                     // as loaded; only AHEAD + 1 rows are ever live
+    float S[W][W];                                          // the stash (AGPRs)
+    f32x2 F1[W1][P1];
+    f32x2 facc[3][W1];                                      // F1 rows in flight: (sum over even taps, sum over odd taps) per output
+    auto load_row = [&](int r) {
+        ra.row(xb, r, [&](auto qc, gcptr base, unsigned voff, auto immc) {
+            PixLd<TIO>::template ld<decltype(immc)::value>(raw[r][decltype(qc)::value], base, voff);
+        });
+    };
+    lanes::sfor<AHEAD>([&](auto rc) { load_row(decltype(rc)::value); });
+    Taps td;                                                // the shared down conv (model/recnext.py:21, :28); its taps come from L2
+    load_taps<CT>(td, wpack, bpack, 0, C, vow, has_bias);   // behind the first x rows: the compiler's wait for them covers those too
+    lanes::sfor<W>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        if constexpr (r + AHEAD < W) load_row(r + AHEAD);
+        // the row requested AHEAD rows ago is first touched HERE: one counted wait for the whole row (the younger loads stay in flight)
+        pin_row<14 * (W - 1 - r < AHEAD ? W - 1 - r : AHEAD)>(raw[r]);
+        f32x2 xr[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) xr[j] = f32x2{PixLd<TIO>::cvt(raw[r][2 * j]), PixLd<TIO>::cvt(raw[r][2 * j + 1])};
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            S[r][2 * j] = stash(xr[j].x);
+            S[r][2 * j + 1] = stash(xr[j].y);
+        }
+#pragma unroll
+        for (int o = 0; o < W1; ++o) {
+            const int u = r - 2 * o + 2;
+            if (u < 0 || u > 4) continue;
+            f32x2(&a)[W1] = facc[o % 3];
+            const bool first = (u == 0) || (r == 0);                     // first input row of output row o
+            if (first) {
+#pragma unroll
+                for (int i = 0; i < W1; ++i) a[i] = f32x2{td.bias, 0.f};
+            }
+#pragma unroll
+            for (int i = 1; i < W1; ++i) a[i] = pfma(xr[i - 1], td.p[u][0], a[i]);
+#pragma unroll
+            for (int i = 0; i < W1; ++i) a[i] = pfma(xr[i], td.p[u][1], a[i]);
+#pragma unroll
+            for (int i = 0; i + 1 < P; ++i) a[i].x = fmaf(xr[i + 1].x, td.p[u][2].x, a[i].x);
+            const bool last = (u == 4) || (r == W - 1);
+            if (last) {
+#pragma unroll
+                for (int i = 0; i < W1; ++i) {
+                    const float v = a[i].x + a[i].y;
+                    if (i & 1) F1[o][i >> 1].y = v;
+                    else F1[o][i >> 1].x = v;
+                }
+                F1[o][P1 - 1].y = 0.f;
+                pin(F1[o]);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < W1; ++o) if (r - 2 * o + 2 >= 0 && r - 2 * o + 2 <= 4 && !((r - 2 * o + 2 == 4) || (r == W - 1))) pin(facc[o % 3]);
+        RCX_FENCE;
+    });
+    RCX_FENCE;
+
+    // ---- the level-1 block on the 7x7 plane: C1 = conv_1(F1 + resize(conv_0(down(F1))))          (:27-33)
+    f32x2 C1[W1][P1];
+    Taps t2;
+    {
+        Taps t0;                                            // tap sets are fetched one stage ahead of their use and no earlier
+        load_taps<CT>(t0, wpack, bpack, 1, C, vow, has_bias);
+        f32x2 F2[W2][P2];
+        down5<W1, W2>(F1, F2, td);
+        Taps t1;
+        load_taps<CT>(t1, wpack, bpack, 2, C, vow, has_bias);
+        RCX_FENCE;
+        f32x2 C2[W2][P2];
+        conv5_plane<W2>(F2, C2, t0);
+        f32x2 H2[W2][P1];
+#pragma unroll
+        for (int i = 0; i < W2; ++i) resize_row<MODE, W2, W1>(C2[i], H2[i]);
+#pragma unroll
+        for (int r = 0; r < W1; ++r) add_resized_row<MODE, W2, W1, P1>(F1[r], H2, r);       // F1 becomes T1
+        pin(F1);
+        RCX_FENCE;
+        load_taps<CT>(t2, wpack, bpack, 3, C, vow, has_bias);
+        RCX_FENCE;
+        conv5_plane<W1>(F1, C1, t1);
+    }
+
+    // ---- y = conv_2(x + resize(C1)): input-row stationary, five accumulator rows in flight                     (:34)
+    f32x2 H1[W1][P];            // C1 rows resized horizontally, each computed just before its first use
+    f32x2 acc[5][P];
+#pragma unroll
+    for (int t = 0; t < W; ++t) {
+        // accumulator rows entering the window (rows 0..2 with the first input row, then row t+2); constant trip counts with
+        // constant-folded conditions: a loop whose bounds depend on t is not unrolled and would push acc[] into scratch
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const bool enters = (t == 0) ? (s <= 2) : (s == (t + 2) % 5 && t + 2 < W);
+            if (enters) {
+#pragma unroll
+                for (int j = 0; j < P; ++j) acc[s][j] = splat(t2.bias);
+            }
+        }
+        const VT vt = vtab(MODE, W1, W, t);
+#pragma unroll
+        for (int i = 0; i < W1; ++i) {
+            const bool first_use = (i == vt.i0 || i == vt.i1) && (t == 0 || (i != vtab(MODE, W1, W, t - 1).i0 && i != vtab(MODE, W1, W, t - 1).i1));
+            if (first_use) resize_row<MODE, W1, W>(C1[i], H1[i]);
+        }
+        f32x2 row[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) row[j] = f32x2{unstash(S[t][2 * j]), unstash(S[t][2 * j + 1])};
+        add_resized_row<MODE, W1, W, P>(row, H1, t);                                         // T0 row t
+        conv5_row<W>(row, t, t2, [&](int o) -> f32x2(&)[P] { return acc[o % 5]; });
+        // rows that have seen their last input row leave: row t-2, and with the last input row also rows 12 and 13
+#pragma unroll
+        for (int d = 2; d >= 0; --d) {
+            const int o = t - d;
+            if (o < 0 || (d < 2 && t != W - 1)) continue;
+            typename PixSt<TIO>::packed pk[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) pk[j] = PixSt<TIO>::prep(acc[o % 5][j]);
+            ra.row(yb, o, [&](auto qc, gcptr base, unsigned voff, auto immc) {
+                constexpr int q = decltype(qc)::value;
+                PixSt<TIO>::st(base + decltype(immc)::value + voff, pk[q >> 1], q & 1);
+            });
+        }
+#pragma unroll
+        for (int o = 0; o < W; ++o) if (o > t - 2 && o <= t + 2 && t != W - 1) pin(acc[o % 5]);
+        RCX_FENCE;
+    }
+}
+
+// A/B switches, read per call like the other schedules' (tests flip them inside one process): RCX_CPL14=0 gives the block
+// back to the lanes kernel, RCX_LANES=0 / RCX_FORCE_GENERIC=1 switch every register-resident schedule off
+static inline bool enabled()
+{
+    const char* v = getenv("RCX_CPL14");
+    const char* l = getenv("RCX_LANES");
+    return !(v && *v == '0') && !(l && *l == '0');
+}
+
+template <int MODE, int CT, typename TIO>
+static hipError_t launch(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s)
+{
+    const unsigned grid = (unsigned)(N * ((C + 63) / 64));
+    hipLaunchKernelGGL((k_recconv_cpl14<MODE, CT, TIO>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr);
+    return hipGetLastError();
+}
+
+template <int MODE, typename TIO>
+static hipError_t launch_c(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s)
+{
+    if (C == 256) return launch<MODE, 256, TIO>(x, y, wpack, bpack, N, C, s);          // RecNeXt-M3/M4 stage 2: immediates instead of scalar adds
+    return launch<MODE, 0, TIO>(x, y, wpack, bpack, N, C, s);
+}
+
+}  // namespace cpl14
+
+bool cpl14_applicable(int N, int C, int H, int W, int level, int k, int dtype)
+{
+    (void)N;
+    return cpl14::enabled() && H == 14 && W == 14 && level == 2 && k == 5 && C >= 1 && (dtype == 0 || dtype == 1);
+}
+
+int cpl14_describe(int N, int C, int mode, char* buf, int len)
+{
+    return snprintf(buf, len, "cpl(k_recconv_cpl14<%d, %d>,cb=64,nt=64,blocks=%d,lds=0)", mode, C == 256 ? 256 : 0, N * ((C + 63) / 64));
+}
+
+hipError_t cpl14_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s)
+{
+    if (dtype == 1) return mode == 1 ? cpl14::launch_c<1, bf16_t>(x, y, wpack, bpack, N, C, s) : cpl14::launch_c<0, bf16_t>(x, y, wpack, bpack, N, C, s);
+    return mode == 1 ? cpl14::launch_c<1, float>(x, y, wpack, bpack, N, C, s) : cpl14::launch_c<0, float>(x, y, wpack, bpack, N, C, s);
+}
+
+}  // namespace rcx

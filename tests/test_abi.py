@@ -49,7 +49,13 @@ def test_abi_version_and_argument_errors_without_gpu():
     assert lib.rcx_recconv2d_fwd(one, two, one, None, None, 0, 1, 8, 7, 7, 1, 3, 0, 0, None) == -3      # workspace
     assert lib.rcx_recconv2d_fwd_workspace_bytes(256, 64, 56, 56, 4, 5, 1) == 0
     assert lib.rcx_recconv2d_fwd_plan(256, 64, 56, 56, 4, 5, 0, 1).startswith(b"lanes(k_recconv_lanes_banded<56, 4, 16, 0,")
-    assert lib.rcx_recconv2d_fwd_plan(256, 256, 14, 14, 2, 5, 1, 0).startswith(b"lanes(k_recconv_lanes<14, 2, 8, 1,")
+    assert lib.rcx_recconv2d_fwd_plan(256, 256, 14, 14, 2, 5, 1, 0).startswith(b"cpl(k_recconv_cpl14<1, 256>")       # channel per lane
+    assert lib.rcx_recconv2d_fwd_plan(256, 192, 14, 14, 2, 5, 0, 1).startswith(b"cpl(k_recconv_cpl14<0, 0>")          # any channel count
+    os.environ["RCX_CPL14"] = "0"
+    try:
+        assert lib.rcx_recconv2d_fwd_plan(256, 256, 14, 14, 2, 5, 1, 0).startswith(b"lanes(k_recconv_lanes<14, 2, 8, 1,")
+    finally:
+        del os.environ["RCX_CPL14"]
     assert lib.rcx_recconv2d_fwd_plan(32, 64, 32, 32, 2, 5, 0, 1).startswith(b"lanes(k_recconv_lanes_banded<32, 2, 16, 0,")
     assert lib.rcx_recconv2d_fwd_plan(32, 64, 24, 40, 2, 5, 0, 1).startswith(b"plane(")          # neither 7*2^k nor 16*2^k
     assert lib.rcx_recconv2d_fwd_plan(256, 512, 7, 7, 1, 5, 0, 1).startswith(b"cpl(k_recconv_cpl7<0>")     # channel per lane
