@@ -128,7 +128,8 @@ def kernel_name(plan, elem_bytes):
         return f"rcx::lanes::{kern}, {t}>"
     if plan.startswith("cpl(k_recconv_cpl"):
         kern = plan[len("cpl("):plan.index(">")]
-        return f"rcx::cpl::{kern}, {t}>"
+        ns = "cpl" if kern.startswith("k_recconv_cpl7<") else "cpl14"       # rcx_cpl.hip (round 1) / rcx_cpl14.hip
+        return f"rcx::{ns}::{kern}, {t}>"
     return "rcx::k_conv_generic<...> (one launch per ladder step)"
 
 

@@ -76,6 +76,11 @@ __device__ __forceinline__ void pin_row(uint32_t (&v)[14])
     asm volatile("s_waitcnt vmcnt(%14)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
                  "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]) : "n"(PENDING));
 }
+template <int PENDING>
+__device__ __forceinline__ void pin_row(uint32_t (&v)[7])
+{
+    asm volatile("s_waitcnt vmcnt(%7)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]) : "n"(PENDING));
+}
 
 // AGPR stash: the accumulator half of the unified register file holds x between its two uses (one VALU move each way)
 // (volatile: they stay in the row they are written in)
@@ -84,9 +89,9 @@ __device__ __forceinline__ float unstash(float a) { float v; asm volatile("v_acc
 
 // Row access.  CT > 0: the channel count is a compile-time constant, a row needs one scalar base (two for float32 I/O) and the
 // columns are immediates; CT == 0: one scalar base per row and 14 per-lane column offsets computed once.
-template <int CT, typename TIO>
+template <int W_, int CT, typename TIO>
 struct RowAddr {
-    static constexpr int W = 14;
+    static constexpr int W = W_;
     static constexpr int PIXB = CT * (int)sizeof(TIO);
     static constexpr int GROUP = CT > 0 ? ((8192 / (PIXB > 0 ? PIXB : 1) >= W) ? W : 8192 / (PIXB > 0 ? PIXB : 1)) : W;   // columns per base
     unsigned col[CT > 0 ? 1 : W];                                                             // CT == 0: vo + q * pix
@@ -94,7 +99,7 @@ struct RowAddr {
     __device__ __forceinline__ RowAddr(unsigned vo, size_t pix_) : pix(pix_)
     {
         if constexpr (CT > 0) {
-            static_assert(GROUP >= 2 && GROUP % 2 == 0, "channel count too large for immediate addressing");
+            static_assert(GROUP >= 2 && (GROUP % 2 == 0 || GROUP >= W), "channel count too large for immediate addressing");
             col[0] = vo;
         } else {
 #pragma unroll
@@ -239,10 +244,11 @@ __device__ __forceinline__ void conv5_row(const f32x2 (&row)[(N + 1) / 2], int t
     constexpr int NP = (N + 1) / 2;
     // the row shifted by one pixel: odd[j] = (x[2j-1], x[2j]), j = 0..NP (x[-1] = x[N] = 0)
     f32x2 odd[NP + 1];
-    odd[0] = f32x2{0.f, row[0].x};
+    const f32x2 zero = f32x2{0.f, 0.f};
+    odd[0] = shift1(zero, row[0]);
 #pragma unroll
     for (int j = 1; j < NP; ++j) odd[j] = shift1(row[j - 1], row[j]);
-    odd[NP] = f32x2{row[NP - 1].y, 0.f};
+    odd[NP] = shift1(row[NP - 1], zero);
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
         const int o = t - u + 2;
@@ -285,19 +291,32 @@ __device__ __forceinline__ void conv5_plane(const f32x2 (&in)[N][(N + 1) / 2], f
     }
 }
 
-// horizontal resize of one row, NI -> NO pixels (ATen index arithmetic, rcx_lanes.h vtab)
+// the pair (x[i], x[i+1]) of a row held as aligned pairs: the pair itself (i even) or one v_pk_mov_b32 (i odd)
+template <int NP>
+__device__ __forceinline__ f32x2 pair_at(const f32x2 (&in)[NP], int i)
+{
+    return (i & 1) ? shift1(in[i >> 1], in[(i >> 1) + 1 < NP ? (i >> 1) + 1 : i >> 1]) : in[i >> 1];
+}
+
+// horizontal resize of one row, NI -> NO pixels (ATen index arithmetic, rcx_lanes.h vtab).  Two output pixels per instruction
+// where their source pixels are adjacent (every interior pair of an exact 2x step): out = W1 * (x[i1], x[i1']) + W0 * (x[i0], x[i0']).
 template <int MODE, int NI, int NO>
 __device__ __forceinline__ void resize_row(const f32x2 (&in)[(NI + 1) / 2], f32x2 (&out)[(NO + 1) / 2])
 {
+    constexpr int NPI = (NI + 1) / 2;
     auto px = [&](int i) -> float { return (i & 1) ? in[i >> 1].y : in[i >> 1].x; };
-#pragma unroll
-    for (int q = 0; q < NO; ++q) {
+    auto one = [&](int q) -> float {
         const VT t = vtab(MODE, NI, NO, q);
-        const float v = (MODE == 1 || t.i0 == t.i1) ? px(t.i0) : fmaf(t.l, px(t.i1), (1.f - t.l) * px(t.i0));
-        if (q & 1) out[q >> 1].y = v;
-        else out[q >> 1].x = v;
+        return (MODE == 1 || t.i0 == t.i1) ? px(t.i0) : fmaf(t.l, px(t.i1), (1.f - t.l) * px(t.i0));
+    };
+#pragma unroll
+    for (int j = 0; j < (NO + 1) / 2; ++j) {
+        const VT a = vtab(MODE, NI, NO, 2 * j), b = vtab(MODE, NI, NO, 2 * j + 1 < NO ? 2 * j + 1 : 2 * j);
+        const bool paired = MODE == 0 && 2 * j + 1 < NO && a.i0 != a.i1 && b.i0 != b.i1 && a.i0 + 1 == b.i0 && a.i1 + 1 == b.i1 &&
+                            b.i1 < NI;
+        if (paired) out[j] = pfma(f32x2{a.l, b.l}, pair_at<NPI>(in, a.i1), f32x2{1.f - a.l, 1.f - b.l} * pair_at<NPI>(in, a.i0));
+        else out[j] = f32x2{one(2 * j), 2 * j + 1 < NO ? one(2 * j + 1) : 0.f};
     }
-    if (NO & 1) out[NO >> 1].y = 0.f;
 }
 
 // dst += vertical resize: dst(row d of NO) += (1-l) * h[i0] + l * h[i1]
@@ -334,7 +353,7 @@ void k_recconv_cpl14(const TIO* __restrict__ x, TIO* __restrict__ y, const float
     const gcptr xb = (gcptr)x + (size_t)n * W * W * pix;
     const gcptr yb = (gcptr)y + (size_t)n * W * W * pix;
     const unsigned vo = (unsigned)c * (unsigned)sizeof(TIO), vow = (unsigned)c * 4u;
-    const RowAddr<CT, TIO> ra(vo, pix);
+    const RowAddr<W, CT, TIO> ra(vo, pix);
 
     // ---- pass 1, one x row at a time (loads run AHEAD rows in front: a wave cannot have more than 64 memory operations in
     // flight anyway): 14 elements straight from HBM (each load instruction moves 128 contiguous bytes per wave), kept for pass 2
@@ -469,6 +488,75 @@ void k_recconv_cpl14(const TIO* __restrict__ x, TIO* __restrict__ y, const float
     }
 }
 
+// ---- the 7x7 / level 1 block (last stage of RecNeXt-M*) from the same pieces: y = conv_1(x + resize(conv_0(down(x)))).
+// 2048 waves at N = 256, C = 512: two per SIMD, so the register budget is 256 and nothing is stashed.
+template <int MODE, int CT, typename TIO>
+__global__ __launch_bounds__(64, 2)
+void k_recconv_cpl7b(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack,
+                     int N, int C_rt, int has_bias)
+{
+    constexpr int W = 7, P = 4, W1 = 4, P1 = 2;
+    const int C = CT > 0 ? CT : C_rt;
+    const int nb = (C + 63) / 64;
+    unsigned b = blockIdx.x;
+    const unsigned G = gridDim.x;
+    if ((G & 7u) == 0) b = (b & 7u) * (G >> 3) + (b >> 3);                 // XCD-aware order, as above
+    const int n = (int)(b / (unsigned)nb), cb = (int)(b - (unsigned)n * (unsigned)nb);
+    if (n >= N) return;
+    const int c = cb * 64 + (int)threadIdx.x;
+    if (c >= C) return;
+    const size_t pix = (size_t)C * sizeof(TIO);
+    const gcptr xb = (gcptr)x + (size_t)n * W * W * pix;
+    const gcptr yb = (gcptr)y + (size_t)n * W * W * pix;
+    const unsigned vo = (unsigned)c * (unsigned)sizeof(TIO), vow = (unsigned)c * 4u;
+    const RowAddr<W, CT, TIO> ra(vo, pix);
+
+    uint32_t raw[W][W];
+    lanes::sfor<W>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        ra.row(xb, r, [&](auto qc, gcptr base, unsigned voff, auto immc) {
+            PixLd<TIO>::template ld<decltype(immc)::value>(raw[r][decltype(qc)::value], base, voff);
+        });
+    });
+    Taps td, t0;
+    load_taps<CT>(td, wpack, bpack, 0, C, vow, has_bias);
+    load_taps<CT>(t0, wpack, bpack, 1, C, vow, has_bias);
+    f32x2 X[W][P];
+    lanes::sfor<W>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        pin_row<7 * (W - 1 - r)>(raw[r]);
+#pragma unroll
+        for (int j = 0; j < P; ++j) X[r][j] = f32x2{PixLd<TIO>::cvt(raw[r][2 * j]), 2 * j + 1 < W ? PixLd<TIO>::cvt(raw[r][2 * j + 1]) : 0.f};
+    });
+    RCX_FENCE;
+    f32x2 F1[W1][P1];
+    down5<W, W1>(X, F1, td);
+    Taps t1;
+    load_taps<CT>(t1, wpack, bpack, 2, C, vow, has_bias);
+    RCX_FENCE;
+    f32x2 C1[W1][P1];
+    conv5_plane<W1>(F1, C1, t0);
+    f32x2 H1[W1][P];
+#pragma unroll
+    for (int i = 0; i < W1; ++i) resize_row<MODE, W1, W>(C1[i], H1[i]);
+#pragma unroll
+    for (int r = 0; r < W; ++r) add_resized_row<MODE, W1, W, P>(X[r], H1, r);                  // X becomes T0
+    pin(X);
+    RCX_FENCE;
+    f32x2 Y[W][P];
+    conv5_plane<W>(X, Y, t1);
+    lanes::sfor<W>([&](auto rc) {
+        constexpr int o = decltype(rc)::value;
+        typename PixSt<TIO>::packed pk[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) pk[j] = PixSt<TIO>::prep(Y[o][j]);
+        ra.row(yb, o, [&](auto qc, gcptr base, unsigned voff, auto immc) {
+            constexpr int q = decltype(qc)::value;
+            PixSt<TIO>::st(base + decltype(immc)::value + voff, pk[q >> 1], q & 1);
+        });
+    });
+}
+
 // A/B switches, read per call like the other schedules' (tests flip them inside one process): RCX_CPL14=0 gives the block
 // back to the lanes kernel, RCX_LANES=0 / RCX_FORCE_GENERIC=1 switch every register-resident schedule off
 static inline bool enabled()
@@ -493,7 +581,42 @@ static hipError_t launch_c(const void* x, void* y, const float* wpack, const flo
     return launch<MODE, 0, TIO>(x, y, wpack, bpack, N, C, s);
 }
 
+template <int MODE, int CT, typename TIO>
+static hipError_t launch7(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s)
+{
+    const unsigned grid = (unsigned)(N * ((C + 63) / 64));
+    hipLaunchKernelGGL((k_recconv_cpl7b<MODE, CT, TIO>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr);
+    return hipGetLastError();
+}
+
+template <int MODE, typename TIO>
+static hipError_t launch7_c(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s)
+{
+    if (C == 512) return launch7<MODE, 512, TIO>(x, y, wpack, bpack, N, C, s);         // RecNeXt-M3/M4 stage 3
+    return launch7<MODE, 0, TIO>(x, y, wpack, bpack, N, C, s);
+}
+
 }  // namespace cpl14
+
+// the 7x7 / level 1 block on the pieces of this file (RCX_CPL7=old keeps rcx_cpl.hip's first version for A/B runs)
+bool cpl7b_applicable(int N, int C, int H, int W, int level, int k, int dtype)
+{
+    (void)N;
+    const char* v = getenv("RCX_CPL7");
+    const char* all = getenv("RCX_CPL");                          // RCX_CPL=0: no channel-per-lane kernel on 7x7 (the lanes kernel instead)
+    return cpl14::enabled() && !(v && *v == 'o') && !(all && *all == '0') && H == 7 && W == 7 && level == 1 && k == 5 && C >= 1 && (dtype == 0 || dtype == 1);
+}
+
+int cpl7b_describe(int N, int C, int mode, char* buf, int len)
+{
+    return snprintf(buf, len, "cpl(k_recconv_cpl7b<%d, %d>,cb=64,nt=64,blocks=%d,lds=0)", mode, C == 512 ? 512 : 0, N * ((C + 63) / 64));
+}
+
+hipError_t cpl7b_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s)
+{
+    if (dtype == 1) return mode == 1 ? cpl14::launch7_c<1, bf16_t>(x, y, wpack, bpack, N, C, s) : cpl14::launch7_c<0, bf16_t>(x, y, wpack, bpack, N, C, s);
+    return mode == 1 ? cpl14::launch7_c<1, float>(x, y, wpack, bpack, N, C, s) : cpl14::launch7_c<0, float>(x, y, wpack, bpack, N, C, s);
+}
 
 bool cpl14_applicable(int N, int C, int H, int W, int level, int k, int dtype)
 {

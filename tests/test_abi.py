@@ -58,8 +58,14 @@ def test_abi_version_and_argument_errors_without_gpu():
         del os.environ["RCX_CPL14"]
     assert lib.rcx_recconv2d_fwd_plan(32, 64, 32, 32, 2, 5, 0, 1).startswith(b"lanes(k_recconv_lanes_banded<32, 2, 16, 0,")
     assert lib.rcx_recconv2d_fwd_plan(32, 64, 24, 40, 2, 5, 0, 1).startswith(b"plane(")          # neither 7*2^k nor 16*2^k
-    assert lib.rcx_recconv2d_fwd_plan(256, 512, 7, 7, 1, 5, 0, 1).startswith(b"cpl(k_recconv_cpl7<0>")     # channel per lane
-    assert lib.rcx_recconv2d_fwd_plan(2, 40, 7, 7, 1, 5, 0, 1).startswith(b"lanes(k_recconv_lanes<7, 1, 8, 0,")   # C % 64 != 0
+    assert lib.rcx_recconv2d_fwd_plan(256, 512, 7, 7, 1, 5, 0, 1).startswith(b"cpl(k_recconv_cpl7b<0, 512>")     # channel per lane
+    assert lib.rcx_recconv2d_fwd_plan(2, 40, 7, 7, 1, 5, 0, 1).startswith(b"cpl(k_recconv_cpl7b<0, 0>")          # any channel count
+    os.environ["RCX_CPL7"] = "old"
+    try:
+        assert lib.rcx_recconv2d_fwd_plan(256, 512, 7, 7, 1, 5, 0, 1).startswith(b"cpl(k_recconv_cpl7<0>")       # round 1's version
+        assert lib.rcx_recconv2d_fwd_plan(2, 40, 7, 7, 1, 5, 0, 1).startswith(b"lanes(k_recconv_lanes<7, 1, 8, 0,")   # C % 64 != 0
+    finally:
+        del os.environ["RCX_CPL7"]
     assert lib.rcx_recconv2d_fwd_plan(1, 8, 7, 7, 1, 3, 0, 0) == b"generic"
     assert lib.rcx_recconv2d_fwd(one, one, one, None, None, 0, 1, 8, 7, 7, 0, 5, 0, 0, None) == -1      # alias
     assert lib.rcx_dwconv2d_fwd(one, two, one, None, 1, 8, 7, 7, 5, 3, 0, 0, None) == -2                # stride 3

@@ -129,17 +129,24 @@ def test_sweep_against_c_oracle(case):
 @pytest.mark.parametrize("mode", ["bilinear", "nearest"])
 @pytest.mark.parametrize("bias", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-def test_channel_per_lane_kernel_against_oracle_and_lanes_kernel(mode, bias, dtype, monkeypatch):
+@pytest.mark.parametrize("c", [128, 512, 40])
+def test_channel_per_lane_kernel_against_oracle_and_lanes_kernel(mode, bias, dtype, c, monkeypatch):
     """The 7x7 / level 1 block has two register-resident kernels (rcx_cpl.hip, rcx_lanes.hip): both against the oracle and
     against each other (the lanes kernel pairs taps in another order: float32 rounding differences only)."""
-    n, c, level, k = 5, 128, 1, 5
-    rng = np.random.default_rng(zlib.crc32(repr((mode, bias, str(dtype))).encode()))
+    n, level, k = 5, 1, 5
+    rng = np.random.default_rng(zlib.crc32(repr((mode, bias, str(dtype), c)).encode()))
     x, wd, wc, bd, bc = _rand_case(rng, n, c, 7, 7, level, k, bias)
     if dtype == torch.bfloat16:
         x = bf16_round_np(x)
     ref = c_oracle.recconv2d(x, wd, wc, bd, bc, level, mode)
-    assert ops.recconv2d_plan(n, c, 7, 7, level, k, mode, dtype).startswith("cpl(")
+    assert ops.recconv2d_plan(n, c, 7, 7, level, k, mode, dtype).startswith("cpl(k_recconv_cpl7b<")
     got = _run_hip(x, wd, wc, bd, bc, level, k, mode, dtype)
+    if c % 64 == 0:                                   # round 1's channel-per-lane kernel (whole waves only), kept for A/B runs
+        monkeypatch.setenv("RCX_CPL7", "old")
+        assert ops.recconv2d_plan(n, c, 7, 7, level, k, mode, dtype).startswith("cpl(k_recconv_cpl7<")
+        old = _run_hip(x, wd, wc, bd, bc, level, k, mode, dtype)
+        assert np.allclose(old, got, atol=2e-5 if dtype == torch.float32 else 1e-2, rtol=1e-2)
+        monkeypatch.delenv("RCX_CPL7")
     monkeypatch.setenv("RCX_CPL", "0")
     assert ops.recconv2d_plan(n, c, 7, 7, level, k, mode, dtype).startswith("lanes(")
     other = _run_hip(x, wd, wc, bd, bc, level, k, mode, dtype)
