@@ -46,6 +46,11 @@ bool cpl7b_applicable(int N, int C, int H, int W, int level, int k, int dtype);
 int cpl7b_describe(int N, int C, int mode, char* buf, int len);
 hipError_t cpl7b_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s);
 
+// channel-per-lane, tiled kernel of the 56x56 / level 4 and 28x28 / level 3 blocks (rcx_cpt.hip): any channel count
+bool cpt_applicable(int N, int C, int H, int W, int level, int k, int dtype);
+int cpt_describe(int N, int C, int H, int mode, char* buf, int len);
+hipError_t cpt_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int H, int mode, int dtype, hipStream_t s);
+
 // rcx_down.hip -- register-resident depthwise 7x7 stride-2 conv with channel multiplier 2 (Downsample) on the 7*2^k planes
 bool down_lanes_applicable(int N, int Cin, int H, int W, int k, int stride, int dtype);
 hipError_t down_lanes(const void* x, void* y, const float* w, const float* b, int N, int Cin, int H, int W, int k, int stride, int dtype, hipStream_t s);

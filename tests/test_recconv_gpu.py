@@ -189,6 +189,39 @@ def test_channel_per_lane_14x14_kernel_against_oracle_and_lanes_kernel(mode, bia
         assert np.allclose(other, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
 
 
+@pytest.mark.parametrize("mode", ["bilinear", "nearest"])
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 64, 56, 4), (1, 48, 56, 4), (2, 80, 56, 4), (1, 8, 56, 4), (2, 128, 28, 3), (1, 96, 28, 3), (3, 160, 28, 3),
+                                   (2, 40, 28, 3)], ids=lambda v: "x".join(map(str, v)))
+def test_tiled_channel_per_lane_kernel_against_oracle_and_lanes_kernel(mode, bias, dtype, shape, monkeypatch):
+    """The 56x56 / level 4 and 28x28 / level 3 blocks on rcx_cpt.hip (a lane owns one channel of one 14x14 tile, the planes of
+    level >= 1 in LDS) against the oracle: whole channel blocks (64, 128), ragged last blocks (48, 80, 8, 96, 160, 40), both
+    resize modes, bias.  The banded lanes kernel it replaces must agree with it to float32 round-off."""
+    n, c, hw, level = shape
+    k = 5
+    rng = np.random.default_rng(zlib.crc32(repr((mode, bias, str(dtype), shape)).encode()))
+    x, wd, wc, bd, bc = _rand_case(rng, n, c, hw, hw, level, k, bias)
+    if dtype == torch.bfloat16:
+        x = bf16_round_np(x)
+    ref = c_oracle.recconv2d(x, wd, wc, bd, bc, level, mode)
+    assert ops.recconv2d_plan(n, c, hw, hw, level, k, mode, dtype).startswith("cpt(k_recconv_cpt<")
+    got = _run_hip(x, wd, wc, bd, bc, level, k, mode, dtype)
+    if dtype == torch.float32:
+        assert np.abs(got - ref).max() < F32_TIGHT
+    else:
+        assert np.allclose(got, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
+        assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 1e-5)          # one rounding, at the store
+    monkeypatch.setenv("RCX_CPT", "0")
+    plan = ops.recconv2d_plan(n, c, hw, hw, level, k, mode, dtype)
+    assert not plan.startswith("cpt(")
+    other = _run_hip(x, wd, wc, bd, bc, level, k, mode, dtype)
+    if dtype == torch.float32:
+        assert np.abs(other - ref).max() < F32_TIGHT and np.abs(got - other).max() < 2e-5 * max(1.0, float(np.abs(ref).max()))
+    else:
+        assert np.allclose(other, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
+
+
 @pytest.mark.parametrize("stride", [1, 2])
 @pytest.mark.parametrize("k", [3, 5, 7])
 @pytest.mark.parametrize("dtypes", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32),
