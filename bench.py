@@ -126,6 +126,9 @@ def kernel_name(plan, elem_bytes):
     if plan.startswith("lanes(k_recconv_lanes"):
         kern = plan[len("lanes("):plan.index(">")]
         return f"rcx::lanes::{kern}, {t}>"
+    if plan.startswith("cpt(k_recconv_cpt"):
+        kern = plan[len("cpt("):plan.index(">")]
+        return f"rcx::cpt::{kern}, {t}>"
     if plan.startswith("cpl(k_recconv_cpl"):
         kern = plan[len("cpl("):plan.index(">")]
         ns = "cpl" if kern.startswith("k_recconv_cpl7<") else "cpl14"       # rcx_cpl.hip (round 1) / rcx_cpl14.hip

@@ -39,12 +39,37 @@ using lanes::VT;
 
 #define CPT_FENCE __builtin_amdgcn_sched_barrier(0)
 
+// diagnostic build only (-DRCX_STAMPS, tools/cpt_bench.hip): lane 0 of every wave of the first workgroups writes the clock at phase boundaries
+#ifdef RCX_STAMPS
+__device__ unsigned long long* g_cpt_stamps = nullptr;
+#define CPT_STAMP(id)                                                                                                    \
+    do {                                                                                                                 \
+        if ((threadIdx.x & 63) == 0 && g_cpt_stamps && blockIdx.x < 512)                                                 \
+            g_cpt_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (id)] = __builtin_readcyclecounter();             \
+    } while (0)
+#define CPT_STAMP_RT(id)                                                                                                 \
+    do {                                                                                                                 \
+        if ((threadIdx.x & 63) == 0 && g_cpt_stamps && blockIdx.x < 512)                                                 \
+            g_cpt_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (id)] = __builtin_amdgcn_s_memrealtime();         \
+    } while (0)
+#else
+#define CPT_STAMP(id) do { } while (0)
+#define CPT_STAMP_RT(id) do { } while (0)
+#endif
+
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) char* gcptr;
 typedef __attribute__((address_space(1))) char* gptr;
 
 __device__ __forceinline__ f32x2 pfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 splat(float v) { return f32x2{v, v}; }
+// (a[A], b[B]) in one instruction; the compiler spends two v_mov_b32 on a shuffle whose sources come from LDS reads
+template <int A, int B> __device__ __forceinline__ f32x2 pkmov(f32x2 a, f32x2 b)
+{
+    f32x2 d;
+    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[%3,%4]" : "=v"(d) : "v"(a), "v"(b), "n"(A), "n"(B));
+    return d;
+}
 __device__ __forceinline__ f32x2 shift1(f32x2 a, f32x2 b) { return __builtin_shufflevector(a, b, 1, 2); }
 __device__ __forceinline__ gcptr opaque(gcptr p) { asm volatile("" : "+s"(p)); return p; }
 __device__ __forceinline__ void pin(f32x2& v) { asm volatile("" : "+v"(v)); }
@@ -61,24 +86,138 @@ template <int A> __device__ __forceinline__ void pin(float (&v)[A]) {
 // ---- x rows: hand-issued buffer loads (the compiler would sink them to their first use and the prefetch distance collapses;
 // rcx_cpl14.hip).  address = image base (descriptor) + soff (uniform: row and column) + voff (this lane: tile column origin and
 // channel, or 0x80000000 = out of range -> the load returns 0: the zero padding left and right of the image)
-template <typename TIO> struct BufLd;
-// The scalar offset the load reads is produced by an SALU add INSIDE the statement: an SGPR operand handed in from outside may
-// have just been reloaded from a spill lane by v_readlane_b32 (a VALU write), and a vector-memory instruction that reads an SGPR
-// within 5 wait states of a VALU write to it sees the old value -- the hazard recognizer does not look inside inline asm.
-// (s_add_i32 writes SCC: declared, or a scalar select scheduled behind the statement reads the wrong condition.)
-template <> struct BufLd<float> {
-    static __device__ __forceinline__ void ld(uint32_t& dst, unsigned voff, i32x4 rsrc, int rb, int koff)
+// A whole row = ONE asm statement: 18 loads (or 14 stores) back to back, no compiler-inserted padding between them.  The scalar
+// offset the instructions read is produced by an SALU instruction INSIDE the statement: an SGPR operand handed in from outside
+// may have just been written by a VALU instruction (v_readfirstlane_b32, or v_readlane_b32 reloading a spill), and a
+// vector-memory instruction that reads an SGPR within 5 wait states of a VALU write to it sees the old value -- the hazard
+// recognizer does not look inside inline asm.  s_add_i32 writes SCC: declared, or a scalar select scheduled behind the
+// statement reads the wrong condition.  Outputs are early-clobber: a destination must not share a register with an offset that
+// a later load of the same statement still reads.
+// PIXB = bytes between horizontally adjacent pixels when that is a compile-time constant (columns become immediate offsets:
+// 12-bit, so the columns past 4095 bytes go through a second scalar base), 0 = run-time pitch (one scalar add per column).
+#define CPT_OUT18(v) "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]), \
+                     "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15]), "=&v"(v[16]), "=&v"(v[17])
+// immediate columns: L = columns -2, -1 (voffL), M k = column k (voffM), R = columns 14, 15 (voffR)
+#define CPT_LI(OP, d, V, S, k) OP " %" #d ", %[" V "], %[rs], %[" S "] offen offset:%[pb]*" #k "\n\t"
+#define CPT_ROW_IMM(OP)                                                                                                              \
+    "s_add_i32 %[t], %[rb], 0\n\t"                                                                                                  \
+    CPT_LI(OP, 0, "vl", "t", 0) CPT_LI(OP, 1, "vl", "t", 1)                                                                          \
+    CPT_LI(OP, 2, "vm", "t", 0) CPT_LI(OP, 3, "vm", "t", 1) CPT_LI(OP, 4, "vm", "t", 2) CPT_LI(OP, 5, "vm", "t", 3)                  \
+    CPT_LI(OP, 6, "vm", "t", 4) CPT_LI(OP, 7, "vm", "t", 5) CPT_LI(OP, 8, "vm", "t", 6) CPT_LI(OP, 9, "vm", "t", 7)                  \
+    CPT_LI(OP, 10, "vm", "t", 8) CPT_LI(OP, 11, "vm", "t", 9) CPT_LI(OP, 12, "vm", "t", 10) CPT_LI(OP, 13, "vm", "t", 11)            \
+    CPT_LI(OP, 14, "vm", "t", 12) CPT_LI(OP, 15, "vm", "t", 13)                                                                      \
+    CPT_LI(OP, 16, "vr", "t", 0) CPT_LI(OP, 17, "vr", "t", 1)
+#define CPT_ROW_BIG(OP)                                                                                                              \
+    "s_add_i32 %[t], %[rb], 0\n\ts_add_i32 %[t2], %[rb], %[pb]*7\n\t"                                                               \
+    CPT_LI(OP, 0, "vl", "t", 0) CPT_LI(OP, 1, "vl", "t", 1)                                                                          \
+    CPT_LI(OP, 2, "vm", "t", 0) CPT_LI(OP, 3, "vm", "t", 1) CPT_LI(OP, 4, "vm", "t", 2) CPT_LI(OP, 5, "vm", "t", 3)                  \
+    CPT_LI(OP, 6, "vm", "t", 4) CPT_LI(OP, 7, "vm", "t", 5) CPT_LI(OP, 8, "vm", "t", 6) CPT_LI(OP, 9, "vm", "t2", 0)                 \
+    CPT_LI(OP, 10, "vm", "t2", 1) CPT_LI(OP, 11, "vm", "t2", 2) CPT_LI(OP, 12, "vm", "t2", 3) CPT_LI(OP, 13, "vm", "t2", 4)          \
+    CPT_LI(OP, 14, "vm", "t2", 5) CPT_LI(OP, 15, "vm", "t2", 6)                                                                      \
+    CPT_LI(OP, 16, "vr", "t", 0) CPT_LI(OP, 17, "vr", "t", 1)
+// run-time pitch: t2 walks along the row
+#define CPT_LG(OP, d, V, S) OP " %" #d ", %[" V "], %[rs], %[" S "] offen\n\t"
+#define CPT_LGN(OP, d) "s_add_i32 %[t2], %[t2], %[pix]\n\t" CPT_LG(OP, d, "vm", "t2")
+#define CPT_ROW_GEN(OP)                                                                                                              \
+    "s_add_i32 %[t], %[rb], 0\n\ts_add_i32 %[t2], %[rb], %[pix]\n\t"                                                                \
+    CPT_LG(OP, 0, "vl", "t") CPT_LG(OP, 1, "vl", "t2") CPT_LG(OP, 16, "vr", "t") CPT_LG(OP, 17, "vr", "t2")                          \
+    CPT_LG(OP, 2, "vm", "t") CPT_LG(OP, 3, "vm", "t2")                                                                               \
+    CPT_LGN(OP, 4) CPT_LGN(OP, 5) CPT_LGN(OP, 6) CPT_LGN(OP, 7) CPT_LGN(OP, 8) CPT_LGN(OP, 9) CPT_LGN(OP, 10) CPT_LGN(OP, 11)         \
+    CPT_LGN(OP, 12) CPT_LGN(OP, 13) CPT_LGN(OP, 14) CPT_LGN(OP, 15)
+
+template <typename TIO> struct IoOp;
+// bf16 -> float32 without an instruction: the D16 "hi" load fills the upper half and zeroes the lower (tools/ubench/d16_probe.hip)
+#define CPT_LD16 "buffer_load_short_d16_hi"
+#define CPT_LD32 "buffer_load_dword"
+
+template <typename TIO, int PIXB>
+__device__ __forceinline__ void row_load(uint32_t (&v)[18], unsigned vl, unsigned vm, unsigned vr, i32x4 rs, int rb, int pix)
+{
+    int t, t2;
+    if constexpr (PIXB > 0 && PIXB * 13 <= 4095) {
+        (void)pix; (void)t2;
+        if constexpr (sizeof(TIO) == 2)
+            asm volatile(CPT_ROW_IMM(CPT_LD16) : CPT_OUT18(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+        else
+            asm volatile(CPT_ROW_IMM(CPT_LD32) : CPT_OUT18(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+    } else if constexpr (PIXB > 0) {
+        static_assert(PIXB * 6 <= 4095, "pixel pitch too large for two immediate ranges");
+        (void)pix;
+        if constexpr (sizeof(TIO) == 2)
+            asm volatile(CPT_ROW_BIG(CPT_LD16) : CPT_OUT18(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+        else
+            asm volatile(CPT_ROW_BIG(CPT_LD32) : CPT_OUT18(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+    } else {
+        if constexpr (sizeof(TIO) == 2)
+            asm volatile(CPT_ROW_GEN(CPT_LD16) : CPT_OUT18(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+        else
+            asm volatile(CPT_ROW_GEN(CPT_LD32) : CPT_OUT18(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+    }
+}
+
+// ---- one output row of the tile: 14 stores in one statement.  vo = this lane's offset, or out of range (the store is dropped:
+// the lanes of a ragged last channel block).  bf16: 7 registers of two converted pixels each, low half = even column.
+#define CPT_SI(OP, d, S, k) OP " %[p" #d "], %[vo], %[rs], %[" S "] offen offset:%[pb]*" #k "\n\t"
+#define CPT_SG(OP, d, S) OP " %[p" #d "], %[vo], %[rs], %[" S "] offen\n\t"
+#define CPT_SGN(OP, d) "s_add_i32 %[t2], %[t2], %[pix]\n\t" CPT_SG(OP, d, "t2")
+#define CPT_ST16_IMM(S0, S1, k0)                                                                                                     \
+    CPT_SI("buffer_store_short", 0, S0, 0) CPT_SI("buffer_store_short_d16_hi", 0, S0, 1) CPT_SI("buffer_store_short", 1, S0, 2)      \
+    CPT_SI("buffer_store_short_d16_hi", 1, S0, 3) CPT_SI("buffer_store_short", 2, S0, 4) CPT_SI("buffer_store_short_d16_hi", 2, S0, 5) \
+    CPT_SI("buffer_store_short", 3, S0, 6)
+template <typename TIO, int PIXB> struct RowSt;
+template <int PIXB> struct RowSt<bf16_t, PIXB> {
+    static __device__ __forceinline__ void st(const f32x2 (&a)[7], unsigned vo, i32x4 rs, int rb, int pix)
     {
-        int tmp;
-        asm volatile("s_add_i32 %0, %3, %4\n\tbuffer_load_dword %1, %2, %5, %0 offen" : "=&s"(tmp), "=v"(dst) : "v"(voff), "s"(rb), "s"(koff), "s"(rsrc) : "scc");
+        uint32_t p[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p[j]) : "v"(a[j].x), "v"(a[j].y));      // RNE, NaN stays NaN
+        int t, t2;
+        if constexpr (PIXB > 0 && PIXB * 13 <= 4095) {
+            (void)pix; (void)t2;
+            asm volatile("s_add_i32 %[t], %[rb], 0\n\t"
+                         CPT_SI("buffer_store_short", 0, "t", 0) CPT_SI("buffer_store_short_d16_hi", 0, "t", 1)
+                         CPT_SI("buffer_store_short", 1, "t", 2) CPT_SI("buffer_store_short_d16_hi", 1, "t", 3)
+                         CPT_SI("buffer_store_short", 2, "t", 4) CPT_SI("buffer_store_short_d16_hi", 2, "t", 5)
+                         CPT_SI("buffer_store_short", 3, "t", 6) CPT_SI("buffer_store_short_d16_hi", 3, "t", 7)
+                         CPT_SI("buffer_store_short", 4, "t", 8) CPT_SI("buffer_store_short_d16_hi", 4, "t", 9)
+                         CPT_SI("buffer_store_short", 5, "t", 10) CPT_SI("buffer_store_short_d16_hi", 5, "t", 11)
+                         CPT_SI("buffer_store_short", 6, "t", 12) CPT_SI("buffer_store_short_d16_hi", 6, "t", 13)
+                         : [t] "=&s"(t)
+                         : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [p4] "v"(p[4]), [p5] "v"(p[5]), [p6] "v"(p[6]),
+                           [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc", "memory");
+        } else {
+            // run-time pitch (and the large compile-time ones): t2 walks along the row
+            asm volatile("s_add_i32 %[t2], %[rb], 0\n\t"
+                         CPT_SG("buffer_store_short", 0, "t2") CPT_SGN("buffer_store_short_d16_hi", 0)
+                         CPT_SGN("buffer_store_short", 1) CPT_SGN("buffer_store_short_d16_hi", 1)
+                         CPT_SGN("buffer_store_short", 2) CPT_SGN("buffer_store_short_d16_hi", 2)
+                         CPT_SGN("buffer_store_short", 3) CPT_SGN("buffer_store_short_d16_hi", 3)
+                         CPT_SGN("buffer_store_short", 4) CPT_SGN("buffer_store_short_d16_hi", 4)
+                         CPT_SGN("buffer_store_short", 5) CPT_SGN("buffer_store_short_d16_hi", 5)
+                         CPT_SGN("buffer_store_short", 6) CPT_SGN("buffer_store_short_d16_hi", 6)
+                         : [t2] "=&s"(t2)
+                         : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [p4] "v"(p[4]), [p5] "v"(p[5]), [p6] "v"(p[6]),
+                           [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc", "memory");
+            (void)t;
+        }
     }
 };
-template <> struct BufLd<bf16_t> {
-    // bf16 -> float32 without an instruction: the D16 "hi" load fills the upper half and zeroes the lower (tools/ubench/d16_probe.hip)
-    static __device__ __forceinline__ void ld(uint32_t& dst, unsigned voff, i32x4 rsrc, int rb, int koff)
+template <int PIXB> struct RowSt<float, PIXB> {
+    static __device__ __forceinline__ void st(const f32x2 (&a)[7], unsigned vo, i32x4 rs, int rb, int pix)
     {
-        int tmp;
-        asm volatile("s_add_i32 %0, %3, %4\n\tbuffer_load_short_d16_hi %1, %2, %5, %0 offen" : "=&s"(tmp), "=v"(dst) : "v"(voff), "s"(rb), "s"(koff), "s"(rsrc) : "scc");
+        int t2;
+        float p[14];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) { p[2 * j] = a[j].x; p[2 * j + 1] = a[j].y; }
+        asm volatile("s_add_i32 %[t2], %[rb], 0\n\t"
+                     CPT_SG("buffer_store_dword", 0, "t2") CPT_SGN("buffer_store_dword", 1) CPT_SGN("buffer_store_dword", 2) CPT_SGN("buffer_store_dword", 3)
+                     CPT_SGN("buffer_store_dword", 4) CPT_SGN("buffer_store_dword", 5) CPT_SGN("buffer_store_dword", 6) CPT_SGN("buffer_store_dword", 7)
+                     CPT_SGN("buffer_store_dword", 8) CPT_SGN("buffer_store_dword", 9) CPT_SGN("buffer_store_dword", 10) CPT_SGN("buffer_store_dword", 11)
+                     CPT_SGN("buffer_store_dword", 12) CPT_SGN("buffer_store_dword", 13)
+                     : [t2] "=&s"(t2)
+                     : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [p4] "v"(p[4]), [p5] "v"(p[5]), [p6] "v"(p[6]), [p7] "v"(p[7]),
+                       [p8] "v"(p[8]), [p9] "v"(p[9]), [p10] "v"(p[10]), [p11] "v"(p[11]), [p12] "v"(p[12]), [p13] "v"(p[13]),
+                       [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc", "memory");
     }
 };
 
@@ -92,26 +231,6 @@ __device__ __forceinline__ void pin_row(uint32_t (&v)[18])
                  "+v"(v[17]) : "n"(PENDING));
 }
 
-template <typename TIO> struct PixSt;
-template <> struct PixSt<float> {
-    typedef f32x2 packed;
-    static __device__ __forceinline__ packed prep(f32x2 v) { return v; }
-    static __device__ __forceinline__ void st(gcptr p, packed v, int half) { *(__attribute__((address_space(1))) float*)(p) = half ? v.y : v.x; }
-};
-template <> struct PixSt<bf16_t> {
-    typedef uint32_t packed;
-    static __device__ __forceinline__ packed prep(f32x2 v)
-    {
-        uint32_t pk;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(v.x), "v"(v.y));
-        return pk;
-    }
-    static __device__ __forceinline__ void st(gcptr p, packed v, int half)
-    {
-        *(__attribute__((address_space(1))) bf16_t*)(p) = half ? (bf16_t)(v >> 16) : (bf16_t)v;
-    }
-};
-
 // the 25 taps of one conv for this lane's channel as three register pairs per tap row: (w0,w1) (w2,w3) (w4,0)
 struct Taps {
     f32x2 p[5][3];
@@ -119,16 +238,15 @@ struct Taps {
     __device__ __forceinline__ float at(int u, int v) const { return (v & 1) ? p[u][v >> 1].y : p[u][v >> 1].x; }
 };
 
-__device__ __forceinline__ void load_taps(Taps& t, const float* __restrict__ wpack, const float* __restrict__ bpack, int conv, int C, int c, int has_bias)
+// wsrc = the weight pack as a raw buffer: one scalar add and one load per tap, no 64-bit vector address arithmetic
+__device__ __forceinline__ void load_taps(Taps& t, __amdgpu_buffer_rsrc_t wsrc, const float* __restrict__ bpack, int conv, int C, int c, int has_bias)
 {
-    const gcptr wb = (gcptr)(wpack + (size_t)conv * 25 * C);
-    const unsigned vow = (unsigned)c * 4u;
+    const int vow = c * 4, base = conv * 25 * C * 4;
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
 #pragma unroll
         for (int v = 0; v < 5; ++v) {
-            const gcptr tb = opaque(wb + (size_t)(u * 5 + v) * C * 4);     // uniform base (SGPR pair) + this lane's 32-bit offset
-            const float w = *reinterpret_cast<const __attribute__((address_space(1))) float*>(tb + vow);
+            const float w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wsrc, vow, base + (u * 5 + v) * C * 4, 0));
             if (v & 1) t.p[u][v >> 1].y = w;
             else t.p[u][v >> 1].x = w;
         }
@@ -259,7 +377,7 @@ struct Geo {
     static constexpr int LDS_BYTES = NPIX * PIXF * 4;
 };
 
-template <int T, int HALVES, int MODE, typename TIO>
+template <int T, int HALVES, int MODE, int PIXB, typename TIO>
 __global__ __launch_bounds__(T * T / HALVES * 64, T == 4 ? 1 : 2)
 void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack,
                    int N, int C, int has_bias)
@@ -269,14 +387,26 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     constexpr int ESZ = (int)sizeof(TIO);
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
+    // Persistent workgroups: the grid is at most what the chip holds at once and a workgroup walks over its units (image,
+    // channel block) -- no relaunch gap between the rounds, LDS zeroed once.  XCD-aware order: workgroups are dealt round-robin
+    // over the 8 XCDs; each XCD gets a contiguous run of units, so the channel blocks of one image (the two halves of its
+    // 128-byte lines) pass through the same L2 at about the same time.
     const int nb = (C + PIXF - 1) / PIXF;
-    unsigned b = blockIdx.x;
-    const unsigned GD = gridDim.x;
-    if ((GD & 7u) == 0) b = (b & 7u) * (GD >> 3) + (b >> 3);            // XCD-aware order: each XCD gets a contiguous run of (image, channel block) units
-    const int n = (int)(b / (unsigned)nb), cb = (int)(b - (unsigned)n * (unsigned)nb);
-    if (n >= N) return;
-
+    const unsigned total = (unsigned)N * (unsigned)nb, GD = gridDim.x;
+    const bool xcd = (total & 7u) == 0 && (GD & 7u) == 0;
     const int tid = (int)threadIdx.x;
+  for (unsigned it = 0;; ++it) {
+    unsigned unit;
+    if (xcd) {
+        const unsigned k = (blockIdx.x >> 3) + it * (GD >> 3);
+        if (k >= (total >> 3)) break;
+        unit = (blockIdx.x & 7u) * (total >> 3) + k;
+    } else {
+        unit = blockIdx.x + it * GD;
+        if (unit >= total) break;
+    }
+    const int n = (int)(unit / (unsigned)nb), cb = (int)(unit - (unsigned)n * (unsigned)nb);
+
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int h = HALVES == 2 ? (lane >> 5) : 0;
@@ -291,6 +421,8 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     const int cc = cvalid ? c : C - 1;
     const int pix = C * ESZ;                                            // bytes between horizontally adjacent pixels
 
+    CPT_STAMP(0);
+    CPT_STAMP_RT(9);
     float* const L = lds + ch;
     const float* const Lzero = L;
     float* const L1 = L + G::O1 * PIXF;
@@ -298,8 +430,9 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     float* const L3 = L + G::O3 * PIXF;
     float* const L4 = L + G::O4 * PIXF;
 
-    // ---- zero the whole LDS image (zero row, guards; and every later read is of finite data)
-    for (int i = tid; i < G::LDS_BYTES / 16; i += G::NT) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // ---- zero the whole LDS image once (zero row, guards; and every later read is of finite data)
+    if (it == 0)
+        for (int i = tid; i < G::LDS_BYTES / 16; i += G::NT) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // x image as a raw buffer: base, num_records = bytes of the image (offsets past it read 0)
     const char* ximg = reinterpret_cast<const char*>(x) + (size_t)n * P0 * P0 * pix;
@@ -320,23 +453,21 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         int ar = 14 * tr + r;
         ar = ar < 0 ? 0 : (ar > P0 - 1 ? P0 - 1 : ar);
         const int rb = __builtin_amdgcn_readfirstlane(ar * (P0 * pix));     // uniform by construction; the asm below needs it in an SGPR
-        BufLd<TIO>::ld(raw[0], voffL, rsrc, rb, 0);
-        BufLd<TIO>::ld(raw[1], voffL, rsrc, rb, pix);
-#pragma unroll
-        for (int k = 0; k < 14; ++k) BufLd<TIO>::ld(raw[2 + k], voffM, rsrc, rb, k * pix);
-        BufLd<TIO>::ld(raw[16], voffR, rsrc, rb, 0);
-        BufLd<TIO>::ld(raw[17], voffR, rsrc, rb, pix);
+        row_load<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
     };
     auto row_valid = [&](int r) -> bool { const int ar = 14 * tr + r; return ar >= 0 && ar < P0; };   // uniform
 
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, (NL + 2) * 25 * C * 4, 0x00020000);
     Taps td;
-    load_taps(td, wpack, bpack, 0, C, cc, has_bias);
+    load_taps(td, wsrc, bpack, 0, C, cc, has_bias);
     __syncthreads();
+    CPT_STAMP(1);
 
     // ================= pass 1: F1 tile = down(x), rows -2 .. 14 of the tile, input-row stationary (tap pairs) =================
     float f1[7][7];                                          // this lane's F1 tile stays in registers until T1 is formed
     {
-        constexpr int AHEAD = 2, R0 = -2, NR = 17;
+        constexpr int AHEAD = 3, R0 = -2, NR = 17;
+        const f32x2 b0 = f32x2{td.bias, 0.f};
         uint32_t raw[NR][18];
         f32x2 facc[3][7];
         sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], R0 + decltype(rc)::value); });
@@ -353,17 +484,17 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                 const int u = r - 2 * o + 2;
                 if (u < 0 || u > 4) continue;
                 f32x2(&a)[7] = facc[o % 3];
-                if (u == 0) {
-#pragma unroll
-                    for (int i = 0; i < 7; ++i) a[i] = f32x2{td.bias, 0.f};
-                }
                 if (rv) {
+                    // u == 0: the first contribution of output row o carries the initial value (bias, 0) as its addend
 #pragma unroll
-                    for (int i = 0; i < 7; ++i) a[i] = pfma(xr[i], td.p[u][0], a[i]);
+                    for (int i = 0; i < 7; ++i) a[i] = pfma(xr[i], td.p[u][0], u == 0 ? b0 : a[i]);
 #pragma unroll
                     for (int i = 0; i < 7; ++i) a[i] = pfma(xr[i + 1], td.p[u][1], a[i]);
 #pragma unroll
                     for (int i = 0; i < 7; ++i) a[i].x = fmaf(xr[i + 2].x, td.p[u][2].x, a[i].x);
+                } else if (u == 0) {
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) a[i] = b0;
                 }
                 if (u == 4) {
                     float* dst = L1 + ((7 * tr + o) * P1 + 7 * tc) * PIXF;
@@ -380,7 +511,9 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             CPT_FENCE;
         });
     }
+    CPT_STAMP(2);
     __syncthreads();
+    CPT_STAMP(3);
 
     // ================= chain: the small planes, pieces dealt over the T*T tile-lanes =================
     // conv j of the pack: 0 = down, 1 + (NL - l) = the conv of level l, 1 + NL = the final conv
@@ -406,6 +539,8 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             });
         }
     };
+    Taps tnx;
+    load_taps(tnx, wsrc, bpack, 1, C, cc, has_bias);           // conv of the coarsest level: requested here, used after the down ladder
     // down ladder: F_l = down(F_{l-1}), l = 2 .. NL
     sfor<NL - 1>([&](auto lc) {
         constexpr int l = 2 + decltype(lc)::value;
@@ -422,12 +557,14 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         });
         __syncthreads();
     });
-    // up recursion on the piece planes: l = NL .. 2: T_l = F_l + resize(C_{l+1}) in place (l < NL), C_l = conv(T_l) in place
+    CPT_STAMP(4);
+    // up recursion on the piece planes: l = NL .. 2: T_l = F_l + resize(C_{l+1}) in place (l < NL), C_l = conv(T_l) in place.
+    // The taps of a level are requested one level ahead of their use (tnx was requested before the down ladder).
     sfor<NL - 1>([&](auto lc) {
         constexpr int l = NL - decltype(lc)::value;
         constexpr int P = PL[l];
-        Taps tc_;
-        load_taps(tc_, wpack, bpack, 1 + (NL - l), C, cc, has_bias);
+        const Taps tc_ = tnx;
+        load_taps(tnx, wsrc, bpack, 1 + (NL - (l - 1)), C, cc, has_bias);        // level l - 1 (for l == 2: the taps of level 1)
         if constexpr (l < NL) {
             constexpr int PC = PL[l + 1];
             for_pieces(IC<P>{}, [&](auto, auto col0c, auto noutc, int row, bool act) {
@@ -456,9 +593,11 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         __syncthreads();
     });
 
+    CPT_STAMP(5);
     // ================= level 1, per tile: T1 = F1 + resize(C2) (exact 2x), C1 = conv(T1) =================
-    Taps t1;
-    load_taps(t1, wpack, bpack, NL, C, cc, has_bias);        // conv of level 1 = pack 1 + (NL - 1)
+    const Taps t1 = tnx;                                     // conv of level 1 = pack 1 + (NL - 1), requested during level 2
+    Taps tf;
+    load_taps(tf, wsrc, bpack, 1 + NL, C, cc, has_bias);     // the final conv's, used after C1
     {
         // columns: run of 7 starting at absolute column 7*tc (parity uniform), source columns b .. b+4 of C2, clamped
         const int d0 = 7 * tc;
@@ -504,16 +643,14 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             for (int cI = 0; cI < 7; ++cI) dst[(r * P1 + cI) * PIXF] = f1[r][cI];
     }
     __syncthreads();
+    CPT_STAMP(6);
     // halo masks of the tile (per lane): columns outside the plane contribute nothing
     const float lmask = ledge ? 0.f : 1.f, rmask = redge ? 0.f : 1.f;
     {
         // C1 tile, input-row stationary over T1 rows -2 .. 8, columns -2 .. 8 (the guards before and after the plane make every
         // address valid; what a masked column reads is finite)
         f32x2 c1[7][4];
-#pragma unroll
-        for (int o = 0; o < 7; ++o)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) c1[o][j] = splat(t1.bias);
+        const f32x2 b1 = splat(t1.bias);
         const float* base = L1 + ((7 * tr) * P1 + 7 * tc) * PIXF;
 #pragma unroll
         for (int t = -2; t <= 8; ++t) {
@@ -536,7 +673,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                     const int o = t - u + 2;
                     if (o < 0 || o > 6) continue;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) c1[o][j] = pfma(in[j], splat(t1.at(u, 0)), c1[o][j]);
+                    for (int j = 0; j < 4; ++j) c1[o][j] = pfma(in[j], splat(t1.at(u, 0)), u == 0 ? b1 : c1[o][j]);     // u == 0: first contribution of row o
 #pragma unroll
                     for (int j = 0; j < 4; ++j) c1[o][j] = pfma(odd[j], splat(t1.at(u, 1)), c1[o][j]);
 #pragma unroll
@@ -546,6 +683,9 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) c1[o][j] = pfma(in[j + 2], splat(t1.at(u, 4)), c1[o][j]);
                 }
+            } else if (t + 2 <= 6) {                         // a row above the plane: the output row it would have opened starts from the bias
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c1[t + 2][j] = b1;
             }
             CPT_FENCE;
         }
@@ -556,9 +696,8 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
 #pragma unroll
             for (int cI = 0; cI < 7; ++cI) dst[(o * P1 + cI) * PIXF] = (cI & 1) ? c1[o][cI >> 1].y : c1[o][cI >> 1].x;
     }
-    Taps tf;
-    load_taps(tf, wpack, bpack, 1 + NL, C, cc, has_bias);
     __syncthreads();
+    CPT_STAMP(7);
 
     // ================= pass 2: y tile = conv(x + resize(C1)), input rows -2 .. 15, five accumulator rows in flight =================
     {
@@ -572,8 +711,16 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         uint32_t raw[NR][18];
         f32x2 H[2][9];
         f32x2 acc[5][7];
-        const gcptr yimg = (gcptr)(reinterpret_cast<char*>(y) + (size_t)n * P0 * P0 * pix);
-        const unsigned yoff = (unsigned)((14 * tc) * pix + c * ESZ);
+        const f32x2 bf = splat(tf.bias);
+        i32x4 ysrc;                                           // y image as a raw buffer; lanes past the last channel store out of range (dropped)
+        {
+            const unsigned long long a = (unsigned long long)(reinterpret_cast<char*>(y) + (size_t)n * P0 * P0 * pix);
+            ysrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+            ysrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+            ysrc.z = P0 * P0 * pix;
+            ysrc.w = 0x00020000;
+        }
+        const unsigned yoff = cvalid ? (unsigned)((14 * tc) * pix + c * ESZ) : OOB;
         // H[i]: C1 row i (tile-local, -2 .. 8; clamped into the plane) resized horizontally to the 18 columns -2 .. 15
         auto build_H = [&](f32x2 (&Hs)[9], int i) {
             int ar = 7 * tr + i;
@@ -586,12 +733,17 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             for (int k = 0; k < 7; ++k) cv[2 + k] = rp[(cb0 + k) * PIXF];
             cv[9] = rp[cR0];
             cv[10] = rp[cR1];
+            f32x2 P[6];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                // columns 2j-2 (even) and 2j-1 (odd): 0.25 c[j] + 0.75 c[j+1] and 0.75 c[j+1] + 0.25 c[j+2]; nearest: c[j+1] twice
-                const f32x2 e = f32x2{cv[j], cv[j + 2]};
-                Hs[j] = pfma(splat(cv[j + 1]), wt, e * wq);
-            }
+            for (int m = 0; m < 6; ++m) P[m] = f32x2{cv[2 * m], m < 5 ? cv[2 * m + 1] : 0.f};
+            sfor<9>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                // columns 2j-2 (even) and 2j-1 (odd): 0.25 c[j] + 0.75 c[j+1] and 0.75 c[j+1] + 0.25 c[j+2]; nearest: c[j+1] twice.
+                // (c[j], c[j+2]) = the same halves of two neighbouring pairs: one v_pk_mov_b32
+                const f32x2 e = pkmov<(j & 1), (j & 1)>(P[j >> 1], P[(j >> 1) + 1]);
+                const float mid = ((j + 1) & 1) ? P[(j + 1) >> 1].y : P[(j + 1) >> 1].x;
+                Hs[j] = pfma(splat(mid), wt, e * wq);
+            });
             Hs[0] = Hs[0] * splat(lmask);
             Hs[8] = Hs[8] * splat(rmask);
         };
@@ -601,11 +753,6 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         sfor<NR>([&](auto rc) {
             constexpr int ri = decltype(rc)::value, t = R0 + ri;
             if constexpr (ri + AHEAD < NR) load_row(raw[ri + AHEAD], t + AHEAD);
-            // accumulator row entering the window: output row t + 2
-            if constexpr (t + 2 >= 0 && t + 2 <= 13) {
-#pragma unroll
-                for (int j = 0; j < 7; ++j) acc[(t + 2) % 5][j] = splat(tf.bias);
-            }
             // vertical source rows (tile origin is even): t even -> (t/2 - 1, t/2) weight 0.75; t odd -> ((t-1)/2, (t+1)/2) weight 0.25
             constexpr int te = (t + 2) & 1;                  // parity of t (t + 2 >= 0)
             constexpr int i0 = MODE == 1 ? ((t + 2) >> 1) - 1 : (te ? (t - 1) / 2 : t / 2 - 1);
@@ -614,7 +761,11 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             // H[i1] is first needed here when t is odd (H[-2], H[-1] were built up front)
             if constexpr (MODE == 0 && te && t >= -1) build_H(H[(i1 + 2) & 1], i1);
             if constexpr (MODE == 1 && !te && t >= 0) build_H(H[(i0 + 2) & 1], i0);
-            pin_row<18 * (NR - 1 - ri < AHEAD ? NR - 1 - ri : AHEAD)>(raw[ri]);
+            // younger memory operations at this point: the rows requested since (18 loads each) and the output rows stored at the
+            // end of the iterations in between (14 stores each; iteration i stores a row for 4 <= i <= 17); the counter holds 63
+            constexpr int NLD = NR - 1 - ri < AHEAD ? NR - 1 - ri : AHEAD;
+            constexpr int NST = (ri - 1 >= 4 && ri - 1 <= 17 ? 1 : 0) + (AHEAD >= 2 && ri - 2 >= 4 && ri - 2 <= 17 ? 1 : 0) + (AHEAD >= 3 && ri - 3 >= 4 && ri - 3 <= 17 ? 1 : 0);
+            pin_row<(18 * NLD + 14 * NST > 63 ? 63 : 18 * NLD + 14 * NST)>(raw[ri]);
             if (row_valid(t)) {
                 f32x2 row[9], odd[8];
 #pragma unroll
@@ -631,7 +782,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                     if (o < 0 || o > 13) continue;
                     f32x2(&a)[7] = acc[o % 5];
 #pragma unroll
-                    for (int j = 0; j < 7; ++j) a[j] = pfma(row[j], splat(tf.at(u, 0)), a[j]);
+                    for (int j = 0; j < 7; ++j) a[j] = pfma(row[j], splat(tf.at(u, 0)), u == 0 ? bf : a[j]);     // u == 0: output row t + 2 enters the window
 #pragma unroll
                     for (int j = 0; j < 7; ++j) a[j] = pfma(odd[j], splat(tf.at(u, 1)), a[j]);
 #pragma unroll
@@ -641,18 +792,15 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
 #pragma unroll
                     for (int j = 0; j < 7; ++j) a[j] = pfma(row[j + 2], splat(tf.at(u, 4)), a[j]);
                 }
+            } else if constexpr (t + 2 >= 0 && t + 2 <= 13) {  // a row outside the image: the output row it would have opened starts from the bias
+#pragma unroll
+                for (int j = 0; j < 7; ++j) acc[(t + 2) % 5][j] = bf;
             }
             // output row t - 2 has seen its last input row
             if constexpr (t - 2 >= 0 && t - 2 <= 13) {
                 constexpr int o = t - 2;
-                typename PixSt<TIO>::packed pk[7];
-#pragma unroll
-                for (int j = 0; j < 7; ++j) pk[j] = PixSt<TIO>::prep(acc[o % 5][j]);
-                const gcptr rowb = opaque(yimg + (size_t)((14 * tr + o) * P0) * pix);
-                if (cvalid) {
-#pragma unroll
-                    for (int k = 0; k < 14; ++k) PixSt<TIO>::st(opaque(rowb + (size_t)(k * pix)) + yoff, pk[k >> 1], k & 1);
-                }
+                const int yrb = __builtin_amdgcn_readfirstlane((14 * tr + o) * (P0 * pix));
+                RowSt<TIO, PIXB>::st(acc[o % 5], yoff, ysrc, yrb, pix);
             }
 #pragma unroll
             for (int o = 0; o < 14; ++o) if (o > t - 2 && o <= t + 2) pin(acc[o % 5]);
@@ -661,6 +809,10 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             CPT_FENCE;
         });
     }
+    CPT_STAMP(8);
+    CPT_STAMP_RT(10);
+    __syncthreads();                                         // the next unit's pass 1 writes F1 where this unit's pass 2 read C1
+  }
 }
 
 static inline bool enabled()
@@ -670,43 +822,72 @@ static inline bool enabled()
     return !(v && *v == '0') && !(l && *l == '0');
 }
 
-template <int T, int HALVES, int MODE, typename TIO>
+template <int T, int HALVES, int MODE, int PIXB, typename TIO>
 static hipError_t launch(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s)
 {
     using G = Geo<T, HALVES, MODE, TIO>;
-    auto kfn = k_recconv_cpt<T, HALVES, MODE, TIO>;
+    auto kfn = k_recconv_cpt<T, HALVES, MODE, PIXB, TIO>;
     static bool attr_set = false;                              // once per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const unsigned grid = (unsigned)(N * ((C + G::PIXF - 1) / G::PIXF));
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus = v;
+    }
+    const unsigned total = (unsigned)(N * ((C + G::PIXF - 1) / G::PIXF));
+    unsigned cap = (unsigned)cus * (T == 4 ? 1u : 2u);         // workgroups resident at once (LDS: one / two per CU)
+    if (const char* e = getenv("RCX_CPT_GRID")) { const int g = atoi(e); if (g > 0) cap = (unsigned)g; }    // A/B knob
+    cap &= ~7u;
+    const unsigned grid = total <= cap || cap == 0 ? total : cap;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(G::NT), G::LDS_BYTES, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr);
     return hipGetLastError();
+}
+
+// the channel counts of RecNeXt-M3 / M4 get the compile-time pixel pitch (immediate column offsets), the rest the run-time one
+template <int T, int HALVES, int MODE, typename TIO>
+static hipError_t launch_c(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s)
+{
+    constexpr int CM3 = T == 4 ? 64 : 128;
+    if (C == CM3) return launch<T, HALVES, MODE, CM3 * (int)sizeof(TIO), TIO>(x, y, wpack, bpack, N, C, s);
+    return launch<T, HALVES, MODE, 0, TIO>(x, y, wpack, bpack, N, C, s);
 }
 
 template <int T, int HALVES>
 static hipError_t launch_md(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s)
 {
-    if (dtype == 1) return mode == 1 ? launch<T, HALVES, 1, bf16_t>(x, y, wpack, bpack, N, C, s) : launch<T, HALVES, 0, bf16_t>(x, y, wpack, bpack, N, C, s);
-    return mode == 1 ? launch<T, HALVES, 1, float>(x, y, wpack, bpack, N, C, s) : launch<T, HALVES, 0, float>(x, y, wpack, bpack, N, C, s);
+    if (dtype == 1) return mode == 1 ? launch_c<T, HALVES, 1, bf16_t>(x, y, wpack, bpack, N, C, s) : launch_c<T, HALVES, 0, bf16_t>(x, y, wpack, bpack, N, C, s);
+    return mode == 1 ? launch_c<T, HALVES, 1, float>(x, y, wpack, bpack, N, C, s) : launch_c<T, HALVES, 0, float>(x, y, wpack, bpack, N, C, s);
 }
 
 }  // namespace cpt
 
+// A/B switches read per call like the other schedules' (tests flip them inside one process): RCX_CPT=0 gives both blocks back to
+// the banded lanes kernels, RCX_CPT=all takes the 28x28 block also where the banded kernel measures faster (ragged last channel
+// block: 64-channel waves with idle lanes; 256 x 96 x 28 x 28 bf16: 58.7 us against 46.0)
 bool cpt_applicable(int N, int C, int H, int W, int level, int k, int dtype)
 {
     (void)N;
     if (!cpt::enabled() || k != 5 || C < 1 || !(dtype == 0 || dtype == 1)) return false;
-    return (H == 56 && W == 56 && level == 4) || (H == 28 && W == 28 && level == 3);
+    if (H == 56 && W == 56 && level == 4) return true;
+    if (H == 28 && W == 28 && level == 3) {
+        const char* v = getenv("RCX_CPT");
+        return C % 64 == 0 || (v && *v == 'a');
+    }
+    return false;
 }
 
-int cpt_describe(int N, int C, int H, int mode, char* buf, int len)
+int cpt_describe(int N, int C, int H, int mode, int dtype, char* buf, int len)
 {
     const int T = H / 14, halves = T == 4 ? 2 : 1, pixf = 64 / halves;
-    return snprintf(buf, len, "cpt(k_recconv_cpt<%d, %d, %d>,cb=%d,nt=%d,blocks=%d,lds=%d)", T, halves, mode, pixf, T * T / halves * 64,
-                    N * ((C + pixf - 1) / pixf), T == 4 ? cpt::Geo<4, 2, 0, float>::LDS_BYTES : cpt::Geo<2, 1, 0, float>::LDS_BYTES);
+    const int pixb = C == (T == 4 ? 64 : 128) ? C * (dtype == 1 ? 2 : 4) : 0;
+    const int total = N * ((C + pixf - 1) / pixf);
+    return snprintf(buf, len, "cpt(k_recconv_cpt<%d, %d, %d, %d>,cb=%d,nt=%d,units=%d,lds=%d)", T, halves, mode, pixb, pixf, T * T / halves * 64, total,
+                    T == 4 ? cpt::Geo<4, 2, 0, float>::LDS_BYTES : cpt::Geo<2, 1, 0, float>::LDS_BYTES);
 }
 
 hipError_t cpt_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int H, int mode, int dtype, hipStream_t s)

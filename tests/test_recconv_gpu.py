@@ -205,6 +205,7 @@ def test_tiled_channel_per_lane_kernel_against_oracle_and_lanes_kernel(mode, bia
     if dtype == torch.bfloat16:
         x = bf16_round_np(x)
     ref = c_oracle.recconv2d(x, wd, wc, bd, bc, level, mode)
+    monkeypatch.setenv("RCX_CPT", "all")               # also the channel counts that default to the banded kernel (28x28, C % 64 != 0)
     assert ops.recconv2d_plan(n, c, hw, hw, level, k, mode, dtype).startswith("cpt(k_recconv_cpt<")
     got = _run_hip(x, wd, wc, bd, bc, level, k, mode, dtype)
     if dtype == torch.float32:
