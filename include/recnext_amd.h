@@ -10,7 +10,7 @@
  *
  * Conventions
  *   - Activations: device pointers to NHWC-contiguous memory (the storage of a torch.channels_last
- *     tensor of logical shape N x C x H x W).  dtype: RCX_DTYPE_F32 or RCX_DTYPE_BF16.
+ *     tensor of logical shape N x C x H x W).  dtype: RCX_DTYPE_F32, RCX_DTYPE_BF16 or RCX_DTYPE_F16 (arithmetic is float32 for all three).
  *   - Weights: float32 device memory, *packed* tap-major (k,k,C) by rcx_pack_dw_weight from the
  *     reference's (C,1,k,k) parameter layout; biases float32 (C).  A RecConv2d parameter pack is
  *     (level+2) such blocks back to back: [down, convs[0], ..., convs[level]]  (convs[0] pairs with
@@ -31,7 +31,7 @@ extern "C" {
 
 #define RCX_ABI_VERSION 1
 
-enum { RCX_DTYPE_F32 = 0, RCX_DTYPE_BF16 = 1 };
+enum { RCX_DTYPE_F32 = 0, RCX_DTYPE_BF16 = 1, RCX_DTYPE_F16 = 2 };   /* F16: the reference's autocast dtype (engine.py:48) */
 enum { RCX_MODE_BILINEAR = 0, RCX_MODE_NEAREST = 1 };   /* F.interpolate(mode=...), model/recnext.py:33 */
 enum { RCX_MAX_LEVEL = 8 };
 

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RCX_LIBRARY points development tools at a diagnostic build of the same ABI (tools/stamps.py)
 LIB_PATH = os.environ.get("RCX_LIBRARY") or os.path.join(_HERE, "lib", "librecnext_amd.so")
 
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 MODE_BILINEAR, MODE_NEAREST = 0, 1
 MODES = {"bilinear": MODE_BILINEAR, "nearest": MODE_NEAREST}
 MAX_LEVEL = 8

@@ -26,6 +26,7 @@ int hip_fail(hipError_t e, const char* what)
     return (int)e;
 }
 
+inline bool known_dtype(int d) { return d == RCX_DTYPE_F32 || d == RCX_DTYPE_BF16 || d == RCX_DTYPE_F16; }
 inline int down_size(int h, int k) { const int p = k / 2; return (h + 2 * p - k) / 2 + 1; }
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -60,7 +61,7 @@ int check_common(const void* x, const void* y, int N, int C, int H, int W, int k
     if (!x || !y) return fail(RCX_ERR_BAD_ARG, "null activation pointer");
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive extent N=%d C=%d H=%d W=%d", N, C, H, W);
     if (k <= 0 || (k & 1) == 0) return fail(RCX_ERR_BAD_ARG, "kernel_size must be odd and positive, got %d", k);
-    if (dtype != RCX_DTYPE_F32 && dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
+    if (!known_dtype(dtype)) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
     return 0;
 }
 
@@ -156,7 +157,7 @@ const char* rcx_recconv2d_fwd_plan(int N, int C, int H, int W, int level, int k,
 int rcx_pack_dw_weight(const void* w_ckk, float* dst_kkc, int C, int k, int dtype, void* stream)
 {
     if (!w_ckk || !dst_kkc || C <= 0 || k <= 0) return fail(RCX_ERR_BAD_ARG, "rcx_pack_dw_weight: bad argument");
-    if (dtype != RCX_DTYPE_F32 && dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
+    if (!known_dtype(dtype)) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
     hipError_t e = rcx::pack_dw_weight(w_ckk, dst_kkc, C, k, dtype, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_pack_dw_weight");
 }
@@ -164,7 +165,7 @@ int rcx_pack_dw_weight(const void* w_ckk, float* dst_kkc, int C, int k, int dtyp
 int rcx_pack_bias(const void* b, float* dst, int C, int dtype, void* stream)
 {
     if (!b || !dst || C <= 0) return fail(RCX_ERR_BAD_ARG, "rcx_pack_bias: bad argument");
-    if (dtype != RCX_DTYPE_F32 && dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
+    if (!known_dtype(dtype)) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
     hipError_t e = rcx::pack_bias(b, dst, C, dtype, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_pack_bias");
 }
@@ -386,7 +387,7 @@ int rcx_dwconv2d_fwd(const void* x, void* y, const float* w_kkc, const float* bi
                      int N, int C, int H, int W, int k, int stride, int in_dtype, int out_dtype, void* stream)
 {
     if (int rc = check_common(x, y, N, C, H, W, k, in_dtype)) return rc;
-    if (out_dtype != RCX_DTYPE_F32 && out_dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", out_dtype);
+    if (!known_dtype(out_dtype)) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", out_dtype);
     if (!w_kkc) return fail(RCX_ERR_BAD_ARG, "null weight");
     if (stride != 1 && stride != 2) return fail(RCX_ERR_UNSUPPORTED, "stride %d not supported (1 or 2)", stride);
     hipError_t e = step_dwconv(x, y, w_kkc, bias, N, C, H, W, k, stride, in_dtype, out_dtype, (hipStream_t)stream);
@@ -413,12 +414,12 @@ int rcx_upadd_dwconv_fwd(const void* x, const void* coarse, void* y, const float
                          int x_dtype, int coarse_dtype, int out_dtype, void* stream)
 {
     if (int rc = check_common(x, y, N, C, H, W, k, x_dtype)) return rc;
-    if (out_dtype != RCX_DTYPE_F32 && out_dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", out_dtype);
+    if (!known_dtype(out_dtype)) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", out_dtype);
     if (!w_kkc) return fail(RCX_ERR_BAD_ARG, "null weight");
     if (mode != RCX_MODE_BILINEAR && mode != RCX_MODE_NEAREST) return fail(RCX_ERR_BAD_ARG, "unknown mode %d", mode);
     if (coarse) {
         if (Hc <= 0 || Wc <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive coarse extent %dx%d", Hc, Wc);
-        if (coarse_dtype != RCX_DTYPE_F32 && coarse_dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", coarse_dtype);
+        if (!known_dtype(coarse_dtype)) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", coarse_dtype);
     }
     hipError_t e = step_upadd(x, coarse, y, w_kkc, bias, N, C, H, W, Hc, Wc, k, mode, x_dtype, coarse_dtype, out_dtype, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_upadd_dwconv_fwd");
@@ -437,7 +438,7 @@ int rcx_dwconv2d_bwd(const void* x, const float* gy, const float* w_kkc, const f
     if (!x || !gy || !gw) return fail(RCX_ERR_BAD_ARG, "rcx_dwconv2d_bwd: null pointer");
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive extent N=%d C=%d H=%d W=%d", N, C, H, W);
     if (k <= 0 || (k & 1) == 0) return fail(RCX_ERR_BAD_ARG, "kernel_size must be odd and positive, got %d", k);
-    if (x_dtype != RCX_DTYPE_F32 && x_dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", x_dtype);
+    if (!known_dtype(x_dtype)) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", x_dtype);
     if (stride != 1 && stride != 2) return fail(RCX_ERR_UNSUPPORTED, "stride %d not supported (1 or 2)", stride);
     if (C % 4) return fail(RCX_ERR_UNSUPPORTED, "the backward kernels need C %% 4 == 0, got C=%d", C);
     if (gx && (!w_kkc || !w_flipped_kkc)) return fail(RCX_ERR_BAD_ARG, "rcx_dwconv2d_bwd: weights are needed for the input gradient");
@@ -460,7 +461,7 @@ int rcx_dwconv2d_mult2_bwd(const void* x, const float* gy, const float* w_kkc, v
 {
     if (!x || !gy || !gw) return fail(RCX_ERR_BAD_ARG, "rcx_dwconv2d_mult2_bwd: null pointer");
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive extent N=%d C=%d H=%d W=%d", N, Cin, H, W);
-    if (dtype != RCX_DTYPE_F32 && dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
+    if (!known_dtype(dtype)) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
     if (k != 3 && k != 5 && k != 7) return fail(RCX_ERR_UNSUPPORTED, "kernel_size %d not supported by the multiplier-2 backward (3, 5, 7)", k);
     if (Cin % 2) return fail(RCX_ERR_UNSUPPORTED, "the multiplier-2 backward needs an even channel count, got %d", Cin);
     if (gx && !w_kkc) return fail(RCX_ERR_BAD_ARG, "rcx_dwconv2d_mult2_bwd: weights are needed for the input gradient");
@@ -475,7 +476,7 @@ int rcx_linear_attention_fwd(const void* qpre, const void* kpre, const void* v, 
 {
     if (!qpre || !kpre || !v || !pe || !out) return fail(RCX_ERR_BAD_ARG, "rcx_linear_attention_fwd: null pointer");
     if (B <= 0 || n <= 0 || C <= 0 || heads <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive extent B=%d n=%d C=%d heads=%d", B, n, C, heads);
-    if (dtype != RCX_DTYPE_F32 && dtype != RCX_DTYPE_BF16) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
+    if (!known_dtype(dtype)) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
     if (C % heads) return fail(RCX_ERR_BAD_ARG, "C=%d is not a multiple of heads=%d", C, heads);
     const int D = C / heads;
     if (D > 64 || (D % 4 != 0 && D > 32)) return fail(RCX_ERR_UNSUPPORTED, "head dimension %d not supported (at most 64; at most 32 unless a multiple of 4)", D);

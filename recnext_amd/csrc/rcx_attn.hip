@@ -26,6 +26,8 @@ __device__ __forceinline__ float la_ld(const float* p) { return *p; }
 __device__ __forceinline__ float la_ld(const bf16_t* p) { return bf16_to_f32(*p); }
 __device__ __forceinline__ void la_st(float* p, float v) { *p = v; }
 __device__ __forceinline__ void la_st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+__device__ __forceinline__ float la_ld(const f16_t* p) { return (float)*p; }
+__device__ __forceinline__ void la_st(f16_t* p, float v) { *p = (f16_t)v; }
 // elu(x) + 1 = x + 1 (x > 0) | exp(x) (x <= 0): no expm1 needed, and none of its cancellation
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.f : __expf(x); }
 
@@ -34,6 +36,8 @@ template <int G> __device__ __forceinline__ void la_ldv(const float* p, float (&
 template <int G> __device__ __forceinline__ void la_ldv(const bf16_t* p, float (&o)[G]) { load_vec<G>(p, o); }
 template <int G> __device__ __forceinline__ void la_stv(float* p, const float (&o)[G]) { store_vec<G>(p, o); }
 template <int G> __device__ __forceinline__ void la_stv(bf16_t* p, const float (&o)[G]) { store_vec<G>(p, o); }
+template <int G> __device__ __forceinline__ void la_ldv(const f16_t* p, float (&o)[G]) { load_vec<G>(p, o); }
+template <int G> __device__ __forceinline__ void la_stv(f16_t* p, const float (&o)[G]) { store_vec<G>(p, o); }
 
 template <typename T, int G>
 __global__ void __launch_bounds__(LA_NT)
@@ -307,10 +311,12 @@ hipError_t linattn_core(const void* qpre, const void* kpre, const void* v, const
 #define RCX_LA4(T, DM) hipLaunchKernelGGL((k_linattn_core4<T, DM>), grid, block, 0, s, (const T*)qpre, (const T*)kpre, (const T*)v, (const T*)pe, (T*)out, n, C, heads)
         const bool small = C / heads <= 32;
         if (dtype == 1) { if (small) RCX_LA4(bf16_t, 32); else RCX_LA4(bf16_t, 64); }
+        else if (dtype == 2) { if (small) RCX_LA4(f16_t, 32); else RCX_LA4(f16_t, 64); }
         else { if (small) RCX_LA4(float, 32); else RCX_LA4(float, 64); }
 #undef RCX_LA4
     }
     else if (dtype == 1) { if (wide) RCX_LA_LAUNCH(bf16_t, 4); else RCX_LA_LAUNCH(bf16_t, 1); }
+    else if (dtype == 2) { if (wide) RCX_LA_LAUNCH(f16_t, 4); else RCX_LA_LAUNCH(f16_t, 1); }
     else { if (wide) RCX_LA_LAUNCH(float, 4); else RCX_LA_LAUNCH(float, 1); }
 #undef RCX_LA_LAUNCH
     return hipGetLastError();

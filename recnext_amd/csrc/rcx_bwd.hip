@@ -233,6 +233,8 @@ __device__ __forceinline__ void ld2(const bf16_t* p, float (&o)[2])
 
 __device__ __forceinline__ float ld1(const float* p) { return *p; }
 __device__ __forceinline__ float ld1(const bf16_t* p) { return bf16_to_f32(*p); }
+__device__ __forceinline__ float ld1(const f16_t* p) { return (float)*p; }
+__device__ __forceinline__ void ld2(const f16_t* p, float (&o)[2]) { load_vec<2>(p, o); }
 
 // K = 3, 5, 7.  MULT = 2: nn.Conv2d(C, 2C, groups=C) -- the thread's two OUTPUT channels (2cp, 2cp+1) share input channel cp
 // (q.C is the number of output channels, `a` has q.C / MULT).
@@ -500,6 +502,7 @@ hipError_t bwd_wgrad(const void* a, int a_dt, const float* coarse, const float* 
     q.sy = Hc > 0 ? (float)Hc / (float)H : 0.f;
     q.sx = Wc > 0 ? (float)Wc / (float)W : 0.f;
     if (a_dt == 1) return wgrad_launch<bf16_t>(a, coarse, g, partial, gw, gb, q, Ho, Wo, stride, accumulate, s);
+    if (a_dt == 2) return wgrad_launch<f16_t>(a, coarse, g, partial, gw, gb, q, Ho, Wo, stride, accumulate, s);
     return wgrad_launch<float>(a, coarse, g, partial, gw, gb, q, Ho, Wo, stride, accumulate, s);
 }
 
@@ -514,6 +517,7 @@ hipError_t bwd_mult2(const void* x, int x_dt, const float* g, const float* w, vo
     if (gx) {
         const unsigned grid = grid_for((long long)N * H * W * (Cin / 2));
         if (x_dt == 1) hipLaunchKernelGGL(k_down_bwd_input_mult2<bf16_t>, dim3(grid), dim3(256), 0, s, g, (bf16_t*)gx, w, q);
+        else if (x_dt == 2) hipLaunchKernelGGL(k_down_bwd_input_mult2<f16_t>, dim3(grid), dim3(256), 0, s, g, (f16_t*)gx, w, q);
         else hipLaunchKernelGGL(k_down_bwd_input_mult2<float>, dim3(grid), dim3(256), 0, s, g, (float*)gx, w, q);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -525,6 +529,7 @@ hipError_t bwd_mult2(const void* x, int x_dt, const float* g, const float* w, vo
     dim3 block(WR_LANES, WR_SLOTS), grid((q.C / 2 + WR_LANES - 1) / WR_LANES, gy);
 #define RCX_WGM(TA_, K_) hipLaunchKernelGGL((k_wgrad_rows<TA_, 2, false, K_, 2>), grid, block, 0, s, (const TA_*)x, (const float*)nullptr, g, partial, q, Ho, Wo)
     if (x_dt == 1) { if (k == 3) RCX_WGM(bf16_t, 3); else if (k == 5) RCX_WGM(bf16_t, 5); else RCX_WGM(bf16_t, 7); }
+    else if (x_dt == 2) { if (k == 3) RCX_WGM(f16_t, 3); else if (k == 5) RCX_WGM(f16_t, 5); else RCX_WGM(f16_t, 7); }
     else { if (k == 3) RCX_WGM(float, 3); else if (k == 5) RCX_WGM(float, 5); else RCX_WGM(float, 7); }
 #undef RCX_WGM
     hipError_t e = hipGetLastError();
@@ -541,6 +546,7 @@ hipError_t bwd_down_input(const float* base, const float* g, void* out, int out_
     q.N = N; q.C = C; q.H = H; q.W = W; q.Hc = Hc; q.Wc = Wc; q.k = k;
     const unsigned grid = grid_for((long long)N * H * W * (C / BW_V));
     if (out_dt == 1) hipLaunchKernelGGL(k_down_bwd_input<bf16_t>, dim3(grid), dim3(256), 0, s, base, g, (bf16_t*)out, w, q);
+    else if (out_dt == 2) hipLaunchKernelGGL(k_down_bwd_input<f16_t>, dim3(grid), dim3(256), 0, s, base, g, (f16_t*)out, w, q);
     else hipLaunchKernelGGL(k_down_bwd_input<float>, dim3(grid), dim3(256), 0, s, base, g, (float*)out, w, q);
     return hipGetLastError();
 }

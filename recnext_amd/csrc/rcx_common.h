@@ -7,6 +7,13 @@
 namespace rcx {
 
 typedef uint16_t bf16_t;   // raw bf16 bits
+typedef _Float16 f16_t;    // IEEE half (the reference's autocast dtype, engine.py:48); dtype id RCX_DTYPE_F16 = 2
+
+// dtype id of an element type (include/recnext_amd.h)
+template <typename T> struct DtId;
+template <> struct DtId<float> { static constexpr int id = 0; };
+template <> struct DtId<bf16_t> { static constexpr int id = 1; };
+template <> struct DtId<f16_t> { static constexpr int id = 2; };
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
@@ -57,6 +64,33 @@ __device__ __forceinline__ void load_vec(const bf16_t* __restrict__ p, float (&o
     }
 }
 
+template <int V>
+__device__ __forceinline__ void load_vec(const f16_t* __restrict__ p, float (&out)[V])
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    if constexpr (V == 1) { out[0] = (float)p[0]; }
+    else {
+        static_assert(V == 2 || V == 4 || V == 8, "V");
+        uint32_t raw[V / 2];
+        if constexpr (V == 2) raw[0] = *reinterpret_cast<const uint32_t*>(p);
+        else if constexpr (V == 4) { uint2 t = *reinterpret_cast<const uint2*>(p); raw[0] = t.x; raw[1] = t.y; }
+        else { uint4 t = *reinterpret_cast<const uint4*>(p); raw[0] = t.x; raw[1] = t.y; raw[2] = t.z; raw[3] = t.w; }
+#pragma unroll
+        for (int i = 0; i < V / 2; ++i) {
+            const h2 h = __builtin_bit_cast(h2, raw[i]);
+            out[2 * i] = (float)h.x; out[2 * i + 1] = (float)h.y;
+        }
+    }
+}
+
+// round-to-nearest-even (v_cvt_pk_f16_f32 on gfx950)
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi)
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 h = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, h);
+}
+
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
 {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
@@ -87,6 +121,25 @@ __device__ __forceinline__ void store_vec(bf16_t* __restrict__ p, const float (&
                                                   pack_bf16x2(in[4], in[5]), pack_bf16x2(in[6], in[7]));
     }
 }
+
+template <int V>
+__device__ __forceinline__ void store_vec(f16_t* __restrict__ p, const float (&in)[V])
+{
+    if constexpr (V == 1) { p[0] = (f16_t)in[0]; }
+    else if constexpr (V == 2) { *reinterpret_cast<uint32_t*>(p) = pack_f16x2(in[0], in[1]); }
+    else if constexpr (V == 4) {
+        *reinterpret_cast<uint2*>(p) = make_uint2(pack_f16x2(in[0], in[1]), pack_f16x2(in[2], in[3]));
+    } else {
+        static_assert(V == 8, "V");
+        *reinterpret_cast<uint4*>(p) = make_uint4(pack_f16x2(in[0], in[1]), pack_f16x2(in[2], in[3]),
+                                                  pack_f16x2(in[4], in[5]), pack_f16x2(in[6], in[7]));
+    }
+}
+
+// one element of any supported type as float32
+__device__ __forceinline__ float elem_to_f32(float v) { return v; }
+__device__ __forceinline__ float elem_to_f32(bf16_t v) { return bf16_to_f32(v); }
+__device__ __forceinline__ float elem_to_f32(f16_t v) { return (float)v; }
 
 // ---- resize source indices (per axis), float arithmetic exactly as ATen's upsample kernels ----
 struct Lerp { int i0, i1; float lam; };

@@ -150,6 +150,15 @@ template <> struct PixLd<bf16_t> {
     static __device__ __forceinline__ float cvt(uint32_t r) { return __uint_as_float(r); }
 };
 
+template <> struct PixLd<f16_t> {
+    // float16: zero-extended 16-bit load, one v_cvt_f32_f16 per element
+    template <int IMM> static __device__ __forceinline__ void ld(uint32_t& dst, gcptr base, unsigned voff)
+    {
+        asm volatile("global_load_ushort %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM));
+    }
+    static __device__ __forceinline__ float cvt(uint32_t r) { return (float)__builtin_bit_cast(_Float16, (uint16_t)r); }
+};
+
 // a pair of horizontally adjacent output pixels: converted once, stored as two elements (the lanes of a wave write 128
 // contiguous bytes per instruction)
 template <typename TIO> struct PixSt;
@@ -169,6 +178,20 @@ template <> struct PixSt<bf16_t> {
     static __device__ __forceinline__ void st(gcptr p, packed v, int half)
     {
         gstore<bf16_t>(p, half ? (bf16_t)(v >> 16) : (bf16_t)v);                    // global_store_short / global_store_short_d16_hi
+    }
+};
+
+template <> struct PixSt<f16_t> {
+    typedef uint32_t packed;
+    static __device__ __forceinline__ packed prep(f32x2 v)
+    {
+        uint32_t pk;                                                   // RNE
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(v.x), "v"(v.y));
+        return pk;
+    }
+    static __device__ __forceinline__ void st(gcptr p, packed v, int half)
+    {
+        gstore<bf16_t>(p, half ? (bf16_t)(v >> 16) : (bf16_t)v);                    // 16 raw bits either way
     }
 };
 
@@ -604,7 +627,7 @@ bool cpl7b_applicable(int N, int C, int H, int W, int level, int k, int dtype)
     (void)N;
     const char* v = getenv("RCX_CPL7");
     const char* all = getenv("RCX_CPL");                          // RCX_CPL=0: no channel-per-lane kernel on 7x7 (the lanes kernel instead)
-    return cpl14::enabled() && !(v && *v == 'o') && !(all && *all == '0') && H == 7 && W == 7 && level == 1 && k == 5 && C >= 1 && (dtype == 0 || dtype == 1);
+    return cpl14::enabled() && !(v && *v == 'o') && !(all && *all == '0') && H == 7 && W == 7 && level == 1 && k == 5 && C >= 1 && (dtype == 0 || dtype == 1 || dtype == 2);
 }
 
 int cpl7b_describe(int N, int C, int mode, char* buf, int len)
@@ -615,13 +638,14 @@ int cpl7b_describe(int N, int C, int mode, char* buf, int len)
 hipError_t cpl7b_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s)
 {
     if (dtype == 1) return mode == 1 ? cpl14::launch7_c<1, bf16_t>(x, y, wpack, bpack, N, C, s) : cpl14::launch7_c<0, bf16_t>(x, y, wpack, bpack, N, C, s);
+    if (dtype == 2) return mode == 1 ? cpl14::launch7_c<1, f16_t>(x, y, wpack, bpack, N, C, s) : cpl14::launch7_c<0, f16_t>(x, y, wpack, bpack, N, C, s);
     return mode == 1 ? cpl14::launch7_c<1, float>(x, y, wpack, bpack, N, C, s) : cpl14::launch7_c<0, float>(x, y, wpack, bpack, N, C, s);
 }
 
 bool cpl14_applicable(int N, int C, int H, int W, int level, int k, int dtype)
 {
     (void)N;
-    return cpl14::enabled() && H == 14 && W == 14 && level == 2 && k == 5 && C >= 1 && (dtype == 0 || dtype == 1);
+    return cpl14::enabled() && H == 14 && W == 14 && level == 2 && k == 5 && C >= 1 && (dtype == 0 || dtype == 1 || dtype == 2);
 }
 
 int cpl14_describe(int N, int C, int mode, char* buf, int len)
@@ -632,6 +656,7 @@ int cpl14_describe(int N, int C, int mode, char* buf, int len)
 hipError_t cpl14_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s)
 {
     if (dtype == 1) return mode == 1 ? cpl14::launch_c<1, bf16_t>(x, y, wpack, bpack, N, C, s) : cpl14::launch_c<0, bf16_t>(x, y, wpack, bpack, N, C, s);
+    if (dtype == 2) return mode == 1 ? cpl14::launch_c<1, f16_t>(x, y, wpack, bpack, N, C, s) : cpl14::launch_c<0, f16_t>(x, y, wpack, bpack, N, C, s);
     return mode == 1 ? cpl14::launch_c<1, float>(x, y, wpack, bpack, N, C, s) : cpl14::launch_c<0, float>(x, y, wpack, bpack, N, C, s);
 }
 

@@ -23,6 +23,7 @@
 // pixel, 0.25 v + 0.75 v instead of ATen's v -- one ulp); the 4 -> 7 step uses ATen's float formulas (rcx_common.h).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "rcx_common.h"
 #include "rcx_lanes.h"
@@ -128,6 +129,7 @@ template <int A> __device__ __forceinline__ void pin(float (&v)[A]) {
 template <typename TIO> struct IoOp;
 // bf16 -> float32 without an instruction: the D16 "hi" load fills the upper half and zeroes the lower (tools/ubench/d16_probe.hip)
 #define CPT_LD16 "buffer_load_short_d16_hi"
+#define CPT_LDH "buffer_load_ushort"                  /* float16: zero-extended, then one v_cvt_f32_f16 per element */
 #define CPT_LD32 "buffer_load_dword"
 
 template <typename TIO, int PIXB>
@@ -136,23 +138,36 @@ __device__ __forceinline__ void row_load(uint32_t (&v)[18], unsigned vl, unsigne
     int t, t2;
     if constexpr (PIXB > 0 && PIXB * 13 <= 4095) {
         (void)pix; (void)t2;
-        if constexpr (sizeof(TIO) == 2)
+        if constexpr (std::is_same<TIO, f16_t>::value)
+            asm volatile(CPT_ROW_IMM(CPT_LDH) : CPT_OUT18(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+        else if constexpr (sizeof(TIO) == 2)
             asm volatile(CPT_ROW_IMM(CPT_LD16) : CPT_OUT18(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
         else
             asm volatile(CPT_ROW_IMM(CPT_LD32) : CPT_OUT18(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
     } else if constexpr (PIXB > 0) {
         static_assert(PIXB * 6 <= 4095, "pixel pitch too large for two immediate ranges");
         (void)pix;
-        if constexpr (sizeof(TIO) == 2)
+        if constexpr (std::is_same<TIO, f16_t>::value)
+            asm volatile(CPT_ROW_BIG(CPT_LDH) : CPT_OUT18(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+        else if constexpr (sizeof(TIO) == 2)
             asm volatile(CPT_ROW_BIG(CPT_LD16) : CPT_OUT18(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
         else
             asm volatile(CPT_ROW_BIG(CPT_LD32) : CPT_OUT18(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
     } else {
-        if constexpr (sizeof(TIO) == 2)
+        if constexpr (std::is_same<TIO, f16_t>::value)
+            asm volatile(CPT_ROW_GEN(CPT_LDH) : CPT_OUT18(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+        else if constexpr (sizeof(TIO) == 2)
             asm volatile(CPT_ROW_GEN(CPT_LD16) : CPT_OUT18(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
         else
             asm volatile(CPT_ROW_GEN(CPT_LD32) : CPT_OUT18(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
     }
+}
+
+// a loaded element as float32: float32 and bf16 (D16-hi load) are already there, float16 takes one conversion
+template <typename TIO> __device__ __forceinline__ float raw_f32(uint32_t r)
+{
+    if constexpr (std::is_same<TIO, f16_t>::value) return (float)__builtin_bit_cast(_Float16, (uint16_t)r);
+    else return __uint_as_float(r);
 }
 
 // ---- one output row of the tile: 14 stores in one statement.  vo = this lane's offset, or out of range (the store is dropped:
@@ -165,12 +180,15 @@ __device__ __forceinline__ void row_load(uint32_t (&v)[18], unsigned vl, unsigne
     CPT_SI("buffer_store_short_d16_hi", 1, S0, 3) CPT_SI("buffer_store_short", 2, S0, 4) CPT_SI("buffer_store_short_d16_hi", 2, S0, 5) \
     CPT_SI("buffer_store_short", 3, S0, 6)
 template <typename TIO, int PIXB> struct RowSt;
-template <int PIXB> struct RowSt<bf16_t, PIXB> {
+template <typename T16, int PIXB> struct RowSt16 {
     static __device__ __forceinline__ void st(const f32x2 (&a)[7], unsigned vo, i32x4 rs, int rb, int pix)
     {
         uint32_t p[7];
 #pragma unroll
-        for (int j = 0; j < 7; ++j) asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p[j]) : "v"(a[j].x), "v"(a[j].y));      // RNE, NaN stays NaN
+        for (int j = 0; j < 7; ++j) {                         // one conversion for the two pixels (RNE, NaN stays NaN)
+            if constexpr (std::is_same<T16, f16_t>::value) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p[j]) : "v"(a[j].x), "v"(a[j].y));
+            else asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p[j]) : "v"(a[j].x), "v"(a[j].y));
+        }
         int t, t2;
         if constexpr (PIXB > 0 && PIXB * 13 <= 4095) {
             (void)pix; (void)t2;
@@ -202,6 +220,8 @@ template <int PIXB> struct RowSt<bf16_t, PIXB> {
         }
     }
 };
+template <int PIXB> struct RowSt<bf16_t, PIXB> : RowSt16<bf16_t, PIXB> {};
+template <int PIXB> struct RowSt<f16_t, PIXB> : RowSt16<f16_t, PIXB> {};
 template <int PIXB> struct RowSt<float, PIXB> {
     static __device__ __forceinline__ void st(const f32x2 (&a)[7], unsigned vo, i32x4 rs, int rb, int pix)
     {
@@ -477,7 +497,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             pin_row<18 * (NR - 1 - ri < AHEAD ? NR - 1 - ri : AHEAD)>(raw[ri]);
             f32x2 xr[9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) xr[k] = f32x2{__uint_as_float(raw[ri][2 * k]), __uint_as_float(raw[ri][2 * k + 1])};
+            for (int k = 0; k < 9; ++k) xr[k] = f32x2{raw_f32<TIO>(raw[ri][2 * k]), raw_f32<TIO>(raw[ri][2 * k + 1])};
             const bool rv = row_valid(r);
 #pragma unroll
             for (int o = 0; o < 7; ++o) {
@@ -770,7 +790,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                 f32x2 row[9], odd[8];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
-                    const f32x2 xv = f32x2{__uint_as_float(raw[ri][2 * k]), __uint_as_float(raw[ri][2 * k + 1])};
+                    const f32x2 xv = f32x2{raw_f32<TIO>(raw[ri][2 * k]), raw_f32<TIO>(raw[ri][2 * k + 1])};
                     if (MODE == 1) row[k] = xv + H[(i0 + 2) & 1][k];
                     else row[k] = pfma(splat(lam), H[(i1 + 2) & 1][k], pfma(splat(1.f - lam), H[(i0 + 2) & 1][k], xv));
                 }
@@ -861,6 +881,7 @@ template <int T, int HALVES>
 static hipError_t launch_md(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s)
 {
     if (dtype == 1) return mode == 1 ? launch_c<T, HALVES, 1, bf16_t>(x, y, wpack, bpack, N, C, s) : launch_c<T, HALVES, 0, bf16_t>(x, y, wpack, bpack, N, C, s);
+    if (dtype == 2) return mode == 1 ? launch_c<T, HALVES, 1, f16_t>(x, y, wpack, bpack, N, C, s) : launch_c<T, HALVES, 0, f16_t>(x, y, wpack, bpack, N, C, s);
     return mode == 1 ? launch_c<T, HALVES, 1, float>(x, y, wpack, bpack, N, C, s) : launch_c<T, HALVES, 0, float>(x, y, wpack, bpack, N, C, s);
 }
 
@@ -872,7 +893,7 @@ static hipError_t launch_md(const void* x, void* y, const float* wpack, const fl
 bool cpt_applicable(int N, int C, int H, int W, int level, int k, int dtype)
 {
     (void)N;
-    if (!cpt::enabled() || k != 5 || C < 1 || !(dtype == 0 || dtype == 1)) return false;
+    if (!cpt::enabled() || k != 5 || C < 1 || !(dtype == 0 || dtype == 1 || dtype == 2)) return false;
     if (H == 56 && W == 56 && level == 4) return true;
     if (H == 28 && W == 28 && level == 3) {
         const char* v = getenv("RCX_CPT");
@@ -884,7 +905,7 @@ bool cpt_applicable(int N, int C, int H, int W, int level, int k, int dtype)
 int cpt_describe(int N, int C, int H, int mode, int dtype, char* buf, int len)
 {
     const int T = H / 14, halves = T == 4 ? 2 : 1, pixf = 64 / halves;
-    const int pixb = C == (T == 4 ? 64 : 128) ? C * (dtype == 1 ? 2 : 4) : 0;
+    const int pixb = C == (T == 4 ? 64 : 128) ? C * (dtype == 0 ? 4 : 2) : 0;
     const int total = N * ((C + pixf - 1) / pixf);
     return snprintf(buf, len, "cpt(k_recconv_cpt<%d, %d, %d, %d>,cb=%d,nt=%d,units=%d,lds=%d)", T, halves, mode, pixb, pixf, T * T / halves * 64, total,
                     T == 4 ? cpt::Geo<4, 2, 0, float>::LDS_BYTES : cpt::Geo<2, 1, 0, float>::LDS_BYTES);

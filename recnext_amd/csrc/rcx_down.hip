@@ -335,6 +335,7 @@ static hipError_t launch_down(const void* x, void* y, const float* w, const floa
 
 bool down_lanes_applicable(int N, int Cin, int H, int W, int k, int stride, int dtype)
 {
+    if (dtype > 1) return false;                       // float16 I/O: the channel-per-lane kernels and the generic schedule (rcx_api.hip)
     const lanes::DownPlan p = lanes::plan_down(N, Cin, H, W, k, stride, dtype);
     return p.ok && (p.waves == 16 || p.waves == 8 || p.waves == 4);
 }

@@ -16,6 +16,7 @@ namespace rcx {
 template <typename T> struct DT;
 template <> struct DT<float> { static constexpr int id = 0; };
 template <> struct DT<bf16_t> { static constexpr int id = 1; };
+template <> struct DT<f16_t> { static constexpr int id = 2; };
 
 struct ConvGeom {
     int N, C, H, W;       // input extent (of x); C = OUTPUT channels (= weights' channel count)
@@ -185,7 +186,12 @@ hipError_t generic_dwconv(const void* x, void* y, const float* w, const float* b
     if (in_dt == 0 && out_dt == 0) return dwconv_io<float, float>(x, y, w, b, g, s);
     if (in_dt == 1 && out_dt == 0) return dwconv_io<bf16_t, float>(x, y, w, b, g, s);
     if (in_dt == 0 && out_dt == 1) return dwconv_io<float, bf16_t>(x, y, w, b, g, s);
-    return dwconv_io<bf16_t, bf16_t>(x, y, w, b, g, s);
+    if (in_dt == 1 && out_dt == 1) return dwconv_io<bf16_t, bf16_t>(x, y, w, b, g, s);
+    // float16 pairs with itself and with the float32 intermediates
+    if (in_dt == 2 && out_dt == 0) return dwconv_io<f16_t, float>(x, y, w, b, g, s);
+    if (in_dt == 0 && out_dt == 2) return dwconv_io<float, f16_t>(x, y, w, b, g, s);
+    if (in_dt == 2 && out_dt == 2) return dwconv_io<f16_t, f16_t>(x, y, w, b, g, s);
+    return hipErrorInvalidValue;
 }
 
 template <typename TX, typename TC, typename TO>
@@ -205,6 +211,14 @@ hipError_t generic_upadd_dwconv(const void* x, const void* coarse, void* y, cons
     g.N = N; g.C = C; g.Cin = C; g.H = H; g.W = W; g.Ho = H; g.Wo = W; g.Hc = Hc; g.Wc = Wc; g.k = k; g.stride = 1;
     g.sy = (float)Hc / (float)H;
     g.sx = (float)Wc / (float)W;
+    if (x_dt == 2 || c_dt == 2 || out_dt == 2) {
+        // float16: x and y float16 with a float32 (RecConv2d) or float16 (RecAttn2d) coarse operand; float32 x with float16 y
+        if (x_dt == 2 && c_dt == 0 && out_dt == 2) return upadd_io<f16_t, float, f16_t>(x, coarse, y, w, b, g, mode, s);
+        if (x_dt == 2 && c_dt == 2 && out_dt == 2) return upadd_io<f16_t, f16_t, f16_t>(x, coarse, y, w, b, g, mode, s);
+        if (x_dt == 2 && c_dt == 0 && out_dt == 0) return upadd_io<f16_t, float, float>(x, coarse, y, w, b, g, mode, s);
+        if (x_dt == 0 && c_dt == 0 && out_dt == 2) return upadd_io<float, float, f16_t>(x, coarse, y, w, b, g, mode, s);
+        return hipErrorInvalidValue;
+    }
     const int key = x_dt * 4 + c_dt * 2 + out_dt;
     switch (key) {
     case 0: return upadd_io<float, float, float>(x, coarse, y, w, b, g, mode, s);
@@ -256,6 +270,7 @@ hipError_t generic_dwconv_mult2(const void* x, void* y, const float* w, const fl
     g.Ho = (H + 2 * p - k) / stride + 1;
     g.Wo = (W + 2 * p - k) / stride + 1;
     if (dt == 0) return mult2_ks<float, float>(x, y, w, b, g, s);
+    if (dt == 2) return mult2_ks<f16_t, f16_t>(x, y, w, b, g, s);
     return mult2_ks<bf16_t, bf16_t>(x, y, w, b, g, s);
 }
 
@@ -267,7 +282,7 @@ __global__ void k_pack_dw_weight(const T* __restrict__ w, float* __restrict__ ds
     if (i >= C * kk) return;
     const int tap = i / C, c = i % C;
     float v;
-    if constexpr (sizeof(T) == 2) v = bf16_to_f32(w[(size_t)c * kk + tap]); else v = w[(size_t)c * kk + tap];
+    v = elem_to_f32(w[(size_t)c * kk + tap]);
     dst[i] = v;
 }
 
@@ -275,6 +290,7 @@ hipError_t pack_dw_weight(const void* w, float* dst, int C, int k, int dt, hipSt
 {
     const int n = C * k * k;
     if (dt == 0) hipLaunchKernelGGL(k_pack_dw_weight<float>, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)w, dst, C, k * k);
+    else if (dt == 2) hipLaunchKernelGGL(k_pack_dw_weight<f16_t>, dim3((n + 255) / 256), dim3(256), 0, s, (const f16_t*)w, dst, C, k * k);
     else hipLaunchKernelGGL(k_pack_dw_weight<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16_t*)w, dst, C, k * k);
     return hipGetLastError();
 }
@@ -283,6 +299,7 @@ hipError_t pack_bias(const void* b, float* dst, int C, int dt, hipStream_t s)
 {
     // a bias is a (C,1,1,1) weight with one tap
     if (dt == 0) hipLaunchKernelGGL(k_pack_dw_weight<float>, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)b, dst, C, 1);
+    else if (dt == 2) hipLaunchKernelGGL(k_pack_dw_weight<f16_t>, dim3((C + 255) / 256), dim3(256), 0, s, (const f16_t*)b, dst, C, 1);
     else hipLaunchKernelGGL(k_pack_dw_weight<bf16_t>, dim3((C + 255) / 256), dim3(256), 0, s, (const bf16_t*)b, dst, C, 1);
     return hipGetLastError();
 }

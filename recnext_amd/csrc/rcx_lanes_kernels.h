@@ -536,6 +536,7 @@ static inline LanesPlan plan(int N, int C, int H, int W, int level, int k, int d
     LanesPlan p{};
     if (env_int("RCX_LANES", 1) == 0) return p;
     if (k != 5 || H != W) return p;
+    if (dtype > 1) return p;                       // float16 I/O: the channel-per-lane kernels and the generic schedule (rcx_api.hip)
     int natural = -1, lpc = 8;
     if (W == 7) natural = 1;
     else if (W == 14) natural = 2;

@@ -823,6 +823,7 @@ PlanePlan plan_plane(int N, int C, int H, int W, int level, int k, int dtype)
     PlanePlan none{};
     none.ok = false;
     if (k != PL_K || level < 0 || level > PL_MAXL || (C % 8) != 0) return none;
+    if (dtype > 1) return none;                       // float16 I/O: the channel-per-lane kernels and the generic schedule (rcx_api.hip)
     if ((long long)H * W > (1 << 18)) return none;        // fast_div range
     if ((long long)H * W * C >= (1LL << 30)) return none; // per-image element offsets are 32-bit in the kernels
     const size_t LDS_CU = 160 * 1024;

@@ -573,6 +573,7 @@ static StepPlan plan_upadd(int N, int C, int H, int W, int xb, int cbytes)
 // plain stride-1 conv5 (no coarse operand) in the same kernel
 bool conv5_lanes_applicable(int N, int C, int H, int W, int k, int x_dt, int out_dt)
 {
+    if (x_dt > 1 || out_dt > 1) return false;                       // float16 I/O: the channel-per-lane kernels and the generic schedule (rcx_api.hip)
     if (k != 5 || out_dt != x_dt) return false;
     return lanes::plan_upadd(N, C, H, W, x_dt == 1 ? 2 : 4, 4).ok;
 }
@@ -587,6 +588,7 @@ hipError_t conv5_lanes(const void* x, void* y, const float* w, const float* b, i
 
 bool upadd_lanes_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int x_dt, int c_dt, int out_dt)
 {
+    if (x_dt > 1 || c_dt > 1 || out_dt > 1) return false;                       // float16 I/O: the channel-per-lane kernels and the generic schedule (rcx_api.hip)
     if (k != 5 || out_dt != x_dt || Hc * 2 != H || Wc * 2 != W) return false;
     if (!(c_dt == x_dt || c_dt == 0)) return false;
     const int xb = x_dt == 1 ? 2 : 4, cbytes = c_dt == 1 ? 2 : 4;
@@ -608,6 +610,7 @@ hipError_t upadd_lanes(const void* x, const void* coarse, void* y, const float* 
 
 bool down5_lanes_applicable(int N, int C, int H, int W, int k, int stride, int in_dt, int out_dt)
 {
+    if (in_dt > 1 || out_dt > 1) return false;                       // float16 I/O: the channel-per-lane kernels and the generic schedule (rcx_api.hip)
     if (k != 5 || stride != 2) return false;
     if (!(out_dt == in_dt || out_dt == 0)) return false;
     return lanes::plan_step(N, C, H, W, in_dt == 1 ? 2 : 4).ok;

@@ -7,14 +7,14 @@ import torch
 
 from . import _lib
 
-_DT = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16}
+_DT = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}
 
 
 def _dt(t):
     try:
         return _DT[t.dtype]
     except KeyError:
-        raise TypeError(f"recnext_amd kernels take float32 or bfloat16 tensors, got {t.dtype}") from None
+        raise TypeError(f"recnext_amd kernels take float32, bfloat16 or float16 tensors, got {t.dtype}") from None
 
 
 def _require_gpu(t, name):

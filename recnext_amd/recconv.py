@@ -7,7 +7,7 @@ block (model/recnext.py:8-34), body executed by the gfx950 HIP kernels behind th
 ``convs[0]`` pairs with the coarsest level and ``convs[level]`` is the full-resolution conv, exactly as
 ``zip(self.convs, reversed(features))`` does at model/recnext.py:32-34.  ``level=0`` is legal.
 
-Forward and backward accept float32 or bfloat16 CUDA tensors (logical N x C x H x W; channels_last
+Forward and backward accept float32, bfloat16 or float16 CUDA tensors (logical N x C x H x W; channels_last
 storage is consumed zero-copy, anything else is converted once) and returns a channels_last tensor
 of the same shape and dtype.  All arithmetic is float32 inside the kernels.  There is no CPU path.
 """

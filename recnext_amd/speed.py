@@ -22,7 +22,7 @@ from . import models
 T0 = 5
 T1 = 10
 
-DTYPES = {"fp32": torch.float32, "f32": torch.float32, "bf16": torch.bfloat16}
+DTYPES = {"fp32": torch.float32, "f32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16, "f16": torch.float16}
 
 
 def build_inference_model(name, device, dtype=torch.bfloat16, token_mixer=None, seed=0, fold_mixer_norm=True,

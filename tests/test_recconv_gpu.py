@@ -223,6 +223,73 @@ def test_tiled_channel_per_lane_kernel_against_oracle_and_lanes_kernel(mode, bia
         assert np.allclose(other, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
 
 
+def f16_round_np(a):
+    return a.astype(np.float16).astype(np.float32)
+
+
+# float16 I/O (the reference's autocast dtype, engine.py:48): every block of RecNeXt at 224 (channel-per-lane kernels), ragged channel
+# counts, the generic schedule (odd sizes, k = 3 / 7, level 0 and 5), both modes, bias
+F16_CASES = [
+    (2, 64, 56, 56, 4, 5, "bilinear", False), (2, 128, 28, 28, 3, 5, "bilinear", True), (3, 256, 14, 14, 2, 5, "bilinear", False),
+    (2, 512, 7, 7, 1, 5, "nearest", False), (1, 48, 56, 56, 4, 5, "nearest", True), (2, 96, 28, 28, 3, 5, "bilinear", False),
+    (2, 40, 14, 14, 2, 5, "bilinear", True), (1, 100, 7, 7, 1, 5, "bilinear", False), (1, 20, 19, 23, 4, 5, "bilinear", False),
+    (2, 8, 25, 13, 2, 5, "bilinear", True), (1, 8, 14, 14, 2, 3, "bilinear", False), (1, 6, 14, 14, 2, 7, "nearest", True),
+    (1, 8, 9, 9, 0, 5, "bilinear", False), (1, 8, 40, 40, 5, 5, "bilinear", False), (1, 5, 8, 8, 2, 5, "nearest", False),
+    (2, 64, 32, 32, 2, 5, "bilinear", False), (1, 16, 24, 40, 2, 5, "bilinear", False),
+]
+
+
+@pytest.mark.parametrize("case", F16_CASES, ids=lambda c: "x".join(map(str, c[:6])) + c[6][0] + ("b" if c[7] else ""))
+def test_fp16_matches_fp32_oracle_on_rounded_inputs(case):
+    """float16 in, float16 out, float32 arithmetic in between: against the float32 oracle on float16-rounded inputs the only
+    error is the final rounding (half a float16 ulp = 2^-11 relative); bar 1e-3 / 1e-3."""
+    n, c, h, w, level, k, mode, bias = case
+    rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
+    x, wd, wc, bd, bc = _rand_case(rng, n, c, h, w, level, k, bias)
+    x = f16_round_np(x)
+    ref = c_oracle.recconv2d(x, wd, wc, bd, bc, level, mode)
+    got = _run_hip(x, wd, wc, bd, bc, level, k, mode, torch.float16)
+    assert np.allclose(got, ref, atol=1e-3, rtol=1e-3), float(np.abs(got - ref).max())
+    assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -11 + 2e-5)                    # one rounding, at the store
+    plan = ops.recconv2d_plan(n, c, h, w, level, k, mode, torch.float16)
+    fast = (h, w, level, k) in [(56, 56, 4, 5), (14, 14, 2, 5), (7, 7, 1, 5)] or ((h, w, level, k) == (28, 28, 3, 5) and c % 64 == 0)
+    assert plan.startswith(("cpt(", "cpl(")) == fast, plan
+
+
+def test_fp16_module_trains_under_autocast():
+    """RecConv2d under torch.autocast(float16) as engine.py:48 runs it: float16 activations in and out, float32 parameters and
+    parameter gradients, GradScaler step; gradients against the ATen operator chain in float32 on the same rounded input."""
+    from oracle.torch_eager import EagerRecConv2d
+    torch.manual_seed(3)
+    ours = recnext_amd.RecConv2d(32, kernel_size=5, level=2, bias=True).to(dev()).train()
+    ref = EagerRecConv2d(32, kernel_size=5, level=2, bias=True).to(dev()).train()
+    ref.load_state_dict(ours.state_dict(), strict=True)
+    x = torch.randn(2, 32, 14, 14, device=dev()).half()
+    gy = torch.randn(2, 32, 14, 14, device=dev()).half()
+    xr = x.float().requires_grad_(True)
+    ref(xr).backward(gy.float())
+    xo = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        yo = ours(xo)
+    assert yo.dtype == torch.float16
+    yo.backward(gy)
+    assert xo.grad.dtype == torch.float16
+    rel = lambda a, b: float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-12))
+    assert rel(xo.grad, xr.grad) < 2e-3
+    for (name, pr), (_, po) in zip(ref.named_parameters(), ours.named_parameters()):
+        assert po.grad.dtype == torch.float32 and rel(po.grad, pr.grad) < 1e-3, name
+    scaler = torch.amp.GradScaler("cuda")
+    opt = torch.optim.SGD(ours.parameters(), lr=0.01)
+    opt.zero_grad()
+    with torch.autocast("cuda", dtype=torch.float16):
+        loss = ours(x).float().square().mean()
+    scaler.scale(loss).backward()
+    scaler.step(opt)
+    scaler.update()
+    with torch.no_grad():
+        assert torch.isfinite(ours(x)).all()
+
+
 @pytest.mark.parametrize("stride", [1, 2])
 @pytest.mark.parametrize("k", [3, 5, 7])
 @pytest.mark.parametrize("dtypes", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32),
@@ -319,7 +386,7 @@ def test_repeated_launches_are_bit_identical(case):
 def test_errors_surface_as_exceptions():
     mod = recnext_amd.RecConv2d(8, level=1).to(dev())
     with pytest.raises(TypeError):
-        mod(torch.randn(1, 8, 7, 7, device=dev(), dtype=torch.float16))
+        mod(torch.randn(1, 8, 7, 7, device=dev(), dtype=torch.float64))
     with pytest.raises(ValueError):
         mod(torch.randn(8, 7, 7, device=dev()))
     with pytest.raises(recnext_amd._lib.RcxError):

@@ -60,3 +60,40 @@ def test_ddp_training_step_matches_aten_token_mixers():
             assert torch.isfinite(ddp(x.contiguous(memory_format=torch.channels_last))).all()
     finally:
         dist.destroy_process_group()
+
+
+def test_ddp_training_step_under_fp16_autocast():
+    """The reference's own mixed-precision recipe (engine.py:48: autocast float16; main.py:321: loss scaler) around the HIP token
+    mixers: float16 activations reach RecConv2d, its float32 parameters get float32 gradients through the HIP backward, the
+    scaler unscales and steps.  Loss and gradients against the same skeleton hosting the ATen token mixers under the same autocast."""
+    dev = torch.device("cuda:0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        ref = _tiny(eager_token_mixer("m")).to(dev).train()
+        net = _tiny().to(dev).to(memory_format=torch.channels_last).train()
+        net.load_state_dict(ref.state_dict(), strict=True)
+        ddp = torch.nn.parallel.DistributedDataParallel(net, device_ids=[0])
+        x = torch.randn(4, 3, 64, 64, device=dev)
+        tgt = torch.randint(0, 10, (4,), device=dev)
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss_ref = torch.nn.functional.cross_entropy(ref(x), tgt)
+        loss_ref.backward()
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+        opt = torch.optim.SGD(ddp.parameters(), lr=0.05)
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss = torch.nn.functional.cross_entropy(ddp(x.contiguous(memory_format=torch.channels_last)), tgt)
+        scaler.scale(loss).backward()                           # DDP's bucketed all-reduce (RCCL) fires in here
+        assert abs(float(loss) - float(loss_ref)) < 2e-2
+        scaler.unscale_(opt)
+        scale = max(float(p.grad.abs().max()) for p in ref.parameters())
+        for (name, pr), (_, po) in zip(ref.named_parameters(), net.named_parameters()):
+            assert po.grad is not None and po.grad.dtype == torch.float32 and torch.isfinite(po.grad).all(), name
+            assert float((po.grad - pr.grad).abs().max()) < 5e-2 * float(pr.grad.abs().max()) + 2e-3 * scale, name
+        scaler.step(opt)
+        scaler.update()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            assert torch.isfinite(ddp(x.contiguous(memory_format=torch.channels_last))).all()
+    finally:
+        dist.destroy_process_group()
