@@ -223,6 +223,31 @@ def test_tiled_channel_per_lane_kernel_against_oracle_and_lanes_kernel(mode, bia
         assert np.allclose(other, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
 
 
+# the four stages of a RecNeXt backbone on a COCO-sized input (detection/configs/_base_/datasets/coco_instance.py:9-12: 800 x 1344
+# -> 200 x 336, 100 x 168, 50 x 84, 25 x 42; the last ladder is 25 -> 13 -> 25): real plane sizes and levels, few channels
+COCO = [(1, 16, 200, 336, 4), (1, 16, 100, 168, 3), (1, 32, 50, 84, 2), (2, 64, 25, 42, 1)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", COCO, ids=lambda c: "x".join(map(str, c)))
+def test_detection_pyramid_shapes(case, dtype):
+    n, c, h, w, level = case
+    rng = np.random.default_rng(zlib.crc32(repr((case, str(dtype))).encode()))
+    x, wd, wc, bd, bc = _rand_case(rng, n, c, h, w, level, 5, False)
+    if dtype == torch.bfloat16:
+        x = bf16_round_np(x)
+    elif dtype == torch.float16:
+        x = x.astype(np.float16).astype(np.float32)
+    ref = c_oracle.recconv2d(x, wd, wc, bd, bc, level, "bilinear")
+    got = _run_hip(x, wd, wc, bd, bc, level, 5, "bilinear", dtype)
+    if dtype == torch.float32:
+        assert np.abs(got - ref).max() < F32_TIGHT
+    elif dtype == torch.bfloat16:
+        assert np.allclose(got, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
+    else:
+        assert np.allclose(got, ref, atol=1e-3, rtol=1e-3)
+
+
 def f16_round_np(a):
     return a.astype(np.float16).astype(np.float32)
 

@@ -22,6 +22,8 @@ SHAPES = {
     "m1": [(256, 48, 56, 56, 4), (256, 96, 28, 28, 3), (256, 192, 14, 14, 2), (256, 384, 7, 7, 1)],
     "m5": [(256, 80, 56, 56, 4), (256, 160, 28, 28, 3), (256, 320, 14, 14, 2), (256, 640, 7, 7, 1)],
     "m3_512": [(32, 64, 128, 128, 4), (32, 128, 64, 64, 3), (32, 256, 32, 32, 2), (32, 512, 16, 16, 1)],
+    # RecNeXt-M3 backbone on a COCO batch (detection/configs/_base_/datasets/coco_instance.py:9-12: 800 x 1344 padded, 2 images per GPU)
+    "m3_coco": [(2, 64, 200, 336, 4), (2, 128, 100, 168, 3), (2, 256, 50, 84, 2), (2, 512, 25, 42, 1)],
 }
 
 
