@@ -132,6 +132,9 @@ def kernel_name(plan, elem_bytes):
     if plan.startswith("cpl(k_recconv_cpl"):
         kern = plan[len("cpl("):plan.index(">")]
         ns = "cpl" if kern.startswith("k_recconv_cpl7<") else "cpl14"       # rcx_cpl.hip (round 1) / rcx_cpl14.hip
+        if kern.startswith("k_recconv_cpl14<"):                              # last template argument: x through LDS (A/B variant)
+            xl = kern.endswith(", XL")
+            return f"rcx::{ns}::{kern[:-4] if xl else kern}, {t}, {'true' if xl else 'false'}>"
         return f"rcx::{ns}::{kern}, {t}>"
     return "rcx::k_conv_generic<...> (one launch per ladder step)"
 

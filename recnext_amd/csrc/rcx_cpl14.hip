@@ -354,7 +354,97 @@ __device__ __forceinline__ void add_resized_row(f32x2 (&dst)[NP], const f32x2 (&
     }
 }
 
-template <int MODE, int CT, typename TIO>
+
+// ======== x through LDS (16-bit I/O, whole 64-channel blocks): k_recconv_cpl14<..., XL = true> ========
+// A wave can keep at most 63 memory operations in flight, and a per-lane 2-byte load moves 128 bytes per wave: 8 KB in flight per
+// SIMD, which at the chip's ~2 us loaded latency makes pass 1 latency-bound (rocprofv3: 19.3 us, a third of the wave's cycles in
+// s_waitcnt).  LDS-DMA moves 1 KB per instruction: the wave requests its whole 14 x 14 x 64-channel plane (25 KB) with 25
+// instructions up front and touches the rows as they land (counted vmcnt waits); a lane then reads its channel's pixels with
+// ds_read_u16_d16_hi (the 16 bits arrive in float32 position, the other half zero-filled: tools/ubench/d16_probe.hip).  The same
+// LDS image serves pass 2: no AGPR stash, no second HBM read.  One wave = one workgroup = 25 KB of LDS.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// the whole plane: 25 x buffer_load_dwordx4 ... lds (lane l: pixel 8 i + l / 8, 16-byte chunk l % 8 -> LDS byte 1024 i + 16 l, i.e. the
+// LDS image is [pixel][128 bytes]).  M0 carries the LDS destination; it is saved and restored (the compiler does not know).
+// v1 = the lanes' offsets for the last instruction, whose pixels past 195 are redirected to pixel 195.
+__device__ __forceinline__ void dma_plane(i32x4 xsrc, unsigned v0, unsigned v1, unsigned lds_base, int step)
+{
+    unsigned keep;
+    int t;
+    asm volatile("s_mov_b32 %[keep], m0\n\t"
+                 "s_mov_b32 %[t], 0\n\t"
+                 "s_mov_b32 m0, %[lds]\n\t"
+                 ".rept 24\n\t"
+                 "s_nop 0\n\t"
+                 "buffer_load_dwordx4 %[v0], %[rs], %[t] offen lds\n\t"
+                 "s_add_i32 %[t], %[t], %[step]\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\t"
+                 ".endr\n\t"
+                 "s_nop 0\n\t"
+                 "buffer_load_dwordx4 %[v1], %[rs], %[t] offen lds\n\t"
+                 "s_mov_b32 m0, %[keep]"
+                 : [keep] "=&s"(keep), [t] "=&s"(t)
+                 : [rs] "s"(xsrc), [lds] "s"(lds_base), [step] "s"(step), [v0] "v"(v0), [v1] "v"(v1)
+                 : "scc", "memory");
+}
+
+template <typename TIO> struct LdsPix {      // float32 I/O never takes the LDS form (50 KB per wave)
+    template <int OFF> static __device__ __forceinline__ void ld(uint32_t&, unsigned) {}
+};
+template <> struct LdsPix<bf16_t> {
+    template <int OFF> static __device__ __forceinline__ void ld(uint32_t& dst, unsigned laddr)
+    {
+        asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(dst) : "v"(laddr), "n"(OFF));
+    }
+};
+template <> struct LdsPix<f16_t> {
+    template <int OFF> static __device__ __forceinline__ void ld(uint32_t& dst, unsigned laddr)
+    {
+        asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(dst) : "v"(laddr), "n"(OFF));
+    }
+};
+// first touch of a row read from LDS: LDS operations complete in order, PENDING = the reads issued after this row's
+template <int PENDING>
+__device__ __forceinline__ void pin_lds_row(uint32_t (&v)[14])
+{
+    asm volatile("s_waitcnt lgkmcnt(%14)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                 "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]) : "n"(PENDING));
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// the 25 taps of the down conv, requested by hand BEFORE the plane (they complete first; a compiler-visible load would make hipcc
+// drain the DMAs at its first use): two statements of 13 and 12 loads, scalar offset walked inside
+#define RCX_TL "buffer_load_dword %"
+#define RCX_TSTEP "s_add_i32 %[t], %[t], %[st]\n\t"
+__device__ __forceinline__ void load_taps_asm(float (&w)[25], i32x4 wsrc, unsigned vow, int base, int stride)
+{
+    int t;
+    asm volatile("s_add_i32 %[t], %[b], 0\n\t"
+                 RCX_TL "0, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP RCX_TL "1, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP
+                 RCX_TL "2, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP RCX_TL "3, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP
+                 RCX_TL "4, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP RCX_TL "5, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP
+                 RCX_TL "6, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP RCX_TL "7, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP
+                 RCX_TL "8, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP RCX_TL "9, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP
+                 RCX_TL "10, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP RCX_TL "11, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP
+                 RCX_TL "12, %[vo], %[rs], %[t] offen"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7]), "=&v"(w[8]), "=&v"(w[9]),
+                   "=&v"(w[10]), "=&v"(w[11]), "=&v"(w[12]), [t] "=&s"(t)
+                 : [vo] "v"(vow), [rs] "s"(wsrc), [b] "s"(base), [st] "s"(stride) : "scc");
+    asm volatile("s_add_i32 %[t], %[b], 0\n\t"
+                 RCX_TL "0, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP RCX_TL "1, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP
+                 RCX_TL "2, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP RCX_TL "3, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP
+                 RCX_TL "4, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP RCX_TL "5, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP
+                 RCX_TL "6, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP RCX_TL "7, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP
+                 RCX_TL "8, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP RCX_TL "9, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP
+                 RCX_TL "10, %[vo], %[rs], %[t] offen\n\t" RCX_TSTEP RCX_TL "11, %[vo], %[rs], %[t] offen"
+                 : "=&v"(w[13]), "=&v"(w[14]), "=&v"(w[15]), "=&v"(w[16]), "=&v"(w[17]), "=&v"(w[18]), "=&v"(w[19]), "=&v"(w[20]), "=&v"(w[21]),
+                   "=&v"(w[22]), "=&v"(w[23]), "=&v"(w[24]), [t] "=&s"(t)
+                 : [vo] "v"(vow), [rs] "s"(wsrc), [b] "s"(base + 13 * stride), [st] "s"(stride) : "scc");
+}
+#undef RCX_TL
+#undef RCX_TSTEP
+
+template <int MODE, int CT, typename TIO, bool XL = false>
 __global__ __launch_bounds__(64)
 void k_recconv_cpl14(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack,
                      int N, int C_rt, int has_bias)
@@ -383,7 +473,7 @@ void k_recconv_cpl14(const TIO* __restrict__ x, TIO* __restrict__ y, const float
     // in the accumulator half of the register file, and scattered into the F1 = down(x) rows they feed (14 -> 7, tap pairs)
     constexpr int AHEAD = 3;                                // 3 * 14 + 14 = 56 loads in flight at most (the counter holds 63)
     uint32_t raw[W][W];                                     // as loaded; only AHEAD + 1 rows are ever live
-    float S[W][W];                                          // the stash (AGPRs)
+    float S[W][W];                                          // the stash (AGPRs; not with XL)
     f32x2 F1[W1][P1];
     f32x2 facc[3][W1];                                      // F1 rows in flight: (sum over even taps, sum over odd taps) per output
     auto load_row = [&](int r) {
@@ -391,21 +481,80 @@ void k_recconv_cpl14(const TIO* __restrict__ x, TIO* __restrict__ y, const float
             PixLd<TIO>::template ld<decltype(immc)::value>(raw[r][decltype(qc)::value], base, voff);
         });
     };
-    lanes::sfor<AHEAD>([&](auto rc) { load_row(decltype(rc)::value); });
     Taps td;                                                // the shared down conv (model/recnext.py:21, :28); its taps come from L2
-    load_taps<CT>(td, wpack, bpack, 0, C, vow, has_bias);   // behind the first x rows: the compiler's wait for them covers those too
+    // XL: this lane's LDS byte address of pixel 0 of its channel; row r, column q is at + (14 r + q) * 128 (an immediate)
+    extern __shared__ __attribute__((aligned(16))) unsigned char xlds[];
+    unsigned laddr = 0;
+    uint32_t xl[2][W];                                      // XL: rows as read from LDS, one row ahead
+    auto lds_row = [&](uint32_t (&v)[W], auto rc) {
+        constexpr int r = decltype(rc)::value;
+        lanes::sfor<W>([&](auto qc) { LdsPix<TIO>::template ld<(W * r + decltype(qc)::value) * 128>(v[decltype(qc)::value], laddr); });
+    };
+    if constexpr (XL) {
+        const int lane = (int)threadIdx.x;
+        const unsigned lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)xlds);
+        laddr = lds_base + (unsigned)lane * 2u;
+        i32x4 xsrc, wsrc;
+        {
+            const unsigned long long a = (unsigned long long)xb;
+            xsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+            xsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+            xsrc.z = W * W * (int)pix;
+            xsrc.w = 0x00020000;
+            const unsigned long long wa = (unsigned long long)wpack;
+            wsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)wa);
+            wsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(wa >> 32) & 0xffff);
+            wsrc.z = 5 * 25 * C * 4;
+            wsrc.w = 0x00020000;
+        }
+        td.bias = 0.f;
+        if (has_bias) {                                      // rare: fetched and waited for before anything is in flight
+            td.bias = gload<float>((gcptr)bpack + vow);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(td.bias));
+        }
+        float tw[25];
+        load_taps_asm(tw, wsrc, vow, 0, C * 4);
+        const int pl = lane >> 3, ch16 = (lane & 7) * 16 + cb * 128;
+        const int plast = 192 + pl > 195 ? 3 : pl;          // the last instruction covers pixels 192 .. 199: past 195 re-read 195
+        dma_plane(xsrc, (unsigned)(pl * (int)pix + ch16), (unsigned)(plast * (int)pix + ch16), lds_base, 8 * (int)pix);
+        // row 0 = pixels 0 .. 13 = DMA 0 and 1: 23 younger ones may still be in flight; the taps were requested before and are in
+        wait_vm<23>();
+#pragma unroll
+        for (int i = 0; i < 25; ++i) asm volatile("" : "+v"(tw[i]));
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            td.p[u][0] = f32x2{tw[u * 5], tw[u * 5 + 1]};
+            td.p[u][1] = f32x2{tw[u * 5 + 2], tw[u * 5 + 3]};
+            td.p[u][2] = f32x2{tw[u * 5 + 4], 0.f};
+        }
+        lds_row(xl[0], lanes::IC<0>{});
+    } else {
+        lanes::sfor<AHEAD>([&](auto rc) { load_row(decltype(rc)::value); });
+        load_taps<CT>(td, wpack, bpack, 0, C, vow, has_bias);   // behind the first x rows: the compiler's wait for them covers those too
+    }
     lanes::sfor<W>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
-        if constexpr (r + AHEAD < W) load_row(r + AHEAD);
-        // the row requested AHEAD rows ago is first touched HERE: one counted wait for the whole row (the younger loads stay in flight)
-        pin_row<14 * (W - 1 - r < AHEAD ? W - 1 - r : AHEAD)>(raw[r]);
         f32x2 xr[P];
+        if constexpr (XL) {
+            if constexpr (r + 1 < W) {
+                // row r + 1 = pixels up to 14 r + 27 must have landed before it is read: DMA index (14 r + 27) / 8
+                wait_vm<24 - (W * (r + 1) + W - 1) / 8>();
+                lds_row(xl[(r + 1) & 1], lanes::IC<r + 1>{});
+            }
+            pin_lds_row<(r + 1 < W ? W : 0)>(xl[r & 1]);
 #pragma unroll
-        for (int j = 0; j < P; ++j) xr[j] = f32x2{PixLd<TIO>::cvt(raw[r][2 * j]), PixLd<TIO>::cvt(raw[r][2 * j + 1])};
+            for (int j = 0; j < P; ++j) xr[j] = f32x2{PixLd<TIO>::cvt(xl[r & 1][2 * j]), PixLd<TIO>::cvt(xl[r & 1][2 * j + 1])};
+        } else {
+            if constexpr (r + AHEAD < W) load_row(r + AHEAD);
+            // the row requested AHEAD rows ago is first touched HERE: one counted wait for the whole row (the younger loads stay in flight)
+            pin_row<14 * (W - 1 - r < AHEAD ? W - 1 - r : AHEAD)>(raw[r]);
 #pragma unroll
-        for (int j = 0; j < P; ++j) {
-            S[r][2 * j] = stash(xr[j].x);
-            S[r][2 * j + 1] = stash(xr[j].y);
+            for (int j = 0; j < P; ++j) xr[j] = f32x2{PixLd<TIO>::cvt(raw[r][2 * j]), PixLd<TIO>::cvt(raw[r][2 * j + 1])};
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                S[r][2 * j] = stash(xr[j].x);
+                S[r][2 * j + 1] = stash(xr[j].y);
+            }
         }
 #pragma unroll
         for (int o = 0; o < W1; ++o) {
@@ -488,8 +637,21 @@ void k_recconv_cpl14(const TIO* __restrict__ x, TIO* __restrict__ y, const float
             if (first_use) resize_row<MODE, W1, W>(C1[i], H1[i]);
         }
         f32x2 row[P];
+        if constexpr (XL) {
+            // x a second time, from the LDS image (one row ahead; the row base costs one add, the columns are immediates)
+            auto rd = [&](uint32_t (&v)[W], int tr) {
+                const unsigned ra_ = laddr + (unsigned)(tr * W * 128);
+                lanes::sfor<W>([&](auto qc) { LdsPix<TIO>::template ld<decltype(qc)::value * 128>(v[decltype(qc)::value], ra_); });
+            };
+            if (t == 0) rd(xl[0], 0);
+            if (t + 1 < W) { rd(xl[(t + 1) & 1], t + 1); pin_lds_row<W>(xl[t & 1]); }
+            else pin_lds_row<0>(xl[t & 1]);
 #pragma unroll
-        for (int j = 0; j < P; ++j) row[j] = f32x2{unstash(S[t][2 * j]), unstash(S[t][2 * j + 1])};
+            for (int j = 0; j < P; ++j) row[j] = f32x2{PixLd<TIO>::cvt(xl[t & 1][2 * j]), PixLd<TIO>::cvt(xl[t & 1][2 * j + 1])};
+        } else {
+#pragma unroll
+            for (int j = 0; j < P; ++j) row[j] = f32x2{unstash(S[t][2 * j]), unstash(S[t][2 * j + 1])};
+        }
         add_resized_row<MODE, W1, W, P>(row, H1, t);                                         // T0 row t
         conv5_row<W>(row, t, t2, [&](int o) -> f32x2(&)[P] { return acc[o % 5]; });
         // rows that have seen their last input row leave: row t-2, and with the last input row also rows 12 and 13
@@ -597,9 +759,29 @@ static hipError_t launch(const void* x, void* y, const float* wpack, const float
     return hipGetLastError();
 }
 
+// x through LDS: 16-bit I/O and whole 64-channel blocks.  OFF by default (RCX_CPL14_LDS=1 switches it on for A/B runs): measured
+// 19.96 us against 19.27 us for the register / AGPR-stash form at 256 x 256 x 14 x 14 bf16 (profiles/r02c_cpl14_lds_variant.txt) --
+// the kernel is bound by its ~5.3 k instructions at one wave per SIMD, not by the latency of its x loads.
+static inline bool use_xl(int C, int esz)
+{
+    const char* v = getenv("RCX_CPL14_LDS");
+    return esz == 2 && C % 64 == 0 && v && *v == '1';
+}
+
+template <int MODE, int CT, typename TIO>
+static hipError_t launch_xl(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s)
+{
+    const unsigned grid = (unsigned)(N * (C / 64));
+    hipLaunchKernelGGL((k_recconv_cpl14<MODE, CT, TIO, true>), dim3(grid), dim3(64), 25 * 1024, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr);
+    return hipGetLastError();
+}
+
 template <int MODE, typename TIO>
 static hipError_t launch_c(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s)
 {
+    if constexpr (sizeof(TIO) == 2) {
+        if (use_xl(C, 2)) return C == 256 ? launch_xl<MODE, 256, TIO>(x, y, wpack, bpack, N, C, s) : launch_xl<MODE, 0, TIO>(x, y, wpack, bpack, N, C, s);
+    }
     if (C == 256) return launch<MODE, 256, TIO>(x, y, wpack, bpack, N, C, s);          // RecNeXt-M3/M4 stage 2: immediates instead of scalar adds
     return launch<MODE, 0, TIO>(x, y, wpack, bpack, N, C, s);
 }
@@ -648,9 +830,10 @@ bool cpl14_applicable(int N, int C, int H, int W, int level, int k, int dtype)
     return cpl14::enabled() && H == 14 && W == 14 && level == 2 && k == 5 && C >= 1 && (dtype == 0 || dtype == 1 || dtype == 2);
 }
 
-int cpl14_describe(int N, int C, int mode, char* buf, int len)
+int cpl14_describe(int N, int C, int mode, int dtype, char* buf, int len)
 {
-    return snprintf(buf, len, "cpl(k_recconv_cpl14<%d, %d>,cb=64,nt=64,blocks=%d,lds=0)", mode, C == 256 ? 256 : 0, N * ((C + 63) / 64));
+    const bool xl = cpl14::use_xl(C, dtype == 0 ? 4 : 2);
+    return snprintf(buf, len, "cpl(k_recconv_cpl14<%d, %d%s>,cb=64,nt=64,blocks=%d,lds=%d)", mode, C == 256 ? 256 : 0, xl ? ", XL" : "", N * ((C + 63) / 64), xl ? 25 * 1024 : 0);
 }
 
 hipError_t cpl14_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s)

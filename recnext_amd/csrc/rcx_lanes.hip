@@ -70,7 +70,7 @@ bool lanes_applicable(int N, int C, int H, int W, int level, int k, int dtype)
 int lanes_describe(int N, int C, int H, int W, int level, int k, int mode, int dtype, char* buf, int len)
 {
     if (cpt_applicable(N, C, H, W, level, k, dtype)) return cpt_describe(N, C, H, mode, dtype, buf, len);
-    if (cpl14_applicable(N, C, H, W, level, k, dtype)) return cpl14_describe(N, C, mode, buf, len);
+    if (cpl14_applicable(N, C, H, W, level, k, dtype)) return cpl14_describe(N, C, mode, dtype, buf, len);
     if (cpl7b_applicable(N, C, H, W, level, k, dtype)) return cpl7b_describe(N, C, mode, buf, len);
     const lanes::LanesPlan p = lanes::plan(N, C, H, W, level, k, dtype);
     if (!p.ok) return 0;

@@ -39,7 +39,7 @@ hipError_t cpl7_recconv(const void* x, void* y, const float* wpack, const float*
 
 // channel-per-lane kernel of the 14x14 / level 2 block (rcx_cpl14.hip): any channel count
 bool cpl14_applicable(int N, int C, int H, int W, int level, int k, int dtype);
-int cpl14_describe(int N, int C, int mode, char* buf, int len);
+int cpl14_describe(int N, int C, int mode, int dtype, char* buf, int len);
 hipError_t cpl14_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s);
 
 bool cpl7b_applicable(int N, int C, int H, int W, int level, int k, int dtype);
