@@ -291,10 +291,7 @@ template <int W0, int LPC, int NW, typename TIO>
 static hipError_t launch_down_w(const void* x, void* y, const float* w, const float* b, const DownPlan& p, hipStream_t s)
 {
     auto kfn = k_down_lanes<W0, LPC, NW, 7, TIO>;
-    if (p.lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
-        if (e != hipSuccess) return e;
-    }
+    RCX_SET_LDS_ONCE(kfn, p.lds);
     DownArgs a = p.args;
     a.has_bias = b != nullptr;
     const unsigned grid = (unsigned)(a.nblk * (((a.N + a.ni - 1) / a.ni + 7) / 8 * 8));

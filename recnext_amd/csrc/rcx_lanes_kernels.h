@@ -577,10 +577,7 @@ template <int W0, int LEVEL, int LPC, int MODE, int NW, typename TIO>
 static hipError_t launch_w(const void* x, void* y, const float* wpack, const float* bpack, const LanesPlan& p, hipStream_t s)
 {
     auto kfn = k_recconv_lanes<W0, LEVEL, LPC, MODE, NW, TIO>;
-    if (p.lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
-        if (e != hipSuccess) return e;
-    }
+    RCX_SET_LDS_ONCE(kfn, p.lds);
     LanesArgs a = p.args;
     a.has_bias = bpack != nullptr;
     a.ablate = env_int("RCX_LANES_ABLATE", 0);
@@ -593,10 +590,7 @@ template <int W0, int LEVEL, int LPC, int MODE, int NW, int SR, typename TIO>
 static hipError_t launch_bw(const void* x, void* y, const float* wpack, const float* bpack, const LanesPlan& p, hipStream_t s)
 {
     auto kfn = k_recconv_lanes_banded<W0, LEVEL, LPC, MODE, NW, SR, TIO>;
-    if (p.lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
-        if (e != hipSuccess) return e;
-    }
+    RCX_SET_LDS_ONCE(kfn, p.lds);
     LanesArgs a = p.args;
     a.has_bias = bpack != nullptr;
     const unsigned grid = (unsigned)(a.nblk * (((a.N + a.ni - 1) / a.ni + 7) / 8 * 8));

@@ -3,6 +3,18 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+// Raise a kernel's dynamic-LDS limit once per kernel instantiation (the static lives in the expanding template function), not per
+// launch; a later launch that needs more raises it again.
+#define RCX_SET_LDS_ONCE(kfn, bytes)                                                                                              \
+    do {                                                                                                                          \
+        static size_t rcx_lds_set_ = 0;                                                                                           \
+        if ((size_t)(bytes) > 64 * 1024 && (size_t)(bytes) > rcx_lds_set_) {                                                      \
+            hipError_t rcx_e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            if (rcx_e_ != hipSuccess) return rcx_e_;                                                                              \
+            rcx_lds_set_ = (size_t)(bytes);                                                                                       \
+        }                                                                                                                         \
+    } while (0)
+
 namespace rcx {
 
 // rcx_generic.hip

@@ -874,10 +874,7 @@ template <int LPP, typename TIO>
 static hipError_t launch_plane_t(const void* x, void* y, const float* wpack, const float* bpack, const PlanePlan& p, int mode, hipStream_t s)
 {
     auto kfn = p.args.single ? k_recconv_whole<LPP, TIO> : k_recconv_plane<LPP, TIO>;
-    if (p.lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-        if (e != hipSuccess) return e;
-    }
+    RCX_SET_LDS_ONCE(kfn, p.lds_bytes);
     PlaneArgs a = p.args;
     a.has_bias = bpack != nullptr;
     a.mode = mode;

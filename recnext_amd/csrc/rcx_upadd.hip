@@ -476,10 +476,7 @@ static StepPlan plan_step(int N, int C, int H, int W, int min_bytes_per_channel)
 template <class K, class... Args>
 static hipError_t launch_step(K kfn, size_t lds, const StepPlan& p, bool has_bias, hipStream_t s, Args... args)
 {
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    RCX_SET_LDS_ONCE(kfn, lds);
     StepArgs a = p.args;
     a.has_bias = has_bias;
     const unsigned grid = (unsigned)(a.nblk * (((a.N + a.ni - 1) / a.ni + 7) / 8 * 8));

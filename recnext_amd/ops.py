@@ -108,12 +108,13 @@ def recconv2d_forward(x, wpack, bpack, level, k, mode="bilinear"):
     lib = _lib.load()
     dt = _dt(x)
     y = _empty_nhwc(n, c, h, w, x.dtype, x.device)
-    nbytes = lib.rcx_recconv2d_fwd_workspace_bytes(n, c, h, w, level, k, dt)
-    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
+    nbytes = lib.rcx_recconv2d_fwd_workspace_bytes(n, c, h, w, level, k, dt)    # 0 on the fused schedules: nothing to allocate
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     with torch.cuda.device(x.device):
         rc = lib.rcx_recconv2d_fwd(x.data_ptr(), y.data_ptr(), wpack.data_ptr(),
                                    bpack.data_ptr() if bpack is not None else None,
-                                   ws.data_ptr(), nbytes, n, c, h, w, level, k, _lib.MODES[mode], dt, _stream(x.device))
+                                   ws.data_ptr() if ws is not None else None, nbytes, n, c, h, w, level, k, _lib.MODES[mode], dt,
+                                   _stream(x.device))
     _lib.check(rc, "rcx_recconv2d_fwd")
     return y
 
