@@ -147,6 +147,14 @@ int rcx_dwconv2d_mult2_bwd(const void* x, const float* gy, const float* w_kkc, v
 int rcx_linear_attention_fwd(const void* qpre, const void* kpre, const void* v, const void* pe, void* out,
                              int B, int n, int C, int heads, int dtype, void* stream);
 
+/*
+ * Backward of rcx_linear_attention_fwd (the gradients engine.py:48-64 needs through RecAttn2d, model/recattn.py:16-28 / :39-51):
+ *   given gout = dL/dout (B x n x C), writes gq = dL/dqpre, gk = dL/dkpre, gv = dL/dv (all B x n x C, `dtype`); dL/dpe = gout is the
+ *   caller's.  float32 arithmetic, deterministic (fixed summation order).  C/heads at most 64.
+ */
+int rcx_linear_attention_bwd(const void* qpre, const void* kpre, const void* v, const void* gout, void* gq, void* gk, void* gv,
+                             int B, int n, int C, int heads, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

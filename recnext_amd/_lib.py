@@ -38,6 +38,7 @@ SIGNATURES = {
     "rcx_dwconv2d_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t] + [_i] * 7 + [_vp]),
     "rcx_dwconv2d_mult2_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t] + [_i] * 6 + [_vp]),
     "rcx_linear_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 5 + [_vp]),
+    "rcx_linear_attention_bwd": (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
 }
 
 _lib = None

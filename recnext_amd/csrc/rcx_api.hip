@@ -484,6 +484,18 @@ int rcx_linear_attention_fwd(const void* qpre, const void* kpre, const void* v, 
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_linear_attention_fwd");
 }
 
+int rcx_linear_attention_bwd(const void* qpre, const void* kpre, const void* v, const void* gout, void* gq, void* gk, void* gv,
+                             int B, int n, int C, int heads, int dtype, void* stream)
+{
+    if (!qpre || !kpre || !v || !gout || !gq || !gk || !gv) return fail(RCX_ERR_BAD_ARG, "rcx_linear_attention_bwd: null pointer");
+    if (B <= 0 || n <= 0 || C <= 0 || heads <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive extent B=%d n=%d C=%d heads=%d", B, n, C, heads);
+    if (!known_dtype(dtype)) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
+    if (C % heads) return fail(RCX_ERR_BAD_ARG, "C=%d is not a multiple of heads=%d", C, heads);
+    if (C / heads > 64) return fail(RCX_ERR_UNSUPPORTED, "head dimension %d not supported (at most 64)", C / heads);
+    hipError_t e = rcx::linattn_core_bwd(qpre, kpre, v, gout, gq, gk, gv, B, n, C, heads, dtype, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "rcx_linear_attention_bwd");
+}
+
 #ifdef RCX_STAMPS
 /* diagnostic build only: not part of include/recnext_amd.h */
 int rcx_debug_set_stamp_buffer(void* p) { int e = (int)rcx::set_stamp_buffer(p); return e ? e : (int)rcx::lanes::set_stamp_buffer(p); }

@@ -298,6 +298,165 @@ k_linattn_core4(const T* __restrict__ qpre, const T* __restrict__ kpre, const T*
     }
 }
 
+// ---- backward of the core (engine.py:48-64 reaches it through RecAttn2d in the A-series).  With u = q kv, w = q . kbar + 1e-6,
+// out = u / w + pe and g = dL/dout:
+//     du = g / w ;  dw = -(g . u) / w^2 ;  dq = du kv^T + dw kbar ;  dkv = q^T du ;  dkbar = q^T dw
+//     dk = (1/n) v dkv^T + dkbar / n ;  dv = (1/n) k dkv ;  dqpre = dq * elu'(qpre), dkpre = dk * elu'(kpre), elu'(x) = x > 0 ? 1 : e^x
+// (dpe = g is the caller's).  One block per (image, head), three sweeps over its tokens: kv and kbar as in the forward, then dq
+// with dkv / dkbar accumulated per owner thread in a fixed order (deterministic), then dk and dv.
+template <typename T>
+__global__ void __launch_bounds__(LA_NT)
+k_linattn_bwd(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* __restrict__ v, const T* __restrict__ gout,
+              T* __restrict__ gq, T* __restrict__ gk, T* __restrict__ gv, int n, int C, int heads)
+{
+    __shared__ float a_s[LA_TT][LA_DMAX + 1];                 // k / q tile
+    __shared__ float b_s[LA_TT][LA_DMAX + 1];                 // v / du tile
+    __shared__ float kv_s[LA_DMAX][LA_DMAX + 1];
+    __shared__ float dkv_s[LA_DMAX][LA_DMAX + 1];
+    __shared__ float kbar_s[LA_DMAX], dkbar_s[LA_DMAX];
+    __shared__ float w_s[LA_TT], dw_s[LA_TT];
+    const int D = C / heads;
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+    const size_t base = (size_t)b * n * C + (size_t)h * D;
+    const int tid = threadIdx.x;
+    const float s2 = 1.f / (float)n;
+    const int items = D * D;                                   // (e1, e2) pairs, owner thread = it % LA_NT
+    constexpr int MAXI = LA_DMAX * LA_DMAX / LA_NT;            // 16
+
+    // ---- sweep 1: kv = (1/n) k^T v, kbar = mean k
+    float acc[MAXI];
+#pragma unroll
+    for (int j = 0; j < MAXI; ++j) acc[j] = 0.f;
+    float ksum = 0.f;
+    for (int t0 = 0; t0 < n; t0 += LA_TT) {
+        const int tt = n - t0 < LA_TT ? n - t0 : LA_TT;
+        __syncthreads();
+        for (int i = tid; i < tt * D; i += LA_NT) {
+            const int t = i / D, e = i - t * D;
+            const size_t g = base + (size_t)(t0 + t) * C + e;
+            a_s[t][e] = elu1(la_ld(kpre + g));
+            b_s[t][e] = la_ld(v + g);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MAXI; ++j) {
+            const int it = tid + j * LA_NT;
+            if (it < items) {
+                const int e1 = it / D, e2 = it - e1 * D;
+                float sacc = acc[j];
+                for (int t = 0; t < tt; ++t) sacc = fmaf(a_s[t][e1], b_s[t][e2], sacc);
+                acc[j] = sacc;
+            }
+        }
+        if (tid < D) for (int t = 0; t < tt; ++t) ksum += a_s[t][tid];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MAXI; ++j) {
+        const int it = tid + j * LA_NT;
+        if (it < items) kv_s[it / D][it % D] = acc[j] * s2;
+        acc[j] = 0.f;                                           // becomes the dkv accumulator
+    }
+    if (tid < D) kbar_s[tid] = ksum / (float)n;
+    float dkb = 0.f;
+
+    // ---- sweep 2: per token u, w, du, dw; dq -> gq; dkv += q^T du, dkbar += q^T dw
+    for (int t0 = 0; t0 < n; t0 += LA_TT) {
+        const int tt = n - t0 < LA_TT ? n - t0 : LA_TT;
+        __syncthreads();
+        for (int i = tid; i < tt * D; i += LA_NT) {
+            const int t = i / D, e = i - t * D;
+            const size_t g = base + (size_t)(t0 + t) * C + e;
+            a_s[t][e] = elu1(la_ld(qpre + g));
+            b_s[t][e] = la_ld(gout + g);                        // g for now, du below
+        }
+        __syncthreads();
+        if (tid < tt) {                                         // one thread per token: w and g . u
+            float wsum = 0.f;
+            for (int e = 0; e < D; ++e) wsum = fmaf(a_s[tid][e], kbar_s[e], wsum);
+            wsum += 1e-6f;
+            float gu = 0.f;
+            for (int e2 = 0; e2 < D; ++e2) {
+                float u = 0.f;
+                for (int e1 = 0; e1 < D; ++e1) u = fmaf(a_s[tid][e1], kv_s[e1][e2], u);
+                gu = fmaf(b_s[tid][e2], u, gu);
+            }
+            w_s[tid] = wsum;
+            dw_s[tid] = -gu / (wsum * wsum);
+        }
+        __syncthreads();
+        for (int i = tid; i < tt * D; i += LA_NT) {             // du = g / w (in place)
+            const int t = i / D, e = i - t * D;
+            b_s[t][e] = b_s[t][e] / w_s[t];
+        }
+        __syncthreads();
+        for (int i = tid; i < tt * D; i += LA_NT) {             // dq[t][e1] = sum_e2 du[t][e2] kv[e1][e2] + dw[t] kbar[e1]
+            const int t = i / D, e1 = i - t * D;
+            float dq = dw_s[t] * kbar_s[e1];
+            for (int e2 = 0; e2 < D; ++e2) dq = fmaf(b_s[t][e2], kv_s[e1][e2], dq);
+            const size_t g = base + (size_t)(t0 + t) * C + e1;
+            const float xp = la_ld(qpre + g);
+            la_st(gq + g, dq * (xp > 0.f ? 1.f : a_s[t][e1]));  // elu'(x) = e^x = elu(x) + 1 for x <= 0
+        }
+#pragma unroll
+        for (int j = 0; j < MAXI; ++j) {
+            const int it = tid + j * LA_NT;
+            if (it < items) {
+                const int e1 = it / D, e2 = it - e1 * D;
+                float sacc = acc[j];
+                for (int t = 0; t < tt; ++t) sacc = fmaf(a_s[t][e1], b_s[t][e2], sacc);
+                acc[j] = sacc;
+            }
+        }
+        if (tid < D) for (int t = 0; t < tt; ++t) dkb = fmaf(dw_s[t], a_s[t][tid], dkb);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MAXI; ++j) {
+        const int it = tid + j * LA_NT;
+        if (it < items) dkv_s[it / D][it % D] = acc[j] * s2;    // the 1/n of kv = (1/n) k^T v
+    }
+    if (tid < D) dkbar_s[tid] = dkb / (float)n;
+
+    // ---- sweep 3: dk[t][e1] = sum_e2 v[t][e2] dkv[e1][e2] + dkbar[e1] ; dv[t][e2] = sum_e1 k[t][e1] dkv[e1][e2]
+    for (int t0 = 0; t0 < n; t0 += LA_TT) {
+        const int tt = n - t0 < LA_TT ? n - t0 : LA_TT;
+        __syncthreads();
+        for (int i = tid; i < tt * D; i += LA_NT) {
+            const int t = i / D, e = i - t * D;
+            const size_t g = base + (size_t)(t0 + t) * C + e;
+            a_s[t][e] = elu1(la_ld(kpre + g));
+            b_s[t][e] = la_ld(v + g);
+        }
+        __syncthreads();
+        for (int i = tid; i < tt * D; i += LA_NT) {
+            const int t = i / D, e = i - t * D;
+            float dk = dkbar_s[e], dv = 0.f;
+            for (int f = 0; f < D; ++f) {
+                dk = fmaf(b_s[t][f], dkv_s[e][f], dk);
+                dv = fmaf(a_s[t][f], dkv_s[f][e], dv);
+            }
+            const size_t g = base + (size_t)(t0 + t) * C + e;
+            const float xp = la_ld(kpre + g);
+            la_st(gk + g, dk * (xp > 0.f ? 1.f : a_s[t][e]));
+            la_st(gv + g, dv);
+        }
+    }
+}
+
+hipError_t linattn_core_bwd(const void* qpre, const void* kpre, const void* v, const void* gout, void* gq, void* gk, void* gv,
+                            int B, int n, int C, int heads, int dtype, hipStream_t s)
+{
+    const dim3 grid((unsigned)(B * heads)), block(LA_NT);
+#define RCX_LAB(T) hipLaunchKernelGGL((k_linattn_bwd<T>), grid, block, 0, s, (const T*)qpre, (const T*)kpre, (const T*)v, (const T*)gout, \
+                                      (T*)gq, (T*)gk, (T*)gv, n, C, heads)
+    if (dtype == 1) RCX_LAB(bf16_t);
+    else if (dtype == 2) RCX_LAB(f16_t);
+    else RCX_LAB(float);
+#undef RCX_LAB
+    return hipGetLastError();
+}
+
 hipError_t linattn_core(const void* qpre, const void* kpre, const void* v, const void* pe, void* out,
                         int B, int n, int C, int heads, int dtype, hipStream_t s)
 {

@@ -80,6 +80,9 @@ hipError_t down5_lanes(const void* x, void* y, const float* w, const float* b, i
 hipError_t linattn_core(const void* qpre, const void* kpre, const void* v, const void* pe, void* out,
                         int B, int n, int C, int heads, int dtype, hipStream_t s);
 
+hipError_t linattn_core_bwd(const void* qpre, const void* kpre, const void* v, const void* gout, void* gq, void* gk, void* gv,
+                            int B, int n, int C, int heads, int dtype, hipStream_t s);
+
 // rcx_bwd.hip -- backward pieces (deterministic gathers + two-stage weight-gradient reduction)
 size_t wgrad_partial_bytes(int C, int k);
 hipError_t bwd_wgrad(const void* a, int a_dt, const float* coarse, const float* g, float* partial, float* gw, float* gb,

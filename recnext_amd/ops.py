@@ -235,6 +235,41 @@ def linear_attention_core(qpre, kpre, v, pe, heads):
     return out
 
 
+def linear_attention_core_backward(qpre, kpre, v, gout, heads):
+    """Gradients of linear_attention_core with respect to qpre, kpre (B, n, C) and v (N x C x h x w); dL/dpe = gout."""
+    v = _nhwc(v, "v")
+    gout = _nhwc(gout, "grad_output")
+    b, c, h, w = v.shape
+    n = h * w
+    if gout.dtype != v.dtype:
+        gout = gout.to(v.dtype)
+    gq = torch.empty_like(qpre)
+    gk = torch.empty_like(kpre)
+    gv = _empty_nhwc(b, c, h, w, v.dtype, v.device)
+    with torch.cuda.device(v.device):
+        rc = _lib.load().rcx_linear_attention_bwd(qpre.data_ptr(), kpre.data_ptr(), v.data_ptr(), gout.data_ptr(),
+                                                  gq.data_ptr(), gk.data_ptr(), gv.data_ptr(), b, n, c, heads, _dt(v), _stream(v.device))
+    _lib.check(rc, "rcx_linear_attention_bwd")
+    return gq, gk, gv
+
+
+class LinearAttentionCoreFn(torch.autograd.Function):
+    """linear_attention_core with its HIP backward (rcx_linear_attention_bwd): forward and backward both through the C ABI."""
+
+    @staticmethod
+    def forward(ctx, qpre, kpre, v, pe, heads):
+        out = linear_attention_core(qpre, kpre, v, pe, heads)
+        ctx.save_for_backward(qpre, kpre, v)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        qpre, kpre, v = ctx.saved_tensors
+        gq, gk, gv = linear_attention_core_backward(qpre, kpre, v, gout, ctx.heads)
+        return gq, gk, gv, gout, None
+
+
 def recconv2d_forward_train(x, wpack, bpack, level, k, mode="bilinear"):
     """Training forward: same result as recconv2d_forward, plus the saved fp32 pyramid the backward needs."""
     x = _nhwc(x)

@@ -39,6 +39,14 @@ class LinearAttention(nn.Module):
         b, c, h, w = x.shape
         n = h * w
         s = n ** -0.5
+        if x.is_cuda and c % 4 == 0 and self.head_dim <= 64 and x.dtype in ops._DT:
+            # GPU (training step): the projection as two GEMMs + the module's BatchNorm, then everything after it -- activation,
+            # k v^T, normaliser, + pe -- in one HIP kernel with a HIP backward (rcx_linear_attention_fwd / _bwd)
+            qkpre = self._qk_gpu(x)                             # (b, 2c, h, w), channels_last storage
+            tok = qkpre.permute(0, 2, 3, 1).reshape(b, n, 2 * c)
+            qpre, kpre = tok[..., :c].contiguous(), tok[..., c:].contiguous()
+            pe = _conv_norm_train(self.pe, x, 1)
+            return ops.LinearAttentionCoreFn.apply(qpre, kpre, x.contiguous(memory_format=torch.channels_last), pe, self.num_heads)
         if x.is_cuda:
             qk = F.elu(self._qk_gpu(x)) + 1.0
         else:
@@ -133,8 +141,8 @@ class RecAttn2d(nn.Module):
 
     def forward(self, x):
         if self.training or (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
-            # training step (engine.py:48-64): BatchNorm uses batch statistics, so nothing is folded; the depthwise convs and
-            # their gradients run on HIP, the linear attention and the norms on PyTorch-ROCm operators (autograd)
+            # training step (engine.py:48-64): BatchNorm uses batch statistics, so nothing is folded; the depthwise convs, the
+            # linear-attention core and their gradients run on HIP, the qk GEMMs and the norms on PyTorch-ROCm operators (autograd)
             if x.shape[1] % 4:
                 raise NotImplementedError("the HIP depthwise backward needs a channel count that is a multiple of 4")
             d = _conv_norm_train(self.down[0], x, 2)

@@ -214,3 +214,53 @@ def test_downsample_conv_backward_matches_aten_autograd(case):
     assert _rel(ours.token_mixer.weight.grad, conv.weight.grad) < 1e-3
     assert _rel(ours.token_mixer.bias.grad + 1.0, conv.bias.grad + 1.0) < 1e-3      # analytically zero under train-mode BN
     assert _rel(ours.norm.weight.grad, bn.weight.grad) < 1e-3
+
+
+def _la_reference(qpre, kpre, v, pe, heads):
+    """model/recattn.py:21-27 on token-major (B, n, C) tensors in float32 (LinearAttention1; LinearAttention2 is the same function)."""
+    b, n, c = qpre.shape
+    d = c // heads
+    q = (torch.nn.functional.elu(qpre) + 1.0).view(b, n, heads, d).permute(0, 2, 1, 3)     # b, h, n, d
+    k = (torch.nn.functional.elu(kpre) + 1.0).view(b, n, heads, d).permute(0, 2, 1, 3)
+    vv = v.view(b, n, heads, d).permute(0, 2, 1, 3)
+    s = n ** -0.5
+    kv = (k.transpose(-1, -2) * s) @ (vv * s)                                               # b, h, d, d
+    out = q @ kv / (q @ k.mean(dim=2, keepdim=True).transpose(-1, -2) + 1e-6)
+    return out.permute(0, 2, 1, 3).reshape(b, n, c) + pe
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", [(2, 16, 14, 14, 2), (3, 64, 28, 28, 2), (2, 128, 14, 14, 4), (2, 256, 7, 7, 8), (1, 512, 4, 4, 16), (2, 24, 5, 9, 2),
+                                  (1, 128, 9, 9, 2)], ids=lambda c: "x".join(map(str, c)))
+def test_linear_attention_core_backward(case, dtype):
+    """rcx_linear_attention_bwd against PyTorch autograd of the reference formulation (float32, on the same rounded inputs):
+    the A3 stage shapes (head dimension 32), a head dimension of 12 and one of 64."""
+    from recnext_amd import ops
+    b, c, h, w, heads = case
+    dev = torch.device("cuda:0")
+    torch.manual_seed(zlib_seed(case))
+    n = h * w
+    mk = lambda: (torch.randn(b, n, c, device=dev) * 0.7).to(dtype)
+    qpre, kpre, gout = mk(), mk(), mk()
+    v = torch.randn(b, c, h, w, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    pe = torch.randn(b, c, h, w, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    tokv = lambda t: t.permute(0, 2, 3, 1).reshape(b, n, c)
+    ref_in = [t.float().clone().requires_grad_(True) for t in (qpre, kpre, tokv(v), tokv(pe))]
+    _la_reference(*ref_in, heads).backward(gout.float())
+    ours_in = [t.clone().requires_grad_(True) for t in (qpre, kpre, v, pe)]
+    out = ops.LinearAttentionCoreFn.apply(*ours_in, heads)
+    out.backward(gout.view(b, h, w, c).permute(0, 3, 1, 2))
+    tol = 2e-4 if dtype == torch.float32 else (2e-2 if dtype == torch.bfloat16 else 4e-3)
+    got = [ours_in[0].grad, ours_in[1].grad, tokv(ours_in[2].grad), tokv(ours_in[3].grad)]
+    for name, g, r in zip(("qpre", "kpre", "v", "pe"), got, ref_in):
+        assert g.dtype == dtype
+        assert _rel(g.float(), r.grad) < tol, name
+    # deterministic
+    ours2 = [t.clone().requires_grad_(True) for t in (qpre, kpre, v, pe)]
+    ops.LinearAttentionCoreFn.apply(*ours2, heads).backward(gout.view(b, h, w, c).permute(0, 3, 1, 2))
+    assert torch.equal(ours2[0].grad, ours_in[0].grad) and torch.equal(ours2[2].grad, ours_in[2].grad)
+
+
+def zlib_seed(obj):
+    import zlib
+    return zlib.crc32(repr(obj).encode())
