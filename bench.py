@@ -128,7 +128,8 @@ def kernel_name(plan, elem_bytes):
         return f"rcx::lanes::{kern}, {t}>"
     if plan.startswith("cpt(k_recconv_cpt"):
         kern = plan[len("cpt("):plan.index(">")]
-        return f"rcx::cpt::{kern}, {t}>"
+        img2 = kern.endswith(", IMG2")                                       # last template argument: image-pair variant
+        return f"rcx::cpt::{kern[:-6] if img2 else kern}, {t}, {'true' if img2 else 'false'}>"
     if plan.startswith("cpl(k_recconv_cpl"):
         kern = plan[len("cpl("):plan.index(">")]
         ns = "cpl" if kern.startswith("k_recconv_cpl7<") else "cpl14"       # rcx_cpl.hip (round 1) / rcx_cpl14.hip

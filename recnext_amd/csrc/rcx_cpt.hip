@@ -397,7 +397,9 @@ struct Geo {
     static constexpr int LDS_BYTES = NPIX * PIXF * 4;
 };
 
-template <int T, int HALVES, int MODE, int PIXB, typename TIO>
+// IMG2 (T = 2 only): the two half-waves are two IMAGES (n, n + 1) of the same tile and the same 32 channels -- whole 32-channel
+// blocks for the channel counts that are not multiples of 64 (RecNeXt-M1: 96, M5: 160); geometry and parities stay uniform.
+template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool IMG2 = false>
 __global__ __launch_bounds__(T * T / HALVES * 64, T == 4 ? 1 : 2)
 void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack,
                    int N, int C, int has_bias)
@@ -411,8 +413,11 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     // channel block) -- no relaunch gap between the rounds, LDS zeroed once.  XCD-aware order: workgroups are dealt round-robin
     // over the 8 XCDs; each XCD gets a contiguous run of units, so the channel blocks of one image (the two halves of its
     // 128-byte lines) pass through the same L2 at about the same time.
-    const int nb = (C + PIXF - 1) / PIXF;
-    const unsigned total = (unsigned)N * (unsigned)nb, GD = gridDim.x;
+    static_assert(!IMG2 || HALVES == 1, "image halves use the one-tile-per-wave geometry");
+    constexpr int CHB = IMG2 ? 32 : PIXF;                          // channels per block
+    const int nb = (C + CHB - 1) / CHB;
+    const int NU = IMG2 ? (N + 1) / 2 : N;                          // image units
+    const unsigned total = (unsigned)NU * (unsigned)nb, GD = gridDim.x;
     const bool xcd = (total & 7u) == 0 && (GD & 7u) == 0;
     const int tid = (int)threadIdx.x;
   for (unsigned it = 0;; ++it) {
@@ -425,7 +430,8 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         unit = blockIdx.x + it * GD;
         if (unit >= total) break;
     }
-    const int n = (int)(unit / (unsigned)nb), cb = (int)(unit - (unsigned)n * (unsigned)nb);
+    const int nu = (int)(unit / (unsigned)nb), cb = (int)(unit - (unsigned)nu * (unsigned)nb);
+    const int n = IMG2 ? 2 * nu : nu;                              // first (only) image of the unit
 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -436,8 +442,9 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     const int tc = HALVES == 2 ? tcb + 2 * h : tcb;                      // per lane (HALVES == 2) / uniform
     const int q = tr * T + tc;                                          // this tile-lane's worker id
     const bool ledge = tc == 0, redge = tc == T - 1;
-    const int c = cb * PIXF + ch;
-    const bool cvalid = c < C;
+    const int ih = IMG2 ? (lane >> 5) : 0;                         // IMG2: this lane's image within the pair
+    const int c = cb * CHB + (IMG2 ? (lane & 31) : ch);
+    const bool cvalid = c < C && n + ih < N;
     const int cc = cvalid ? c : C - 1;
     const int pix = C * ESZ;                                            // bytes between horizontally adjacent pixels
 
@@ -461,13 +468,14 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         const unsigned long long a = (unsigned long long)ximg;
         rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
         rsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
-        rsrc.z = P0 * P0 * pix;
+        rsrc.z = (IMG2 && n + 1 < N ? 2 : 1) * P0 * P0 * pix;
         rsrc.w = 0x00020000;
     }
     const unsigned OOB = 0x80000000u;
-    const unsigned voffM = (unsigned)((14 * tc) * pix + cc * ESZ);
-    const unsigned voffL = ledge ? OOB : voffM - 2u * (unsigned)pix;      // columns -2, -1 of the tile
-    const unsigned voffR = redge ? OOB : voffM + 14u * (unsigned)pix;     // columns 14, 15
+    const unsigned imgoff = (unsigned)(ih * P0 * P0 * pix);            // IMG2: the second image of the pair (past the last image: out of range, reads 0)
+    const unsigned voffM = (IMG2 && n + ih >= N) ? OOB : (unsigned)((14 * tc) * pix + cc * ESZ) + imgoff;
+    const unsigned voffL = (ledge || voffM == OOB) ? OOB : voffM - 2u * (unsigned)pix;      // columns -2, -1 of the tile
+    const unsigned voffR = (redge || voffM == OOB) ? OOB : voffM + 14u * (unsigned)pix;     // columns 14, 15
     // row r (tile-local, -2 .. 15), all 18 columns; rows outside the image are redirected to a valid row (loaded, not used)
     auto load_row = [&](uint32_t (&raw)[18], int r) {
         int ar = 14 * tr + r;
@@ -737,10 +745,10 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             const unsigned long long a = (unsigned long long)(reinterpret_cast<char*>(y) + (size_t)n * P0 * P0 * pix);
             ysrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
             ysrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
-            ysrc.z = P0 * P0 * pix;
+            ysrc.z = (IMG2 && n + 1 < N ? 2 : 1) * P0 * P0 * pix;
             ysrc.w = 0x00020000;
         }
-        const unsigned yoff = cvalid ? (unsigned)((14 * tc) * pix + c * ESZ) : OOB;
+        const unsigned yoff = cvalid ? (unsigned)((14 * tc) * pix + c * ESZ) + imgoff : OOB;
         // H[i]: C1 row i (tile-local, -2 .. 8; clamped into the plane) resized horizontally to the 18 columns -2 .. 15
         auto build_H = [&](f32x2 (&Hs)[9], int i) {
             int ar = 7 * tr + i;
@@ -842,11 +850,11 @@ static inline bool enabled()
     return !(v && *v == '0') && !(l && *l == '0');
 }
 
-template <int T, int HALVES, int MODE, int PIXB, typename TIO>
+template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool IMG2 = false>
 static hipError_t launch(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s)
 {
     using G = Geo<T, HALVES, MODE, TIO>;
-    auto kfn = k_recconv_cpt<T, HALVES, MODE, PIXB, TIO>;
+    auto kfn = k_recconv_cpt<T, HALVES, MODE, PIXB, TIO, IMG2>;
     static bool attr_set = false;                              // once per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
@@ -859,7 +867,7 @@ static hipError_t launch(const void* x, void* y, const float* wpack, const float
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
         cus = v;
     }
-    const unsigned total = (unsigned)(N * ((C + G::PIXF - 1) / G::PIXF));
+    const unsigned total = IMG2 ? (unsigned)(((N + 1) / 2) * ((C + 31) / 32)) : (unsigned)(N * ((C + G::PIXF - 1) / G::PIXF));
     unsigned cap = (unsigned)cus * (T == 4 ? 1u : 2u);         // workgroups resident at once (LDS: one / two per CU)
     if (const char* e = getenv("RCX_CPT_GRID")) { const int g = atoi(e); if (g > 0) cap = (unsigned)g; }    // A/B knob
     cap &= ~7u;
@@ -874,6 +882,9 @@ static hipError_t launch_c(const void* x, void* y, const float* wpack, const flo
 {
     constexpr int CM3 = T == 4 ? 64 : 128;
     if (C == CM3) return launch<T, HALVES, MODE, CM3 * (int)sizeof(TIO), TIO>(x, y, wpack, bpack, N, C, s);
+    if constexpr (T == 2) {
+        if (C % 64 != 0) return launch<T, HALVES, MODE, 0, TIO, true>(x, y, wpack, bpack, N, C, s);      // whole 32-channel blocks, image pairs
+    }
     return launch<T, HALVES, MODE, 0, TIO>(x, y, wpack, bpack, N, C, s);
 }
 
@@ -888,8 +899,9 @@ static hipError_t launch_md(const void* x, void* y, const float* wpack, const fl
 }  // namespace cpt
 
 // A/B switches read per call like the other schedules' (tests flip them inside one process): RCX_CPT=0 gives both blocks back to
-// the banded lanes kernels, RCX_CPT=all takes the 28x28 block also where the banded kernel measures faster (ragged last channel
-// block: 64-channel waves with idle lanes; 256 x 96 x 28 x 28 bf16: 58.7 us against 46.0)
+// the banded lanes kernels; RCX_CPT=all also takes the 28x28 block with channel counts that are not multiples of 64 (image-pair
+// variant, IMG2) -- off by default: measured slower than the banded kernel there (256 x 96: 51.7 vs 46.4 us, 256 x 160: 73.7 vs
+// 70.6 us, profiles/r02c_cpt_img2_variant.txt): a workgroup's latency does not shrink with the channel count.
 bool cpt_applicable(int N, int C, int H, int W, int level, int k, int dtype)
 {
     (void)N;
@@ -906,8 +918,9 @@ int cpt_describe(int N, int C, int H, int mode, int dtype, char* buf, int len)
 {
     const int T = H / 14, halves = T == 4 ? 2 : 1, pixf = 64 / halves;
     const int pixb = C == (T == 4 ? 64 : 128) ? C * (dtype == 0 ? 4 : 2) : 0;
-    const int total = N * ((C + pixf - 1) / pixf);
-    return snprintf(buf, len, "cpt(k_recconv_cpt<%d, %d, %d, %d>,cb=%d,nt=%d,units=%d,lds=%d)", T, halves, mode, pixb, pixf, T * T / halves * 64, total,
+    const bool img2 = T == 2 && C % 64 != 0;
+    const int total = img2 ? ((N + 1) / 2) * ((C + 31) / 32) : N * ((C + pixf - 1) / pixf);
+    return snprintf(buf, len, "cpt(k_recconv_cpt<%d, %d, %d, %d%s>,cb=%d,nt=%d,units=%d,lds=%d)", T, halves, mode, pixb, img2 ? ", IMG2" : "", img2 ? 32 : pixf, T * T / halves * 64, total,
                     T == 4 ? cpt::Geo<4, 2, 0, float>::LDS_BYTES : cpt::Geo<2, 1, 0, float>::LDS_BYTES);
 }
 

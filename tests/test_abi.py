@@ -52,6 +52,11 @@ def test_abi_version_and_argument_errors_without_gpu():
     assert lib.rcx_recconv2d_fwd_plan(256, 128, 28, 28, 3, 5, 1, 0).startswith(b"cpt(k_recconv_cpt<2, 1, 1, 512>")
     assert lib.rcx_recconv2d_fwd_plan(256, 48, 56, 56, 4, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<4, 2, 0, 0>")          # run-time pixel pitch
     assert lib.rcx_recconv2d_fwd_plan(256, 96, 28, 28, 3, 5, 0, 1).startswith(b"lanes(k_recconv_lanes_banded<28, 3, 8, 0,")   # ragged 64-channel blocks: banded
+    os.environ["RCX_CPT"] = "all"
+    try:
+        assert lib.rcx_recconv2d_fwd_plan(256, 96, 28, 28, 3, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<2, 1, 0, 0, IMG2>,cb=32")   # image-pair variant
+    finally:
+        del os.environ["RCX_CPT"]
     os.environ["RCX_CPT"] = "0"
     try:
         assert lib.rcx_recconv2d_fwd_plan(256, 64, 56, 56, 4, 5, 0, 1).startswith(b"lanes(k_recconv_lanes_banded<56, 4, 16, 0,")

@@ -193,11 +193,12 @@ def test_channel_per_lane_14x14_kernel_against_oracle_and_lanes_kernel(mode, bia
 @pytest.mark.parametrize("bias", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 64, 56, 4), (1, 48, 56, 4), (2, 80, 56, 4), (1, 8, 56, 4), (2, 128, 28, 3), (1, 96, 28, 3), (3, 160, 28, 3),
-                                   (2, 40, 28, 3)], ids=lambda v: "x".join(map(str, v)))
+                                   (2, 40, 28, 3), (3, 96, 28, 3), (1, 72, 28, 3)], ids=lambda v: "x".join(map(str, v)))
 def test_tiled_channel_per_lane_kernel_against_oracle_and_lanes_kernel(mode, bias, dtype, shape, monkeypatch):
     """The 56x56 / level 4 and 28x28 / level 3 blocks on rcx_cpt.hip (a lane owns one channel of one 14x14 tile, the planes of
     level >= 1 in LDS) against the oracle: whole channel blocks (64, 128), ragged last blocks (48, 80, 8, 96, 160, 40), both
-    resize modes, bias.  The banded lanes kernel it replaces must agree with it to float32 round-off."""
+    resize modes, bias; the ragged 28x28 cases run the image-pair variant (odd batches: the second image of the last pair is
+    out of range).  The banded lanes kernel it replaces must agree with it to float32 round-off."""
     n, c, hw, level = shape
     k = 5
     rng = np.random.default_rng(zlib.crc32(repr((mode, bias, str(dtype), shape)).encode()))
@@ -205,7 +206,7 @@ def test_tiled_channel_per_lane_kernel_against_oracle_and_lanes_kernel(mode, bia
     if dtype == torch.bfloat16:
         x = bf16_round_np(x)
     ref = c_oracle.recconv2d(x, wd, wc, bd, bc, level, mode)
-    monkeypatch.setenv("RCX_CPT", "all")               # also the channel counts that default to the banded kernel (28x28, C % 64 != 0)
+    monkeypatch.setenv("RCX_CPT", "all")               # also the image-pair variant (28x28, C % 64 != 0), off by default
     assert ops.recconv2d_plan(n, c, hw, hw, level, k, mode, dtype).startswith("cpt(k_recconv_cpt<")
     got = _run_hip(x, wd, wc, bd, bc, level, k, mode, dtype)
     if dtype == torch.float32:
