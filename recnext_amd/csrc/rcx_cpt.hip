@@ -59,6 +59,7 @@ __device__ unsigned long long* g_cpt_stamps = nullptr;
 #endif
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4pf __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) char* gcptr;
 typedef __attribute__((address_space(1))) char* gptr;
 
@@ -494,15 +495,57 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     // ================= pass 1: F1 tile = down(x), rows -2 .. 14 of the tile, input-row stationary (tap pairs) =================
     float f1[7][7];                                          // this lane's F1 tile stays in registers until T1 is formed
     {
-        constexpr int AHEAD = 3, R0 = -2, NR = 17;
+#ifndef RCX_CPT_PF
+#define RCX_CPT_PF 0
+#endif
+        constexpr int AHEAD = RCX_CPT_PF > 0 ? 2 : 3, R0 = -2, NR = 17;
         const f32x2 b0 = f32x2{td.bias, 0.f};
         uint32_t raw[NR][18];
         f32x2 facc[3][7];
+        // The per-lane loads move 2 bytes each and a wave holds at most 63 memory operations: 3 rows in flight do not cover the HBM
+        // latency (stamps: this pass takes 20 k cycles for 11 k cycles of issue).  Tried (-DRCX_CPT_PF=2): pull each row into L2 first
+        // with a few WIDE loads (16 bytes per lane, results discarded) PF rows ahead of the element loads.  Measured slower (pass 1:
+        // 26 k cycles, 56x56 launch 111.7 vs 105.3 us): a wave's memory operations complete in issue order, so the element loads
+        // queue behind the wide loads' HBM latency instead of overtaking them.  Off by default, kept for A/B builds.
+        constexpr int PF = RCX_CPT_PF;
+        constexpr int CPP = PIXF * ESZ / 16;                   // 16-byte chunks per pixel of the block
+        constexpr int PPI = (64 / HALVES) / CPP;               // pixels per instruction and tile
+        constexpr int NPF = PF > 0 ? (18 + PPI - 1) / PPI : 0; // instructions per row
+        u32x4pf sink = {0u, 0u, 0u, 0u};                       // destination of the wide loads: kept live to the end of the pass
+        const int pj = (lane & (64 / HALVES - 1)) / CPP, pchunk = lane & (CPP - 1);
+        unsigned pvo[NPF > 0 ? NPF : 1];                       // this lane's offsets inside a row, one per instruction
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            int colp = 14 * tc - 2 + i * PPI + pj;             // columns left of the image: re-read column 0; right of it: the next row or out of range
+            colp = colp < 0 ? 0 : colp;
+            pvo[i] = (unsigned)(colp * pix + (cb * PIXF) * ESZ + pchunk * 16);
+        }
+        auto prefetch_row = [&](int r) {
+            if constexpr (PF > 0) {
+                int ar = 14 * tr + r;
+                ar = ar < 0 ? 0 : (ar > P0 - 1 ? P0 - 1 : ar);
+                const int rb = __builtin_amdgcn_readfirstlane(ar * (P0 * pix));
+#pragma unroll
+                for (int i = 0; i < NPF; ++i) {
+                    int t;
+                    asm volatile("s_add_i32 %[t], %[rb], 0\n\tbuffer_load_dwordx4 %[d], %[vo], %[rs], %[t] offen"
+                                 : [d] "+v"(sink), [t] "=&s"(t) : [vo] "v"(pvo[i]), [rs] "s"(rsrc), [rb] "s"(rb) : "scc");
+                }
+            }
+        };
+        sfor<AHEAD + PF>([&](auto rc) { prefetch_row(R0 + decltype(rc)::value); });
         sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], R0 + decltype(rc)::value); });
         sfor<NR>([&](auto rc) {
             constexpr int ri = decltype(rc)::value, r = R0 + ri;
+            if constexpr (ri + AHEAD + PF < NR) prefetch_row(r + AHEAD + PF);
             if constexpr (ri + AHEAD < NR) load_row(raw[ri + AHEAD], r + AHEAD);
-            pin_row<18 * (NR - 1 - ri < AHEAD ? NR - 1 - ri : AHEAD)>(raw[ri]);
+            // younger memory operations: what the iterations since row ri was requested have issued (wide loads first, then a row)
+            constexpr int NY = [] {
+                int k = 0;
+                for (int j = 1; j <= AHEAD; ++j) k += (ri + j < NR ? 18 : 0) + (ri + j + PF < NR ? NPF : 0);
+                return k > 63 ? 63 : k;
+            }();
+            pin_row<NY>(raw[ri]);
             f32x2 xr[9];
 #pragma unroll
             for (int k = 0; k < 9; ++k) xr[k] = f32x2{raw_f32<TIO>(raw[ri][2 * k]), raw_f32<TIO>(raw[ri][2 * k + 1])};
@@ -538,6 +581,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             for (int o = 0; o < 7; ++o) if (r - 2 * o + 2 >= 0 && r - 2 * o + 2 < 4) pin(facc[o % 3]);
             CPT_FENCE;
         });
+        asm volatile("" : "+v"(sink));                         // every wide load has landed by now (the last rows' waits were vmcnt(0))
     }
     CPT_STAMP(2);
     __syncthreads();
@@ -567,8 +611,6 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             });
         }
     };
-    Taps tnx;
-    load_taps(tnx, wsrc, bpack, 1, C, cc, has_bias);           // conv of the coarsest level: requested here, used after the down ladder
     // down ladder: F_l = down(F_{l-1}), l = 2 .. NL
     sfor<NL - 1>([&](auto lc) {
         constexpr int l = 2 + decltype(lc)::value;
@@ -587,12 +629,12 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     });
     CPT_STAMP(4);
     // up recursion on the piece planes: l = NL .. 2: T_l = F_l + resize(C_{l+1}) in place (l < NL), C_l = conv(T_l) in place.
-    // The taps of a level are requested one level ahead of their use (tnx was requested before the down ladder).
+    // (Requesting a level's taps one level ahead was measured: no gain -- the small planes are issue-bound -- and 20 VGPRs.)
     sfor<NL - 1>([&](auto lc) {
         constexpr int l = NL - decltype(lc)::value;
         constexpr int P = PL[l];
-        const Taps tc_ = tnx;
-        load_taps(tnx, wsrc, bpack, 1 + (NL - (l - 1)), C, cc, has_bias);        // level l - 1 (for l == 2: the taps of level 1)
+        Taps tc_;
+        load_taps(tc_, wsrc, bpack, 1 + (NL - l), C, cc, has_bias);
         if constexpr (l < NL) {
             constexpr int PC = PL[l + 1];
             for_pieces(IC<P>{}, [&](auto, auto col0c, auto noutc, int row, bool act) {
@@ -623,9 +665,8 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
 
     CPT_STAMP(5);
     // ================= level 1, per tile: T1 = F1 + resize(C2) (exact 2x), C1 = conv(T1) =================
-    const Taps t1 = tnx;                                     // conv of level 1 = pack 1 + (NL - 1), requested during level 2
-    Taps tf;
-    load_taps(tf, wsrc, bpack, 1 + NL, C, cc, has_bias);     // the final conv's, used after C1
+    Taps t1;
+    load_taps(t1, wsrc, bpack, NL, C, cc, has_bias);         // conv of level 1 = pack 1 + (NL - 1)
     {
         // columns: run of 7 starting at absolute column 7*tc (parity uniform), source columns b .. b+4 of C2, clamped
         const int d0 = 7 * tc;
@@ -724,6 +765,8 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
 #pragma unroll
             for (int cI = 0; cI < 7; ++cI) dst[(o * P1 + cI) * PIXF] = (cI & 1) ? c1[o][cI >> 1].y : c1[o][cI >> 1].x;
     }
+    Taps tf;
+    load_taps(tf, wsrc, bpack, 1 + NL, C, cc, has_bias);
     __syncthreads();
     CPT_STAMP(7);
 
