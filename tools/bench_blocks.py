@@ -55,8 +55,8 @@ def main():
     for sname in args.sets.split(","):
         for (n, c, h, w, level) in SHAPES[sname]:
             for dname in args.dtypes.split(","):
-                dtype = torch.bfloat16 if dname == "bf16" else torch.float32
-                eb = 2 if dname == "bf16" else 4
+                dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "f16": torch.float16}.get(dname, torch.float32)
+                eb = 4 if dtype == torch.float32 else 2
                 torch.manual_seed(0)
                 mod = recnext_amd.RecConv2d(c, kernel_size=5, level=level, mode=args.mode).to(dev).eval()
                 x = torch.randn(n, c, h, w, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
