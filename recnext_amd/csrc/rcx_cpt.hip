@@ -39,6 +39,9 @@ using lanes::vtab;
 using lanes::VT;
 
 #define CPT_FENCE __builtin_amdgcn_sched_barrier(0)
+#ifndef RCX_CPT_PF
+#define RCX_CPT_PF 0                       /* wide-load L2 prefetch ahead of pass 1: measured slower, see pass 1 */
+#endif
 
 // diagnostic build only (-DRCX_STAMPS, tools/cpt_bench.hip): lane 0 of every wave of the first workgroups writes the clock at phase boundaries
 #ifdef RCX_STAMPS
@@ -486,6 +489,10 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     };
     auto row_valid = [&](int r) -> bool { const int ar = 14 * tr + r; return ar >= 0 && ar < P0; };   // uniform
 
+    // pass 1's first rows are requested before the taps, the LDS clearing's tail and the barrier: their HBM latency runs behind those
+    constexpr int AHEAD1 = RCX_CPT_PF > 0 ? 2 : 3, R01 = -2, NR1 = 17;
+    uint32_t raw1[NR1][18];
+    if constexpr (RCX_CPT_PF == 0) sfor<AHEAD1>([&](auto rc) { load_row(raw1[decltype(rc)::value], R01 + decltype(rc)::value); });
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, (NL + 2) * 25 * C * 4, 0x00020000);
     Taps td;
     load_taps(td, wsrc, bpack, 0, C, cc, has_bias);
@@ -495,12 +502,9 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     // ================= pass 1: F1 tile = down(x), rows -2 .. 14 of the tile, input-row stationary (tap pairs) =================
     float f1[7][7];                                          // this lane's F1 tile stays in registers until T1 is formed
     {
-#ifndef RCX_CPT_PF
-#define RCX_CPT_PF 0
-#endif
-        constexpr int AHEAD = RCX_CPT_PF > 0 ? 2 : 3, R0 = -2, NR = 17;
+        constexpr int AHEAD = AHEAD1, R0 = R01, NR = NR1;
         const f32x2 b0 = f32x2{td.bias, 0.f};
-        uint32_t raw[NR][18];
+        uint32_t (&raw)[NR][18] = raw1;
         f32x2 facc[3][7];
         // The per-lane loads move 2 bytes each and a wave holds at most 63 memory operations: 3 rows in flight do not cover the HBM
         // latency (stamps: this pass takes 20 k cycles for 11 k cycles of issue).  Tried (-DRCX_CPT_PF=2): pull each row into L2 first
@@ -534,7 +538,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             }
         };
         sfor<AHEAD + PF>([&](auto rc) { prefetch_row(R0 + decltype(rc)::value); });
-        sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], R0 + decltype(rc)::value); });
+        if constexpr (PF > 0) sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], R0 + decltype(rc)::value); });
         sfor<NR>([&](auto rc) {
             constexpr int ri = decltype(rc)::value, r = R0 + ri;
             if constexpr (ri + AHEAD + PF < NR) prefetch_row(r + AHEAD + PF);
@@ -736,7 +740,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                 in[4].y *= rmask;                            // column 7
                 in[5].x *= rmask;                            // column 8
 #pragma unroll
-                for (int j = 0; j < 5; ++j) odd[j] = shift1(in[j], in[j + 1]);
+                for (int j = 0; j < 5; ++j) odd[j] = pkmov<1, 0>(in[j], in[j + 1]);       // one v_pk_mov_b32 (the compiler: two v_mov_b32 on LDS data)
 #pragma unroll
                 for (int u = 0; u < 5; ++u) {
                     const int o = t - u + 2;
@@ -804,16 +808,16 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             for (int k = 0; k < 7; ++k) cv[2 + k] = rp[(cb0 + k) * PIXF];
             cv[9] = rp[cR0];
             cv[10] = rp[cR1];
-            f32x2 P[6];
+            f32x2 P[6], Pq[6];                                   // pairs of C1 pixels, and the same times the outer weight (0.25)
 #pragma unroll
-            for (int m = 0; m < 6; ++m) P[m] = f32x2{cv[2 * m], m < 5 ? cv[2 * m + 1] : 0.f};
+            for (int m = 0; m < 6; ++m) { P[m] = f32x2{cv[2 * m], m < 5 ? cv[2 * m + 1] : 0.f}; Pq[m] = P[m] * wq; }
             sfor<9>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 // columns 2j-2 (even) and 2j-1 (odd): 0.25 c[j] + 0.75 c[j+1] and 0.75 c[j+1] + 0.25 c[j+2]; nearest: c[j+1] twice.
                 // (c[j], c[j+2]) = the same halves of two neighbouring pairs: one v_pk_mov_b32
-                const f32x2 e = pkmov<(j & 1), (j & 1)>(P[j >> 1], P[(j >> 1) + 1]);
+                const f32x2 e = pkmov<(j & 1), (j & 1)>(Pq[j >> 1], Pq[(j >> 1) + 1]);
                 const float mid = ((j + 1) & 1) ? P[(j + 1) >> 1].y : P[(j + 1) >> 1].x;
-                Hs[j] = pfma(splat(mid), wt, e * wq);
+                Hs[j] = pfma(splat(mid), wt, e);
             });
             Hs[0] = Hs[0] * splat(lmask);
             Hs[8] = Hs[8] * splat(rmask);
