@@ -298,6 +298,148 @@ k_linattn_core4(const T* __restrict__ qpre, const T* __restrict__ kpre, const T*
     }
 }
 
+// ---- matrix-core form for head dimension 32 and 16-bit I/O (every head of the A-series: 64/2 = 128/4 = 256/8 = 512/16 = 32).
+// The two products of the core ARE dense contractions -- kv = k^T v over the tokens, out = q kv over the head dimension -- so they go
+// to MFMA (v_mfma_f32_32x32x16_bf16 / _f16), float32 accumulation; q and k are rounded to the I/O type after the activation and kv
+// before the second product, which is what the reference's own 16-bit autocast run does with these matmuls.
+// LM_NW waves per (image, head), the tokens dealt over them:
+//   phase 1: 16 tokens per MFMA, A[e1][token] = k, B[token][e2] = v: lane (r, h) loads tokens 8h .. 8h+7 of column r (two tokens x 64
+//            contiguous bytes per load instruction); column sums of k for the normaliser ride along on the vector pipe;
+//   phase 2: 32 tokens per pair of MFMAs.  The kv accumulator tile has its column e2 on the lane and its rows e1 in the registers,
+//            so it is the B operand of the second product without any lane movement (cdna_hip_programming.md, "An accumulator tile
+//            as the next MFMA's operand"): registers 8s .. 8s+7 converted pairwise are the fragment of k-step s, whose element j of
+//            lane half h is row 16s + 8(j>>2) + 4h + (j&3) -- the q fragment is loaded in that same permuted order (two 8-byte
+//            runs per step).  The normaliser q . kbar is a 16-term partial per lane, the two halves meet in LDS.
+template <typename T> struct Mf;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <> struct Mf<bf16_t> {
+    typedef __bf16 frag __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ __bf16 cvt(float f) { return (__bf16)f; }
+    static __device__ __forceinline__ __bf16 raw(bf16_t v) { return __builtin_bit_cast(__bf16, v); }
+    static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mf<f16_t> {
+    typedef _Float16 frag __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ _Float16 cvt(float f) { return (_Float16)f; }
+    static __device__ __forceinline__ _Float16 raw(f16_t v) { return v; }
+    static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+#ifndef RCX_LM_NW
+#define RCX_LM_NW 4
+#endif
+constexpr int LM_NW = RCX_LM_NW;    // waves per (image, head): the tokens are dealt over them (phase 1 partial sums meet in LDS)
+
+template <typename T>
+__global__ void __launch_bounds__(LM_NW * 64)
+k_linattn_mfma(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* __restrict__ v, const T* __restrict__ pe,
+               T* __restrict__ out, int n, int C, int heads)
+{
+    typedef typename Mf<T>::frag frag;
+    __shared__ float kvp_s[LM_NW][16][64];                    // partial kv tiles in accumulator layout
+    __shared__ float ksum_s[LM_NW][2][32];
+    __shared__ float kbar_s[32];
+    __shared__ float den_s[LM_NW][2][32];                      // per wave: the two halves of its 32 tokens' normalisers
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x / heads, hd = blockIdx.x - b * heads;
+    const size_t base = (size_t)b * n * C + (size_t)hd * 32;
+
+    // ---- phase 1: kv[e1][e2] = sum_t k[t][e1] v[t][e2] ; column sums of k.  Wave w takes the token steps w, w + 4, ...
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float ksum = 0.f;
+#pragma unroll 2
+    for (int t0 = 16 * w; t0 < n; t0 += 16 * LM_NW) {
+        float kk[8];
+        frag A, B;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                             // all sixteen loads first, then the arithmetic
+            const int t = t0 + 8 * h + j;
+            const bool ok = t < n;
+            const size_t g = base + (size_t)(ok ? t : n - 1) * C + r;
+            kk[j] = ok ? la_ld(kpre + g) : -1e30f;               // elu1(-1e30) = 0: a token past the end contributes nothing
+            B[j] = ok ? Mf<T>::raw(v[g]) : Mf<T>::cvt(0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float e = elu1(kk[j]);
+            ksum += e;
+            A[j] = Mf<T>::cvt(e);
+        }
+        acc = Mf<T>::mma(A, B, acc);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kvp_s[w][i][lane] = acc[i];
+    ksum_s[w][h][r] = ksum;
+    __syncthreads();
+    if (tid < 32) {
+        float t = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < LM_NW; ++ww) t += ksum_s[ww][0][tid] + ksum_s[ww][1][tid];
+        kbar_s[tid] = t / (float)n;
+    }
+    const float s2 = 1.f / (float)n;
+    frag KV0, KV1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float t = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < LM_NW; ++ww) t += kvp_s[ww][i][lane];
+        if (i < 8) KV0[i] = Mf<T>::cvt(t * s2);
+        else KV1[i - 8] = Mf<T>::cvt(t * s2);
+    }
+    __syncthreads();
+
+    // ---- phase 2: out[t][e2] = (q[t] . kv[.][e2]) / (q[t] . kbar + 1e-6) + pe[t][e2]; wave w takes the 32-token groups w, w + 4, ...
+    for (int g0 = 32 * w; g0 < n; g0 += 32 * LM_NW) {
+        const int t = g0 + r;
+        const size_t gq = base + (size_t)(t < n ? t : n - 1) * C;
+        frag A0, A1;
+        float dpart = 0.f;
+        float qv[4][4];
+#pragma unroll
+        for (int sj = 0; sj < 4; ++sj) la_ldv<4>(qpre + gq + 16 * (sj >> 1) + 8 * (sj & 1) + 4 * h, qv[sj]);   // rows 16s + 8(j>>2) + 4h + (j&3) of kv
+        float pv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int tok = g0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            pv[i] = la_ld(pe + base + (size_t)(tok < n ? tok : n - 1) * C + r);
+        }
+#pragma unroll
+        for (int sj = 0; sj < 4; ++sj) {
+            const int e0 = 16 * (sj >> 1) + 8 * (sj & 1) + 4 * h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float qq = elu1(qv[sj][i]);
+                dpart = fmaf(qq, kbar_s[e0 + i], dpart);
+                if (sj < 2) A0[4 * (sj & 1) + i] = Mf<T>::cvt(qq);
+                else A1[4 * (sj & 1) + i] = Mf<T>::cvt(qq);
+            }
+        }
+        f32x16 o;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] = 0.f;
+        o = Mf<T>::mma(A0, KV0, o);
+        o = Mf<T>::mma(A1, KV1, o);
+        den_s[w][h][r] = dpart;                                   // wave-private: LDS operations of one wave execute in order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;          // token of accumulator register i; the lane is the column e2 = r
+            const int tok = g0 + row;
+            if (tok < n) {
+                const float den = den_s[w][0][row] + den_s[w][1][row] + 1e-6f;
+                la_st(out + base + (size_t)tok * C + r, o[i] / den + pv[i]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- backward of the core (engine.py:48-64 reaches it through RecAttn2d in the A-series).  With u = q kv, w = q . kbar + 1e-6,
 // out = u / w + pe and g = dL/dout:
 //     du = g / w ;  dw = -(g . u) / w^2 ;  dq = du kv^T + dw kbar ;  dkv = q^T du ;  dkbar = q^T dw
@@ -462,6 +604,16 @@ hipError_t linattn_core(const void* qpre, const void* kpre, const void* v, const
 {
     const dim3 grid((unsigned)(B * heads)), block(LA_NT);
     const bool wide = ((C / heads) % 4) == 0;
+    {
+        const char* m = getenv("RCX_ATTN_MFMA");                     // A/B knob: 0 = the vector-pipe kernels for every head dimension
+        // Measured (batch 256, bf16): 784 tokens 88 -> 61 us with 4 waves per head; 196 / 49 / 16 tokens no faster than the vector-pipe kernel
+        // (36 / 23 / 31 against 36 / 20 / 20 us: too few tokens per head to amortise the partial-sum exchange) -- so only the long sequences
+        if (C / heads == 32 && dtype != 0 && n >= 512 && !(m && *m == '0')) {
+            if (dtype == 1) hipLaunchKernelGGL((k_linattn_mfma<bf16_t>), grid, dim3(LM_NW * 64), 0, s, (const bf16_t*)qpre, (const bf16_t*)kpre, (const bf16_t*)v, (const bf16_t*)pe, (bf16_t*)out, n, C, heads);
+            else hipLaunchKernelGGL((k_linattn_mfma<f16_t>), grid, dim3(LM_NW * 64), 0, s, (const f16_t*)qpre, (const f16_t*)kpre, (const f16_t*)v, (const f16_t*)pe, (f16_t*)out, n, C, heads);
+            return hipGetLastError();
+        }
+    }
 #define RCX_LA_LAUNCH(T, G) hipLaunchKernelGGL((k_linattn_core<T, G>), grid, block, 0, s, (const T*)qpre, (const T*)kpre, (const T*)v, \
                                                (const T*)pe, (T*)out, n, C, heads)
     const char* old = getenv("RCX_ATTN_SCALAR");                 // A/B knob: the untiled kernel for every head dimension
