@@ -358,6 +358,7 @@ def test_upadd_dwconv_piece(mode, shape, cdtype):
 FULL = [
     ("M1 cfg2 stage1", 256, 96, 28, 28, 3),
     ("M3 stage0", 256, 64, 56, 56, 4),
+    ("M3 stage1", 256, 128, 28, 28, 3),
     ("M3 stage2", 256, 256, 14, 14, 2),
     ("M3 stage3", 256, 512, 7, 7, 1),
     ("M5 stage0", 128, 80, 56, 56, 4),
@@ -366,7 +367,7 @@ FULL = [
 
 
 @pytest.mark.parametrize("case", FULL, ids=lambda c: c[0])
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16], ids=["bf16", "f32", "f16"])
 def test_full_size_properties(case, dtype):
     _, n, c, h, w, level = case
     torch.manual_seed(1)
@@ -380,7 +381,11 @@ def test_full_size_properties(case, dtype):
         lo, hi = n // 3, n // 3 + 5
         assert torch.equal(mod(x[lo:hi]), y[lo:hi]), "batch shard differs from full batch"
         # homogeneity (no bias): scaling the input by a power of two scales the output exactly
-        assert torch.equal(mod(x * 4), y * 4)
+        if dtype == torch.float16:                           # float16 has subnormals in range: y is rounded on a coarser grid than 4 y there
+            y4, big = mod(x * 4), y.abs() > 1e-3
+            assert torch.equal(y4[big], (y * 4)[big])
+        else:
+            assert torch.equal(mod(x * 4), y * 4)
     assert torch.isfinite(y.float()).all()
     # spot check three images against the oracle
     sd = {k: v.float().cpu().numpy() for k, v in mod.state_dict().items()}
@@ -390,6 +395,8 @@ def test_full_size_properties(case, dtype):
     got = y[idx].float().cpu().numpy()
     if dtype == torch.float32:
         assert np.abs(got - ref).max() < F32_TIGHT
+    elif dtype == torch.float16:
+        assert np.allclose(got, ref, atol=1e-3, rtol=1e-3)
     else:
         assert np.allclose(got, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
 
