@@ -355,6 +355,23 @@ __device__ __forceinline__ void add_resized_row(f32x2 (&dst)[NP], const f32x2 (&
 }
 
 
+// ---- training forward (rcx_recconv2d_fwd_train): the same launch also leaves the float32 pyramid the backward reads -- F_l and C_l,
+// l = 1 .. level, each N x h_l x w_l x C (rcx_api.hip, TrainLadder) -- instead of one launch per ladder step.  base == nullptr: inference.
+struct SavedPyr {
+    float* base;
+    unsigned long long f_off[2], c_off[2];                    // byte offsets of F_1, F_2 / C_1, C_2 (level 1: index 0 only)
+};
+// one plane of NW x NW pixels held as pairs, for this lane's (image, channel)
+template <int NW>
+__device__ __forceinline__ void save_plane(float* base, unsigned long long off, int n, int C, int c, const f32x2 (&p)[NW][(NW + 1) / 2])
+{
+    float* q = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) + ((size_t)n * NW * NW) * C + c;
+#pragma unroll
+    for (int o = 0; o < NW; ++o)
+#pragma unroll
+        for (int i = 0; i < NW; ++i) q[(size_t)(o * NW + i) * C] = (i & 1) ? p[o][i >> 1].y : p[o][i >> 1].x;
+}
+
 // ======== x through LDS (16-bit I/O, whole 64-channel blocks): k_recconv_cpl14<..., XL = true> ========
 // A wave can keep at most 63 memory operations in flight, and a per-lane 2-byte load moves 128 bytes per wave: 8 KB in flight per
 // SIMD, which at the chip's ~2 us loaded latency makes pass 1 latency-bound (rocprofv3: 19.3 us, a third of the wave's cycles in
@@ -447,7 +464,7 @@ __device__ __forceinline__ void load_taps_asm(float (&w)[25], i32x4 wsrc, unsign
 template <int MODE, int CT, typename TIO, bool XL = false>
 __global__ __launch_bounds__(64)
 void k_recconv_cpl14(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack,
-                     int N, int C_rt, int has_bias)
+                     int N, int C_rt, int has_bias, SavedPyr sv)
 {
     constexpr int W = 14, P = 7, W1 = 7, P1 = 4, W2 = 4, P2 = 2;
     const int C = CT > 0 ? CT : C_rt;
@@ -590,6 +607,7 @@ void k_recconv_cpl14(const TIO* __restrict__ x, TIO* __restrict__ y, const float
     });
     RCX_FENCE;
 
+    if (sv.base) save_plane<W1>(sv.base, sv.f_off[0], n, C, c, F1);                               // training forward: F_1
     // ---- the level-1 block on the 7x7 plane: C1 = conv_1(F1 + resize(conv_0(down(F1))))          (:27-33)
     f32x2 C1[W1][P1];
     Taps t2;
@@ -598,11 +616,13 @@ void k_recconv_cpl14(const TIO* __restrict__ x, TIO* __restrict__ y, const float
         load_taps<CT>(t0, wpack, bpack, 1, C, vow, has_bias);
         f32x2 F2[W2][P2];
         down5<W1, W2>(F1, F2, td);
+        if (sv.base) save_plane<W2>(sv.base, sv.f_off[1], n, C, c, F2);                           // F_2
         Taps t1;
         load_taps<CT>(t1, wpack, bpack, 2, C, vow, has_bias);
         RCX_FENCE;
         f32x2 C2[W2][P2];
         conv5_plane<W2>(F2, C2, t0);
+        if (sv.base) save_plane<W2>(sv.base, sv.c_off[1], n, C, c, C2);                           // C_2
         f32x2 H2[W2][P1];
 #pragma unroll
         for (int i = 0; i < W2; ++i) resize_row<MODE, W2, W1>(C2[i], H2[i]);
@@ -613,6 +633,7 @@ void k_recconv_cpl14(const TIO* __restrict__ x, TIO* __restrict__ y, const float
         load_taps<CT>(t2, wpack, bpack, 3, C, vow, has_bias);
         RCX_FENCE;
         conv5_plane<W1>(F1, C1, t1);
+        if (sv.base) save_plane<W1>(sv.base, sv.c_off[0], n, C, c, C1);                           // C_1
     }
 
     // ---- y = conv_2(x + resize(C1)): input-row stationary, five accumulator rows in flight                     (:34)
@@ -678,7 +699,7 @@ void k_recconv_cpl14(const TIO* __restrict__ x, TIO* __restrict__ y, const float
 template <int MODE, int CT, typename TIO>
 __global__ __launch_bounds__(64, 2)
 void k_recconv_cpl7b(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack,
-                     int N, int C_rt, int has_bias)
+                     int N, int C_rt, int has_bias, SavedPyr sv)
 {
     constexpr int W = 7, P = 4, W1 = 4, P1 = 2;
     const int C = CT > 0 ? CT : C_rt;
@@ -716,11 +737,13 @@ void k_recconv_cpl7b(const TIO* __restrict__ x, TIO* __restrict__ y, const float
     RCX_FENCE;
     f32x2 F1[W1][P1];
     down5<W, W1>(X, F1, td);
+    if (sv.base) save_plane<W1>(sv.base, sv.f_off[0], n, C, c, F1);                               // training forward: F_1
     Taps t1;
     load_taps<CT>(t1, wpack, bpack, 2, C, vow, has_bias);
     RCX_FENCE;
     f32x2 C1[W1][P1];
     conv5_plane<W1>(F1, C1, t0);
+    if (sv.base) save_plane<W1>(sv.base, sv.c_off[0], n, C, c, C1);                               // C_1
     f32x2 H1[W1][P];
 #pragma unroll
     for (int i = 0; i < W1; ++i) resize_row<MODE, W1, W>(C1[i], H1[i]);
@@ -752,10 +775,10 @@ static inline bool enabled()
 }
 
 template <int MODE, int CT, typename TIO>
-static hipError_t launch(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s)
+static hipError_t launch(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv)
 {
     const unsigned grid = (unsigned)(N * ((C + 63) / 64));
-    hipLaunchKernelGGL((k_recconv_cpl14<MODE, CT, TIO>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr);
+    hipLaunchKernelGGL((k_recconv_cpl14<MODE, CT, TIO>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
     return hipGetLastError();
 }
 
@@ -769,36 +792,36 @@ static inline bool use_xl(int C, int esz)
 }
 
 template <int MODE, int CT, typename TIO>
-static hipError_t launch_xl(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s)
+static hipError_t launch_xl(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv)
 {
     const unsigned grid = (unsigned)(N * (C / 64));
-    hipLaunchKernelGGL((k_recconv_cpl14<MODE, CT, TIO, true>), dim3(grid), dim3(64), 25 * 1024, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr);
+    hipLaunchKernelGGL((k_recconv_cpl14<MODE, CT, TIO, true>), dim3(grid), dim3(64), 25 * 1024, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
     return hipGetLastError();
 }
 
 template <int MODE, typename TIO>
-static hipError_t launch_c(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s)
+static hipError_t launch_c(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv)
 {
     if constexpr (sizeof(TIO) == 2) {
-        if (use_xl(C, 2)) return C == 256 ? launch_xl<MODE, 256, TIO>(x, y, wpack, bpack, N, C, s) : launch_xl<MODE, 0, TIO>(x, y, wpack, bpack, N, C, s);
+        if (use_xl(C, 2)) return C == 256 ? launch_xl<MODE, 256, TIO>(x, y, wpack, bpack, N, C, s, sv) : launch_xl<MODE, 0, TIO>(x, y, wpack, bpack, N, C, s, sv);
     }
-    if (C == 256) return launch<MODE, 256, TIO>(x, y, wpack, bpack, N, C, s);          // RecNeXt-M3/M4 stage 2: immediates instead of scalar adds
-    return launch<MODE, 0, TIO>(x, y, wpack, bpack, N, C, s);
+    if (C == 256) return launch<MODE, 256, TIO>(x, y, wpack, bpack, N, C, s, sv);          // RecNeXt-M3/M4 stage 2: immediates instead of scalar adds
+    return launch<MODE, 0, TIO>(x, y, wpack, bpack, N, C, s, sv);
 }
 
 template <int MODE, int CT, typename TIO>
-static hipError_t launch7(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s)
+static hipError_t launch7(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv)
 {
     const unsigned grid = (unsigned)(N * ((C + 63) / 64));
-    hipLaunchKernelGGL((k_recconv_cpl7b<MODE, CT, TIO>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr);
+    hipLaunchKernelGGL((k_recconv_cpl7b<MODE, CT, TIO>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
     return hipGetLastError();
 }
 
 template <int MODE, typename TIO>
-static hipError_t launch7_c(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s)
+static hipError_t launch7_c(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv)
 {
-    if (C == 512) return launch7<MODE, 512, TIO>(x, y, wpack, bpack, N, C, s);         // RecNeXt-M3/M4 stage 3
-    return launch7<MODE, 0, TIO>(x, y, wpack, bpack, N, C, s);
+    if (C == 512) return launch7<MODE, 512, TIO>(x, y, wpack, bpack, N, C, s, sv);         // RecNeXt-M3/M4 stage 3
+    return launch7<MODE, 0, TIO>(x, y, wpack, bpack, N, C, s, sv);
 }
 
 }  // namespace cpl14
@@ -817,11 +840,15 @@ int cpl7b_describe(int N, int C, int mode, char* buf, int len)
     return snprintf(buf, len, "cpl(k_recconv_cpl7b<%d, %d>,cb=64,nt=64,blocks=%d,lds=0)", mode, C == 512 ? 512 : 0, N * ((C + 63) / 64));
 }
 
-hipError_t cpl7b_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s)
+hipError_t cpl7b_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s,
+                         float* saved, const size_t* f_off, const size_t* c_off)
 {
-    if (dtype == 1) return mode == 1 ? cpl14::launch7_c<1, bf16_t>(x, y, wpack, bpack, N, C, s) : cpl14::launch7_c<0, bf16_t>(x, y, wpack, bpack, N, C, s);
-    if (dtype == 2) return mode == 1 ? cpl14::launch7_c<1, f16_t>(x, y, wpack, bpack, N, C, s) : cpl14::launch7_c<0, f16_t>(x, y, wpack, bpack, N, C, s);
-    return mode == 1 ? cpl14::launch7_c<1, float>(x, y, wpack, bpack, N, C, s) : cpl14::launch7_c<0, float>(x, y, wpack, bpack, N, C, s);
+    cpl14::SavedPyr sv{};
+    sv.base = saved;
+    if (saved) { sv.f_off[0] = f_off[1]; sv.c_off[0] = c_off[1]; }
+    if (dtype == 1) return mode == 1 ? cpl14::launch7_c<1, bf16_t>(x, y, wpack, bpack, N, C, s, sv) : cpl14::launch7_c<0, bf16_t>(x, y, wpack, bpack, N, C, s, sv);
+    if (dtype == 2) return mode == 1 ? cpl14::launch7_c<1, f16_t>(x, y, wpack, bpack, N, C, s, sv) : cpl14::launch7_c<0, f16_t>(x, y, wpack, bpack, N, C, s, sv);
+    return mode == 1 ? cpl14::launch7_c<1, float>(x, y, wpack, bpack, N, C, s, sv) : cpl14::launch7_c<0, float>(x, y, wpack, bpack, N, C, s, sv);
 }
 
 bool cpl14_applicable(int N, int C, int H, int W, int level, int k, int dtype)
@@ -836,11 +863,15 @@ int cpl14_describe(int N, int C, int mode, int dtype, char* buf, int len)
     return snprintf(buf, len, "cpl(k_recconv_cpl14<%d, %d%s>,cb=64,nt=64,blocks=%d,lds=%d)", mode, C == 256 ? 256 : 0, xl ? ", XL" : "", N * ((C + 63) / 64), xl ? 25 * 1024 : 0);
 }
 
-hipError_t cpl14_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s)
+hipError_t cpl14_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s,
+                         float* saved, const size_t* f_off, const size_t* c_off)
 {
-    if (dtype == 1) return mode == 1 ? cpl14::launch_c<1, bf16_t>(x, y, wpack, bpack, N, C, s) : cpl14::launch_c<0, bf16_t>(x, y, wpack, bpack, N, C, s);
-    if (dtype == 2) return mode == 1 ? cpl14::launch_c<1, f16_t>(x, y, wpack, bpack, N, C, s) : cpl14::launch_c<0, f16_t>(x, y, wpack, bpack, N, C, s);
-    return mode == 1 ? cpl14::launch_c<1, float>(x, y, wpack, bpack, N, C, s) : cpl14::launch_c<0, float>(x, y, wpack, bpack, N, C, s);
+    cpl14::SavedPyr sv{};
+    sv.base = saved;
+    if (saved) { sv.f_off[0] = f_off[1]; sv.f_off[1] = f_off[2]; sv.c_off[0] = c_off[1]; sv.c_off[1] = c_off[2]; }
+    if (dtype == 1) return mode == 1 ? cpl14::launch_c<1, bf16_t>(x, y, wpack, bpack, N, C, s, sv) : cpl14::launch_c<0, bf16_t>(x, y, wpack, bpack, N, C, s, sv);
+    if (dtype == 2) return mode == 1 ? cpl14::launch_c<1, f16_t>(x, y, wpack, bpack, N, C, s, sv) : cpl14::launch_c<0, f16_t>(x, y, wpack, bpack, N, C, s, sv);
+    return mode == 1 ? cpl14::launch_c<1, float>(x, y, wpack, bpack, N, C, s, sv) : cpl14::launch_c<0, float>(x, y, wpack, bpack, N, C, s, sv);
 }
 
 }  // namespace rcx

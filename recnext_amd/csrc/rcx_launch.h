@@ -52,11 +52,14 @@ hipError_t cpl7_recconv(const void* x, void* y, const float* wpack, const float*
 // channel-per-lane kernel of the 14x14 / level 2 block (rcx_cpl14.hip): any channel count
 bool cpl14_applicable(int N, int C, int H, int W, int level, int k, int dtype);
 int cpl14_describe(int N, int C, int mode, int dtype, char* buf, int len);
-hipError_t cpl14_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s);
+// saved != nullptr (training forward): the launch also writes the float32 pyramid F_l at saved + f_off[l], C_l at saved + c_off[l] (bytes, l >= 1)
+hipError_t cpl14_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s,
+                         float* saved = nullptr, const size_t* f_off = nullptr, const size_t* c_off = nullptr);
 
 bool cpl7b_applicable(int N, int C, int H, int W, int level, int k, int dtype);
 int cpl7b_describe(int N, int C, int mode, char* buf, int len);
-hipError_t cpl7b_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s);
+hipError_t cpl7b_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s,
+                         float* saved = nullptr, const size_t* f_off = nullptr, const size_t* c_off = nullptr);
 
 // channel-per-lane, tiled kernel of the 56x56 / level 4 and 28x28 / level 3 blocks (rcx_cpt.hip): any channel count
 bool cpt_applicable(int N, int C, int H, int W, int level, int k, int dtype);
