@@ -303,12 +303,16 @@ int rcx_recconv2d_fwd_train(const void* x, void* y, const float* wpack, const fl
     if (L.saved_total > 0 && (!saved || saved_bytes < L.saved_total))
         return fail(RCX_ERR_WORKSPACE, "saved-activation buffer too small: need %zu bytes, got %zu", L.saved_total, saved_bytes);
     hipStream_t s = (hipStream_t)stream;
-    // the 14x14 / level 2 and 7x7 / level 1 blocks (15 of RecNeXt-M3's 21): the inference kernel itself leaves the pyramid behind --
+    // the blocks of RecNeXt at 224x224 (channel-per-lane kernels): the inference kernel itself leaves the pyramid behind --
     // one launch instead of 2 * level + 1 (RCX_TRAIN_FUSED=0: the per-step schedule, for A/B runs)
     {
         const char* tf = getenv("RCX_TRAIN_FUSED");
         const bool fused_ok = !(tf && *tf == '0') && !lanes_off() && !(getenv("RCX_FORCE_SPLIT"));
         const int md = mode == RCX_MODE_NEAREST ? 1 : 0;
+        if (fused_ok && rcx::cpt_train_applicable(N, C, H, W, level, k, md, dtype)) {
+            hipError_t fe = rcx::cpt_recconv(x, y, wpack, bpack, N, C, H, md, dtype, s, (float*)saved, L.f_off, L.c_off);
+            return fe == hipSuccess ? 0 : hip_fail(fe, "train fwd: fused tiled block");
+        }
         if (fused_ok && rcx::cpl14_applicable(N, C, H, W, level, k, dtype)) {
             hipError_t fe = rcx::cpl14_recconv(x, y, wpack, bpack, N, C, md, dtype, s, (float*)saved, L.f_off, L.c_off);
             return fe == hipSuccess ? 0 : hip_fail(fe, "train fwd: fused 14x14 block");

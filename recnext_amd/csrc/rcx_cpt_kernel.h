@@ -1,0 +1,984 @@
+// Channel-per-lane, TILED RecConv2d for the two large blocks of RecNeXt at 224x224 (model/recnext.py:24-34):
+//   56x56 / level 4 (stage 0) and 28x28 / level 3 (stage 1).
+//
+// Layout.  A LANE owns one channel of one 14x14 tile of the full-resolution plane; a workgroup owns one image x one block of
+// channels and all T x T tiles of its plane (T = 4: 56x56, T = 2: 28x28):
+//   T = 4: 8 waves, a wave = 32 channels x 2 tiles (lanes 0-31 / 32-63 own the tiles (tr, tc) and (tr, tc + 2): same row,
+//          same column parity, so every row quantity and every parity is wave-uniform and only the column origin and the two
+//          image-edge flags differ per lane); 64 contiguous bytes per pixel and half-wave in NHWC bf16;
+//   T = 2: 4 waves, a wave = 64 channels x 1 tile (128 contiguous bytes per pixel).
+// Nothing is ever exchanged between lanes: no DPP (rcx_lanes.h: a DPP move puts the SIMD into its slow issue mode), and the
+// level-0 work -- 80 % of the FMAs -- never touches LDS: both passes stream x one row at a time straight from global memory
+// into registers (hand-issued buffer loads that run AHEAD rows in front; out-of-image halo columns are out-of-range buffer
+// offsets and read 0) and are input-row stationary on v_pk_fma_f32 pairs exactly as rcx_cpl14.hip (column pairs for the
+// stride-1 convs, tap pairs for the stride-2 conv).  What tiles must share -- the planes of level >= 1, at most 28x28 -- lives in
+// LDS as float32 [pixel][channel of the block], lane-contiguous (conflict-free 32-bit accesses):
+//   pass 1   F1 tile (7x7) = down(x tile + halo)                    -> LDS                                        (:27-29)
+//   chain    F2..FL = down ladder, C_L .. C_2 = conv(F_l + resize(C_{l+1})) on the small planes, row segments dealt over
+//            the T*T tile-lanes ("pieces", gathered from LDS; rows outside a plane are redirected to a zero row)    (:27-33)
+//   level 1  T1 = F1 + resize(C2) and C1 = conv(T1) per tile (halo read from the neighbours' LDS pixels)          (:31-33)
+//   pass 2   y tile = conv(x + resize(C1)) with an 18x18 input window, five accumulator rows in flight             (:34)
+// Same arithmetic as the other schedules: float32 throughout, one rounding at the final store.  The exact-2x bilinear steps use
+// the closed form of ATen's index arithmetic (weights 0.25 / 0.75, clamped borders: at a clamped border both taps read the same
+// pixel, 0.25 v + 0.75 v instead of ATen's v -- one ulp); the 4 -> 7 step uses ATen's float formulas (rcx_common.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <type_traits>
+
+#include "rcx_common.h"
+#include "rcx_lanes.h"
+#include "rcx_launch.h"
+
+namespace rcx {
+namespace cpt {
+
+using lanes::f32x2;
+using lanes::IC;
+using lanes::sfor;
+using lanes::vtab;
+using lanes::VT;
+
+#define CPT_FENCE __builtin_amdgcn_sched_barrier(0)
+#ifndef RCX_CPT_PF
+#define RCX_CPT_PF 0                       /* wide-load L2 prefetch ahead of pass 1: measured slower, see pass 1 */
+#endif
+
+// diagnostic build only (-DRCX_STAMPS, tools/cpt_bench.hip): lane 0 of every wave of the first workgroups writes the clock at phase boundaries
+#ifdef RCX_STAMPS
+static __device__ unsigned long long* g_cpt_stamps = nullptr;
+#define CPT_STAMP(id)                                                                                                    \
+    do {                                                                                                                 \
+        if ((threadIdx.x & 63) == 0 && g_cpt_stamps && blockIdx.x < 512)                                                 \
+            g_cpt_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (id)] = __builtin_readcyclecounter();             \
+    } while (0)
+#define CPT_STAMP_RT(id)                                                                                                 \
+    do {                                                                                                                 \
+        if ((threadIdx.x & 63) == 0 && g_cpt_stamps && blockIdx.x < 512)                                                 \
+            g_cpt_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (id)] = __builtin_amdgcn_s_memrealtime();         \
+    } while (0)
+#else
+#define CPT_STAMP(id) do { } while (0)
+#define CPT_STAMP_RT(id) do { } while (0)
+#endif
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4pf __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) char* gcptr;
+typedef __attribute__((address_space(1))) char* gptr;
+
+__device__ __forceinline__ f32x2 pfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat(float v) { return f32x2{v, v}; }
+// (a[A], b[B]) in one instruction; the compiler spends two v_mov_b32 on a shuffle whose sources come from LDS reads
+template <int A, int B> __device__ __forceinline__ f32x2 pkmov(f32x2 a, f32x2 b)
+{
+    f32x2 d;
+    asm("v_pk_mov_b32 %0, %1, %2 op_sel:[%3,%4]" : "=v"(d) : "v"(a), "v"(b), "n"(A), "n"(B));
+    return d;
+}
+__device__ __forceinline__ f32x2 shift1(f32x2 a, f32x2 b) { return __builtin_shufflevector(a, b, 1, 2); }
+__device__ __forceinline__ gcptr opaque(gcptr p) { asm volatile("" : "+s"(p)); return p; }
+__device__ __forceinline__ void pin(f32x2& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+template <int A> __device__ __forceinline__ void pin(f32x2 (&v)[A]) {
+#pragma unroll
+    for (int i = 0; i < A; ++i) pin(v[i]);
+}
+template <int A> __device__ __forceinline__ void pin(float (&v)[A]) {
+#pragma unroll
+    for (int i = 0; i < A; ++i) pin(v[i]);
+}
+
+// ---- x rows: hand-issued buffer loads (the compiler would sink them to their first use and the prefetch distance collapses;
+// rcx_cpl14.hip).  address = image base (descriptor) + soff (uniform: row and column) + voff (this lane: tile column origin and
+// channel, or 0x80000000 = out of range -> the load returns 0: the zero padding left and right of the image)
+// A whole row = ONE asm statement: 18 loads (or 14 stores) back to back, no compiler-inserted padding between them.  The scalar
+// offset the instructions read is produced by an SALU instruction INSIDE the statement: an SGPR operand handed in from outside
+// may have just been written by a VALU instruction (v_readfirstlane_b32, or v_readlane_b32 reloading a spill), and a
+// vector-memory instruction that reads an SGPR within 5 wait states of a VALU write to it sees the old value -- the hazard
+// recognizer does not look inside inline asm.  s_add_i32 writes SCC: declared, or a scalar select scheduled behind the
+// statement reads the wrong condition.  Outputs are early-clobber: a destination must not share a register with an offset that
+// a later load of the same statement still reads.
+// PIXB = bytes between horizontally adjacent pixels when that is a compile-time constant (columns become immediate offsets:
+// 12-bit, so the columns past 4095 bytes go through a second scalar base), 0 = run-time pitch (one scalar add per column).
+#define CPT_OUT18(v) "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]), \
+                     "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15]), "=&v"(v[16]), "=&v"(v[17])
+// immediate columns: L = columns -2, -1 (voffL), M k = column k (voffM), R = columns 14, 15 (voffR)
+#define CPT_LI(OP, d, V, S, k) OP " %" #d ", %[" V "], %[rs], %[" S "] offen offset:%[pb]*" #k "\n\t"
+#define CPT_ROW_IMM(OP)                                                                                                              \
+    "s_add_i32 %[t], %[rb], 0\n\t"                                                                                                  \
+    CPT_LI(OP, 0, "vl", "t", 0) CPT_LI(OP, 1, "vl", "t", 1)                                                                          \
+    CPT_LI(OP, 2, "vm", "t", 0) CPT_LI(OP, 3, "vm", "t", 1) CPT_LI(OP, 4, "vm", "t", 2) CPT_LI(OP, 5, "vm", "t", 3)                  \
+    CPT_LI(OP, 6, "vm", "t", 4) CPT_LI(OP, 7, "vm", "t", 5) CPT_LI(OP, 8, "vm", "t", 6) CPT_LI(OP, 9, "vm", "t", 7)                  \
+    CPT_LI(OP, 10, "vm", "t", 8) CPT_LI(OP, 11, "vm", "t", 9) CPT_LI(OP, 12, "vm", "t", 10) CPT_LI(OP, 13, "vm", "t", 11)            \
+    CPT_LI(OP, 14, "vm", "t", 12) CPT_LI(OP, 15, "vm", "t", 13)                                                                      \
+    CPT_LI(OP, 16, "vr", "t", 0) CPT_LI(OP, 17, "vr", "t", 1)
+#define CPT_ROW_BIG(OP)                                                                                                              \
+    "s_add_i32 %[t], %[rb], 0\n\ts_add_i32 %[t2], %[rb], %[pb]*7\n\t"                                                               \
+    CPT_LI(OP, 0, "vl", "t", 0) CPT_LI(OP, 1, "vl", "t", 1)                                                                          \
+    CPT_LI(OP, 2, "vm", "t", 0) CPT_LI(OP, 3, "vm", "t", 1) CPT_LI(OP, 4, "vm", "t", 2) CPT_LI(OP, 5, "vm", "t", 3)                  \
+    CPT_LI(OP, 6, "vm", "t", 4) CPT_LI(OP, 7, "vm", "t", 5) CPT_LI(OP, 8, "vm", "t", 6) CPT_LI(OP, 9, "vm", "t2", 0)                 \
+    CPT_LI(OP, 10, "vm", "t2", 1) CPT_LI(OP, 11, "vm", "t2", 2) CPT_LI(OP, 12, "vm", "t2", 3) CPT_LI(OP, 13, "vm", "t2", 4)          \
+    CPT_LI(OP, 14, "vm", "t2", 5) CPT_LI(OP, 15, "vm", "t2", 6)                                                                      \
+    CPT_LI(OP, 16, "vr", "t", 0) CPT_LI(OP, 17, "vr", "t", 1)
+// run-time pitch: t2 walks along the row
+#define CPT_LG(OP, d, V, S) OP " %" #d ", %[" V "], %[rs], %[" S "] offen\n\t"
+#define CPT_LGN(OP, d) "s_add_i32 %[t2], %[t2], %[pix]\n\t" CPT_LG(OP, d, "vm", "t2")
+#define CPT_ROW_GEN(OP)                                                                                                              \
+    "s_add_i32 %[t], %[rb], 0\n\ts_add_i32 %[t2], %[rb], %[pix]\n\t"                                                                \
+    CPT_LG(OP, 0, "vl", "t") CPT_LG(OP, 1, "vl", "t2") CPT_LG(OP, 16, "vr", "t") CPT_LG(OP, 17, "vr", "t2")                          \
+    CPT_LG(OP, 2, "vm", "t") CPT_LG(OP, 3, "vm", "t2")                                                                               \
+    CPT_LGN(OP, 4) CPT_LGN(OP, 5) CPT_LGN(OP, 6) CPT_LGN(OP, 7) CPT_LGN(OP, 8) CPT_LGN(OP, 9) CPT_LGN(OP, 10) CPT_LGN(OP, 11)         \
+    CPT_LGN(OP, 12) CPT_LGN(OP, 13) CPT_LGN(OP, 14) CPT_LGN(OP, 15)
+
+template <typename TIO> struct IoOp;
+// bf16 -> float32 without an instruction: the D16 "hi" load fills the upper half and zeroes the lower (tools/ubench/d16_probe.hip)
+#define CPT_LD16 "buffer_load_short_d16_hi"
+#define CPT_LDH "buffer_load_ushort"                  /* float16: zero-extended, then one v_cvt_f32_f16 per element */
+#define CPT_LD32 "buffer_load_dword"
+
+template <typename TIO, int PIXB>
+__device__ __forceinline__ void row_load(uint32_t (&v)[18], unsigned vl, unsigned vm, unsigned vr, i32x4 rs, int rb, int pix)
+{
+    int t, t2;
+    if constexpr (PIXB > 0 && PIXB * 13 <= 4095) {
+        (void)pix; (void)t2;
+        if constexpr (std::is_same<TIO, f16_t>::value)
+            asm volatile(CPT_ROW_IMM(CPT_LDH) : CPT_OUT18(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+        else if constexpr (sizeof(TIO) == 2)
+            asm volatile(CPT_ROW_IMM(CPT_LD16) : CPT_OUT18(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+        else
+            asm volatile(CPT_ROW_IMM(CPT_LD32) : CPT_OUT18(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+    } else if constexpr (PIXB > 0) {
+        static_assert(PIXB * 6 <= 4095, "pixel pitch too large for two immediate ranges");
+        (void)pix;
+        if constexpr (std::is_same<TIO, f16_t>::value)
+            asm volatile(CPT_ROW_BIG(CPT_LDH) : CPT_OUT18(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+        else if constexpr (sizeof(TIO) == 2)
+            asm volatile(CPT_ROW_BIG(CPT_LD16) : CPT_OUT18(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+        else
+            asm volatile(CPT_ROW_BIG(CPT_LD32) : CPT_OUT18(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+    } else {
+        if constexpr (std::is_same<TIO, f16_t>::value)
+            asm volatile(CPT_ROW_GEN(CPT_LDH) : CPT_OUT18(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+        else if constexpr (sizeof(TIO) == 2)
+            asm volatile(CPT_ROW_GEN(CPT_LD16) : CPT_OUT18(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+        else
+            asm volatile(CPT_ROW_GEN(CPT_LD32) : CPT_OUT18(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+    }
+}
+
+// a loaded element as float32: float32 and bf16 (D16-hi load) are already there, float16 takes one conversion
+template <typename TIO> __device__ __forceinline__ float raw_f32(uint32_t r)
+{
+    if constexpr (std::is_same<TIO, f16_t>::value) return (float)__builtin_bit_cast(_Float16, (uint16_t)r);
+    else return __uint_as_float(r);
+}
+
+// ---- one output row of the tile: 14 stores in one statement.  vo = this lane's offset, or out of range (the store is dropped:
+// the lanes of a ragged last channel block).  bf16: 7 registers of two converted pixels each, low half = even column.
+#define CPT_SI(OP, d, S, k) OP " %[p" #d "], %[vo], %[rs], %[" S "] offen offset:%[pb]*" #k "\n\t"
+#define CPT_SG(OP, d, S) OP " %[p" #d "], %[vo], %[rs], %[" S "] offen\n\t"
+#define CPT_SGN(OP, d) "s_add_i32 %[t2], %[t2], %[pix]\n\t" CPT_SG(OP, d, "t2")
+#define CPT_ST16_IMM(S0, S1, k0)                                                                                                     \
+    CPT_SI("buffer_store_short", 0, S0, 0) CPT_SI("buffer_store_short_d16_hi", 0, S0, 1) CPT_SI("buffer_store_short", 1, S0, 2)      \
+    CPT_SI("buffer_store_short_d16_hi", 1, S0, 3) CPT_SI("buffer_store_short", 2, S0, 4) CPT_SI("buffer_store_short_d16_hi", 2, S0, 5) \
+    CPT_SI("buffer_store_short", 3, S0, 6)
+template <typename TIO, int PIXB> struct RowSt;
+template <typename T16, int PIXB> struct RowSt16 {
+    static __device__ __forceinline__ void st(const f32x2 (&a)[7], unsigned vo, i32x4 rs, int rb, int pix)
+    {
+        uint32_t p[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {                         // one conversion for the two pixels (RNE, NaN stays NaN)
+            if constexpr (std::is_same<T16, f16_t>::value) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p[j]) : "v"(a[j].x), "v"(a[j].y));
+            else asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p[j]) : "v"(a[j].x), "v"(a[j].y));
+        }
+        int t, t2;
+        if constexpr (PIXB > 0 && PIXB * 13 <= 4095) {
+            (void)pix; (void)t2;
+            asm volatile("s_add_i32 %[t], %[rb], 0\n\t"
+                         CPT_SI("buffer_store_short", 0, "t", 0) CPT_SI("buffer_store_short_d16_hi", 0, "t", 1)
+                         CPT_SI("buffer_store_short", 1, "t", 2) CPT_SI("buffer_store_short_d16_hi", 1, "t", 3)
+                         CPT_SI("buffer_store_short", 2, "t", 4) CPT_SI("buffer_store_short_d16_hi", 2, "t", 5)
+                         CPT_SI("buffer_store_short", 3, "t", 6) CPT_SI("buffer_store_short_d16_hi", 3, "t", 7)
+                         CPT_SI("buffer_store_short", 4, "t", 8) CPT_SI("buffer_store_short_d16_hi", 4, "t", 9)
+                         CPT_SI("buffer_store_short", 5, "t", 10) CPT_SI("buffer_store_short_d16_hi", 5, "t", 11)
+                         CPT_SI("buffer_store_short", 6, "t", 12) CPT_SI("buffer_store_short_d16_hi", 6, "t", 13)
+                         : [t] "=&s"(t)
+                         : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [p4] "v"(p[4]), [p5] "v"(p[5]), [p6] "v"(p[6]),
+                           [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc", "memory");
+        } else {
+            // run-time pitch (and the large compile-time ones): t2 walks along the row
+            asm volatile("s_add_i32 %[t2], %[rb], 0\n\t"
+                         CPT_SG("buffer_store_short", 0, "t2") CPT_SGN("buffer_store_short_d16_hi", 0)
+                         CPT_SGN("buffer_store_short", 1) CPT_SGN("buffer_store_short_d16_hi", 1)
+                         CPT_SGN("buffer_store_short", 2) CPT_SGN("buffer_store_short_d16_hi", 2)
+                         CPT_SGN("buffer_store_short", 3) CPT_SGN("buffer_store_short_d16_hi", 3)
+                         CPT_SGN("buffer_store_short", 4) CPT_SGN("buffer_store_short_d16_hi", 4)
+                         CPT_SGN("buffer_store_short", 5) CPT_SGN("buffer_store_short_d16_hi", 5)
+                         CPT_SGN("buffer_store_short", 6) CPT_SGN("buffer_store_short_d16_hi", 6)
+                         : [t2] "=&s"(t2)
+                         : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [p4] "v"(p[4]), [p5] "v"(p[5]), [p6] "v"(p[6]),
+                           [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc", "memory");
+            (void)t;
+        }
+    }
+};
+template <int PIXB> struct RowSt<bf16_t, PIXB> : RowSt16<bf16_t, PIXB> {};
+template <int PIXB> struct RowSt<f16_t, PIXB> : RowSt16<f16_t, PIXB> {};
+template <int PIXB> struct RowSt<float, PIXB> {
+    static __device__ __forceinline__ void st(const f32x2 (&a)[7], unsigned vo, i32x4 rs, int rb, int pix)
+    {
+        int t2;
+        float p[14];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) { p[2 * j] = a[j].x; p[2 * j + 1] = a[j].y; }
+        asm volatile("s_add_i32 %[t2], %[rb], 0\n\t"
+                     CPT_SG("buffer_store_dword", 0, "t2") CPT_SGN("buffer_store_dword", 1) CPT_SGN("buffer_store_dword", 2) CPT_SGN("buffer_store_dword", 3)
+                     CPT_SGN("buffer_store_dword", 4) CPT_SGN("buffer_store_dword", 5) CPT_SGN("buffer_store_dword", 6) CPT_SGN("buffer_store_dword", 7)
+                     CPT_SGN("buffer_store_dword", 8) CPT_SGN("buffer_store_dword", 9) CPT_SGN("buffer_store_dword", 10) CPT_SGN("buffer_store_dword", 11)
+                     CPT_SGN("buffer_store_dword", 12) CPT_SGN("buffer_store_dword", 13)
+                     : [t2] "=&s"(t2)
+                     : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [p4] "v"(p[4]), [p5] "v"(p[5]), [p6] "v"(p[6]), [p7] "v"(p[7]),
+                       [p8] "v"(p[8]), [p9] "v"(p[9]), [p10] "v"(p[10]), [p11] "v"(p[11]), [p12] "v"(p[12]), [p13] "v"(p[13]),
+                       [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc", "memory");
+    }
+};
+
+// first touch of a row of 18 hand-issued loads: wait until at most PENDING younger memory operations are outstanding (stores
+// issued in between only make the true count larger: the wait can come out longer than necessary, never shorter)
+template <int PENDING>
+__device__ __forceinline__ void pin_row(uint32_t (&v)[18])
+{
+    asm volatile("s_waitcnt vmcnt(%18)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                 "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]),
+                 "+v"(v[17]) : "n"(PENDING));
+}
+
+// the 25 taps of one conv for this lane's channel as three register pairs per tap row: (w0,w1) (w2,w3) (w4,0)
+struct Taps {
+    f32x2 p[5][3];
+    float bias;
+    __device__ __forceinline__ float at(int u, int v) const { return (v & 1) ? p[u][v >> 1].y : p[u][v >> 1].x; }
+};
+
+// wsrc = the weight pack as a raw buffer: one scalar add and one load per tap, no 64-bit vector address arithmetic
+__device__ __forceinline__ void load_taps(Taps& t, __amdgpu_buffer_rsrc_t wsrc, const float* __restrict__ bpack, int conv, int C, int c, int has_bias)
+{
+    const int vow = c * 4, base = conv * 25 * C * 4;
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            const float w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wsrc, vow, base + (u * 5 + v) * C * 4, 0));
+            if (v & 1) t.p[u][v >> 1].y = w;
+            else t.p[u][v >> 1].x = w;
+        }
+        t.p[u][2].y = 0.f;
+    }
+    t.bias = has_bias ? bpack[(size_t)conv * C + c] : 0.f;
+}
+
+// training forward (rcx_recconv2d_fwd_train): base != nullptr -> the launch also leaves the float32 pyramid the backward reads, F_l at
+// base + f_off[l] and C_l at base + c_off[l] (bytes; each N x P_l x P_l x C), l = 1 .. level
+struct SavedPyr {
+    float* base;
+    unsigned long long f_off[5], c_off[5];
+};
+
+constexpr int plane_size(int T, int l) { return l == 0 ? 14 * T : (plane_size(T, l - 1) + 1) / 2; }
+
+// ---- pieces: one output row segment of a small plane, gathered from LDS.  L* point at this lane's channel column; a pixel is
+// PIXF floats.  Rows outside the plane read the zero row; columns outside are compile-time zeros.
+// stride-2 conv: outputs COL0 .. COL0+NOUT-1 of row `orow` of down(PIN x PIN)
+template <int PIN, int COL0, int NOUT, int PIXF>
+__device__ __forceinline__ void down_piece(const float* Lin, const float* Lzero, int orow, const Taps& t, float (&out)[NOUT])
+{
+    f32x2 acc[NOUT];
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) acc[i] = f32x2{t.bias, 0.f};
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int r = 2 * orow + u - 2;
+        const float* rp = ((unsigned)r < (unsigned)PIN) ? Lin + r * (PIN * PIXF) : Lzero;
+        f32x2 in[NOUT + 2];
+#pragma unroll
+        for (int k = 0; k < NOUT + 2; ++k) {
+            const int c0 = 2 * COL0 - 2 + 2 * k, c1 = c0 + 1;
+            in[k].x = (c0 >= 0 && c0 < PIN) ? rp[c0 * PIXF] : 0.f;
+            in[k].y = (c1 >= 0 && c1 < PIN && k < NOUT + 1) ? rp[c1 * PIXF] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) acc[i] = pfma(in[i], t.p[u][0], acc[i]);
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) acc[i] = pfma(in[i + 1], t.p[u][1], acc[i]);
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) acc[i].x = fmaf(in[i + 2].x, t.p[u][2].x, acc[i].x);
+    }
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) out[i] = acc[i].x + acc[i].y;
+}
+
+// stride-1 conv: outputs COL0 .. COL0+NOUT-1 of row `orow` of a P x P plane, as pairs (the odd tail element is not an output)
+template <int P, int COL0, int NOUT, int PIXF>
+__device__ __forceinline__ void conv_piece(const float* Lin, const float* Lzero, int orow, const Taps& t, f32x2 (&acc)[(NOUT + 1) / 2])
+{
+    constexpr int NP = (NOUT + 1) / 2;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) acc[j] = splat(t.bias);
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int r = orow + u - 2;
+        const float* rp = ((unsigned)r < (unsigned)P) ? Lin + r * (P * PIXF) : Lzero;
+        f32x2 in[NP + 2], odd[NP + 1];
+#pragma unroll
+        for (int k = 0; k < NP + 2; ++k) {
+            const int c0 = COL0 - 2 + 2 * k, c1 = c0 + 1;
+            in[k].x = (c0 >= 0 && c0 < P && c0 <= COL0 + NOUT + 1) ? rp[c0 * PIXF] : 0.f;
+            in[k].y = (c1 >= 0 && c1 < P && c1 <= COL0 + NOUT + 1) ? rp[c1 * PIXF] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NP + 1; ++j) odd[j] = shift1(in[j], in[j + 1]);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) acc[j] = pfma(in[j], splat(t.at(u, 0)), acc[j]);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) acc[j] = pfma(odd[j], splat(t.at(u, 1)), acc[j]);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) acc[j] = pfma(in[j + 1], splat(t.at(u, 2)), acc[j]);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) acc[j] = pfma(odd[j + 1], splat(t.at(u, 3)), acc[j]);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) acc[j] = pfma(in[j + 2], splat(t.at(u, 4)), acc[j]);
+    }
+}
+
+// T = F + resize(C): row `orow`, columns COL0 .. COL0+NOUT-1 of the P x P plane Lf, in place; C is PC x PC.  The row index is
+// this lane's (ATen's float formulas at run time), the columns are compile-time table entries.
+template <int MODE, int PC, int P, int COL0, int NOUT, int PIXF>
+__device__ __forceinline__ void tform_piece(float* Lf, const float* Lc, int orow, bool active)
+{
+    constexpr float scale = (float)PC / (float)P;
+    int i0, i1;
+    float lam;
+    if (MODE == 1) { i0 = i1 = nearest_src(orow, PC, scale); lam = 0.f; }
+    else { const Lerp lr = bilinear_src(orow, PC, scale); i0 = lr.i0; i1 = lr.i1; lam = lr.lam; }
+    const float* r0 = Lc + i0 * (PC * PIXF);
+    const float* r1 = Lc + i1 * (PC * PIXF);
+    constexpr int cmin = vtab(MODE, PC, P, COL0).i0, cmax = vtab(MODE, PC, P, COL0 + NOUT - 1).i1;
+    float V[cmax - cmin + 1];
+    const float l0 = 1.f - lam;
+#pragma unroll
+    for (int c = cmin; c <= cmax; ++c) V[c - cmin] = MODE == 1 ? r0[c * PIXF] : fmaf(lam, r1[c * PIXF], l0 * r0[c * PIXF]);
+    float* fp = Lf + (orow * P + COL0) * PIXF;
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) {
+        const VT h = vtab(MODE, PC, P, COL0 + j);
+        const float up = (MODE == 1 || h.i0 == h.i1) ? V[h.i0 - cmin] : fmaf(h.l, V[h.i1 - cmin], (1.f - h.l) * V[h.i0 - cmin]);
+        const float f = fp[j * PIXF];
+        if (active) fp[j * PIXF] = f + up;
+    }
+}
+
+// exact-2x step, source index relative to the base column b and weight of the second tap, for destination column c of a run
+// that starts at an even (par = 0) or odd (par = 1) absolute position.  bilinear: b = (d0 - 1) >> 1, nearest: b = d0 >> 1
+struct Rel { int idx; float l; };
+constexpr Rel rel2(int mode, int par, int c)
+{
+    if (mode == 1) return Rel{par ? (c + 1) / 2 : c / 2, 0.f};
+    if (par == 0) return Rel{(c & 1) ? (c + 1) / 2 : c / 2, (c & 1) ? 0.25f : 0.75f};
+    return Rel{(c & 1) ? (c - 1) / 2 : c / 2, (c & 1) ? 0.75f : 0.25f};
+}
+
+template <int T_, int HALVES, int MODE, typename TIO>
+struct Geo {
+    static constexpr int T = T_;
+    static constexpr int NL = T == 4 ? 4 : 3;
+    static constexpr int NW = T * T / HALVES;
+    static constexpr int NT = NW * 64;
+    static constexpr int PIXF = 64 / HALVES;
+    static constexpr int NWORK = T * T;
+    static constexpr int P0 = 14 * T, P1 = 7 * T, P2 = plane_size(T, 2), P3 = plane_size(T, 3), P4 = plane_size(T, 4);
+    // LDS, in pixels: zero row | guard | L1 | guard | L2 | L3 | L4
+    static constexpr int ZR = P1;
+    static constexpr int O1 = ZR + 2;
+    static constexpr int O2 = O1 + P1 * P1 + 2;
+    static constexpr int O3 = O2 + P2 * P2;
+    static constexpr int O4 = O3 + P3 * P3;
+    static constexpr int NPIX = O4 + (NL >= 4 ? P4 * P4 : 0);
+    static constexpr int LDS_BYTES = NPIX * PIXF * 4;
+};
+
+// IMG2 (T = 2 only): the two half-waves are two IMAGES (n, n + 1) of the same tile and the same 32 channels -- whole 32-channel
+// blocks for the channel counts that are not multiples of 64 (RecNeXt-M1: 96, M5: 160); geometry and parities stay uniform.
+// TRAIN: the training-forward instantiation (saves the pyramid); the inference instantiations carry none of that code.
+template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool IMG2 = false, bool TRAIN = false>
+__global__ __launch_bounds__(T * T / HALVES * 64, T == 4 ? 1 : 2)
+void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack,
+                   int N, int C, int has_bias, SavedPyr sv)
+{
+    using G = Geo<T, HALVES, MODE, TIO>;
+    constexpr int NL = G::NL, PIXF = G::PIXF, NWORK = G::NWORK, P0 = G::P0, P1 = G::P1, P2 = G::P2, P3 = G::P3, P4 = G::P4;
+    constexpr int ESZ = (int)sizeof(TIO);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    // Persistent workgroups: the grid is at most what the chip holds at once and a workgroup walks over its units (image,
+    // channel block) -- no relaunch gap between the rounds, LDS zeroed once.  XCD-aware order: workgroups are dealt round-robin
+    // over the 8 XCDs; each XCD gets a contiguous run of units, so the channel blocks of one image (the two halves of its
+    // 128-byte lines) pass through the same L2 at about the same time.
+    static_assert(!IMG2 || HALVES == 1, "image halves use the one-tile-per-wave geometry");
+    constexpr int CHB = IMG2 ? 32 : PIXF;                          // channels per block
+    const int nb = (C + CHB - 1) / CHB;
+    const int NU = IMG2 ? (N + 1) / 2 : N;                          // image units
+    const unsigned total = (unsigned)NU * (unsigned)nb, GD = gridDim.x;
+    const bool xcd = (total & 7u) == 0 && (GD & 7u) == 0;
+    const int tid = (int)threadIdx.x;
+  for (unsigned it = 0;; ++it) {
+    unsigned unit;
+    if (xcd) {
+        const unsigned k = (blockIdx.x >> 3) + it * (GD >> 3);
+        if (k >= (total >> 3)) break;
+        unit = (blockIdx.x & 7u) * (total >> 3) + k;
+    } else {
+        unit = blockIdx.x + it * GD;
+        if (unit >= total) break;
+    }
+    const int nu = (int)(unit / (unsigned)nb), cb = (int)(unit - (unsigned)nu * (unsigned)nb);
+    const int n = IMG2 ? 2 * nu : nu;                              // first (only) image of the unit
+
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int h = HALVES == 2 ? (lane >> 5) : 0;
+    const int ch = lane & (PIXF - 1);
+    const int tr = T == 4 ? (w >> 1) : (w >> 1);
+    const int tcb = w & 1;
+    const int tc = HALVES == 2 ? tcb + 2 * h : tcb;                      // per lane (HALVES == 2) / uniform
+    const int q = tr * T + tc;                                          // this tile-lane's worker id
+    const bool ledge = tc == 0, redge = tc == T - 1;
+    const int ih = IMG2 ? (lane >> 5) : 0;                         // IMG2: this lane's image within the pair
+    const int c = cb * CHB + (IMG2 ? (lane & 31) : ch);
+    const bool cvalid = c < C && n + ih < N;
+    const int cc = cvalid ? c : C - 1;
+    const int pix = C * ESZ;                                            // bytes between horizontally adjacent pixels
+    // training forward: this lane's element (row, col) of the saved plane at byte offset `off` (P x P pixels per image)
+    auto sv_ptr = [&](unsigned long long off, int P, int row, int col) -> float* {
+        return reinterpret_cast<float*>(reinterpret_cast<char*>(sv.base) + off) + (((size_t)(n + ih) * P + row) * P + col) * C + c;
+    };
+    const bool svon = TRAIN && sv.base != nullptr && cvalid;
+
+    CPT_STAMP(0);
+    CPT_STAMP_RT(9);
+    float* const L = lds + ch;
+    const float* const Lzero = L;
+    float* const L1 = L + G::O1 * PIXF;
+    float* const L2 = L + G::O2 * PIXF;
+    float* const L3 = L + G::O3 * PIXF;
+    float* const L4 = L + G::O4 * PIXF;
+
+    // ---- zero the whole LDS image once (zero row, guards; and every later read is of finite data)
+    if (it == 0)
+        for (int i = tid; i < G::LDS_BYTES / 16; i += G::NT) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // x image as a raw buffer: base, num_records = bytes of the image (offsets past it read 0)
+    const char* ximg = reinterpret_cast<const char*>(x) + (size_t)n * P0 * P0 * pix;
+    i32x4 rsrc;
+    {
+        const unsigned long long a = (unsigned long long)ximg;
+        rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        rsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+        rsrc.z = (IMG2 && n + 1 < N ? 2 : 1) * P0 * P0 * pix;
+        rsrc.w = 0x00020000;
+    }
+    const unsigned OOB = 0x80000000u;
+    const unsigned imgoff = (unsigned)(ih * P0 * P0 * pix);            // IMG2: the second image of the pair (past the last image: out of range, reads 0)
+    const unsigned voffM = (IMG2 && n + ih >= N) ? OOB : (unsigned)((14 * tc) * pix + cc * ESZ) + imgoff;
+    const unsigned voffL = (ledge || voffM == OOB) ? OOB : voffM - 2u * (unsigned)pix;      // columns -2, -1 of the tile
+    const unsigned voffR = (redge || voffM == OOB) ? OOB : voffM + 14u * (unsigned)pix;     // columns 14, 15
+    // row r (tile-local, -2 .. 15), all 18 columns; rows outside the image are redirected to a valid row (loaded, not used)
+    auto load_row = [&](uint32_t (&raw)[18], int r) {
+        int ar = 14 * tr + r;
+        ar = ar < 0 ? 0 : (ar > P0 - 1 ? P0 - 1 : ar);
+        const int rb = __builtin_amdgcn_readfirstlane(ar * (P0 * pix));     // uniform by construction; the asm below needs it in an SGPR
+        row_load<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
+    };
+    auto row_valid = [&](int r) -> bool { const int ar = 14 * tr + r; return ar >= 0 && ar < P0; };   // uniform
+
+    // pass 1's first rows are requested before the taps, the LDS clearing's tail and the barrier: their HBM latency runs behind those
+    constexpr int AHEAD1 = RCX_CPT_PF > 0 ? 2 : 3, R01 = -2, NR1 = 17;
+    uint32_t raw1[NR1][18];
+    if constexpr (RCX_CPT_PF == 0) sfor<AHEAD1>([&](auto rc) { load_row(raw1[decltype(rc)::value], R01 + decltype(rc)::value); });
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, (NL + 2) * 25 * C * 4, 0x00020000);
+    Taps td;
+    load_taps(td, wsrc, bpack, 0, C, cc, has_bias);
+    __syncthreads();
+    CPT_STAMP(1);
+
+    // ================= pass 1: F1 tile = down(x), rows -2 .. 14 of the tile, input-row stationary (tap pairs) =================
+    float f1[7][7];                                          // this lane's F1 tile stays in registers until T1 is formed
+    {
+        constexpr int AHEAD = AHEAD1, R0 = R01, NR = NR1;
+        const f32x2 b0 = f32x2{td.bias, 0.f};
+        uint32_t (&raw)[NR][18] = raw1;
+        f32x2 facc[3][7];
+        // The per-lane loads move 2 bytes each and a wave holds at most 63 memory operations: 3 rows in flight do not cover the HBM
+        // latency (stamps: this pass takes 20 k cycles for 11 k cycles of issue).  Tried (-DRCX_CPT_PF=2): pull each row into L2 first
+        // with a few WIDE loads (16 bytes per lane, results discarded) PF rows ahead of the element loads.  Measured slower (pass 1:
+        // 26 k cycles, 56x56 launch 111.7 vs 105.3 us): a wave's memory operations complete in issue order, so the element loads
+        // queue behind the wide loads' HBM latency instead of overtaking them.  Off by default, kept for A/B builds.
+        constexpr int PF = RCX_CPT_PF;
+        constexpr int CPP = PIXF * ESZ / 16;                   // 16-byte chunks per pixel of the block
+        constexpr int PPI = (64 / HALVES) / CPP;               // pixels per instruction and tile
+        constexpr int NPF = PF > 0 ? (18 + PPI - 1) / PPI : 0; // instructions per row
+        u32x4pf sink = {0u, 0u, 0u, 0u};                       // destination of the wide loads: kept live to the end of the pass
+        const int pj = (lane & (64 / HALVES - 1)) / CPP, pchunk = lane & (CPP - 1);
+        unsigned pvo[NPF > 0 ? NPF : 1];                       // this lane's offsets inside a row, one per instruction
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            int colp = 14 * tc - 2 + i * PPI + pj;             // columns left of the image: re-read column 0; right of it: the next row or out of range
+            colp = colp < 0 ? 0 : colp;
+            pvo[i] = (unsigned)(colp * pix + (cb * PIXF) * ESZ + pchunk * 16);
+        }
+        auto prefetch_row = [&](int r) {
+            if constexpr (PF > 0) {
+                int ar = 14 * tr + r;
+                ar = ar < 0 ? 0 : (ar > P0 - 1 ? P0 - 1 : ar);
+                const int rb = __builtin_amdgcn_readfirstlane(ar * (P0 * pix));
+#pragma unroll
+                for (int i = 0; i < NPF; ++i) {
+                    int t;
+                    asm volatile("s_add_i32 %[t], %[rb], 0\n\tbuffer_load_dwordx4 %[d], %[vo], %[rs], %[t] offen"
+                                 : [d] "+v"(sink), [t] "=&s"(t) : [vo] "v"(pvo[i]), [rs] "s"(rsrc), [rb] "s"(rb) : "scc");
+                }
+            }
+        };
+        sfor<AHEAD + PF>([&](auto rc) { prefetch_row(R0 + decltype(rc)::value); });
+        if constexpr (PF > 0) sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], R0 + decltype(rc)::value); });
+        sfor<NR>([&](auto rc) {
+            constexpr int ri = decltype(rc)::value, r = R0 + ri;
+            if constexpr (ri + AHEAD + PF < NR) prefetch_row(r + AHEAD + PF);
+            if constexpr (ri + AHEAD < NR) load_row(raw[ri + AHEAD], r + AHEAD);
+            // younger memory operations: what the iterations since row ri was requested have issued (wide loads first, then a row)
+            constexpr int NY = [] {
+                int k = 0;
+                for (int j = 1; j <= AHEAD; ++j) k += (ri + j < NR ? 18 : 0) + (ri + j + PF < NR ? NPF : 0);
+                return k > 63 ? 63 : k;
+            }();
+            pin_row<NY>(raw[ri]);
+            f32x2 xr[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) xr[k] = f32x2{raw_f32<TIO>(raw[ri][2 * k]), raw_f32<TIO>(raw[ri][2 * k + 1])};
+            const bool rv = row_valid(r);
+#pragma unroll
+            for (int o = 0; o < 7; ++o) {
+                const int u = r - 2 * o + 2;
+                if (u < 0 || u > 4) continue;
+                f32x2(&a)[7] = facc[o % 3];
+                if (rv) {
+                    // u == 0: the first contribution of output row o carries the initial value (bias, 0) as its addend
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) a[i] = pfma(xr[i], td.p[u][0], u == 0 ? b0 : a[i]);
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) a[i] = pfma(xr[i + 1], td.p[u][1], a[i]);
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) a[i].x = fmaf(xr[i + 2].x, td.p[u][2].x, a[i].x);
+                } else if (u == 0) {
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) a[i] = b0;
+                }
+                if (u == 4) {
+                    float* dst = L1 + ((7 * tr + o) * P1 + 7 * tc) * PIXF;
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) {
+                        f1[o][i] = a[i].x + a[i].y;
+                        dst[i * PIXF] = f1[o][i];
+                    }
+                    if constexpr (TRAIN) if (svon) {
+#pragma unroll
+                        for (int i = 0; i < 7; ++i) *sv_ptr(sv.f_off[1], P1, 7 * tr + o, 7 * tc + i) = f1[o][i];
+                    }
+                    pin(f1[o]);
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 7; ++o) if (r - 2 * o + 2 >= 0 && r - 2 * o + 2 < 4) pin(facc[o % 3]);
+            CPT_FENCE;
+        });
+        asm volatile("" : "+v"(sink));                         // every wide load has landed by now (the last rows' waits were vmcnt(0))
+    }
+    CPT_STAMP(2);
+    __syncthreads();
+    CPT_STAMP(3);
+
+    // ================= chain: the small planes, pieces dealt over the T*T tile-lanes =================
+    // conv j of the pack: 0 = down, 1 + (NL - l) = the conv of level l, 1 + NL = the final conv
+    constexpr int PL[5] = {P0, P1, P2, P3, P4};
+    float* const LP[5] = {nullptr, L1, L2, L3, L4};
+    // piece rounds of a P-wide plane: P == 14 (16 workers): two rounds = the two 7-wide column segments, row = q; else full rows,
+    // row = q + NWORK * round
+    auto for_pieces = [&](auto pc, auto&& f) {
+        constexpr int P = decltype(pc)::value;
+        if constexpr (P == 14) {
+            static_assert(NWORK == 16, "14-wide piece planes are dealt over 16 workers");
+            const bool act = q < 14;
+            const int row = act ? q : 0;
+            f(IC<0>{}, IC<0>{}, IC<7>{}, row, act);
+            f(IC<1>{}, IC<7>{}, IC<7>{}, row, act);
+        } else {
+            constexpr int RNDS = (P + NWORK - 1) / NWORK;
+            sfor<RNDS>([&](auto rc) {
+                constexpr int rnd = decltype(rc)::value;
+                const int rr = q + NWORK * rnd;
+                const bool act = rr < P;
+                f(rc, IC<0>{}, IC<P>{}, act ? rr : 0, act);
+            });
+        }
+    };
+    // down ladder: F_l = down(F_{l-1}), l = 2 .. NL
+    sfor<NL - 1>([&](auto lc) {
+        constexpr int l = 2 + decltype(lc)::value;
+        constexpr int PIN = PL[l - 1], PO = PL[l];
+        for_pieces(IC<PO>{}, [&](auto, auto col0c, auto noutc, int row, bool act) {
+            constexpr int COL0 = decltype(col0c)::value, NOUT = decltype(noutc)::value;
+            float out[NOUT];
+            down_piece<PIN, COL0, NOUT, PIXF>(LP[l - 1], Lzero, row, td, out);
+            if (act) {
+                float* dst = LP[l] + (row * PO + COL0) * PIXF;
+#pragma unroll
+                for (int i = 0; i < NOUT; ++i) dst[i * PIXF] = out[i];
+                if constexpr (TRAIN) if (svon) {
+#pragma unroll
+                    for (int i = 0; i < NOUT; ++i) *sv_ptr(sv.f_off[l], PO, row, COL0 + i) = out[i];
+                }
+            }
+        });
+        __syncthreads();
+    });
+    CPT_STAMP(4);
+    // up recursion on the piece planes: l = NL .. 2: T_l = F_l + resize(C_{l+1}) in place (l < NL), C_l = conv(T_l) in place.
+    // (Requesting a level's taps one level ahead was measured: no gain -- the small planes are issue-bound -- and 20 VGPRs.)
+    sfor<NL - 1>([&](auto lc) {
+        constexpr int l = NL - decltype(lc)::value;
+        constexpr int P = PL[l];
+        Taps tc_;
+        load_taps(tc_, wsrc, bpack, 1 + (NL - l), C, cc, has_bias);
+        if constexpr (l < NL) {
+            constexpr int PC = PL[l + 1];
+            for_pieces(IC<P>{}, [&](auto, auto col0c, auto noutc, int row, bool act) {
+                tform_piece<MODE, PC, P, decltype(col0c)::value, decltype(noutc)::value, PIXF>(LP[l], LP[l + 1], row, act);
+            });
+            __syncthreads();
+        }
+        constexpr int RN = P == 14 ? 2 : (P + NWORK - 1) / NWORK;
+        f32x2 res[RN][4];
+        for_pieces(IC<P>{}, [&](auto rc, auto col0c, auto noutc, int row, bool) {
+            constexpr int COL0 = decltype(col0c)::value, NOUT = decltype(noutc)::value;
+            f32x2 acc[(NOUT + 1) / 2];
+            conv_piece<P, COL0, NOUT, PIXF>(LP[l], Lzero, row, tc_, acc);
+#pragma unroll
+            for (int j = 0; j < (NOUT + 1) / 2; ++j) res[decltype(rc)::value][j] = acc[j];
+        });
+        __syncthreads();                                     // every read of T_l is done: C_l may replace it
+        for_pieces(IC<P>{}, [&](auto rc, auto col0c, auto noutc, int row, bool act) {
+            constexpr int COL0 = decltype(col0c)::value, NOUT = decltype(noutc)::value;
+            if (act) {
+                float* dst = LP[l] + (row * P + COL0) * PIXF;
+#pragma unroll
+                for (int i = 0; i < NOUT; ++i) dst[i * PIXF] = (i & 1) ? res[decltype(rc)::value][i >> 1].y : res[decltype(rc)::value][i >> 1].x;
+                if constexpr (TRAIN) if (svon) {
+#pragma unroll
+                    for (int i = 0; i < NOUT; ++i)
+                        *sv_ptr(sv.c_off[l], P, row, COL0 + i) = (i & 1) ? res[decltype(rc)::value][i >> 1].y : res[decltype(rc)::value][i >> 1].x;
+                }
+            }
+        });
+        __syncthreads();
+    });
+
+    CPT_STAMP(5);
+    // ================= level 1, per tile: T1 = F1 + resize(C2) (exact 2x), C1 = conv(T1) =================
+    Taps t1;
+    load_taps(t1, wsrc, bpack, NL, C, cc, has_bias);         // conv of level 1 = pack 1 + (NL - 1)
+    {
+        // columns: run of 7 starting at absolute column 7*tc (parity uniform), source columns b .. b+4 of C2, clamped
+        const int d0 = 7 * tc;
+        const int bcol = MODE == 1 ? (d0 >> 1) : ((d0 - 1) >> 1);
+        int cofs[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            int cx = bcol + k;
+            cx = cx < 0 ? 0 : (cx > P2 - 1 ? P2 - 1 : cx);
+            cofs[k] = cx * PIXF;
+        }
+        const int cpar = __builtin_amdgcn_readfirstlane(d0 & 1);
+        auto form = [&](auto parc) {
+            constexpr int PAR = decltype(parc)::value;
+#pragma unroll
+            for (int r = 0; r < 7; ++r) {
+                const int dr = 7 * tr + r;                      // uniform
+                int i0, i1;
+                float lam;
+                if (MODE == 1) { i0 = i1 = dr >> 1; lam = 0.f; }
+                else if (dr & 1) { i0 = (dr - 1) >> 1; i1 = i0 + 1; lam = 0.25f; }
+                else { i0 = (dr >> 1) - 1; i1 = i0 + 1; lam = 0.75f; }
+                i0 = i0 < 0 ? 0 : (i0 > P2 - 1 ? P2 - 1 : i0);
+                i1 = i1 < 0 ? 0 : (i1 > P2 - 1 ? P2 - 1 : i1);
+                const float* r0 = L2 + i0 * (P2 * PIXF);
+                const float* r1 = L2 + i1 * (P2 * PIXF);
+                float V[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) V[k] = MODE == 1 ? r0[cofs[k]] : fmaf(lam, r1[cofs[k]], (1.f - lam) * r0[cofs[k]]);
+                sfor<7>([&](auto cic) {
+                    constexpr int cI = decltype(cic)::value;
+                    constexpr Rel rl = rel2(MODE, PAR, cI);
+                    const float up = MODE == 1 ? V[rl.idx] : fmaf(rl.l, V[rl.idx + 1], (1.f - rl.l) * V[rl.idx]);
+                    f1[r][cI] += up;
+                });
+            }
+        };
+        if (cpar) form(IC<1>{}); else form(IC<0>{});
+        float* dst = L1 + ((7 * tr) * P1 + 7 * tc) * PIXF;
+#pragma unroll
+        for (int r = 0; r < 7; ++r)
+#pragma unroll
+            for (int cI = 0; cI < 7; ++cI) dst[(r * P1 + cI) * PIXF] = f1[r][cI];
+    }
+    __syncthreads();
+    CPT_STAMP(6);
+    // halo masks of the tile (per lane): columns outside the plane contribute nothing
+    const float lmask = ledge ? 0.f : 1.f, rmask = redge ? 0.f : 1.f;
+    {
+        // C1 tile, input-row stationary over T1 rows -2 .. 8, columns -2 .. 8 (the guards before and after the plane make every
+        // address valid; what a masked column reads is finite)
+        f32x2 c1[7][4];
+        const f32x2 b1 = splat(t1.bias);
+        const float* base = L1 + ((7 * tr) * P1 + 7 * tc) * PIXF;
+#pragma unroll
+        for (int t = -2; t <= 8; ++t) {
+            const int ar = 7 * tr + t;
+            if (ar >= 0 && ar < P1) {                        // uniform
+                const float* rp = base + t * (P1 * PIXF);
+                f32x2 in[6], odd[5];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    in[k].x = rp[(2 * k - 2) * PIXF];
+                    in[k].y = k < 5 ? rp[(2 * k - 1) * PIXF] : 0.f;
+                }
+                in[0] = in[0] * splat(lmask);
+                in[4].y *= rmask;                            // column 7
+                in[5].x *= rmask;                            // column 8
+#pragma unroll
+                for (int j = 0; j < 5; ++j) odd[j] = pkmov<1, 0>(in[j], in[j + 1]);       // one v_pk_mov_b32 (the compiler: two v_mov_b32 on LDS data)
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const int o = t - u + 2;
+                    if (o < 0 || o > 6) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) c1[o][j] = pfma(in[j], splat(t1.at(u, 0)), u == 0 ? b1 : c1[o][j]);     // u == 0: first contribution of row o
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) c1[o][j] = pfma(odd[j], splat(t1.at(u, 1)), c1[o][j]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) c1[o][j] = pfma(in[j + 1], splat(t1.at(u, 2)), c1[o][j]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) c1[o][j] = pfma(odd[j + 1], splat(t1.at(u, 3)), c1[o][j]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) c1[o][j] = pfma(in[j + 2], splat(t1.at(u, 4)), c1[o][j]);
+                }
+            } else if (t + 2 <= 6) {                         // a row above the plane: the output row it would have opened starts from the bias
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c1[t + 2][j] = b1;
+            }
+            CPT_FENCE;
+        }
+        __syncthreads();                                     // every read of T1 is done
+        float* dst = L1 + ((7 * tr) * P1 + 7 * tc) * PIXF;
+#pragma unroll
+        for (int o = 0; o < 7; ++o)
+#pragma unroll
+            for (int cI = 0; cI < 7; ++cI) dst[(o * P1 + cI) * PIXF] = (cI & 1) ? c1[o][cI >> 1].y : c1[o][cI >> 1].x;
+        if constexpr (TRAIN) if (svon) {
+#pragma unroll
+            for (int o = 0; o < 7; ++o)
+#pragma unroll
+                for (int cI = 0; cI < 7; ++cI) *sv_ptr(sv.c_off[1], P1, 7 * tr + o, 7 * tc + cI) = (cI & 1) ? c1[o][cI >> 1].y : c1[o][cI >> 1].x;
+        }
+    }
+    Taps tf;
+    load_taps(tf, wsrc, bpack, 1 + NL, C, cc, has_bias);
+    __syncthreads();
+    CPT_STAMP(7);
+
+    // ================= pass 2: y tile = conv(x + resize(C1)), input rows -2 .. 15, five accumulator rows in flight =================
+    {
+        constexpr int AHEAD = 2, R0 = -2, NR = 18;
+        // C1 columns -2 .. 8 of the tile: the two on each side may lie outside the plane (clamped: ATen's border rule)
+        const int cb0 = 7 * tc;
+        const int cL0 = (ledge ? 0 : cb0 - 2) * PIXF, cL1 = (ledge ? 0 : cb0 - 1) * PIXF;
+        const int cR0 = (redge ? P1 - 1 : cb0 + 7) * PIXF, cR1 = (redge ? P1 - 1 : cb0 + 8) * PIXF;
+        // horizontal weights; the pairs that lie outside the image (columns -2, -1 at the left edge, 14, 15 at the right) are zeroed here
+        const f32x2 wq = MODE == 1 ? splat(0.f) : splat(0.25f), wt = MODE == 1 ? splat(1.f) : splat(0.75f);
+        uint32_t raw[NR][18];
+        f32x2 H[2][9];
+        f32x2 acc[5][7];
+        const f32x2 bf = splat(tf.bias);
+        i32x4 ysrc;                                           // y image as a raw buffer; lanes past the last channel store out of range (dropped)
+        {
+            const unsigned long long a = (unsigned long long)(reinterpret_cast<char*>(y) + (size_t)n * P0 * P0 * pix);
+            ysrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+            ysrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+            ysrc.z = (IMG2 && n + 1 < N ? 2 : 1) * P0 * P0 * pix;
+            ysrc.w = 0x00020000;
+        }
+        const unsigned yoff = cvalid ? (unsigned)((14 * tc) * pix + c * ESZ) + imgoff : OOB;
+        // H[i]: C1 row i (tile-local, -2 .. 8; clamped into the plane) resized horizontally to the 18 columns -2 .. 15
+        auto build_H = [&](f32x2 (&Hs)[9], int i) {
+            int ar = 7 * tr + i;
+            ar = ar < 0 ? 0 : (ar > P1 - 1 ? P1 - 1 : ar);
+            const float* rp = L1 + ar * (P1 * PIXF);
+            float cv[11];
+            cv[0] = rp[cL0];
+            cv[1] = rp[cL1];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) cv[2 + k] = rp[(cb0 + k) * PIXF];
+            cv[9] = rp[cR0];
+            cv[10] = rp[cR1];
+            f32x2 P[6], Pq[6];                                   // pairs of C1 pixels, and the same times the outer weight (0.25)
+#pragma unroll
+            for (int m = 0; m < 6; ++m) { P[m] = f32x2{cv[2 * m], m < 5 ? cv[2 * m + 1] : 0.f}; Pq[m] = P[m] * wq; }
+            sfor<9>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                // columns 2j-2 (even) and 2j-1 (odd): 0.25 c[j] + 0.75 c[j+1] and 0.75 c[j+1] + 0.25 c[j+2]; nearest: c[j+1] twice.
+                // (c[j], c[j+2]) = the same halves of two neighbouring pairs: one v_pk_mov_b32
+                const f32x2 e = pkmov<(j & 1), (j & 1)>(Pq[j >> 1], Pq[(j >> 1) + 1]);
+                const float mid = ((j + 1) & 1) ? P[(j + 1) >> 1].y : P[(j + 1) >> 1].x;
+                Hs[j] = pfma(splat(mid), wt, e);
+            });
+            Hs[0] = Hs[0] * splat(lmask);
+            Hs[8] = Hs[8] * splat(rmask);
+        };
+        sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], R0 + decltype(rc)::value); });
+        build_H(H[0], -2);
+        build_H(H[1], -1);
+        sfor<NR>([&](auto rc) {
+            constexpr int ri = decltype(rc)::value, t = R0 + ri;
+            if constexpr (ri + AHEAD < NR) load_row(raw[ri + AHEAD], t + AHEAD);
+            // vertical source rows (tile origin is even): t even -> (t/2 - 1, t/2) weight 0.75; t odd -> ((t-1)/2, (t+1)/2) weight 0.25
+            constexpr int te = (t + 2) & 1;                  // parity of t (t + 2 >= 0)
+            constexpr int i0 = MODE == 1 ? ((t + 2) >> 1) - 1 : (te ? (t - 1) / 2 : t / 2 - 1);
+            constexpr int i1 = MODE == 1 ? i0 : i0 + 1;
+            constexpr float lam = MODE == 1 ? 0.f : (te ? 0.25f : 0.75f);
+            // H[i1] is first needed here when t is odd (H[-2], H[-1] were built up front)
+            if constexpr (MODE == 0 && te && t >= -1) build_H(H[(i1 + 2) & 1], i1);
+            if constexpr (MODE == 1 && !te && t >= 0) build_H(H[(i0 + 2) & 1], i0);
+            // younger memory operations at this point: the rows requested since (18 loads each) and the output rows stored at the
+            // end of the iterations in between (14 stores each; iteration i stores a row for 4 <= i <= 17); the counter holds 63
+            constexpr int NLD = NR - 1 - ri < AHEAD ? NR - 1 - ri : AHEAD;
+            constexpr int NST = (ri - 1 >= 4 && ri - 1 <= 17 ? 1 : 0) + (AHEAD >= 2 && ri - 2 >= 4 && ri - 2 <= 17 ? 1 : 0) + (AHEAD >= 3 && ri - 3 >= 4 && ri - 3 <= 17 ? 1 : 0);
+            pin_row<(18 * NLD + 14 * NST > 63 ? 63 : 18 * NLD + 14 * NST)>(raw[ri]);
+            if (row_valid(t)) {
+                f32x2 row[9], odd[8];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const f32x2 xv = f32x2{raw_f32<TIO>(raw[ri][2 * k]), raw_f32<TIO>(raw[ri][2 * k + 1])};
+                    if (MODE == 1) row[k] = xv + H[(i0 + 2) & 1][k];
+                    else row[k] = pfma(splat(lam), H[(i1 + 2) & 1][k], pfma(splat(1.f - lam), H[(i0 + 2) & 1][k], xv));
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) odd[j] = shift1(row[j], row[j + 1]);
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const int o = t - u + 2;
+                    if (o < 0 || o > 13) continue;
+                    f32x2(&a)[7] = acc[o % 5];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) a[j] = pfma(row[j], splat(tf.at(u, 0)), u == 0 ? bf : a[j]);     // u == 0: output row t + 2 enters the window
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) a[j] = pfma(odd[j], splat(tf.at(u, 1)), a[j]);
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) a[j] = pfma(row[j + 1], splat(tf.at(u, 2)), a[j]);
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) a[j] = pfma(odd[j + 1], splat(tf.at(u, 3)), a[j]);
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) a[j] = pfma(row[j + 2], splat(tf.at(u, 4)), a[j]);
+                }
+            } else if constexpr (t + 2 >= 0 && t + 2 <= 13) {  // a row outside the image: the output row it would have opened starts from the bias
+#pragma unroll
+                for (int j = 0; j < 7; ++j) acc[(t + 2) % 5][j] = bf;
+            }
+            // output row t - 2 has seen its last input row
+            if constexpr (t - 2 >= 0 && t - 2 <= 13) {
+                constexpr int o = t - 2;
+                const int yrb = __builtin_amdgcn_readfirstlane((14 * tr + o) * (P0 * pix));
+                RowSt<TIO, PIXB>::st(acc[o % 5], yoff, ysrc, yrb, pix);
+            }
+#pragma unroll
+            for (int o = 0; o < 14; ++o) if (o > t - 2 && o <= t + 2) pin(acc[o % 5]);
+            pin(H[0]);
+            pin(H[1]);
+            CPT_FENCE;
+        });
+    }
+    CPT_STAMP(8);
+    CPT_STAMP_RT(10);
+    __syncthreads();                                         // the next unit's pass 1 writes F1 where this unit's pass 2 read C1
+  }
+}
+
+static inline bool enabled()
+{
+    const char* v = getenv("RCX_CPT");
+    const char* l = getenv("RCX_LANES");
+    return !(v && *v == '0') && !(l && *l == '0');
+}
+
+template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool IMG2 = false, bool TRAIN = false>
+static hipError_t launch(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv)
+{
+    using G = Geo<T, HALVES, MODE, TIO>;
+    if constexpr (!TRAIN && MODE == 0 && !IMG2) {             // training forward: bilinear only (what RecConv2d trains with), whole-block variants
+        if (sv.base) return launch<T, HALVES, MODE, PIXB, TIO, IMG2, true>(x, y, wpack, bpack, N, C, s, sv);
+    }
+    if (!TRAIN && sv.base) return hipErrorInvalidConfiguration;
+    auto kfn = k_recconv_cpt<T, HALVES, MODE, PIXB, TIO, IMG2, TRAIN>;
+    static bool attr_set = false;                              // once per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus = v;
+    }
+    const unsigned total = IMG2 ? (unsigned)(((N + 1) / 2) * ((C + 31) / 32)) : (unsigned)(N * ((C + G::PIXF - 1) / G::PIXF));
+    unsigned cap = (unsigned)cus * (T == 4 ? 1u : 2u);         // workgroups resident at once (LDS: one / two per CU)
+    if (const char* e = getenv("RCX_CPT_GRID")) { const int g = atoi(e); if (g > 0) cap = (unsigned)g; }    // A/B knob
+    cap &= ~7u;
+    const unsigned grid = total <= cap || cap == 0 ? total : cap;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(G::NT), G::LDS_BYTES, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
+    return hipGetLastError();
+}
+
+// the channel counts of RecNeXt-M3 / M4 get the compile-time pixel pitch (immediate column offsets), the rest the run-time one
+template <int T, int HALVES, int MODE, typename TIO>
+static hipError_t launch_c(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv)
+{
+    constexpr int CM3 = T == 4 ? 64 : 128;
+    if (C == CM3) return launch<T, HALVES, MODE, CM3 * (int)sizeof(TIO), TIO>(x, y, wpack, bpack, N, C, s, sv);
+    if constexpr (T == 2) {
+        if (C % 64 != 0) return launch<T, HALVES, MODE, 0, TIO, true>(x, y, wpack, bpack, N, C, s, sv);      // whole 32-channel blocks, image pairs
+    }
+    return launch<T, HALVES, MODE, 0, TIO>(x, y, wpack, bpack, N, C, s, sv);
+}
+
+template <int T, int HALVES>
+static hipError_t launch_md(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s, const SavedPyr& sv)
+{
+    if (dtype == 1) return mode == 1 ? launch_c<T, HALVES, 1, bf16_t>(x, y, wpack, bpack, N, C, s, sv) : launch_c<T, HALVES, 0, bf16_t>(x, y, wpack, bpack, N, C, s, sv);
+    if (dtype == 2) return mode == 1 ? launch_c<T, HALVES, 1, f16_t>(x, y, wpack, bpack, N, C, s, sv) : launch_c<T, HALVES, 0, f16_t>(x, y, wpack, bpack, N, C, s, sv);
+    return mode == 1 ? launch_c<T, HALVES, 1, float>(x, y, wpack, bpack, N, C, s, sv) : launch_c<T, HALVES, 0, float>(x, y, wpack, bpack, N, C, s, sv);
+}
+
+}  // namespace cpt
+}  // namespace rcx

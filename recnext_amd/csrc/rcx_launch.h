@@ -64,7 +64,9 @@ hipError_t cpl7b_recconv(const void* x, void* y, const float* wpack, const float
 // channel-per-lane, tiled kernel of the 56x56 / level 4 and 28x28 / level 3 blocks (rcx_cpt.hip): any channel count
 bool cpt_applicable(int N, int C, int H, int W, int level, int k, int dtype);
 int cpt_describe(int N, int C, int H, int mode, int dtype, char* buf, int len);
-hipError_t cpt_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int H, int mode, int dtype, hipStream_t s);
+bool cpt_train_applicable(int N, int C, int H, int W, int level, int k, int mode, int dtype);
+hipError_t cpt_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int H, int mode, int dtype, hipStream_t s,
+                       float* saved = nullptr, const size_t* f_off = nullptr, const size_t* c_off = nullptr);
 
 // rcx_down.hip -- register-resident depthwise 7x7 stride-2 conv with channel multiplier 2 (Downsample) on the 7*2^k planes
 bool down_lanes_applicable(int N, int Cin, int H, int W, int k, int stride, int dtype);

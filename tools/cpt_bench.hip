@@ -3,6 +3,7 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize [-DRCX_STAMPS] [-D...] tools/cpt_bench.hip -o tools/cpt_bench
 //   tools/cpt_bench [H=56] [C=64] [N=256] [dtype: 1=bf16 0=f32] [iters=20]
 #include "../recnext_amd/csrc/rcx_cpt.hip"
+#include "../recnext_amd/csrc/rcx_cpt2.hip"
 
 #include <algorithm>
 #include <cstdio>
