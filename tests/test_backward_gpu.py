@@ -264,3 +264,34 @@ def test_linear_attention_core_backward(case, dtype):
 def zlib_seed(obj):
     import zlib
     return zlib.crc32(repr(obj).encode())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 64, 56, 4), (3, 128, 28, 3), (2, 192, 28, 3), (2, 256, 14, 2), (3, 100, 14, 2), (2, 512, 7, 1)],
+                         ids=lambda v: "x".join(map(str, v)))
+def test_fused_training_forward_leaves_the_same_pyramid(shape, dtype, monkeypatch):
+    """rcx_recconv2d_fwd_train on the channel-per-lane kernels (one launch that also writes F_l and C_l) against the per-step schedule
+    (RCX_TRAIN_FUSED=0): same output, same saved float32 pyramid up to summation order -- the backward reads it either way."""
+    from recnext_amd import ops
+    n, c, hw, level = shape
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    mod = recnext_amd.RecConv2d(c, kernel_size=5, level=level, bias=True).to(dev)
+    wpack, bpack = mod.packed_params()
+    x = torch.randn(n, c, hw, hw, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    y1, s1 = ops.recconv2d_forward_train(x, wpack, bpack, level, 5, "bilinear")
+    monkeypatch.setenv("RCX_TRAIN_FUSED", "0")
+    y0, s0 = ops.recconv2d_forward_train(x, wpack, bpack, level, 5, "bilinear")
+    assert s0.numel() == s1.numel()
+    off, h = 0, hw                                            # the planes F_l, C_l (l = 1 .. level), each padded to 256 bytes
+    for l in range(1, level + 1):
+        h = (h + 1) // 2
+        nb = 4 * n * c * h * h
+        for name in ("F", "C"):
+            a0, a1 = s0[off:off + nb].view(torch.float32), s1[off:off + nb].view(torch.float32)
+            assert torch.isfinite(a1).all(), (name, l)
+            assert float((a1 - a0).abs().max()) < 2e-5 * max(1.0, float(a0.abs().max())), (name, l)
+            off += (nb + 255) // 256 * 256
+    assert off == s0.numel()
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert float((y1.float() - y0.float()).abs().max()) < tol * max(1.0, float(y0.float().abs().max()))
