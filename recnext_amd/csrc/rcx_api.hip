@@ -255,7 +255,7 @@ struct TrainLadder {
     size_t f_off[RCX_MAX_LEVEL + 1], c_off[RCX_MAX_LEVEL + 1];   // F_l, C_l (l >= 1), all distinct
     size_t saved_total;
     size_t g_off[RCX_MAX_LEVEL + 1];                               // backward scratch: gT_0..gT_L
-    size_t gc_off, part_off, bwd_total;
+    size_t gc_off, part_off, part_bytes, bwd_total;
 };
 
 TrainLadder make_train_ladder(int N, int C, int H, int W, int level, int k)
@@ -273,7 +273,8 @@ TrainLadder make_train_ladder(int N, int C, int H, int W, int level, int k)
     off = 0;
     for (int l = 0; l <= level; ++l) { L.g_off[l] = off; off += align256(sizeof(float) * (size_t)N * C * L.h[l] * L.w[l]); }
     L.gc_off = off; off += level >= 1 ? align256(sizeof(float) * (size_t)N * C * L.h[1] * L.w[1]) : 0;
-    L.part_off = off; off += align256(rcx::wgrad_partial_bytes(C, k));
+    L.part_bytes = align256(rcx::wgrad_partial_bytes(C, k));
+    L.part_off = off; off += L.part_bytes * (size_t)(2 * level + 1);     // one partial buffer per weight-gradient call: reduced together
     L.bwd_total = off;
     return L;
 }
@@ -370,29 +371,45 @@ int rcx_recconv2d_bwd(const void* x, const float* gy, const float* wpack, const 
     char* ws = (char*)workspace;
     auto G_ = [&](int l) { return (float*)(ws + L.g_off[l]); };
     float* gC = (float*)(ws + L.gc_off);
-    float* part = (float*)(ws + L.part_off);
+    int slot = 0;
+    auto PART = [&](int i) { return (float*)(ws + L.part_off + (size_t)i * L.part_bytes); };
+    rcx::WgradJobs J{};
+    J.kk = k * k; J.C = C;
+    // job 0 = the shared down conv (its partial buffers are appended as the ladder is walked), job 1 + j = convs[j]
+    J.njobs = level + 2;
+    J.gw[0] = GW(0); J.gb[0] = GB(0); J.nslots[0] = 0;
+    for (int i = 0; i <= level; ++i) { J.gw[1 + i] = GW(1 + i); J.gb[1 + i] = GB(1 + i); J.nslots[1 + i] = 0; }
+    auto add_slot = [&](int job, const float* p, int rows) { J.part[job][J.nslots[job]] = p; J.rows[job][J.nslots[job]] = rows; ++J.nslots[job]; };
+    int rows = 0;
     hipError_t e;
 #define RCX_TRY(call, what) do { e = (call); if (e != hipSuccess) return hip_fail(e, what); } while (0)
     // final conv (model/recnext.py:34): gT_0 = K_L^T gy ; gW_L = <x + R(C_1), gy>
     if (level == 0) RCX_TRY(step_dwconv(gy, gx, Wf(1), nullptr, N, C, H, W, k, 1, RCX_DTYPE_F32, dtype, s), "bwd: final conv input grad");
     else RCX_TRY(step_dwconv(gy, G_(0), Wf(1 + level), nullptr, N, C, H, W, k, 1, RCX_DTYPE_F32, RCX_DTYPE_F32, s), "bwd: final conv input grad");
-    RCX_TRY(rcx::bwd_wgrad(x, dtype, level >= 1 ? C_(1) : nullptr, gy, part, GW(1 + level), GB(1 + level), N, C, H, W,
-                           level >= 1 ? L.h[1] : 0, level >= 1 ? L.w[1] : 0, H, W, k, 1, mode, 0, s), "bwd: final conv weight grad");
+    RCX_TRY(rcx::bwd_wgrad(x, dtype, level >= 1 ? C_(1) : nullptr, gy, PART(slot), GW(1 + level), GB(1 + level), N, C, H, W,
+                           level >= 1 ? L.h[1] : 0, level >= 1 ? L.w[1] : 0, H, W, k, 1, mode, 0, s, &rows), "bwd: final conv weight grad");
+    add_slot(1 + level, PART(slot++), rows);
     // up recursion (:31-33), finest level first in the backward direction
     for (int l = 1; l <= level; ++l) {
         const int j = level - l;
         RCX_TRY(rcx::bwd_resize(G_(l - 1), gC, N, C, L.h[l - 1], L.w[l - 1], L.h[l], L.w[l], mode, s), "bwd: resize adjoint");
         RCX_TRY(step_dwconv(gC, G_(l), Wf(1 + j), nullptr, N, C, L.h[l], L.w[l], k, 1, RCX_DTYPE_F32, RCX_DTYPE_F32, s), "bwd: conv input grad");
-        RCX_TRY(rcx::bwd_wgrad(F_(l), RCX_DTYPE_F32, l < level ? C_(l + 1) : nullptr, gC, part, GW(1 + j), GB(1 + j), N, C, L.h[l], L.w[l],
-                               l < level ? L.h[l + 1] : 0, l < level ? L.w[l + 1] : 0, L.h[l], L.w[l], k, 1, mode, 0, s), "bwd: conv weight grad");
+        RCX_TRY(rcx::bwd_wgrad(F_(l), RCX_DTYPE_F32, l < level ? C_(l + 1) : nullptr, gC, PART(slot), GW(1 + j), GB(1 + j), N, C, L.h[l], L.w[l],
+                               l < level ? L.h[l + 1] : 0, l < level ? L.w[l + 1] : 0, L.h[l], L.w[l], k, 1, mode, 0, s, &rows), "bwd: conv weight grad");
+        add_slot(1 + j, PART(slot++), rows);
     }
     // down ladder (:27-29), coarsest first: the shared weight accumulates over all levels
     for (int l = level; l >= 1; --l) {
-        RCX_TRY(rcx::bwd_wgrad(l == 1 ? x : (const void*)F_(l - 1), l == 1 ? dtype : RCX_DTYPE_F32, nullptr, G_(l), part, GW(0), GB(0),
-                               N, C, L.h[l - 1], L.w[l - 1], 0, 0, L.h[l], L.w[l], k, 2, mode, l < level ? 1 : 0, s), "bwd: down weight grad");
+        RCX_TRY(rcx::bwd_wgrad(l == 1 ? x : (const void*)F_(l - 1), l == 1 ? dtype : RCX_DTYPE_F32, nullptr, G_(l), PART(slot), GW(0), GB(0),
+                               N, C, L.h[l - 1], L.w[l - 1], 0, 0, L.h[l], L.w[l], k, 2, mode, 0, s, &rows), "bwd: down weight grad");
+        add_slot(0, PART(slot++), rows);
         RCX_TRY(rcx::bwd_down_input(G_(l - 1), G_(l), l == 1 ? gx : (void*)G_(l - 1), l == 1 ? dtype : RCX_DTYPE_F32, W_(0),
                                     N, C, L.h[l - 1], L.w[l - 1], L.h[l], L.w[l], k, s), "bwd: down input grad");
     }
+    // every weight gradient of the block in one reduction launch (job 0 sums the down conv's levels, coarsest first); with no ladder
+    // job 0 has no buffer and writes zeros -- replaced by the memset below
+    if (level == 0) { J.njobs = 1; J.gw[0] = GW(1); J.gb[0] = GB(1); J.nslots[0] = J.nslots[1]; J.part[0][0] = J.part[1][0]; J.rows[0][0] = J.rows[1][0]; }
+    RCX_TRY(rcx::bwd_wgrad_reduce_jobs(J, s), "bwd: weight-gradient reduction");
 #undef RCX_TRY
     if (level == 0) {   // no ladder: the shared down weight is unused, its gradient is zero
         e = hipMemsetAsync(GW(0), 0, sizeof(float) * wsz, s);

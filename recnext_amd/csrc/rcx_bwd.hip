@@ -423,6 +423,32 @@ k_wgrad_reduce8(const float* __restrict__ partial, float* __restrict__ gw, float
     }
 }
 
+// stage 2 for a whole block's backward in ONE launch (blockIdx.y = job): every conv of the block has its own partial buffer(s); the
+// shared down conv sums the buffers of all its levels (coarsest first).  Fixed order throughout: deterministic.
+__global__ void __launch_bounds__(256)
+k_wgrad_reduce_jobs(WgradJobs J)
+{
+    __shared__ float red[8][32];
+    const int job = blockIdx.y;
+    const int i = blockIdx.x * 32 + threadIdx.x, j = threadIdx.y, total = (J.kk + 1) * J.C;
+    float s = 0.f;
+    if (i < total)
+        for (int sl = 0; sl < J.nslots[job]; ++sl) {
+            const float* part = J.part[job][sl];
+            const int rows = J.rows[job][sl];
+            for (int r = j; r < rows; r += 8) s += part[(size_t)r * total + i];
+        }
+    red[j][threadIdx.x] = s;
+    __syncthreads();
+    if (j == 0 && i < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += red[r][threadIdx.x];
+        if (i < J.kk * J.C) J.gw[job][i] = t;
+        else if (J.gb[job]) J.gb[job][i - J.kk * J.C] = t;
+    }
+}
+
 // stage 2: dst[i] (+)= sum over rows of partial[row][i], fixed order
 __global__ void __launch_bounds__(256)
 k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ gw, float* __restrict__ gb, int rows, int kk, int C, int accumulate)
@@ -463,7 +489,7 @@ size_t wgrad_partial_bytes(int C, int k)
 
 template <typename TA>
 static hipError_t wgrad_launch(const void* a, const float* coarse, const float* g, float* partial, float* gw, float* gb,
-                               BwGeom q, int Ho, int Wo, int stride, int accumulate, hipStream_t s)
+                               BwGeom q, int Ho, int Wo, int stride, int accumulate, hipStream_t s, int* rows_out)
 {
     if ((q.k == 3 || q.k == 5 || q.k == 7) && (q.C % 2) == 0 && !(coarse && q.k != 5)) {
         const int rows_total = stride == 2 ? q.N * Ho : q.N * q.H;
@@ -478,6 +504,7 @@ static hipError_t wgrad_launch(const void* a, const float* coarse, const float* 
 #undef RCX_WG
         hipError_t e5 = hipGetLastError();
         if (e5 != hipSuccess) return e5;
+        if (rows_out) { *rows_out = gy; return hipSuccess; }          // the caller reduces all its partial buffers in one launch
         const int kk = q.k * q.k, n5 = (kk + 1) * q.C;
         hipLaunchKernelGGL(k_wgrad_reduce8, dim3((n5 + 31) / 32), dim3(32, 8), 0, s, partial, gw, gb, gy, kk, q.C, accumulate);
         return hipGetLastError();
@@ -489,21 +516,30 @@ static hipError_t wgrad_launch(const void* a, const float* coarse, const float* 
     else hipLaunchKernelGGL((k_wgrad_partial<TA, 1, false>), grid, block, 0, s, (const TA*)a, coarse, g, partial, q, Ho, Wo);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (rows_out) { *rows_out = WG_ROWS_Y * WG_BLOCKS_Y; return hipSuccess; }
     const int kk = q.k * q.k, n = (kk + 1) * q.C;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((n + 255) / 256), dim3(256), 0, s, partial, gw, gb, WG_ROWS_Y * WG_BLOCKS_Y, kk, q.C, accumulate);
     return hipGetLastError();
 }
 
 hipError_t bwd_wgrad(const void* a, int a_dt, const float* coarse, const float* g, float* partial, float* gw, float* gb,
-                     int N, int C, int H, int W, int Hc, int Wc, int Ho, int Wo, int k, int stride, int mode, int accumulate, hipStream_t s)
+                     int N, int C, int H, int W, int Hc, int Wc, int Ho, int Wo, int k, int stride, int mode, int accumulate, hipStream_t s,
+                     int* rows_out)
 {
     BwGeom q{};
     q.N = N; q.C = C; q.H = H; q.W = W; q.Hc = Hc; q.Wc = Wc; q.k = k; q.mode = mode;
     q.sy = Hc > 0 ? (float)Hc / (float)H : 0.f;
     q.sx = Wc > 0 ? (float)Wc / (float)W : 0.f;
-    if (a_dt == 1) return wgrad_launch<bf16_t>(a, coarse, g, partial, gw, gb, q, Ho, Wo, stride, accumulate, s);
-    if (a_dt == 2) return wgrad_launch<f16_t>(a, coarse, g, partial, gw, gb, q, Ho, Wo, stride, accumulate, s);
-    return wgrad_launch<float>(a, coarse, g, partial, gw, gb, q, Ho, Wo, stride, accumulate, s);
+    if (a_dt == 1) return wgrad_launch<bf16_t>(a, coarse, g, partial, gw, gb, q, Ho, Wo, stride, accumulate, s, rows_out);
+    if (a_dt == 2) return wgrad_launch<f16_t>(a, coarse, g, partial, gw, gb, q, Ho, Wo, stride, accumulate, s, rows_out);
+    return wgrad_launch<float>(a, coarse, g, partial, gw, gb, q, Ho, Wo, stride, accumulate, s, rows_out);
+}
+
+hipError_t bwd_wgrad_reduce_jobs(const WgradJobs& J, hipStream_t s)
+{
+    const int n5 = (J.kk + 1) * J.C;
+    hipLaunchKernelGGL(k_wgrad_reduce_jobs, dim3((n5 + 31) / 32, J.njobs), dim3(32, 8), 0, s, J);
+    return hipGetLastError();
 }
 
 // Downsample conv (channel multiplier 2, stride 2): input gradient and weight/bias gradients; Cin % 2 == 0

@@ -91,7 +91,18 @@ hipError_t linattn_core_bwd(const void* qpre, const void* kpre, const void* v, c
 // rcx_bwd.hip -- backward pieces (deterministic gathers + two-stage weight-gradient reduction)
 size_t wgrad_partial_bytes(int C, int k);
 hipError_t bwd_wgrad(const void* a, int a_dt, const float* coarse, const float* g, float* partial, float* gw, float* gb,
-                     int N, int C, int H, int W, int Hc, int Wc, int Ho, int Wo, int k, int stride, int mode, int accumulate, hipStream_t s);
+                     int N, int C, int H, int W, int Hc, int Wc, int Ho, int Wo, int k, int stride, int mode, int accumulate, hipStream_t s,
+                     int* rows_out = nullptr);   // rows_out: leave the partial sums in `partial` (that many rows) for bwd_wgrad_reduce_jobs
+// every weight gradient of one block's backward reduced in one launch: job j sums nslots[j] partial buffers (rows[j][.] rows each) into gw[j] / gb[j]
+struct WgradJobs {
+    int njobs, kk, C;
+    int nslots[10];
+    int rows[10][8];
+    const float* part[10][8];
+    float* gw[10];
+    float* gb[10];
+};
+hipError_t bwd_wgrad_reduce_jobs(const WgradJobs& J, hipStream_t s);
 hipError_t bwd_mult2(const void* x, int x_dt, const float* g, const float* w, void* gx, float* partial, float* gw, float* gb,
                      int N, int Cin, int H, int W, int k, hipStream_t s);
 hipError_t bwd_down_input(const float* base, const float* g, void* out, int out_dt, const float* w,
