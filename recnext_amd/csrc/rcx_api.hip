@@ -383,6 +383,15 @@ int rcx_recconv2d_bwd(const void* x, const float* gy, const float* wpack, const 
     int rows = 0;
     hipError_t e;
 #define RCX_TRY(call, what) do { e = (call); if (e != hipSuccess) return hip_fail(e, what); } while (0)
+    // the blocks whose planes fit one lane: the whole backward in one launch + the batch reduction (RCX_BWD_FUSED=0: per-step schedule)
+    if (level >= 1 && !lanes_off() && rcx::cplbwd_applicable(N, C, H, W, level, k, dtype)) {
+        float* parts[RCX_MAX_LEVEL + 2];
+        for (int j = 0; j < level + 2; ++j) { parts[j] = PART(j); add_slot(j, PART(j), N); }
+        RCX_TRY(rcx::cplbwd_recconv(x, gy, wpack, wpack_flipped, saved, L.f_off, L.c_off, gx, parts, N, C, H, level,
+                                    mode == RCX_MODE_NEAREST ? 1 : 0, dtype, s), "bwd: fused block");
+        RCX_TRY(rcx::bwd_wgrad_reduce_jobs(J, s), "bwd: weight-gradient reduction");
+        return 0;
+    }
     // final conv (model/recnext.py:34): gT_0 = K_L^T gy ; gW_L = <x + R(C_1), gy>
     if (level == 0) RCX_TRY(step_dwconv(gy, gx, Wf(1), nullptr, N, C, H, W, k, 1, RCX_DTYPE_F32, dtype, s), "bwd: final conv input grad");
     else RCX_TRY(step_dwconv(gy, G_(0), Wf(1 + level), nullptr, N, C, H, W, k, 1, RCX_DTYPE_F32, RCX_DTYPE_F32, s), "bwd: final conv input grad");

@@ -1,0 +1,437 @@
+// Channel-per-lane BACKWARD of the RecConv2d block (the adjoint of model/recnext.py:24-34) for the two blocks
+// of RecNeXt at 224x224 whose planes fit one lane: 14x14 / level 2 (13 of M3's 21 blocks) and 7x7 / level 1.  One launch per
+// block instead of ~30: a lane owns one (image, channel) plane -- x, the saved pyramid, the incoming gradient and every
+// intermediate gradient live in its registers (rcx_cpl14_pieces.h: float32 pairs of horizontally adjacent pixels), nothing is
+// exchanged between lanes, and the only HBM traffic is x, gy, the small saved planes, gx, and one row of weight-gradient partial
+// sums per image (reduced over the batch by k_wgrad_reduce_jobs, the same fixed-order second stage as the per-step schedule).
+//
+//   forward (level 1 shown; level 2 nests it once more):  F = down(X); C = conv_a(F); T = X + R(C); Y = conv_b(T)
+//   backward:  gT = conv_b^T(gY)            gW_b = <gY, T>       gb_b = sum gY
+//              gC = R^T(gT)                 gW_a = <gC, F>       gb_a = sum gC
+//              gF = conv_a^T(gC)            gW_d += <gF, X>_s2   gb_d += sum gF
+//              gX = gT + down^T(gF)
+// Every convolution is again v_pk_fma_f32 on operands that sit where the instruction wants them:
+//   * conv^T: the forward's input-row-stationary stride-1 conv with the flipped taps (conv5_row);
+//   * weight gradients pair TAPS: acc(v, v+1) += splat(g[r][c]) * T(c+v-2, c+v-1).  Even c reads T's aligned pairs for the tap
+//     pairs (0,1)(2,3)(4,-), odd c for (-,0)(1,2)(3,4): two accumulator sets per conv, added at the end -- no shifted copies;
+//   * down^T pairs output columns: gx(2j,2j+1) += g[j+1]*(w0,w1) + g[j]*(w2,w3) + (g[j-1]*w4, 0) -- the forward's tap pairs;
+//   * the resize adjoint is scalar (a few hundred instructions per plane).
+// Same arithmetic as the per-step backward (float32 throughout, one rounding at the gx store); the summation ORDER differs, so
+// results agree with it to float32 rounding, not bit for bit -- both are checked against autograd (tests/test_backward_gpu.py).
+#include "rcx_cpl14_pieces.h"
+
+namespace rcx {
+namespace cplbwd {
+
+using namespace cpl14;
+using lanes::sfor;
+using lanes::IC;
+
+__device__ __forceinline__ float elem(const f32x2& p, int half) { return half ? p.y : p.x; }
+template <int NP> __device__ __forceinline__ float at(const f32x2 (&row)[NP], int i) { return (i & 1) ? row[i >> 1].y : row[i >> 1].x; }
+template <int NP> __device__ __forceinline__ void add_at(f32x2 (&row)[NP], int i, float v)
+{
+    if (i & 1) row[i >> 1].y += v;
+    else row[i >> 1].x += v;
+}
+template <int NP> __device__ __forceinline__ void fma_at(f32x2 (&row)[NP], int i, float a, float b)
+{
+    if (i & 1) row[i >> 1].y = fmaf(a, b, row[i >> 1].y);
+    else row[i >> 1].x = fmaf(a, b, row[i >> 1].x);
+}
+
+// Loads the compiler counts itself.  The forward kernels issue their x rows from inline asm and wait for them by hand; that is only
+// sound while the register allocator never copies a destination register between the load and the wait (it believes the value is
+// there), and in these kernels it does (v_mov_b64 of two in-flight registers right behind the loads: measured, wrong gradients).
+// An ordered (relaxed, wavefront-scope atomic) load stays where it is written as well, and every move or use of its result gets
+// the compiler's own counted s_waitcnt: correct by construction; the pin AHEAD rows later is where the wait lands.
+template <typename TIO> struct SafeLd;
+template <> struct SafeLd<float> {
+    static __device__ __forceinline__ uint32_t ld(gcptr p) { return gload_here<uint32_t>(p); }
+    static __device__ __forceinline__ float cvt(uint32_t r) { return __uint_as_float(r); }
+};
+template <> struct SafeLd<bf16_t> {
+    static __device__ __forceinline__ uint32_t ld(gcptr p) { return (uint32_t)gload_here<uint16_t>(p); }
+    static __device__ __forceinline__ float cvt(uint32_t r) { return __uint_as_float(r << 16); }
+};
+template <> struct SafeLd<f16_t> {
+    static __device__ __forceinline__ uint32_t ld(gcptr p) { return (uint32_t)gload_here<uint16_t>(p); }
+    static __device__ __forceinline__ float cvt(uint32_t r) { return (float)__builtin_bit_cast(_Float16, (uint16_t)r); }
+};
+template <int A> __device__ __forceinline__ void pin_raw(uint32_t (&v)[A])
+{
+#pragma unroll
+    for (int i = 0; i < A; ++i) asm volatile("" : "+v"(v[i]));
+}
+
+// weight-gradient accumulators of one stride-1 5x5 conv: E[u] = tap pairs (0,1)(2,3)(4,-) from even columns, O[u] = (-,0)(1,2)(3,4)
+struct WAcc {
+    f32x2 E[5][3], O[5][3];
+    f32x2 bs;
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { E[u][k] = f32x2{0.f, 0.f}; O[u][k] = f32x2{0.f, 0.f}; }
+        bs = f32x2{0.f, 0.f};
+    }
+    __device__ __forceinline__ float tap(int u, int v) const
+    {
+        switch (v) {
+        case 0: return E[u][0].x + O[u][0].y;
+        case 1: return E[u][0].y + O[u][1].x;
+        case 2: return E[u][1].x + O[u][1].y;
+        case 3: return E[u][1].y + O[u][2].x;
+        default: return E[u][2].x + O[u][2].y;
+        }
+    }
+    __device__ __forceinline__ float bias() const { return bs.x + bs.y; }
+};
+// the shared stride-2 conv: tap pairs (0,1)(2,3)(4,-), one set
+struct DAcc {
+    f32x2 a[5][3];
+    f32x2 bs;
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a[u][k] = f32x2{0.f, 0.f};
+        bs = f32x2{0.f, 0.f};
+    }
+    __device__ __forceinline__ float tap(int u, int v) const { return (v & 1) ? a[u][v >> 1].y : a[u][v >> 1].x; }
+    __device__ __forceinline__ float bias() const { return bs.x + bs.y; }
+};
+
+// one gradient row t of a stride-1 conv's output against the rows of its input: gW[u][v] += sum_c g[t][c] * T[t+u-2][c+v-2].
+// g: the N-wide row as pairs (odd N: last .y = 0); T_of(r): the pairs of input row r (pad column zero).
+template <int N, class RowOf>
+__device__ __forceinline__ void wgrad_row(const f32x2 (&g)[(N + 1) / 2], int t, RowOf&& T_of, WAcc& a)
+{
+    constexpr int NP = (N + 1) / 2;
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        const f32x2 gv = splat(at<NP>(g, c));
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int r = t + u - 2;
+            if (r < 0 || r >= N) continue;
+            const f32x2(&T)[NP] = T_of(r);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int p = (c & 1) ? (c - 3) / 2 + k : c / 2 - 1 + k;
+                if (p < 0 || p >= NP) continue;
+                if (c & 1) a.O[u][k] = pfma(gv, T[p], a.O[u][k]);
+                else a.E[u][k] = pfma(gv, T[p], a.E[u][k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) a.bs = a.bs + g[j];
+}
+
+// one input row r of the stride-2 conv against the gradient of its output: gW[u][v] += sum_i G[o][i] * x[r][2i+v-2], u = r-2o+2
+template <int NI, int NO>
+__device__ __forceinline__ void wgrad2_row(const f32x2 (&xr)[(NI + 1) / 2], int r, const f32x2 (&G)[NO][(NO + 1) / 2], DAcc& d)
+{
+    constexpr int PI = (NI + 1) / 2, PO = (NO + 1) / 2;
+#pragma unroll
+    for (int i = 0; i < NO; ++i) {
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const int u = r - 2 * o + 2;
+            if (u < 0 || u > 4) continue;
+            const f32x2 gv = splat(at<PO>(G[o], i));
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int p = i - 1 + k;
+                if (p < 0 || p >= PI) continue;
+                d.a[u][k] = pfma(gv, xr[p], d.a[u][k]);
+            }
+        }
+    }
+}
+template <int NO>
+__device__ __forceinline__ void wgrad2_bias(const f32x2 (&G)[NO][(NO + 1) / 2], DAcc& d)
+{
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+        for (int j = 0; j < (NO + 1) / 2; ++j) d.bs = d.bs + G[o][j];       // pad column of an odd-width plane is kept zero
+}
+
+// out(row r of the NI-wide input gradient) += down^T(G): out(2j,2j+1) += G[o][j+1]*(w0,w1) + G[o][j]*(w2,w3) + (G[o][j-1]*w4, 0),
+// o = (r+2-u)/2 for the u of r's parity.  Odd NI: the pad column collects garbage -- the caller clears it where it matters.
+template <int NI, int NO>
+__device__ __forceinline__ void downT_row(const f32x2 (&G)[NO][(NO + 1) / 2], int r, const Taps& td, f32x2 (&out)[(NI + 1) / 2])
+{
+    constexpr int PI = (NI + 1) / 2, PO = (NO + 1) / 2;
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        if ((r + 2 - u) & 1) continue;
+        const int o = (r + 2 - u) / 2;
+        if (r + 2 - u < 0 || o >= NO) continue;
+#pragma unroll
+        for (int j = 0; j < PI; ++j) if (j + 1 < NO) out[j] = pfma(splat(at<PO>(G[o], j + 1)), td.p[u][0], out[j]);
+#pragma unroll
+        for (int j = 0; j < PI; ++j) if (j < NO) out[j] = pfma(splat(at<PO>(G[o], j)), td.p[u][1], out[j]);
+#pragma unroll
+        for (int j = 1; j < PI; ++j) if (j - 1 < NO) out[j].x = fmaf(at<PO>(G[o], j - 1), td.p[u][2].x, out[j].x);
+    }
+}
+
+// gC (NI x NI) += R^T(row d of the NO x NO fine gradient): horizontal adjoint into NI scalars, then the vertical one
+template <int MODE, int NI, int NO>
+__device__ __forceinline__ void resizeT_row(const f32x2 (&row)[(NO + 1) / 2], int d, f32x2 (&gC)[NI][(NI + 1) / 2])
+{
+    constexpr int PO = (NO + 1) / 2, PI = (NI + 1) / 2;
+    float h[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) h[i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < NO; ++q) {
+        const VT t = vtab(MODE, NI, NO, q);
+        const float v = at<PO>(row, q);
+        if (MODE == 1 || t.i0 == t.i1) h[t.i0] += v;
+        else { h[t.i0] = fmaf(1.f - t.l, v, h[t.i0]); h[t.i1] = fmaf(t.l, v, h[t.i1]); }
+    }
+    const VT tv = vtab(MODE, NI, NO, d);
+#pragma unroll
+    for (int j = 0; j < PI; ++j) {
+        const f32x2 hp = f32x2{h[2 * j], 2 * j + 1 < NI ? h[2 * j + 1] : 0.f};
+        if (MODE == 1 || tv.i0 == tv.i1) gC[tv.i0][j] = gC[tv.i0][j] + hp;
+        else {
+            gC[tv.i0][j] = pfma(splat(1.f - tv.l), hp, gC[tv.i0][j]);
+            gC[tv.i1][j] = pfma(splat(tv.l), hp, gC[tv.i1][j]);
+        }
+    }
+}
+
+// a float32 plane of the saved pyramid (N x NW x NW x C) for this lane's (image, channel), as pairs
+template <int NW>
+__device__ __forceinline__ void load_plane(const char* base, unsigned long long off, int n, int C, int c, f32x2 (&p)[NW][(NW + 1) / 2])
+{
+    const float* q = reinterpret_cast<const float*>(base + off) + ((size_t)n * NW * NW) * C + c;
+#pragma unroll
+    for (int o = 0; o < NW; ++o)
+#pragma unroll
+        for (int j = 0; j < (NW + 1) / 2; ++j)
+            p[o][j] = f32x2{q[(size_t)(o * NW + 2 * j) * C], 2 * j + 1 < NW ? q[(size_t)(o * NW + 2 * j + 1) * C] : 0.f};
+}
+
+// one row of weight-gradient partial sums per image: part[(n * 26 + tap) * C + c], tap 25 = the bias gradient
+template <class Acc>
+__device__ __forceinline__ void store_wacc(float* part, int n, int C, int c, const Acc& a)
+{
+    float* q = part + (size_t)n * 26 * C + c;
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+#pragma unroll
+        for (int v = 0; v < 5; ++v) q[(size_t)(u * 5 + v) * C] = a.tap(u, v);
+    q[(size_t)25 * C] = a.bias();
+}
+
+struct BwdArgs {
+    const void* x;                 // N x W x W x C, the block's input (TIO)
+    const float* gy;               // N x W x W x C float32
+    const float* wpack;            // (level+2, 25, C): the down conv's taps are read from here
+    const float* wflip;            // the same pack with every 5x5 flipped: conv^T = conv with these
+    const char* saved;             // the training forward's pyramid
+    unsigned long long f_off[2], c_off[2];
+    void* gx;
+    float* part[4];                // partial rows: job 0 = down, 1 + j = convs[j]
+    int N, C;
+};
+
+// The level-1 block's backward on resident planes.  X: in = the block input, out = its gradient.  GY: gradient of the block
+// output (destroyed).  F, Cc: saved down(X), conv_a(F).  conv ids: a = pack 1 + ia, b = a + 1.
+template <int MODE, int CT, int NW, int NC>
+__device__ __forceinline__ void level1_bwd(f32x2 (&X)[NW][(NW + 1) / 2], f32x2 (&GY)[NW][(NW + 1) / 2], const BwdArgs& A, int ia,
+                                           unsigned long long f_off, unsigned long long c_off, int n, int C, int c, unsigned vow,
+                                           WAcc& wb, WAcc& wa, DAcc& wd)
+{
+    constexpr int PW = (NW + 1) / 2, PC = (NC + 1) / 2;
+    f32x2 gT[NW][PW];
+    {
+        // T = X + R(Cc) and the final conv's weight gradient
+        f32x2 T[NW][PW];
+        {
+            f32x2 Cc[NC][PC];
+            load_plane<NC>(A.saved, c_off, n, C, c, Cc);
+            f32x2 H[NC][PW];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) resize_row<MODE, NC, NW>(Cc[i], H[i]);
+#pragma unroll
+            for (int r = 0; r < NW; ++r) {
+#pragma unroll
+                for (int j = 0; j < PW; ++j) T[r][j] = X[r][j];
+                add_resized_row<MODE, NC, NW, PW>(T[r], H, r);
+            }
+            pin(T);
+            RCX_FENCE;
+        }
+#pragma unroll
+        for (int t = 0; t < NW; ++t) {
+            wgrad_row<NW>(GY[t], t, [&](int r) -> const f32x2(&)[PW] { return T[r]; }, wb);
+            RCX_FENCE;
+        }
+    }
+    {
+        Taps tfb;
+        load_taps<CT>(tfb, A.wflip, nullptr, 2 + ia, C, vow, 0);
+        conv5_plane<NW>(GY, gT, tfb);                       // gT = conv_b^T(gY)
+    }
+    f32x2 gF[NC][PC];
+    {
+        f32x2 gC[NC][PC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+#pragma unroll
+            for (int j = 0; j < PC; ++j) gC[i][j] = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < NW; ++d) resizeT_row<MODE, NC, NW>(gT[d], d, gC);
+        pin(gC);
+        RCX_FENCE;
+        {
+            f32x2 F[NC][PC];
+            load_plane<NC>(A.saved, f_off, n, C, c, F);
+#pragma unroll
+            for (int t = 0; t < NC; ++t) wgrad_row<NC>(gC[t], t, [&](int r) -> const f32x2(&)[PC] { return F[r]; }, wa);
+            RCX_FENCE;
+        }
+        Taps tfa;
+        load_taps<CT>(tfa, A.wflip, nullptr, 1 + ia, C, vow, 0);
+        conv5_plane<NC>(gC, gF, tfa);                       // gF = conv_a^T(gC)
+    }
+    // the shared down conv: weight gradient against X, and gX = gT + down^T(gF)
+#pragma unroll
+    for (int r = 0; r < NW; ++r) {
+        wgrad2_row<NW, NC>(X[r], r, gF, wd);
+        RCX_FENCE;
+    }
+    wgrad2_bias<NC>(gF, wd);
+    Taps td;
+    load_taps<CT>(td, A.wpack, nullptr, 0, C, vow, 0);
+#pragma unroll
+    for (int r = 0; r < NW; ++r) {
+#pragma unroll
+        for (int j = 0; j < PW; ++j) X[r][j] = gT[r][j];
+        downT_row<NW, NC>(gF, r, td, X[r]);
+        if (NW & 1) X[r][PW - 1].y = 0.f;
+        pin(X[r]);
+        RCX_FENCE;
+    }
+}
+
+// ---- 7x7 / level 1 ----
+template <int MODE, int CT, typename TIO>
+__global__ __launch_bounds__(64)
+void k_recconv_bwd_cpl7(BwdArgs A)
+{
+    constexpr int W = 7, P = 4, W1 = 4;
+    const int C = CT > 0 ? CT : A.C;
+    const int nb = (C + 63) / 64;
+    unsigned b = blockIdx.x;
+    const unsigned G = gridDim.x;
+    if ((G & 7u) == 0) b = (b & 7u) * (G >> 3) + (b >> 3);                 // XCD-aware order (rcx_cpl14.hip)
+    const int n = (int)(b / (unsigned)nb), cb = (int)(b - (unsigned)n * (unsigned)nb);
+    if (n >= A.N) return;
+    const int c = cb * 64 + (int)threadIdx.x;
+    if (c >= C) return;
+    const size_t pix = (size_t)C * sizeof(TIO);
+    const gcptr xb = (gcptr)A.x + (size_t)n * W * W * pix;
+    const gcptr gxb = (gcptr)A.gx + (size_t)n * W * W * pix;
+    const gcptr gyb = (gcptr)A.gy + (size_t)n * W * W * (size_t)C * 4;
+    const unsigned vo = (unsigned)c * (unsigned)sizeof(TIO), vow = (unsigned)c * 4u;
+    const RowAddr<W, CT, TIO> ra(vo, pix);
+    const RowAddr<W, CT, float> rg(vow, (size_t)C * 4);
+
+    uint32_t raw[W][W], rawg[W][W];
+    sfor<W>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        ra.row(xb, r, [&](auto qc, gcptr base, unsigned voff, auto immc) {
+            raw[r][decltype(qc)::value] = SafeLd<TIO>::ld(base + decltype(immc)::value + voff);
+        });
+    });
+    sfor<W>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        rg.row(gyb, r, [&](auto qc, gcptr base, unsigned voff, auto immc) {
+            rawg[r][decltype(qc)::value] = SafeLd<float>::ld(base + decltype(immc)::value + voff);
+        });
+    });
+    RCX_FENCE;
+    f32x2 X[W][P], GY[W][P];
+#pragma unroll
+    for (int r = 0; r < W; ++r) {
+        pin_raw(raw[r]);
+#pragma unroll
+        for (int j = 0; j < P; ++j) X[r][j] = f32x2{SafeLd<TIO>::cvt(raw[r][2 * j]), 2 * j + 1 < W ? SafeLd<TIO>::cvt(raw[r][2 * j + 1]) : 0.f};
+    }
+#pragma unroll
+    for (int r = 0; r < W; ++r) {
+        pin_raw(rawg[r]);
+#pragma unroll
+        for (int j = 0; j < P; ++j) GY[r][j] = f32x2{__uint_as_float(rawg[r][2 * j]), 2 * j + 1 < W ? __uint_as_float(rawg[r][2 * j + 1]) : 0.f};
+    }
+    RCX_FENCE;
+    WAcc wb, wa;
+    DAcc wd;
+    wb.zero(); wa.zero(); wd.zero();
+    level1_bwd<MODE, CT, W, W1>(X, GY, A, 0, A.f_off[0], A.c_off[0], n, C, c, vow, wb, wa, wd);
+    // gx
+    sfor<W>([&](auto rc) {
+        constexpr int o = decltype(rc)::value;
+        typename PixSt<TIO>::packed pk[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) pk[j] = PixSt<TIO>::prep(X[o][j]);
+        ra.row(gxb, o, [&](auto qc, gcptr base, unsigned voff, auto immc) {
+            constexpr int q = decltype(qc)::value;
+            PixSt<TIO>::st(base + decltype(immc)::value + voff, pk[q >> 1], q & 1);
+        });
+    });
+    store_wacc(A.part[0], n, C, c, wd);
+    store_wacc(A.part[1], n, C, c, wa);
+    store_wacc(A.part[2], n, C, c, wb);
+}
+
+template <int MODE, int CT, typename TIO>
+static hipError_t launch7(const BwdArgs& A, hipStream_t s)
+{
+    const unsigned grid = (unsigned)(A.N * ((A.C + 63) / 64));
+    hipLaunchKernelGGL((k_recconv_bwd_cpl7<MODE, CT, TIO>), dim3(grid), dim3(64), 0, s, A);
+    return hipGetLastError();
+}
+template <int MODE, typename TIO>
+static hipError_t launch7_c(const BwdArgs& A, hipStream_t s)
+{
+    if (A.C == 512) return launch7<MODE, 512, TIO>(A, s);
+    return launch7<MODE, 0, TIO>(A, s);
+}
+
+}  // namespace cplbwd
+
+// the fused backward applies where the fused training forward does, and needs one partial row per image in a 512-row slot
+bool cplbwd_applicable(int N, int C, int H, int W, int level, int k, int dtype)
+{
+    const char* v = getenv("RCX_BWD_FUSED");
+    if (v && *v == '0') return false;
+    if (N > 512) return false;
+    return cpl7b_applicable(N, C, H, W, level, k, dtype);
+}
+
+hipError_t cplbwd_recconv(const void* x, const float* gy, const float* wpack, const float* wflip, const void* saved,
+                          const size_t* f_off, const size_t* c_off, void* gx, float* const* part,
+                          int N, int C, int H, int level, int mode, int dtype, hipStream_t s)
+{
+    cplbwd::BwdArgs A{};
+    A.x = x; A.gy = gy; A.wpack = wpack; A.wflip = wflip; A.saved = (const char*)saved; A.gx = gx; A.N = N; A.C = C;
+    for (int l = 1; l <= level; ++l) { A.f_off[l - 1] = f_off[l]; A.c_off[l - 1] = c_off[l]; }
+    for (int j = 0; j < level + 2; ++j) A.part[j] = part[j];
+    (void)H;
+#define RCX_BW7(MD_) (dtype == 1 ? cplbwd::launch7_c<MD_, bf16_t>(A, s) : dtype == 2 ? cplbwd::launch7_c<MD_, f16_t>(A, s) : cplbwd::launch7_c<MD_, float>(A, s))
+    return mode == 1 ? RCX_BW7(1) : RCX_BW7(0);
+#undef RCX_BW7
+}
+
+}  // namespace rcx

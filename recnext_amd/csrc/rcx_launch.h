@@ -61,6 +61,13 @@ int cpl7b_describe(int N, int C, int mode, char* buf, int len);
 hipError_t cpl7b_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s,
                          float* saved = nullptr, const size_t* f_off = nullptr, const size_t* c_off = nullptr);
 
+// channel-per-lane backward of the 14x14 / level 2 and 7x7 / level 1 blocks in one launch (rcx_cplbwd.hip).  part[j]: one row of
+// (25 + 1) * C partial sums per image for job j (0 = the shared down conv, 1 + j = convs[j]), reduced by bwd_wgrad_reduce_jobs
+bool cplbwd_applicable(int N, int C, int H, int W, int level, int k, int dtype);
+hipError_t cplbwd_recconv(const void* x, const float* gy, const float* wpack, const float* wflip, const void* saved,
+                          const size_t* f_off, const size_t* c_off, void* gx, float* const* part,
+                          int N, int C, int H, int level, int mode, int dtype, hipStream_t s);
+
 // channel-per-lane, tiled kernel of the 56x56 / level 4 and 28x28 / level 3 blocks (rcx_cpt.hip): any channel count
 bool cpt_applicable(int N, int C, int H, int W, int level, int k, int dtype);
 int cpt_describe(int N, int C, int H, int mode, int dtype, char* buf, int len);

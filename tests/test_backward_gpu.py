@@ -4,6 +4,8 @@ Bar: float32 gradients agree to 1e-4 relative to the gradient's max-abs (both si
 orders); bfloat16 inputs: the HIP path keeps float32 intermediates, compared against the float32 autograd on the
 bf16-rounded input at 1e-2.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -295,3 +297,30 @@ def test_fused_training_forward_leaves_the_same_pyramid(shape, dtype, monkeypatc
     assert off == s0.numel()
     tol = 2e-5 if dtype == torch.float32 else 1e-2
     assert float((y1.float() - y0.float()).abs().max()) < tol * max(1.0, float(y0.float().abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("mode", ["bilinear", "nearest"])
+@pytest.mark.parametrize("shape", [(2, 512, 7, 1), (3, 40, 7, 1), (2, 64, 7, 1), (2, 256, 14, 2), (3, 100, 14, 2), (1, 192, 14, 2)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_fused_backward_matches_the_per_step_backward(shape, mode, dtype, monkeypatch):
+    """rcx_recconv2d_bwd on the channel-per-lane backward kernels (rcx_cplbwd.hip: the block's whole adjoint in one launch, one
+    partial row per image, then the batch reduction) against the per-step schedule (RCX_BWD_FUSED=0): same gx, gW, gb up to the
+    float32 summation order (and, for 16-bit I/O, one rounding of gx)."""
+    from recnext_amd import ops
+    n, c, hw, level = shape
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    mod = recnext_amd.RecConv2d(c, kernel_size=5, level=level, bias=True, mode=mode).to(dev)
+    wpack, bpack = mod.packed_params()
+    x = torch.randn(n, c, hw, hw, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(n, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+    _, saved = ops.recconv2d_forward_train(x, wpack, bpack, level, 5, mode)
+    assert "RCX_BWD_FUSED" not in os.environ
+    gx1, gw1, gb1 = ops.recconv2d_backward(x, gy, wpack, saved, level, 5, mode, need_bias=True)
+    monkeypatch.setenv("RCX_BWD_FUSED", "0")
+    gx0, gw0, gb0 = ops.recconv2d_backward(x, gy, wpack, saved, level, 5, mode, need_bias=True)
+    tol = 3e-5 if dtype == torch.float32 else 1e-2
+    for name, a1, a0, t in (("gx", gx1.float(), gx0.float(), tol), ("gw", gw1, gw0, 3e-5), ("gb", gb1, gb0, 3e-5)):
+        assert torch.isfinite(a1).all(), name
+        assert float((a1 - a0).abs().max()) < t * max(1.0, float(a0.abs().max())), (name, float((a1 - a0).abs().max()), float(a0.abs().max()))
