@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RCX_ABI_VERSION 1
+#define RCX_ABI_VERSION 2
 
 enum { RCX_DTYPE_F32 = 0, RCX_DTYPE_BF16 = 1, RCX_DTYPE_F16 = 2 };   /* F16: the reference's autocast dtype (engine.py:48) */
 enum { RCX_MODE_BILINEAR = 0, RCX_MODE_NEAREST = 1 };   /* F.interpolate(mode=...), model/recnext.py:33 */
@@ -51,6 +51,15 @@ const char* rcx_recconv2d_fwd_plan(int N, int C, int H, int W, int level, int k,
 /* Repack one depthwise weight (C,1,k,k) [dtype f32|bf16] -> float32 (k,k,C).
  * Replaces nothing in the reference (layout plumbing for nn.Conv2d(groups=C).weight, model/recnext.py:21-22). */
 int rcx_pack_dw_weight(const void* w_ckk, float* dst_kkc, int C, int k, int dtype, void* stream);
+/* All parameters of one RecConv2d block in one launch: w[j] (C,1,k,k) and b[j] (C) [dtype f32|bf16|f16], j = 0 .. count-1 in pack
+ * order [down, convs[0], ..., convs[level]] (HOST arrays of DEVICE pointers; b may be NULL, b[j] may be NULL) -> wpack (count,k,k,C),
+ * wpack_flipped (the same with every k x k rotated by 180 degrees: the taps rcx_recconv2d_bwd wants; may be NULL) and bpack (count,C)
+ * (may be NULL), all float32.  A training step repacks after every optimizer step (engine.py:38-71): this replaces 2*(level+2)
+ * rcx_pack_dw_weight / rcx_pack_bias launches and the flip. */
+int rcx_pack_recconv_params(const void* const* w, const void* const* b, float* wpack, float* wpack_flipped, float* bpack,
+                            int count, int C, int k, int dtype, void* stream);
+/* The inverse layout change for the gradients: gwpack (count,k,k,C) float32 -> gw[j] (C,1,k,k) float32 contiguous, one launch. */
+int rcx_unpack_recconv_grads(const float* gwpack, void* const* gw, int count, int C, int k, void* stream);
 /* Convert one bias vector (C) [dtype f32|bf16] -> float32 (C). */
 int rcx_pack_bias(const void* b, float* dst, int C, int dtype, void* stream);
 

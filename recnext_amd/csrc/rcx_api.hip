@@ -162,6 +162,34 @@ int rcx_pack_dw_weight(const void* w_ckk, float* dst_kkc, int C, int k, int dtyp
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_pack_dw_weight");
 }
 
+int rcx_pack_recconv_params(const void* const* w, const void* const* b, float* wpack, float* wpack_flipped, float* bpack,
+                            int count, int C, int k, int dtype, void* stream)
+{
+    if (!w || !wpack || count <= 0 || count > RCX_MAX_LEVEL + 2 || C <= 0 || k <= 0) return fail(RCX_ERR_BAD_ARG, "rcx_pack_recconv_params: bad argument");
+    if (!known_dtype(dtype)) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
+    if (bpack && !b) return fail(RCX_ERR_BAD_ARG, "rcx_pack_recconv_params: bias destination without bias sources");
+    rcx::PackPtrs P{};
+    for (int j = 0; j < count; ++j) {
+        if (!w[j]) return fail(RCX_ERR_BAD_ARG, "rcx_pack_recconv_params: null weight %d", j);
+        P.w[j] = w[j];
+        P.b[j] = b ? b[j] : nullptr;
+    }
+    hipError_t e = rcx::pack_params(P, wpack, wpack_flipped, bpack, count, C, k, dtype, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "rcx_pack_recconv_params");
+}
+
+int rcx_unpack_recconv_grads(const float* gwpack, void* const* gw, int count, int C, int k, void* stream)
+{
+    if (!gwpack || !gw || count <= 0 || count > RCX_MAX_LEVEL + 2 || C <= 0 || k <= 0) return fail(RCX_ERR_BAD_ARG, "rcx_unpack_recconv_grads: bad argument");
+    rcx::PackPtrs P{};
+    for (int j = 0; j < count; ++j) {
+        if (!gw[j]) return fail(RCX_ERR_BAD_ARG, "rcx_unpack_recconv_grads: null destination %d", j);
+        P.w[j] = gw[j];
+    }
+    hipError_t e = rcx::unpack_grads(gwpack, P, count, C, k, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "rcx_unpack_recconv_grads");
+}
+
 int rcx_pack_bias(const void* b, float* dst, int C, int dtype, void* stream)
 {
     if (!b || !dst || C <= 0) return fail(RCX_ERR_BAD_ARG, "rcx_pack_bias: bad argument");

@@ -295,6 +295,48 @@ hipError_t pack_dw_weight(const void* w, float* dst, int C, int k, int dt, hipSt
     return hipGetLastError();
 }
 
+// every parameter of a RecConv2d block in ONE launch (a training step repacks them after each optimizer step): blockIdx.y = conv;
+// also writes the pack with every k x k flipped (the backward's conv^T taps) and the float32 biases.  wflip / bpack may be null.
+template <typename T>
+__global__ void k_pack_params(PackPtrs P, float* __restrict__ wpack, float* __restrict__ wflip, float* __restrict__ bpack, int C, int kk)
+{
+    const int j = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * kk) return;
+    const int tap = i / C, c = i % C;
+    const float v = elem_to_f32(reinterpret_cast<const T*>(P.w[j])[(size_t)c * kk + tap]);
+    wpack[(size_t)j * kk * C + i] = v;
+    if (wflip) wflip[(size_t)j * kk * C + (size_t)(kk - 1 - tap) * C + c] = v;
+    if (bpack && tap == 0) bpack[(size_t)j * C + c] = P.b[j] ? elem_to_f32(reinterpret_cast<const T*>(P.b[j])[c]) : 0.f;
+}
+
+hipError_t pack_params(const PackPtrs& P, float* wpack, float* wflip, float* bpack, int count, int C, int k, int dt, hipStream_t s)
+{
+    const int n = C * k * k;
+    dim3 grid((n + 255) / 256, count), block(256);
+    if (dt == 0) hipLaunchKernelGGL(k_pack_params<float>, grid, block, 0, s, P, wpack, wflip, bpack, C, k * k);
+    else if (dt == 2) hipLaunchKernelGGL(k_pack_params<f16_t>, grid, block, 0, s, P, wpack, wflip, bpack, C, k * k);
+    else hipLaunchKernelGGL(k_pack_params<bf16_t>, grid, block, 0, s, P, wpack, wflip, bpack, C, k * k);
+    return hipGetLastError();
+}
+
+// the packed weight gradients (count, k*k, C) back into the parameters' layout, each (C, 1, k, k) float32 contiguous: one launch
+__global__ void k_unpack_grads(const float* __restrict__ gwpack, PackPtrs P, int C, int kk)
+{
+    const int j = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // index into the destination (channel-major)
+    if (i >= C * kk) return;
+    const int c = i / kk, tap = i % kk;
+    reinterpret_cast<float*>(const_cast<void*>(P.w[j]))[i] = gwpack[(size_t)j * kk * C + (size_t)tap * C + c];
+}
+
+hipError_t unpack_grads(const float* gwpack, const PackPtrs& P, int count, int C, int k, hipStream_t s)
+{
+    const int n = C * k * k;
+    hipLaunchKernelGGL(k_unpack_grads, dim3((n + 255) / 256, count), dim3(256), 0, s, gwpack, P, C, k * k);
+    return hipGetLastError();
+}
+
 hipError_t pack_bias(const void* b, float* dst, int C, int dt, hipStream_t s)
 {
     // a bias is a (C,1,1,1) weight with one tap

@@ -27,6 +27,9 @@ hipError_t generic_dwconv_mult2(const void* x, void* y, const float* w, const fl
                                 int N, int Cin, int H, int W, int k, int stride, int dt, hipStream_t s);
 hipError_t pack_dw_weight(const void* w, float* dst, int C, int k, int dt, hipStream_t s);
 hipError_t pack_bias(const void* b, float* dst, int C, int dt, hipStream_t s);
+struct PackPtrs { const void* w[10]; const void* b[10]; };         // RCX_MAX_LEVEL + 2 convs
+hipError_t pack_params(const PackPtrs& P, float* wpack, float* wflip, float* bpack, int count, int C, int k, int dt, hipStream_t s);
+hipError_t unpack_grads(const float* gwpack, const PackPtrs& P, int count, int C, int k, hipStream_t s);
 
 // rcx_plane.hip -- fused single-launch schedule (k=5, C%8==0, pyramid fits in LDS)
 bool plane_applicable(int N, int C, int H, int W, int level, int k, int dtype);

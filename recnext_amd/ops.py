@@ -75,22 +75,55 @@ def pack_bias(b, out=None):
     return out
 
 
-def pack_recconv_params(w_down, w_convs, b_down=None, b_convs=None):
-    """-> (wpack (level+2, k*k*C) f32, bpack (level+2, C) f32 | None): [down, convs[0], ..., convs[level]]."""
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
+
+
+def pack_recconv_params(w_down, w_convs, b_down=None, b_convs=None, with_flipped=False):
+    """-> (wpack (level+2, k*k*C) f32, bpack (level+2, C) f32 | None): [down, convs[0], ..., convs[level]].
+
+    One launch for the whole block (rcx_pack_recconv_params).  with_flipped=True also returns the pack with every k x k
+    rotated by 180 degrees -- the taps of the backward's transposed convolutions -- as a third value."""
     ws = [w_down] + list(w_convs)
     c, k = w_down.shape[0], w_down.shape[-1]
-    wpack = torch.empty((len(ws), k * k * c), dtype=torch.float32, device=w_down.device)
-    for i, w in enumerate(ws):
+    _require_gpu(w_down, "weight")
+    for w in ws:
         if tuple(w.shape[-2:]) != (k, k) or w.shape[0] != c:
             raise ValueError("all RecConv2d weights must share (C,1,k,k)")
-        pack_dw_weight(w, wpack[i])
-    bpack = None
+    dev = w_down.device
+    wpack = torch.empty((len(ws), k * k * c), dtype=torch.float32, device=dev)
+    bs, bpack = None, None
     if b_down is not None:
         bs = [b_down] + list(b_convs)
-        bpack = torch.empty((len(bs), c), dtype=torch.float32, device=w_down.device)
-        for i, b in enumerate(bs):
+        bpack = torch.empty((len(bs), c), dtype=torch.float32, device=dev)
+    if any(p.dtype != w_down.dtype or p.device != dev for p in ws + (bs or [])):
+        # parameters of mixed dtype: one launch per tensor
+        for i, w in enumerate(ws):
+            pack_dw_weight(w, wpack[i])
+        for i, b in enumerate(bs or []):
             pack_bias(b, bpack[i])
-    return wpack, bpack
+        return (wpack, bpack, wpack.view(len(ws), k, k, c).flip(1, 2).reshape(len(ws), -1).contiguous()) if with_flipped else (wpack, bpack)
+    ws = [w.detach().contiguous() for w in ws]
+    bs = [b.detach().contiguous() for b in bs] if bs else None
+    wflip = torch.empty_like(wpack) if with_flipped else None
+    with torch.cuda.device(dev):
+        rc = _lib.load().rcx_pack_recconv_params(_ptr_array(ws), _ptr_array(bs) if bs else None, wpack.data_ptr(),
+                                                 wflip.data_ptr() if wflip is not None else None,
+                                                 bpack.data_ptr() if bpack is not None else None,
+                                                 len(ws), c, k, _dt(w_down), _stream(dev))
+    _lib.check(rc, "rcx_pack_recconv_params")
+    return (wpack, bpack, wflip) if with_flipped else (wpack, bpack)
+
+
+def unpack_recconv_grads(gwpack, count, c, k):
+    """gwpack (count, k*k*C) f32 -> (count, C, 1, k, k) f32, each [i] contiguous in the parameter's layout; one launch."""
+    out = torch.empty((count, c, 1, k, k), dtype=torch.float32, device=gwpack.device)
+    with torch.cuda.device(gwpack.device):
+        rc = _lib.load().rcx_unpack_recconv_grads(gwpack.data_ptr(), _ptr_array([out[i] for i in range(count)]), count, c, k,
+                                                  _stream(gwpack.device))
+    _lib.check(rc, "rcx_unpack_recconv_grads")
+    return out
 
 
 def recconv2d_plan(n, c, h, w, level, k, mode, dtype):
@@ -287,13 +320,15 @@ def recconv2d_forward_train(x, wpack, bpack, level, k, mode="bilinear"):
     return y, saved
 
 
-def recconv2d_backward(x, gy, wpack, saved, level, k, mode="bilinear", need_bias=False):
-    """-> (gx like x, gwpack (level+2, k*k*C) f32, gbpack (level+2, C) f32 | None). Deterministic."""
+def recconv2d_backward(x, gy, wpack, saved, level, k, mode="bilinear", need_bias=False, wflip=None):
+    """-> (gx like x, gwpack (level+2, k*k*C) f32, gbpack (level+2, C) f32 | None). Deterministic.
+    wflip: the flipped pack from pack_recconv_params(with_flipped=True), if the caller has it (else it is made here)."""
     x = _nhwc(x)
     n, c, h, w = x.shape
     gy = _nhwc(gy.to(torch.float32), "grad_output")
     lib = _lib.load()
-    wflip = wpack.view(level + 2, k, k, c).flip(1, 2).contiguous()
+    if wflip is None:
+        wflip = wpack.view(level + 2, k, k, c).flip(1, 2).contiguous()
     gx = _empty_nhwc(n, c, h, w, x.dtype, x.device)
     gw = torch.empty_like(wpack)
     gb = torch.empty((level + 2, c), dtype=torch.float32, device=x.device) if need_bias else None

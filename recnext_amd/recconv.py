@@ -36,6 +36,7 @@ class RecConv2d(nn.Module):
         self.convs = nn.ModuleList([nn.Conv2d(**kwargs) for _ in range(level + 1)])
         self._pack_key = None
         self._pack = None
+        self._wflip = None                                  # the pack with every k x k flipped (the backward's taps)
         # Optional per-channel affine applied to the block's OUTPUT (y*scale + shift), folded into
         # convs[level] when the packs are built: used to absorb the eval-mode BatchNorm that follows the
         # token mixer in MetaNeXtBlock (model/recnext.py:153,158) -- SURVEY.md section 8f row 2.
@@ -68,7 +69,8 @@ class RecConv2d(nn.Module):
         if self.fold_scale is not None:
             key += ((self.fold_scale.data_ptr(), self.fold_scale._version, self.fold_shift._version),)
         if key != self._pack_key:
-            wpack, bpack = ops.pack_recconv_params(ws[0], ws[1:], bs[0] if bs else None, bs[1:] if bs else None)
+            wpack, bpack, self._wflip = ops.pack_recconv_params(ws[0], ws[1:], bs[0] if bs else None, bs[1:] if bs else None,
+                                                                with_flipped=True)
             if self.fold_scale is not None:
                 c, k = self.in_channels, self.kernel_size
                 if bpack is None:
@@ -130,18 +132,18 @@ class _RecConv2dFn(torch.autograd.Function):
         wpack, bpack = module.packed_params()
         y, saved = ops.recconv2d_forward_train(x, wpack, bpack, module.level, module.kernel_size, module.mode)
         ctx.module = module
-        ctx.save_for_backward(x, wpack, saved)
+        ctx.save_for_backward(x, wpack, saved, module._wflip)
         ctx.has_bias = bpack is not None
         ctx.param_dtypes = [p.dtype for p in params]
         return y
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, wpack, saved = ctx.saved_tensors
+        x, wpack, saved, wflip = ctx.saved_tensors
         m = ctx.module
         k, c, L = m.kernel_size, m.in_channels, m.level
-        gx, gw, gb = ops.recconv2d_backward(x, grad_out, wpack, saved, L, k, m.mode, need_bias=ctx.has_bias)
-        gw = gw.view(L + 2, k, k, c).permute(0, 3, 1, 2).unsqueeze(2)        # (L+2, C, 1, k, k)
+        gx, gw, gb = ops.recconv2d_backward(x, grad_out, wpack, saved, L, k, m.mode, need_bias=ctx.has_bias, wflip=wflip)
+        gw = ops.unpack_recconv_grads(gw, L + 2, c, k)                       # (L+2, C, 1, k, k), each [i] contiguous
         grads = []
         # parameter order of nn.Module.parameters(): down.weight, [down.bias], convs.0.weight, [convs.0.bias], ...
         for i in range(L + 2):
