@@ -426,17 +426,34 @@ int rcx_recconv2d_bwd(const void* x, const float* gy, const float* wpack, const 
     RCX_TRY(rcx::bwd_wgrad(x, dtype, level >= 1 ? C_(1) : nullptr, gy, PART(slot), GW(1 + level), GB(1 + level), N, C, H, W,
                            level >= 1 ? L.h[1] : 0, level >= 1 ? L.w[1] : 0, H, W, k, 1, mode, 0, s, &rows), "bwd: final conv weight grad");
     add_slot(1 + level, PART(slot++), rows);
+    // A deeper block whose level (level - 2) plane is 14x14 -- the 28x28 / level 3 and 56x56 / level 4 blocks of RecNeXt at 224x224 --
+    // ends in exactly the 14x14 / level 2 block (input F_m, output C_m, convs[0..2], the shared down conv): its whole backward is
+    // the one fused launch, the levels above it keep the per-step kernels.
+    int m = 0;
+    if (level >= 3 && !lanes_off() && L.h[level - 2] == 14 && L.w[level - 2] == 14 &&
+        rcx::cplbwd_applicable(N, C, 14, 14, 2, k, RCX_DTYPE_F32)) {
+        const char* nv = getenv("RCX_BWD_NESTED");
+        if (!(nv && *nv == '0')) m = level - 2;
+    }
     // up recursion (:31-33), finest level first in the backward direction
     for (int l = 1; l <= level; ++l) {
         const int j = level - l;
         RCX_TRY(rcx::bwd_resize(G_(l - 1), gC, N, C, L.h[l - 1], L.w[l - 1], L.h[l], L.w[l], mode, s), "bwd: resize adjoint");
+        if (m && l == m) {
+            float* parts[4];
+            for (int q = 0; q < 4; ++q) parts[q] = PART(slot++);
+            RCX_TRY(rcx::cplbwd_recconv(F_(m), gC, wpack, wpack_flipped, saved, L.f_off + m, L.c_off + m, G_(m), parts, N, C, 14, 2,
+                                        mode == RCX_MODE_NEAREST ? 1 : 0, RCX_DTYPE_F32, s), "bwd: fused nested block");
+            for (int q = 0; q < 4; ++q) add_slot(q, parts[q], N);
+            break;
+        }
         RCX_TRY(step_dwconv(gC, G_(l), Wf(1 + j), nullptr, N, C, L.h[l], L.w[l], k, 1, RCX_DTYPE_F32, RCX_DTYPE_F32, s), "bwd: conv input grad");
         RCX_TRY(rcx::bwd_wgrad(F_(l), RCX_DTYPE_F32, l < level ? C_(l + 1) : nullptr, gC, PART(slot), GW(1 + j), GB(1 + j), N, C, L.h[l], L.w[l],
                                l < level ? L.h[l + 1] : 0, l < level ? L.w[l + 1] : 0, L.h[l], L.w[l], k, 1, mode, 0, s, &rows), "bwd: conv weight grad");
         add_slot(1 + j, PART(slot++), rows);
     }
     // down ladder (:27-29), coarsest first: the shared weight accumulates over all levels
-    for (int l = level; l >= 1; --l) {
+    for (int l = m ? m : level; l >= 1; --l) {
         RCX_TRY(rcx::bwd_wgrad(l == 1 ? x : (const void*)F_(l - 1), l == 1 ? dtype : RCX_DTYPE_F32, nullptr, G_(l), PART(slot), GW(0), GB(0),
                                N, C, L.h[l - 1], L.w[l - 1], 0, 0, L.h[l], L.w[l], k, 2, mode, 0, s, &rows), "bwd: down weight grad");
         add_slot(0, PART(slot++), rows);

@@ -301,12 +301,14 @@ def test_fused_training_forward_leaves_the_same_pyramid(shape, dtype, monkeypatc
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("mode", ["bilinear", "nearest"])
-@pytest.mark.parametrize("shape", [(2, 512, 7, 1), (3, 40, 7, 1), (2, 64, 7, 1), (2, 256, 14, 2), (3, 100, 14, 2), (1, 192, 14, 2)],
+@pytest.mark.parametrize("shape", [(2, 512, 7, 1), (3, 40, 7, 1), (2, 64, 7, 1), (2, 256, 14, 2), (3, 100, 14, 2), (1, 192, 14, 2),
+                                   (2, 128, 28, 3), (1, 96, 28, 3), (2, 64, 56, 4)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_fused_backward_matches_the_per_step_backward(shape, mode, dtype, monkeypatch):
     """rcx_recconv2d_bwd on the channel-per-lane backward kernels (rcx_cplbwd.hip: the block's whole adjoint in one launch, one
     partial row per image, then the batch reduction) against the per-step schedule (RCX_BWD_FUSED=0): same gx, gW, gb up to the
-    float32 summation order (and, for 16-bit I/O, one rounding of gx)."""
+    float32 summation order (and, for 16-bit I/O, one rounding of gx).  The 28x28 / level 3 and 56x56 / level 4 blocks hand their
+    14x14-and-below part to the same kernel (float32 in and out)."""
     from recnext_amd import ops
     n, c, hw, level = shape
     dev = torch.device("cuda:0")
