@@ -65,6 +65,55 @@ k_down_bwd_input(const float* __restrict__ base, const float* __restrict__ g, TO
     }
 }
 
+// The same two adjoints with the kernel size known at compile time (K = 5: the RecConv2d ladder, K = 7: Downsample).  A fine pixel
+// (iy, ix) only meets the taps u = (iy + P) mod 2 + 2 uu, v = (ix + P) mod 2 + 2 vv: ceil(K/2)^2 candidates instead of K^2 loop
+// trips with a parity test each (the generic kernels above: 381 us for the first Downsample of RecNeXt-M3 at batch 128, whose
+// traffic is worth 25).  MULT = 1: out = base + D^T g on BW_V channels per thread; MULT = 2: two input = four output channels.
+template <typename TO, int K, int MULT>
+__global__ void __launch_bounds__(256)
+k_down_bwd_input_k(const float* __restrict__ base, const float* __restrict__ g, TO* __restrict__ out, const float* __restrict__ w, BwGeom q)
+{
+    constexpr int P = K / 2, NT = (K + 1) / 2, CV = MULT == 2 ? 2 : BW_V;       // input channels per thread
+    const int cvecs = q.C / CV, Cg = MULT * q.C;                                 // g and w have Cg channels
+    const long long total = (long long)q.N * q.H * q.W * cvecs;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        long long r = t;
+        const int c = (int)(r % cvecs) * CV; r /= cvecs;
+        const int ix = (int)(r % q.W); r /= q.W;
+        const int iy = (int)(r % q.H);
+        const int n = (int)(r / q.H);
+        float acc[CV];
+#pragma unroll
+        for (int i = 0; i < CV; ++i) acc[i] = 0.f;
+        if (MULT == 1 && base) load_vec<CV>(base + (((size_t)n * q.H + iy) * q.W + ix) * q.C + c, acc);
+        const int pu = (iy + P) & 1, pv = (ix + P) & 1;
+        const int oy0 = (iy + P - pu) >> 1, ox0 = (ix + P - pv) >> 1;            // the output pixel tap (pu, pv) pairs with
+        const float* gimg = g + (size_t)n * q.Hc * q.Wc * Cg + MULT * c;
+        const float* wc = w + MULT * c;
+#pragma unroll
+        for (int uu = 0; uu < NT; ++uu) {
+            const int u = pu + 2 * uu, oy = oy0 - uu;
+            if (u >= K || oy < 0 || oy >= q.Hc) continue;
+#pragma unroll
+            for (int vv = 0; vv < NT; ++vv) {
+                const int v = pv + 2 * vv, ox = ox0 - vv;
+                if (v >= K || ox < 0 || ox >= q.Wc) continue;
+                float gv[4], wv[4];
+                load_vec<4>(gimg + ((size_t)oy * q.Wc + ox) * Cg, gv);
+                load_vec<4>(wc + (size_t)(u * K + v) * Cg, wv);
+                if constexpr (MULT == 2) {
+                    acc[0] = fmaf(wv[0], gv[0], fmaf(wv[1], gv[1], acc[0]));
+                    acc[1] = fmaf(wv[2], gv[2], fmaf(wv[3], gv[3], acc[1]));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(wv[i], gv[i], acc[i]);
+                }
+            }
+        }
+        store_vec<CV>(out + (((size_t)n * q.H + iy) * q.W + ix) * q.C + c, acc);
+    }
+}
+
 // ---- R^T: gc(coarse) = sum over the fine pixels that read this coarse pixel, with the forward's exact weights ----
 __device__ __forceinline__ float axis_weight(int d, int target, int n_in, float scale, int mode)
 {
@@ -560,6 +609,11 @@ hipError_t bwd_mult2(const void* x, int x_dt, const float* g, const float* w, vo
     q.N = N; q.C = Cin; q.H = H; q.W = W; q.Hc = Ho; q.Wc = Wo; q.k = k;
     if (gx) {
         const unsigned grid = grid_for((long long)N * H * W * (Cin / 2));
+        if (k == 7) {
+            if (x_dt == 1) hipLaunchKernelGGL((k_down_bwd_input_k<bf16_t, 7, 2>), dim3(grid), dim3(256), 0, s, (const float*)nullptr, g, (bf16_t*)gx, w, q);
+            else if (x_dt == 2) hipLaunchKernelGGL((k_down_bwd_input_k<f16_t, 7, 2>), dim3(grid), dim3(256), 0, s, (const float*)nullptr, g, (f16_t*)gx, w, q);
+            else hipLaunchKernelGGL((k_down_bwd_input_k<float, 7, 2>), dim3(grid), dim3(256), 0, s, (const float*)nullptr, g, (float*)gx, w, q);
+        } else
         if (x_dt == 1) hipLaunchKernelGGL(k_down_bwd_input_mult2<bf16_t>, dim3(grid), dim3(256), 0, s, g, (bf16_t*)gx, w, q);
         else if (x_dt == 2) hipLaunchKernelGGL(k_down_bwd_input_mult2<f16_t>, dim3(grid), dim3(256), 0, s, g, (f16_t*)gx, w, q);
         else hipLaunchKernelGGL(k_down_bwd_input_mult2<float>, dim3(grid), dim3(256), 0, s, g, (float*)gx, w, q);
@@ -589,6 +643,12 @@ hipError_t bwd_down_input(const float* base, const float* g, void* out, int out_
     BwGeom q{};
     q.N = N; q.C = C; q.H = H; q.W = W; q.Hc = Hc; q.Wc = Wc; q.k = k;
     const unsigned grid = grid_for((long long)N * H * W * (C / BW_V));
+    if (k == 5) {
+        if (out_dt == 1) hipLaunchKernelGGL((k_down_bwd_input_k<bf16_t, 5, 1>), dim3(grid), dim3(256), 0, s, base, g, (bf16_t*)out, w, q);
+        else if (out_dt == 2) hipLaunchKernelGGL((k_down_bwd_input_k<f16_t, 5, 1>), dim3(grid), dim3(256), 0, s, base, g, (f16_t*)out, w, q);
+        else hipLaunchKernelGGL((k_down_bwd_input_k<float, 5, 1>), dim3(grid), dim3(256), 0, s, base, g, (float*)out, w, q);
+        return hipGetLastError();
+    }
     if (out_dt == 1) hipLaunchKernelGGL(k_down_bwd_input<bf16_t>, dim3(grid), dim3(256), 0, s, base, g, (bf16_t*)out, w, q);
     else if (out_dt == 2) hipLaunchKernelGGL(k_down_bwd_input<f16_t>, dim3(grid), dim3(256), 0, s, base, g, (f16_t*)out, w, q);
     else hipLaunchKernelGGL(k_down_bwd_input<float>, dim3(grid), dim3(256), 0, s, base, g, (float*)out, w, q);
