@@ -338,7 +338,13 @@ k_wgrad_rows(const TA* __restrict__ a, const float* __restrict__ coarse, const f
                         if (gok[u] && ox >= 0 && ox < Wo) ld2(grow[u] + (size_t)ox * q.C, gw[u][d]);
                     }
                 }
-                for (int ix = 0; ix < q.W; ++ix) {
+                // the window is a ring: K pixels per trip of the loop, so that its slots keep their registers (a shifting window costs
+                // 2 K (K - 1) moves per pixel, as many as a third of the FMAs); logical slot d sits in physical slot (d + jj) % K
+                for (int ix0 = 0; ix0 < q.W; ix0 += K) {
+#pragma unroll
+                  for (int jj = 0; jj < K; ++jj) {
+                    const int ix = ix0 + jj;
+                    if (ix >= q.W) break;
                     float tv[AV], t[2];
                     lda(arow + (size_t)ix * Ca, tv);
                     t[0] = tv[0]; t[1] = tv[AV - 1];
@@ -364,18 +370,18 @@ k_wgrad_rows(const TA* __restrict__ a, const float* __restrict__ coarse, const f
                     for (int u = 0; u < K; ++u)
 #pragma unroll
                         for (int v = 0; v < K; ++v) {
-                            acc[u * K + v][0] = fmaf(t[0], gw[u][K - 1 - v][0], acc[u * K + v][0]);
-                            acc[u * K + v][1] = fmaf(t[1], gw[u][K - 1 - v][1], acc[u * K + v][1]);
+                            acc[u * K + v][0] = fmaf(t[0], gw[u][(K - 1 - v + jj) % K][0], acc[u * K + v][0]);
+                            acc[u * K + v][1] = fmaf(t[1], gw[u][(K - 1 - v + jj) % K][1], acc[u * K + v][1]);
                         }
-                    accb[0] += gw[P][P][0]; accb[1] += gw[P][P][1];       // g(iy, ix): every output pixel exactly once
+                    accb[0] += gw[P][(P + jj) % K][0]; accb[1] += gw[P][(P + jj) % K][1];       // g(iy, ix): every output pixel exactly once
+                    // the slot that held logical 0 takes the next pixel's logical K - 1
 #pragma unroll
                     for (int u = 0; u < K; ++u) {
-#pragma unroll
-                        for (int d = 0; d < K - 1; ++d) { gw[u][d][0] = gw[u][d + 1][0]; gw[u][d][1] = gw[u][d + 1][1]; }
                         const int ox = ix + 1 + P;
-                        gw[u][K - 1][0] = gw[u][K - 1][1] = 0.f;
-                        if (gok[u] && ox < Wo) ld2(grow[u] + (size_t)ox * q.C, gw[u][K - 1]);
+                        gw[u][jj][0] = gw[u][jj][1] = 0.f;
+                        if (gok[u] && ox < Wo) ld2(grow[u] + (size_t)ox * q.C, gw[u][jj]);
                     }
+                  }
                 }
             }
         } else {
@@ -401,7 +407,13 @@ k_wgrad_rows(const TA* __restrict__ a, const float* __restrict__ coarse, const f
                         if (aok[u] && ix >= 0 && ix < q.W) lda(arow[u] + (size_t)ix * Ca, aw[u][d]);
                     }
                 }
-                for (int ox = 0; ox < Wo; ++ox) {
+                // ring window again: two slots retire per output pixel, K odd, so K pixels bring every slot back to its register;
+                // logical slot d sits in physical slot (d + 2 jj) % K
+                for (int ox0 = 0; ox0 < Wo; ox0 += K) {
+#pragma unroll
+                  for (int jj = 0; jj < K; ++jj) {
+                    const int ox = ox0 + jj;
+                    if (ox >= Wo) break;
                     float gv[2];
                     ld2(grow + (size_t)ox * q.C, gv);
                     accb[0] += gv[0]; accb[1] += gv[1];
@@ -409,23 +421,21 @@ k_wgrad_rows(const TA* __restrict__ a, const float* __restrict__ coarse, const f
                     for (int u = 0; u < K; ++u)
 #pragma unroll
                         for (int v = 0; v < K; ++v) {
-                            acc[u * K + v][0] = fmaf(aw[u][v][0], gv[0], acc[u * K + v][0]);
-                            acc[u * K + v][1] = fmaf(aw[u][v][AV - 1], gv[1], acc[u * K + v][1]);
+                            acc[u * K + v][0] = fmaf(aw[u][(v + 2 * jj) % K][0], gv[0], acc[u * K + v][0]);
+                            acc[u * K + v][1] = fmaf(aw[u][(v + 2 * jj) % K][AV - 1], gv[1], acc[u * K + v][1]);
                         }
 #pragma unroll
                     for (int u = 0; u < K; ++u) {
 #pragma unroll
-                        for (int d = 0; d < K - 2; ++d)
-#pragma unroll
-                            for (int i = 0; i < AV; ++i) aw[u][d][i] = aw[u][d + 2][i];
-#pragma unroll
                         for (int d = K - 2; d < K; ++d) {
                             const int ix = 2 * (ox + 1) - P + d;
+                            const int ph = (d + 2 * (jj + 1)) % K;          // where logical d of the NEXT pixel lives: a slot that just retired
 #pragma unroll
-                            for (int i = 0; i < AV; ++i) aw[u][d][i] = 0.f;
-                            if (aok[u] && ix < q.W) lda(arow[u] + (size_t)ix * Ca, aw[u][d]);
+                            for (int i = 0; i < AV; ++i) aw[u][ph][i] = 0.f;
+                            if (aok[u] && ix < q.W) lda(arow[u] + (size_t)ix * Ca, aw[u][ph]);
                         }
                     }
+                  }
                 }
             }
         }
