@@ -593,6 +593,11 @@ hipError_t bwd_wgrad(const void* a, int a_dt, const float* coarse, const float* 
                      int N, int C, int H, int W, int Hc, int Wc, int Ho, int Wo, int k, int stride, int mode, int accumulate, hipStream_t s,
                      int* rows_out)
 {
+    // the 56x56 / 28x28 convs over T = a + R(coarse): tiled channel-per-lane kernel (rcx_cplwgrad.hip), when the caller reduces itself
+    if (rows_out && Ho == H && Wo == W && wgrad_cpl_applicable(N, C, H, W, Hc, Wc, k, stride, coarse != nullptr))
+        return wgrad_cpl(a, a_dt, coarse, g, partial, N, C, H, mode, s, rows_out);
+    if (rows_out && wgrad2_cpl_applicable(N, C, H, W, Ho, Wo, k, stride, coarse != nullptr))
+        return wgrad2_cpl(a, a_dt, g, partial, N, C, H, s, rows_out);
     BwGeom q{};
     q.N = N; q.C = C; q.H = H; q.W = W; q.Hc = Hc; q.Wc = Wc; q.k = k; q.mode = mode;
     q.sy = Hc > 0 ? (float)Hc / (float)H : 0.f;

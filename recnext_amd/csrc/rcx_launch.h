@@ -71,6 +71,16 @@ hipError_t cplbwd_recconv(const void* x, const float* gy, const float* wpack, co
                           const size_t* f_off, const size_t* c_off, void* gx, float* const* part,
                           int N, int C, int H, int level, int mode, int dtype, hipStream_t s);
 
+// tiled channel-per-lane weight gradient of a stride-1 5x5 conv over T = a + R(coarse) on the 56x56 / 28x28 planes (rcx_cplwgrad.hip):
+// one partial row of (25 + 1) * C sums per (image, 14-row band)
+bool wgrad_cpl_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int stride, bool has_coarse);
+hipError_t wgrad_cpl(const void* a, int a_dt, const float* coarse, const float* g, float* partial, int N, int C, int H, int mode,
+                     hipStream_t s, int* rows_out);
+
+// ... and of the shared stride-2 5x5 conv (a: H x W, g: H/2 x W/2): one partial row per (image, 14-row band of g)
+bool wgrad2_cpl_applicable(int N, int C, int H, int W, int Ho, int Wo, int k, int stride, bool has_coarse);
+hipError_t wgrad2_cpl(const void* a, int a_dt, const float* g, float* partial, int N, int C, int H, hipStream_t s, int* rows_out);
+
 // channel-per-lane, tiled kernel of the 56x56 / level 4 and 28x28 / level 3 blocks (rcx_cpt.hip): any channel count
 bool cpt_applicable(int N, int C, int H, int W, int level, int k, int dtype);
 int cpt_describe(int N, int C, int H, int mode, int dtype, char* buf, int len);
