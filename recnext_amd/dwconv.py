@@ -89,9 +89,8 @@ class DownsampleDwConv(nn.Module):
 
     def forward(self, x):
         conv = self.token_mixer
-        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
         training = self.norm.training if self.norm is not None else conv.training     # the flags of the modules that own the state
-        if training or needs_grad:
+        if training or (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
             if conv.stride[0] != 2 or conv.kernel_size[0] not in (3, 5, 7) or x.shape[1] % 2:
                 raise NotImplementedError("the HIP backward of the multiplier-2 conv covers stride 2, k in {3,5,7}, even channel counts")
             y = DwConvMult2Fn.apply(x, conv.weight, conv.bias)

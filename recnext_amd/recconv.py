@@ -61,11 +61,21 @@ class RecConv2d(nn.Module):
         bs = [self.down.bias] + [cv.bias for cv in self.convs]
         return ws, (bs if bs[0] is not None else None)
 
+    def _plist(self):
+        """The parameters in nn.Module.parameters() order (down.weight, [down.bias], convs.0.weight, ...) without its module-tree
+        traversal -- that generator costs ~35 us a call, twice per forward, on a training step the host's launches already bound."""
+        out = []
+        for cv in (self.down, *self.convs):
+            out.append(cv.weight)
+            if cv.bias is not None:
+                out.append(cv.bias)
+        return out
+
     def packed_params(self):
         """(wpack, bpack) float32 tap-major copies, rebuilt only when a parameter changed."""
         ws, bs = self._params()
         allp = ws + (bs or [])
-        key = tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in allp)
+        key = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in allp)
         if self.fold_scale is not None:
             key += ((self.fold_scale.data_ptr(), self.fold_scale._version, self.fold_shift._version),)
         if key != self._pack_key:
@@ -87,7 +97,8 @@ class RecConv2d(nn.Module):
         # with grad mode on and something that requires grad takes it -- including a model in eval() called outside
         # torch.no_grad(), which is legal (the block has no train/eval distinction) but several times slower than the fused
         # inference kernels: warn once so that a forgotten no_grad() does not pass for a slow kernel.
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        plist = self._plist() if torch.is_grad_enabled() else ()
+        if plist and (x.requires_grad or any(p.requires_grad for p in plist)):
             if self.fold_scale is not None:
                 raise RuntimeError("this RecConv2d carries a folded output affine (fold_token_mixer_norms / fold_output_affine), an "
                                    "inference-only transform: wrap the call in torch.no_grad() (or torch.inference_mode())")
@@ -96,7 +107,7 @@ class RecConv2d(nn.Module):
                                           f"{self.in_channels}; run inference under torch.no_grad()")
             if not self.training and not x.requires_grad:
                 _warn_eval_with_grad()
-            return _RecConv2dFn.apply(x, self, *self.parameters())
+            return _RecConv2dFn.apply(x, self, *plist)
         wpack, bpack = self.packed_params()
         return ops.recconv2d_forward(x, wpack, bpack, self.level, self.kernel_size, self.mode)
 

@@ -105,3 +105,12 @@ def test_state_dict_keys_match_reference_block():
         ["down.weight", "down.bias"] + [f"convs.{i}.{p}" for i in range(3) for p in ("weight", "bias")])
     assert tuple(mod.down.weight.shape) == (8, 1, 5, 5)
     assert recnext_amd.RecConv2d(8, level=0).state_dict().keys() == {"down.weight", "convs.0.weight"}
+
+
+def test_parameter_list_shortcut_keeps_the_module_order():
+    """RecConv2d._plist() (the training forward's argument list, built without nn.Module.parameters()'s tree walk) must be exactly
+    parameters(): autograd hands the gradients back in that order."""
+    for bias in (False, True):
+        for level in (0, 1, 3):
+            mod = recnext_amd.RecConv2d(8, kernel_size=5, bias=bias, level=level)
+            assert [id(p) for p in mod._plist()] == [id(p) for p in mod.parameters()]

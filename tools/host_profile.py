@@ -44,3 +44,20 @@ for _ in range(200):
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+
+# ---- the backward runs on autograd's thread, which cProfile does not see: call the same functions directly ----
+from recnext_amd import ops
+
+wpack, bpack = mod.packed_params()
+wflip = mod._wflip
+xd = x.detach()
+pr = cProfile.Profile()
+torch.cuda.synchronize()
+pr.enable()
+for _ in range(200):
+    y, saved = ops.recconv2d_forward_train(xd, wpack, bpack, 2, 5, "bilinear")
+    gx, gw, gb = ops.recconv2d_backward(xd, g, wpack, saved, 2, 5, "bilinear", need_bias=False, wflip=wflip)
+    gwu = ops.unpack_recconv_grads(gw, 4, 256, 5)
+pr.disable()
+torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
