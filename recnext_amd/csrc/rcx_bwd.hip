@@ -636,6 +636,14 @@ hipError_t bwd_mult2(const void* x, int x_dt, const float* g, const float* w, vo
         if (e != hipSuccess) return e;
     }
     q.C = 2 * Cin;                                     // the weight-gradient kernel counts output channels
+    if (wgrad2m_cpl_applicable(N, q.C, H, W, k)) {      // the first two Downsample convs of RecNeXt at 224x224: tiled kernel (rcx_cplwgrad.hip)
+        int rows = 0;
+        hipError_t e2 = wgrad2m_cpl(x, x_dt, g, partial, N, q.C, H, s, &rows);
+        if (e2 != hipSuccess) return e2;
+        const int kk2 = k * k, n52 = (kk2 + 1) * q.C;
+        hipLaunchKernelGGL(k_wgrad_reduce8, dim3((n52 + 31) / 32), dim3(32, 8), 0, s, partial, gw, gb, rows, kk2, q.C, 0);
+        return hipGetLastError();
+    }
     int gy = wr_grid_y(q.C);
     const int need = (N * Ho + WR_SLOTS - 1) / WR_SLOTS;
     if (gy > need) gy = need < 1 ? 1 : need;

@@ -201,40 +201,61 @@ static hipError_t launch_h(const void* a, const float* coarse, const float* g, f
     return H == 56 ? launch<MODE, TA, 56>(a, coarse, g, partial, N, C, s) : launch<MODE, TA, 28>(a, coarse, g, partial, N, C, s);
 }
 
-// ---- the shared stride-2 conv (model/recnext.py:21, :28): gW[u][v] += sum_{o,i} G[o][i] * a[2o+u-2][2i+v-2] ----
-// A wave owns 64 channels of a 14 x 14 tile of G = the gradient of the conv's output, i.e. 31 rows x 32 columns of its input a
-// (two halo columns / rows on the low side, one on the high side, zeros outside the image).  Input-row stationary: an `a` row meets
-// the two or three G rows whose window covers it, tap pairs (v, v+1) against a's aligned pairs (rcx_cplbwd_pieces.h, wgrad2_row).
-template <typename TA, int H>
+// ---- stride-2 convs: gW[u][v] += sum_{o,i} G[o][i] * a[2o+u-P][2i+v-P] ----
+// K = 5, MULT = 1: the block's shared down conv (model/recnext.py:21, :28); K = 7, MULT = 2: the Downsample conv between stages
+// (nn.Conv2d(C, 2C, 7, stride 2, groups=C): a lane is an OUTPUT channel and reads input channel c / 2).
+// A wave owns 64 channels of a 14 x 14 tile of G = the gradient of the conv's output, i.e. (26 + K) rows x (26 + K) columns of its
+// input a (P halo pixels on the low side, P - 1 on the high side, zeros outside the image).  Input-row stationary: an `a` row meets
+// the (K + 1) / 2 G rows whose window covers it, tap pairs (v, v+1) against a's aligned pairs (rcx_cplbwd_pieces.h, wgrad2_row).
+template <int K>
+struct DAccK {
+    static constexpr int KP = (K + 1) / 2;
+    f32x2 a[K][KP];
+    f32x2 bs;
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int u = 0; u < K; ++u)
+#pragma unroll
+            for (int k = 0; k < KP; ++k) a[u][k] = f32x2{0.f, 0.f};
+        bs = f32x2{0.f, 0.f};
+    }
+    __device__ __forceinline__ float tap(int u, int v) const { return (v & 1) ? a[u][v >> 1].y : a[u][v >> 1].x; }
+    __device__ __forceinline__ float bias() const { return bs.x + bs.y; }
+};
+
+template <typename TA, int H, int K, int MULT>
 __global__ __launch_bounds__(64 * (H / 28))
 void k_wgrad2_cpl(const TA* __restrict__ a, const float* __restrict__ g, float* __restrict__ partial, int N, int C)
 {
-    constexpr int W = H, Ho = H / 2, Wo = W / 2, NT = Wo / 14, NB = Ho / 14, AP = 16;     // AP: pairs of an `a` row (32 columns)
-    __shared__ float red[NT][26][64];
+    constexpr int W = H, Ho = H / 2, Wo = W / 2, NT = Wo / 14, NB = Ho / 14, P = K / 2, KP = (K + 1) / 2, KK1 = K * K + 1;
+    constexpr int NS = 26 + K, AP = (NS + 1) / 2, RG = (K + 1) / 2;          // `a` rows / pairs per row of a tile, G ring
+    __shared__ float red[NT][KK1][64];
     const int tile = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-    const int nb = (C + 63) / 64;
+    const int nb = (C + 63) / 64;                                          // C: channels of g and of the weight
     const unsigned unit = blockIdx.x;
     const int cb = (int)(unit % (unsigned)nb), band = (int)((unit / (unsigned)nb) % (unsigned)NB), n = (int)(unit / (unsigned)(nb * NB));
     const int c = cb * 64 + lane;
     const bool live = c < C;
     const unsigned cl = (unsigned)(live ? c : C - 1);
     const int o0 = 14 * band, i0 = 14 * tile;
-    const unsigned voa = cl * (unsigned)sizeof(TA), vof = cl * 4u;
-    const size_t pixa = (size_t)C * sizeof(TA), pixf = (size_t)C * 4;
+    const int Ca = C / MULT;
+    const unsigned voa = (cl / (unsigned)MULT) * (unsigned)sizeof(TA), vof = cl * 4u;
+    const size_t pixa = (size_t)Ca * sizeof(TA), pixf = (size_t)C * 4;
     const gcptr ab = (gcptr)a + (size_t)n * H * W * pixa;
     const gcptr gb = (gcptr)g + (size_t)n * Ho * Wo * pixf;
 
-    uint32_t ra[31][32], rg[14][14];
-    auto ld_a = [&](auto sc) {                                             // local row s = image row 2 o0 - 2 + s, columns 2 i0 - 2 .. 2 i0 + 29 (clamped)
+    uint32_t ra[NS][2 * AP], rg[14][14];
+    auto ld_a = [&](auto sc) {                                             // local row s = image row 2 o0 - P + s, local column q = image column 2 i0 - P + q (clamped)
         constexpr int s = decltype(sc)::value;
-        int r = 2 * o0 - 2 + s;
+        int r = 2 * o0 - P + s;
         r = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
         const gcptr rowp = ab + (size_t)r * W * pixa;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            int col = 2 * i0 - 2 + q;
-            if (q < 2) col = col < 0 ? 0 : col;
-            if (q >= 30) col = col > W - 1 ? W - 1 : col;
+        for (int q = 0; q < 2 * AP; ++q) {
+            int col = 2 * i0 - P + q;
+            if (q < P) col = col < 0 ? 0 : col;
+            if (q >= 28 + P) col = col > W - 1 ? W - 1 : col;
             ra[s][q] = SafeLd<TA>::ld(rowp + (size_t)col * pixa + voa);
         }
     };
@@ -244,68 +265,74 @@ void k_wgrad2_cpl(const TA* __restrict__ a, const float* __restrict__ g, float* 
 #pragma unroll
         for (int q = 0; q < 14; ++q) rg[o][q] = SafeLd<float>::ld(rowp + (size_t)q * pixf + vof);
     };
-    f32x2 G[3][7];                                                         // ring: G row o in slot o % 3
-    const f32x2 keep_lo = splat(i0 == 0 ? 0.f : 1.f), keep_hi = splat(2 * i0 + 28 == W ? 0.f : 1.f);   // halo columns outside the image
-    DAcc acc;
+    f32x2 G[RG][7];                                                        // ring: G row o in slot o % RG
+    // columns outside the image (zero padding): masks of the two lowest and the two highest pairs (a multiply, not a branch)
+    f32x2 mlo[2], mhi[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        mlo[m] = f32x2{2 * i0 - P + 2 * m >= 0 ? 1.f : 0.f, 2 * i0 - P + 2 * m + 1 >= 0 ? 1.f : 0.f};
+        mhi[m] = f32x2{2 * i0 - P + 2 * (AP - 2 + m) < W ? 1.f : 0.f, 2 * i0 - P + 2 * (AP - 2 + m) + 1 < W ? 1.f : 0.f};
+    }
+    DAccK<K> acc;
     acc.zero();
     auto take_g = [&](auto oc) {
         constexpr int o = decltype(oc)::value;
         pin_raw(rg[o]);
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
-            G[o % 3][j] = f32x2{__uint_as_float(rg[o][2 * j]), __uint_as_float(rg[o][2 * j + 1])};
-            acc.bs = acc.bs + G[o % 3][j];
+            G[o % RG][j] = f32x2{__uint_as_float(rg[o][2 * j]), __uint_as_float(rg[o][2 * j + 1])};
+            acc.bs = acc.bs + G[o % RG][j];
         }
     };
     ld_g(IC<0>{});
     ld_a(IC<0>{});
     ld_a(IC<1>{});
     take_g(IC<0>{});
-    sfor<31>([&](auto sc) {
+    sfor<NS>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        if constexpr (s + 2 < 31) ld_a(IC<s + 2>{});
+        if constexpr (s + 2 < NS) ld_a(IC<s + 2>{});
         // G row o' is first met by `a` row s = 2 o': fetched two rows earlier, taken one row earlier
         if constexpr ((s & 1) == 0 && s / 2 + 1 < 14) ld_g(IC<s / 2 + 1>{});
         pin_raw(ra[s]);
         f32x2 ar[AP];
 #pragma unroll
         for (int m = 0; m < AP; ++m) ar[m] = f32x2{SafeLd<TA>::cvt(ra[s][2 * m]), SafeLd<TA>::cvt(ra[s][2 * m + 1])};
-        if constexpr (s < 2 || s == 30) {                                  // rows that can fall outside the image: zero padding
-            const int r = 2 * o0 - 2 + s;
+        if constexpr (s < P || s >= 28 + P) {                              // rows that can fall outside the image: zero padding
+            const int r = 2 * o0 - P + s;
             const f32x2 keep = splat(r >= 0 && r < H ? 1.f : 0.f);
 #pragma unroll
             for (int m = 0; m < AP; ++m) ar[m] = ar[m] * keep;
         }
-        ar[0] = ar[0] * keep_lo;
-        ar[AP - 1] = ar[AP - 1] * keep_hi;
+        ar[0] = ar[0] * mlo[0]; ar[1] = ar[1] * mlo[1];
+        ar[AP - 2] = ar[AP - 2] * mhi[0]; ar[AP - 1] = ar[AP - 1] * mhi[1];
 #pragma unroll
         for (int il = 0; il < 14; ++il) {
 #pragma unroll
             for (int o = 0; o < 14; ++o) {
                 const int u = s - 2 * o;
-                if (u < 0 || u > 4) continue;
-                const f32x2 gv = splat(at<7>(G[o % 3], il));
+                if (u < 0 || u > K - 1) continue;
+                const f32x2 gv = splat(at<7>(G[o % RG], il));
 #pragma unroll
-                for (int k = 0; k < 3; ++k) acc.a[u][k] = pfma(gv, ar[il + k], acc.a[u][k]);
+                for (int k = 0; k < KP; ++k) acc.a[u][k] = pfma(gv, ar[il + k], acc.a[u][k]);
             }
         }
 #pragma unroll
-        for (int u = 0; u < 5; ++u) pin(acc.a[u]);
+        for (int u = 0; u < K; ++u) pin(acc.a[u]);
         RCX_FENCE;
         if constexpr ((s & 1) == 1 && (s + 1) / 2 < 14) take_g(IC<(s + 1) / 2>{});       // needed from row s + 1 on; its slot retired with row s
         RCX_FENCE;
     });
 
 #pragma unroll
-    for (int u = 0; u < 5; ++u)
+    for (int u = 0; u < K; ++u)
 #pragma unroll
-        for (int v = 0; v < 5; ++v) red[tile][u * 5 + v][lane] = acc.tap(u, v);
-    red[tile][25][lane] = acc.bias();
+        for (int v = 0; v < K; ++v) red[tile][u * K + v][lane] = acc.tap(u, v);
+    red[tile][K * K][lane] = acc.bias();
     __syncthreads();
     if (tile == 0 && live) {
-        float* q = partial + ((size_t)(n * NB + band) * 26) * C + c;
+        float* q = partial + ((size_t)(n * NB + band) * KK1) * C + c;
 #pragma unroll
-        for (int t = 0; t < 26; ++t) {
+        for (int t = 0; t < KK1; ++t) {
             float sum = red[0][t][lane];
 #pragma unroll
             for (int w = 1; w < NT; ++w) sum += red[w][t][lane];
@@ -314,17 +341,17 @@ void k_wgrad2_cpl(const TA* __restrict__ a, const float* __restrict__ g, float* 
     }
 }
 
-template <typename TA, int H>
+template <typename TA, int H, int K, int MULT>
 static hipError_t launch2(const void* a, const float* g, float* partial, int N, int C, hipStream_t s)
 {
     const unsigned grid = (unsigned)(N * (H / 28) * ((C + 63) / 64));
-    hipLaunchKernelGGL((k_wgrad2_cpl<TA, H>), dim3(grid), dim3(64 * (H / 28)), 0, s, (const TA*)a, g, partial, N, C);
+    hipLaunchKernelGGL((k_wgrad2_cpl<TA, H, K, MULT>), dim3(grid), dim3(64 * (H / 28)), 0, s, (const TA*)a, g, partial, N, C);
     return hipGetLastError();
 }
-template <typename TA>
+template <typename TA, int K, int MULT>
 static hipError_t launch2_h(const void* a, const float* g, float* partial, int N, int C, int H, hipStream_t s)
 {
-    return H == 56 ? launch2<TA, 56>(a, g, partial, N, C, s) : launch2<TA, 28>(a, g, partial, N, C, s);
+    return H == 56 ? launch2<TA, 56, K, MULT>(a, g, partial, N, C, s) : launch2<TA, 28, K, MULT>(a, g, partial, N, C, s);
 }
 
 }  // namespace cplwgrad
@@ -349,8 +376,23 @@ bool wgrad2_cpl_applicable(int N, int C, int H, int W, int Ho, int Wo, int k, in
 hipError_t wgrad2_cpl(const void* a, int a_dt, const float* g, float* partial, int N, int C, int H, hipStream_t s, int* rows_out)
 {
     if (rows_out) *rows_out = N * (H / 28);
-    return a_dt == 1 ? cplwgrad::launch2_h<bf16_t>(a, g, partial, N, C, H, s) : a_dt == 2 ? cplwgrad::launch2_h<f16_t>(a, g, partial, N, C, H, s)
-                                                                                            : cplwgrad::launch2_h<float>(a, g, partial, N, C, H, s);
+    return a_dt == 1 ? cplwgrad::launch2_h<bf16_t, 5, 1>(a, g, partial, N, C, H, s) : a_dt == 2 ? cplwgrad::launch2_h<f16_t, 5, 1>(a, g, partial, N, C, H, s)
+                                                                                                  : cplwgrad::launch2_h<float, 5, 1>(a, g, partial, N, C, H, s);
+}
+
+// the Downsample conv (7x7, stride 2, channel multiplier 2): C = OUTPUT channels; rows of `partial`: N * (H / 28), each (49 + 1) * C
+bool wgrad2m_cpl_applicable(int N, int Cout, int H, int W, int k)
+{
+    const char* v = getenv("RCX_WGRAD_CPL");
+    if (v && *v == '0') return false;
+    return k == 7 && H == W && (H == 56 || H == 28) && Cout >= 2 && Cout % 2 == 0 && N * (H / 28) <= 512;
+}
+
+hipError_t wgrad2m_cpl(const void* a, int a_dt, const float* g, float* partial, int N, int Cout, int H, hipStream_t s, int* rows_out)
+{
+    if (rows_out) *rows_out = N * (H / 28);
+    return a_dt == 1 ? cplwgrad::launch2_h<bf16_t, 7, 2>(a, g, partial, N, Cout, H, s) : a_dt == 2 ? cplwgrad::launch2_h<f16_t, 7, 2>(a, g, partial, N, Cout, H, s)
+                                                                                                     : cplwgrad::launch2_h<float, 7, 2>(a, g, partial, N, Cout, H, s);
 }
 
 hipError_t wgrad_cpl(const void* a, int a_dt, const float* coarse, const float* g, float* partial, int N, int C, int H, int mode,

@@ -80,6 +80,9 @@ hipError_t wgrad_cpl(const void* a, int a_dt, const float* coarse, const float* 
 // ... and of the shared stride-2 5x5 conv (a: H x W, g: H/2 x W/2): one partial row per (image, 14-row band of g)
 bool wgrad2_cpl_applicable(int N, int C, int H, int W, int Ho, int Wo, int k, int stride, bool has_coarse);
 hipError_t wgrad2_cpl(const void* a, int a_dt, const float* g, float* partial, int N, int C, int H, hipStream_t s, int* rows_out);
+// ... and of the Downsample conv (7x7, stride 2, channel multiplier 2; Cout = 2 Cin channels of g and of the weight)
+bool wgrad2m_cpl_applicable(int N, int Cout, int H, int W, int k);
+hipError_t wgrad2m_cpl(const void* a, int a_dt, const float* g, float* partial, int N, int Cout, int H, hipStream_t s, int* rows_out);
 
 // channel-per-lane, tiled kernel of the 56x56 / level 4 and 28x28 / level 3 blocks (rcx_cpt.hip): any channel count
 bool cpt_applicable(int N, int C, int H, int W, int level, int k, int dtype);

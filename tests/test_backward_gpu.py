@@ -193,7 +193,9 @@ def test_recattn2d_training_step_matches_aten(stage, dim, hw):
         assert torch.allclose(br.float(), bo.float(), atol=1e-5, rtol=1e-4), name
 
 
-@pytest.mark.parametrize("case", [(2, 16, 14, 14, 7), (1, 64, 56, 56, 7), (3, 6, 9, 12, 7), (2, 8, 10, 10, 5), (2, 8, 7, 7, 3)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("case", [(2, 16, 14, 14, 7), (1, 64, 56, 56, 7), (3, 6, 9, 12, 7), (2, 8, 10, 10, 5), (2, 8, 7, 7, 3),
+                                  (2, 32, 28, 28, 7), (1, 24, 56, 56, 7), (2, 72, 28, 28, 7)],    # the tiled weight-gradient kernel: both plane sizes, ragged 64-channel blocks
+                         ids=lambda c: "x".join(map(str, c)))
 def test_downsample_conv_backward_matches_aten_autograd(case):
     """nn.Conv2d(C, 2C, k, stride=2, groups=C) + train-mode BatchNorm through DownsampleDwConv against ATen autograd."""
     from recnext_amd.dwconv import DownsampleDwConv
