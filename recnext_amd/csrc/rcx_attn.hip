@@ -453,6 +453,7 @@ k_linattn_bwd(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* _
 {
     __shared__ float a_s[LA_TT][LA_DMAX + 1];                 // k / q tile
     __shared__ float b_s[LA_TT][LA_DMAX + 1];                 // v / du tile
+    __shared__ float c_s[LA_TT][LA_DMAX + 1];                 // g * u, elementwise
     __shared__ float kv_s[LA_DMAX][LA_DMAX + 1];
     __shared__ float dkv_s[LA_DMAX][LA_DMAX + 1];
     __shared__ float kbar_s[LA_DMAX], dkbar_s[LA_DMAX];
@@ -513,16 +514,22 @@ k_linattn_bwd(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* _
             b_s[t][e] = la_ld(gout + g);                        // g for now, du below
         }
         __syncthreads();
-        if (tid < tt) {                                         // one thread per token: w and g . u
-            float wsum = 0.f;
-            for (int e = 0; e < D; ++e) wsum = fmaf(a_s[tid][e], kbar_s[e], wsum);
-            wsum += 1e-6f;
-            float gu = 0.f;
-            for (int e2 = 0; e2 < D; ++e2) {
-                float u = 0.f;
-                for (int e1 = 0; e1 < D; ++e1) u = fmaf(a_s[tid][e1], kv_s[e1][e2], u);
-                gu = fmaf(b_s[tid][e2], u, gu);
+        // g[t][e2] * u[t][e2] with every thread (one thread per token walking all D * D products left three quarters of the block
+        // idle for two thirds of the sweep), then one thread per token adds its row up
+        for (int i = tid; i < tt * D; i += LA_NT) {
+            const int t = i / D, e2 = i - t * D;
+            float u = 0.f;
+            for (int e1 = 0; e1 < D; ++e1) u = fmaf(a_s[t][e1], kv_s[e1][e2], u);
+            c_s[t][e2] = b_s[t][e2] * u;
+        }
+        __syncthreads();
+        if (tid < tt) {
+            float wsum = 0.f, gu = 0.f;
+            for (int e = 0; e < D; ++e) {
+                wsum = fmaf(a_s[tid][e], kbar_s[e], wsum);
+                gu += c_s[tid][e];
             }
+            wsum += 1e-6f;
             w_s[tid] = wsum;
             dw_s[tid] = -gu / (wsum * wsum);
         }
@@ -586,10 +593,281 @@ k_linattn_bwd(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* _
     }
 }
 
+// ---- the same backward on the matrix cores (head dimension 32, 16-bit I/O): every product above is a 32-wide contraction.
+// Layout conventions of v_mfma_f32_32x32x16 as in k_linattn_mfma: lane = (r, h) = (lane & 31, lane >> 5); an A fragment holds
+// A[row r][k = 8h + j], a B fragment B[k = 8h + j][col r], accumulator register i holds C[rho(h, i)][r], rho(h, i) = 8 (i >> 2) + 4 h + (i & 3).
+// Two orientations are used.  TOKEN PER LANE (lane r owns token g0 + r and reads its features rho(h, 0..15) as four 4-element
+// vectors; the products are taken transposed, C[feature][token], so that per-token scalars -- w, g . u, dw -- are lane-local up to
+// one exchange between the two halves): u^T = kv^T q^T, dq^T = kv du^T, dv^T = dkv^T k^T, dk^T = dkv v^T; the 32 x 32 operand is the A
+// fragment, either the accumulator registers themselves (kv^T, dkv^T: k runs over rho) or their LDS transpose (kv, dkv).  FEATURE PER
+// LANE (lane r owns feature r, k runs over 16 tokens, as the forward's first phase): kv = k^T v and dkv = q^T du, summed over the
+// block's waves through LDS in a fixed order.  Operands are rounded to the I/O type (as the forward's), accumulation is float32.
+template <typename T>
+__global__ void __launch_bounds__(LM_NW * 64)
+k_linattn_bwd_mfma(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* __restrict__ v, const T* __restrict__ gout,
+                   T* __restrict__ gq, T* __restrict__ gk, T* __restrict__ gv, int n, int C, int heads)
+{
+    typedef typename Mf<T>::frag frag;
+    __shared__ float part_s[LM_NW][16][64];                   // partial kv / dkv tiles in accumulator layout
+    __shared__ float mat_s[32][33];                           // kv, later dkv: [e1][e2] for the transposed reads
+    __shared__ float sum_s[LM_NW][2][32];                     // partial column sums (k, later dw * q)
+    __shared__ float kbar_s[32], dkbar_s[32];
+    __shared__ float xa_s[LM_NW][2][32], xb_s[LM_NW][2][32];  // per wave: halves of w and of g . u
+    __shared__ float w_s[LM_NW][32], dw_s[LM_NW][32];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x / heads, hd = blockIdx.x - b * heads;
+    const size_t base = (size_t)b * n * C + (size_t)hd * 32;
+    const float s2 = 1.f / (float)n;
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    // ---- phase 1 (feature per lane): kv = (1/n) k^T v, kbar = mean k
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float csum = 0.f;
+#pragma unroll 2
+    for (int t0 = 16 * w; t0 < n; t0 += 16 * LM_NW) {
+        float kk[8];
+        frag A, B;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = t0 + 8 * h + j;
+            const bool ok = t < n;
+            const size_t g = base + (size_t)(ok ? t : n - 1) * C + r;
+            kk[j] = ok ? la_ld(kpre + g) : -1e30f;
+            B[j] = ok ? Mf<T>::raw(v[g]) : Mf<T>::cvt(0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float e = elu1(kk[j]);
+            csum += e;
+            A[j] = Mf<T>::cvt(e);
+        }
+        acc = Mf<T>::mma(A, B, acc);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part_s[w][i][lane] = acc[i];
+    sum_s[w][h][r] = csum;
+    __syncthreads();
+    if (tid < 32) {
+        float t = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < LM_NW; ++ww) t += sum_s[ww][0][tid] + sum_s[ww][1][tid];
+        kbar_s[tid] = t * s2;
+    }
+    frag KVa0, KVa1;                                          // kv^T as the A operand: the accumulator registers (k over rho)
+    {
+        float kvv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float t = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < LM_NW; ++ww) t += part_s[ww][i][lane];
+            kvv[i] = t * s2;
+            if (i < 8) KVa0[i] = Mf<T>::cvt(kvv[i]);
+            else KVa1[i - 8] = Mf<T>::cvt(kvv[i]);
+        }
+        if (w == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mat_s[8 * (i >> 2) + 4 * h + (i & 3)][r] = kvv[i];
+        }
+    }
+    __syncthreads();
+    frag KVr0, KVr1;                                          // kv as the A operand: row r, k over rho
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float t = mat_s[r][8 * (i >> 2) + 4 * h + (i & 3)];
+        if (i < 8) KVr0[i] = Mf<T>::cvt(t);
+        else KVr1[i - 8] = Mf<T>::cvt(t);
+    }
+
+    // ---- phase 2: per 32-token group (wave w takes the groups w, w + LM_NW, ...)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;                // becomes dkv
+    float dsum = 0.f;                                         // dkbar[r], this lane's tokens
+    for (int g0 = 32 * w; g0 < n; g0 += 32 * LM_NW) {
+        // (a) token per lane
+        const int t = g0 + r;
+        const bool tok_ok = t < n;
+        const size_t gt = base + (size_t)(tok_ok ? t : n - 1) * C;
+        float qv[4][4], gvv[4][4], qe[16], gg[16];
+#pragma unroll
+        for (int sj = 0; sj < 4; ++sj) {
+            la_ldv<4>(qpre + gt + 8 * sj + 4 * h, qv[sj]);
+            la_ldv<4>(gout + gt + 8 * sj + 4 * h, gvv[sj]);
+        }
+        frag Q0, Q1;
+        float wpart = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            qe[i] = elu1(qv[i >> 2][i & 3]);
+            gg[i] = tok_ok ? gvv[i >> 2][i & 3] : 0.f;
+            wpart = fmaf(qe[i], kbar_s[8 * (i >> 2) + 4 * h + (i & 3)], wpart);
+            if (i < 8) Q0[i] = Mf<T>::cvt(qe[i]);
+            else Q1[i - 8] = Mf<T>::cvt(qe[i]);
+        }
+        f32x16 uT;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) uT[i] = 0.f;
+        uT = Mf<T>::mma(KVa0, Q0, uT);
+        uT = Mf<T>::mma(KVa1, Q1, uT);
+        float gpart = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gpart = fmaf(gg[i], uT[i], gpart);
+        xa_s[w][h][r] = wpart;
+        xb_s[w][h][r] = gpart;
+        wave_sync();
+        const float wt = xa_s[w][0][r] + xa_s[w][1][r] + 1e-6f;
+        const float gu = xb_s[w][0][r] + xb_s[w][1][r];
+        const float dwt = -gu / (wt * wt);
+        if (h == 0) { w_s[w][r] = tok_ok ? wt : 1.f; dw_s[w][r] = tok_ok ? dwt : 0.f; }
+        frag DU0, DU1;
+        const float rw = 1.f / wt;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i < 8) DU0[i] = Mf<T>::cvt(gg[i] * rw);
+            else DU1[i - 8] = Mf<T>::cvt(gg[i] * rw);
+        }
+        f32x16 dqT;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dqT[i] = 0.f;
+        dqT = Mf<T>::mma(KVr0, DU0, dqT);
+        dqT = Mf<T>::mma(KVr1, DU1, dqT);
+        if (tok_ok) {
+#pragma unroll
+            for (int sj = 0; sj < 4; ++sj) {
+                float o[4];
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int i = 4 * sj + ii;
+                    const float dq = fmaf(dwt, kbar_s[8 * sj + 4 * h + ii], dqT[i]);
+                    o[ii] = dq * (qv[sj][ii] > 0.f ? 1.f : qe[i]);      // elu'(x) = e^x = elu(x) + 1 for x <= 0
+                }
+                store_vec<4>(gq + gt + 8 * sj + 4 * h, o);
+            }
+        }
+        wave_sync();                                           // w_s / dw_s of this group are visible to the wave
+        // (b) feature per lane: dkv += q^T du, dkbar += q^T dw, 16 tokens per product
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            frag A, B;
+            float qq[8], g8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int tl = 16 * hh + 8 * h + j, tk = g0 + tl;
+                const bool ok = tk < n;
+                const size_t g = base + (size_t)(ok ? tk : n - 1) * C + r;
+                qq[j] = ok ? la_ld(qpre + g) : -1e30f;
+                g8[j] = ok ? la_ld(gout + g) : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int tl = 16 * hh + 8 * h + j;
+                const float e = elu1(qq[j]);
+                dsum = fmaf(dw_s[w][tl], e, dsum);
+                A[j] = Mf<T>::cvt(e);
+                B[j] = Mf<T>::cvt(g8[j] / w_s[w][tl]);
+            }
+            acc = Mf<T>::mma(A, B, acc);
+        }
+        wave_sync();                                           // before the next group overwrites the wave's exchange lines
+    }
+    __syncthreads();                                           // every wave is done with part_s / mat_s as kv
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part_s[w][i][lane] = acc[i];
+    sum_s[w][h][r] = dsum;
+    __syncthreads();
+    if (tid < 32) {
+        float t = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < LM_NW; ++ww) t += sum_s[ww][0][tid] + sum_s[ww][1][tid];
+        dkbar_s[tid] = t * s2;
+    }
+    frag DKa0, DKa1;                                          // dkv^T as the A operand (accumulator registers)
+    {
+        float dk[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float t = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < LM_NW; ++ww) t += part_s[ww][i][lane];
+            dk[i] = t * s2;                                     // the 1/n of kv = (1/n) k^T v
+            if (i < 8) DKa0[i] = Mf<T>::cvt(dk[i]);
+            else DKa1[i - 8] = Mf<T>::cvt(dk[i]);
+        }
+        if (w == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mat_s[8 * (i >> 2) + 4 * h + (i & 3)][r] = dk[i];
+        }
+    }
+    __syncthreads();
+    frag DKr0, DKr1;                                          // dkv as the A operand: row r, k over rho
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float t = mat_s[r][8 * (i >> 2) + 4 * h + (i & 3)];
+        if (i < 8) DKr0[i] = Mf<T>::cvt(t);
+        else DKr1[i - 8] = Mf<T>::cvt(t);
+    }
+
+    // ---- phase 3 (token per lane): dk = v dkv^T + dkbar, dv = k dkv
+    for (int g0 = 32 * w; g0 < n; g0 += 32 * LM_NW) {
+        const int t = g0 + r;
+        const bool tok_ok = t < n;                             // (no divergence around the matrix instructions: clamp, and mask the stores)
+        const size_t gt = base + (size_t)(tok_ok ? t : n - 1) * C;
+        float kv4[4][4], vv4[4][4], ke[16];
+#pragma unroll
+        for (int sj = 0; sj < 4; ++sj) {
+            la_ldv<4>(kpre + gt + 8 * sj + 4 * h, kv4[sj]);
+            la_ldv<4>(v + gt + 8 * sj + 4 * h, vv4[sj]);
+        }
+        frag K0, K1, V0, V1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            ke[i] = elu1(kv4[i >> 2][i & 3]);
+            if (i < 8) { K0[i] = Mf<T>::cvt(ke[i]); V0[i] = Mf<T>::cvt(vv4[i >> 2][i & 3]); }
+            else { K1[i - 8] = Mf<T>::cvt(ke[i]); V1[i - 8] = Mf<T>::cvt(vv4[i >> 2][i & 3]); }
+        }
+        f32x16 dvT, dkT;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dvT[i] = 0.f; dkT[i] = 0.f; }
+        dvT = Mf<T>::mma(DKa0, K0, dvT);
+        dvT = Mf<T>::mma(DKa1, K1, dvT);
+        dkT = Mf<T>::mma(DKr0, V0, dkT);
+        dkT = Mf<T>::mma(DKr1, V1, dkT);
+        if (tok_ok) {
+#pragma unroll
+        for (int sj = 0; sj < 4; ++sj) {
+            float ok_[4], ov[4];
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = 4 * sj + ii;
+                const float dk = dkT[i] + dkbar_s[8 * sj + 4 * h + ii];
+                ok_[ii] = dk * (kv4[sj][ii] > 0.f ? 1.f : ke[i]);
+                ov[ii] = dvT[i];
+            }
+            store_vec<4>(gk + gt + 8 * sj + 4 * h, ok_);
+            store_vec<4>(gv + gt + 8 * sj + 4 * h, ov);
+        }
+        }
+    }
+}
+
 hipError_t linattn_core_bwd(const void* qpre, const void* kpre, const void* v, const void* gout, void* gq, void* gk, void* gv,
                             int B, int n, int C, int heads, int dtype, hipStream_t s)
 {
     const dim3 grid((unsigned)(B * heads)), block(LA_NT);
+    {
+        const char* m = getenv("RCX_ATTN_MFMA");                     // A/B knob: 0 = the vector-pipe kernel
+        if (C / heads == 32 && dtype != 0 && !(m && *m == '0')) {
+            if (dtype == 1) hipLaunchKernelGGL((k_linattn_bwd_mfma<bf16_t>), grid, dim3(LM_NW * 64), 0, s, (const bf16_t*)qpre, (const bf16_t*)kpre, (const bf16_t*)v, (const bf16_t*)gout, (bf16_t*)gq, (bf16_t*)gk, (bf16_t*)gv, n, C, heads);
+            else hipLaunchKernelGGL((k_linattn_bwd_mfma<f16_t>), grid, dim3(LM_NW * 64), 0, s, (const f16_t*)qpre, (const f16_t*)kpre, (const f16_t*)v, (const f16_t*)gout, (f16_t*)gq, (f16_t*)gk, (f16_t*)gv, n, C, heads);
+            return hipGetLastError();
+        }
+    }
 #define RCX_LAB(T) hipLaunchKernelGGL((k_linattn_bwd<T>), grid, block, 0, s, (const T*)qpre, (const T*)kpre, (const T*)v, (const T*)gout, \
                                       (T*)gq, (T*)gk, (T*)gv, n, C, heads)
     if (dtype == 1) RCX_LAB(bf16_t);
