@@ -469,8 +469,15 @@ k_wgrad_reduce8(const float* __restrict__ partial, float* __restrict__ gw, float
     __shared__ float red[8][32];
     const int i = blockIdx.x * 32 + threadIdx.x, j = threadIdx.y, total = (kk + 1) * C;
     float s = 0.f;
-    if (i < total)
-        for (int r = j; r < rows; r += 8) s += partial[(size_t)r * total + i];
+    if (i < total) {
+        int r = j;
+        for (; r + 24 < rows; r += 32) {                       // four rows in flight, fixed order (see k_wgrad_reduce_jobs)
+            const float a0 = partial[(size_t)r * total + i], a1 = partial[(size_t)(r + 8) * total + i];
+            const float a2 = partial[(size_t)(r + 16) * total + i], a3 = partial[(size_t)(r + 24) * total + i];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; r < rows; r += 8) s += partial[(size_t)r * total + i];
+    }
     red[j][threadIdx.x] = s;
     __syncthreads();
     if (j == 0 && i < total) {
@@ -594,10 +601,19 @@ hipError_t bwd_wgrad(const void* a, int a_dt, const float* coarse, const float* 
                      int* rows_out)
 {
     // the 56x56 / 28x28 convs over T = a + R(coarse): tiled channel-per-lane kernel (rcx_cplwgrad.hip), when the caller reduces itself
-    if (rows_out && Ho == H && Wo == W && wgrad_cpl_applicable(N, C, H, W, Hc, Wc, k, stride, coarse != nullptr))
-        return wgrad_cpl(a, a_dt, coarse, g, partial, N, C, H, mode, s, rows_out);
-    if (rows_out && wgrad2_cpl_applicable(N, C, H, W, Ho, Wo, k, stride, coarse != nullptr))
-        return wgrad2_cpl(a, a_dt, g, partial, N, C, H, s, rows_out);
+    {
+        const bool t1 = Ho == H && Wo == W && wgrad_cpl_applicable(N, C, H, W, Hc, Wc, k, stride, coarse != nullptr);
+        const bool t2 = !t1 && wgrad2_cpl_applicable(N, C, H, W, Ho, Wo, k, stride, coarse != nullptr);
+        if (t1 || t2) {
+            int rows = 0;
+            hipError_t e = t1 ? wgrad_cpl(a, a_dt, coarse, g, partial, N, C, H, mode, s, &rows) : wgrad2_cpl(a, a_dt, g, partial, N, C, H, s, &rows);
+            if (e != hipSuccess) return e;
+            if (rows_out) { *rows_out = rows; return hipSuccess; }        // the caller reduces all its partial buffers in one launch
+            const int kk = k * k, n5 = (kk + 1) * C;
+            hipLaunchKernelGGL(k_wgrad_reduce8, dim3((n5 + 31) / 32), dim3(32, 8), 0, s, partial, gw, gb, rows, kk, C, accumulate);
+            return hipGetLastError();
+        }
+    }
     BwGeom q{};
     q.N = N; q.C = C; q.H = H; q.W = W; q.Hc = Hc; q.Wc = Wc; q.k = k; q.mode = mode;
     q.sy = Hc > 0 ? (float)Hc / (float)H : 0.f;

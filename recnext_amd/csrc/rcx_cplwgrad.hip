@@ -17,6 +17,7 @@ namespace cplwgrad {
 
 using namespace cplbwd;
 
+// MODE 0 / 1: T = a + bilinear / nearest resize of `coarse`; MODE 2: T = a (a plain depthwise conv, e.g. RecAttn2d's: model/recattn.py:163-171)
 template <int MODE, typename TA, int H>
 __global__ __launch_bounds__(64 * (H / 14))
 void k_wgrad_cpl(const TA* __restrict__ a, const float* __restrict__ coarse, const float* __restrict__ g, float* __restrict__ partial,
@@ -105,7 +106,7 @@ void k_wgrad_cpl(const TA* __restrict__ a, const float* __restrict__ coarse, con
         for (int m = 0; m < TP; ++m) {
             f32x2 v = f32x2{SafeLd<TA>::cvt(ra[s][2 * m]), SafeLd<TA>::cvt(ra[s][2 * m + 1])};
             if (MODE == 1) v = v + Hr[((s + 2) >> 1) % 3][m];
-            else v = pfma(splat(w1), Hr[(i0 + 1) % 3][m], pfma(splat(w0), Hr[i0 % 3][m], v));
+            else if (MODE == 0) v = pfma(splat(w1), Hr[(i0 + 1) % 3][m], pfma(splat(w0), Hr[i0 % 3][m], v));
             T[s % 5][m] = v * keep;
         }
         // and so are the halo columns outside it (a multiply, not a branch: a uniform branch here doubles the code and the registers)
@@ -115,6 +116,7 @@ void k_wgrad_cpl(const TA* __restrict__ a, const float* __restrict__ coarse, con
     // which coarse rows T row s needs: its first use builds the H row
     auto need_h = [&](auto sc) {
         constexpr int s = decltype(sc)::value;
+        if constexpr (MODE == 2) return;
         constexpr int hi = MODE == 1 ? (s + 2) >> 1 : ((s & 1) ? (s + 1) / 2 : s / 2) + 1;       // the highest local coarse row T row s reads
         constexpr int prev = s == 0 ? -1 : (MODE == 1 ? (s + 1) >> 1 : (((s - 1) & 1) ? s / 2 : (s - 1) / 2) + 1);
         if constexpr (s == 0) {
@@ -127,7 +129,7 @@ void k_wgrad_cpl(const TA* __restrict__ a, const float* __restrict__ coarse, con
     acc.zero();
     // prologue: everything the first gradient row needs
     sfor<5>([&](auto sc) { ld_a(sc); });
-    sfor<4>([&](auto ic) { ld_c(ic); });
+    if constexpr (MODE != 2) sfor<4>([&](auto ic) { ld_c(ic); });
     ld_g(IC<0>{});
     sfor<5>([&](auto sc) { need_h(sc); build_t(sc); });
     RCX_FENCE;
@@ -139,7 +141,7 @@ void k_wgrad_cpl(const TA* __restrict__ a, const float* __restrict__ coarse, con
             constexpr int s = t + 5;
             constexpr int hi = MODE == 1 ? (s + 2) >> 1 : ((s & 1) ? (s + 1) / 2 : s / 2) + 1;
             constexpr int prev = MODE == 1 ? (s + 1) >> 1 : (((s - 1) & 1) ? s / 2 : (s - 1) / 2) + 1;
-            if constexpr (hi > prev) ld_c(IC<hi>{});
+            if constexpr (MODE != 2 && hi > prev) ld_c(IC<hi>{});
         }
         if constexpr (t + 1 < 14) ld_g(IC<t + 1>{});
         pin_raw(rg[t]);
@@ -361,7 +363,7 @@ bool wgrad_cpl_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int
 {
     const char* v = getenv("RCX_WGRAD_CPL");
     if (v && *v == '0') return false;
-    return has_coarse && k == 5 && stride == 1 && H == W && (H == 56 || H == 28) && Hc * 2 == H && Wc * 2 == W && C >= 1 &&
+    return k == 5 && stride == 1 && H == W && (H == 56 || H == 28) && (!has_coarse || (Hc * 2 == H && Wc * 2 == W)) && C >= 1 &&
            N * (H / 14) <= 512;
 }
 
@@ -400,6 +402,7 @@ hipError_t wgrad_cpl(const void* a, int a_dt, const float* coarse, const float* 
 {
     if (rows_out) *rows_out = N * (H / 14);
 #define RCX_WC(MD_) (a_dt == 1 ? cplwgrad::launch_h<MD_, bf16_t>(a, coarse, g, partial, N, C, H, s) : a_dt == 2 ? cplwgrad::launch_h<MD_, f16_t>(a, coarse, g, partial, N, C, H, s) : cplwgrad::launch_h<MD_, float>(a, coarse, g, partial, N, C, H, s))
+    if (!coarse) return RCX_WC(2);
     return mode == 1 ? RCX_WC(1) : RCX_WC(0);
 #undef RCX_WC
 }
