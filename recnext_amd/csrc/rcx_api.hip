@@ -119,6 +119,8 @@ hipError_t step_dwconv(const void* x, void* y, const float* w, const float* b, i
 hipError_t step_upadd(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int H, int W,
                       int Hc, int Wc, int k, int mode, int x_dt, int c_dt, int out_dt, hipStream_t s)
 {
+    if (coarse && !lanes_off() && rcx::upadd_cpl14_applicable(N, C, H, W, Hc, Wc, k, x_dt, c_dt, out_dt))
+        return rcx::upadd_cpl14(x, coarse, y, w, b, N, C, mode, x_dt, c_dt, s);
     if (coarse && !lanes_off() && rcx::upadd_lanes_applicable(N, C, H, W, Hc, Wc, k, x_dt, c_dt, out_dt))
         return rcx::upadd_lanes(x, coarse, y, w, b, N, C, H, W, mode, x_dt, c_dt, s);
     if (!coarse && !lanes_off() && rcx::conv5_lanes_applicable(N, C, H, W, k, x_dt, out_dt))

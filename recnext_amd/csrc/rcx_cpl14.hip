@@ -416,6 +416,110 @@ void k_recconv_cpl7b(const TIO* __restrict__ x, TIO* __restrict__ y, const float
     });
 }
 
+// ---- one step on its own: y = conv5(x + resize(coarse)) + bias on the 14x14 plane (coarse 7x7) -- RecAttn2d's fused
+// "upsample + add + depthwise conv" (model/recattn.py:54-67 after ConvNorm.fuse: rcx_upadd_dwconv_fwd) and the training forward's
+// last step.  k_recconv_cpl14's pass 2 with the coarse plane read from memory: x streams once, nothing is stashed.  One wave per SIMD
+// like its parent: under a 256-register cap the compiler spills, and what it spills are destinations of loads still in flight
+// (tools/check_asm_hazards.py flags exactly that).
+template <int MODE, int CT, typename TIO, typename TC>
+__global__ __launch_bounds__(64)
+void k_upadd_cpl14(const TIO* __restrict__ x, const TC* __restrict__ coarse, TIO* __restrict__ y, const float* __restrict__ w,
+                   const float* __restrict__ bias, int N, int C_rt)
+{
+    constexpr int W = 14, P = 7, W1 = 7, P1 = 4;
+    const int C = CT > 0 ? CT : C_rt;
+    const int nb = (C + 63) / 64;
+    unsigned b = blockIdx.x;
+    const unsigned G = gridDim.x;
+    if ((G & 7u) == 0) b = (b & 7u) * (G >> 3) + (b >> 3);                 // XCD-aware order, as above
+    const int n = (int)(b / (unsigned)nb), cb = (int)(b - (unsigned)n * (unsigned)nb);
+    if (n >= N) return;
+    const int c = cb * 64 + (int)threadIdx.x;
+    if (c >= C) return;
+    const size_t pix = (size_t)C * sizeof(TIO);
+    const gcptr xb = (gcptr)x + (size_t)n * W * W * pix;
+    const gcptr yb = (gcptr)y + (size_t)n * W * W * pix;
+    const unsigned vo = (unsigned)c * (unsigned)sizeof(TIO), vow = (unsigned)c * 4u;
+    const RowAddr<W, CT, TIO> ra(vo, pix);
+    constexpr int AHEAD = 3;
+    uint32_t raw[W][W];
+    // ordered loads the compiler counts itself (SafeLd): in this kernel it copies freshly loaded registers around, which hand-issued
+    // loads do not survive (tools/check_asm_hazards.py)
+    auto load_row = [&](int r) {
+        ra.row(xb, r, [&](auto qc, gcptr base, unsigned voff, auto immc) {
+            raw[r][decltype(qc)::value] = SafeLd<TIO>::ld(base + decltype(immc)::value + voff);
+        });
+    };
+    lanes::sfor<AHEAD>([&](auto rc) { load_row(decltype(rc)::value); });
+    // the coarse plane and the taps behind the first x rows
+    f32x2 C1[W1][P1];
+    {
+        const TC* q = coarse + ((size_t)n * W1 * W1) * C + c;
+#pragma unroll
+        for (int o = 0; o < W1; ++o)
+#pragma unroll
+            for (int j = 0; j < P1; ++j)
+                C1[o][j] = f32x2{elem_to_f32(q[(size_t)(o * W1 + 2 * j) * C]), 2 * j + 1 < W1 ? elem_to_f32(q[(size_t)(o * W1 + 2 * j + 1) * C]) : 0.f};
+    }
+    Taps t2;
+    load_taps<CT>(t2, w, bias, 0, C, vow, bias != nullptr);
+    f32x2 H1[W1][P];
+    f32x2 acc[5][P];
+    lanes::sfor<W>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const bool enters = (t == 0) ? (s <= 2) : (s == (t + 2) % 5 && t + 2 < W);
+            if (enters) {
+#pragma unroll
+                for (int j = 0; j < P; ++j) acc[s][j] = splat(t2.bias);
+            }
+        }
+        if constexpr (t + AHEAD < W) load_row(t + AHEAD);
+        const VT vt = vtab(MODE, W1, W, t);
+#pragma unroll
+        for (int i = 0; i < W1; ++i) {
+            const bool first_use = (i == vt.i0 || i == vt.i1) && (t == 0 || (i != vtab(MODE, W1, W, t - 1).i0 && i != vtab(MODE, W1, W, t - 1).i1));
+            if (first_use) resize_row<MODE, W1, W>(C1[i], H1[i]);
+        }
+        pin_raw(raw[t]);
+        f32x2 row[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) row[j] = f32x2{SafeLd<TIO>::cvt(raw[t][2 * j]), SafeLd<TIO>::cvt(raw[t][2 * j + 1])};
+        add_resized_row<MODE, W1, W, P>(row, H1, t);
+        conv5_row<W>(row, t, t2, [&](int o) -> f32x2(&)[P] { return acc[o % 5]; });
+#pragma unroll
+        for (int d = 2; d >= 0; --d) {
+            const int o = t - d;
+            if (o < 0 || (d < 2 && t != W - 1)) continue;
+            typename PixSt<TIO>::packed pk[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) pk[j] = PixSt<TIO>::prep(acc[o % 5][j]);
+            ra.row(yb, o, [&](auto qc, gcptr base, unsigned voff, auto immc) {
+                constexpr int q = decltype(qc)::value;
+                PixSt<TIO>::st(base + decltype(immc)::value + voff, pk[q >> 1], q & 1);
+            });
+        }
+#pragma unroll
+        for (int o = 0; o < W; ++o) if (o > t - 2 && o <= t + 2 && t != W - 1) pin(acc[o % 5]);
+        RCX_FENCE;
+    });
+}
+
+template <int MODE, int CT, typename TIO, typename TC>
+static hipError_t launch_up(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, hipStream_t s)
+{
+    const unsigned grid = (unsigned)(N * ((C + 63) / 64));
+    hipLaunchKernelGGL((k_upadd_cpl14<MODE, CT, TIO, TC>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (const TC*)coarse, (TIO*)y, w, b, N, C);
+    return hipGetLastError();
+}
+template <int MODE, typename TIO, typename TC>
+static hipError_t launch_up_c(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, hipStream_t s)
+{
+    if (C == 256) return launch_up<MODE, 256, TIO, TC>(x, coarse, y, w, b, N, C, s);
+    return launch_up<MODE, 0, TIO, TC>(x, coarse, y, w, b, N, C, s);
+}
+
 // A/B switches, read per call like the other schedules' (tests flip them inside one process): RCX_CPL14=0 gives the block
 // back to the lanes kernel, RCX_LANES=0 / RCX_FORCE_GENERIC=1 switch every register-resident schedule off
 static inline bool enabled()
@@ -500,6 +604,26 @@ hipError_t cpl7b_recconv(const void* x, void* y, const float* wpack, const float
     if (dtype == 1) return mode == 1 ? cpl14::launch7_c<1, bf16_t>(x, y, wpack, bpack, N, C, s, sv) : cpl14::launch7_c<0, bf16_t>(x, y, wpack, bpack, N, C, s, sv);
     if (dtype == 2) return mode == 1 ? cpl14::launch7_c<1, f16_t>(x, y, wpack, bpack, N, C, s, sv) : cpl14::launch7_c<0, f16_t>(x, y, wpack, bpack, N, C, s, sv);
     return mode == 1 ? cpl14::launch7_c<1, float>(x, y, wpack, bpack, N, C, s, sv) : cpl14::launch7_c<0, float>(x, y, wpack, bpack, N, C, s, sv);
+}
+
+// y = conv5(x + resize(coarse)) on the 14x14 plane: coarse in the I/O type or float32
+bool upadd_cpl14_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int x_dt, int c_dt, int out_dt)
+{
+    (void)N;
+    const char* v = getenv("RCX_UPADD_CPL");
+    return cpl14::enabled() && !(v && *v == '0') && H == 14 && W == 14 && Hc == 7 && Wc == 7 && k == 5 && C >= 1 && out_dt == x_dt &&
+           (x_dt == 0 || x_dt == 1 || x_dt == 2) && (c_dt == x_dt || c_dt == 0);
+}
+
+hipError_t upadd_cpl14(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int mode, int x_dt, int c_dt,
+                       hipStream_t s)
+{
+#define RCX_UC(MD_)                                                                                                                  \
+    (x_dt == 0 ? cpl14::launch_up_c<MD_, float, float>(x, coarse, y, w, b, N, C, s)                                                  \
+     : x_dt == 1 ? (c_dt == 1 ? cpl14::launch_up_c<MD_, bf16_t, bf16_t>(x, coarse, y, w, b, N, C, s) : cpl14::launch_up_c<MD_, bf16_t, float>(x, coarse, y, w, b, N, C, s)) \
+                 : (c_dt == 2 ? cpl14::launch_up_c<MD_, f16_t, f16_t>(x, coarse, y, w, b, N, C, s) : cpl14::launch_up_c<MD_, f16_t, float>(x, coarse, y, w, b, N, C, s)))
+    return mode == 1 ? RCX_UC(1) : RCX_UC(0);
+#undef RCX_UC
 }
 
 bool cpl14_applicable(int N, int C, int H, int W, int level, int k, int dtype)

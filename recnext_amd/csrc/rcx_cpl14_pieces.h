@@ -142,6 +142,30 @@ template <> struct PixLd<f16_t> {
     static __device__ __forceinline__ float cvt(uint32_t r) { return (float)__builtin_bit_cast(_Float16, (uint16_t)r); }
 };
 
+// Loads the compiler counts itself.  The forward kernels issue their x rows from inline asm and wait for them by hand; that is only
+// sound while the register allocator never copies a destination register between the load and the wait (it believes the value is
+// there), and in these kernels it does (v_mov_b64 of two in-flight registers right behind the loads: measured, wrong gradients).
+// An ordered (relaxed, wavefront-scope atomic) load stays where it is written as well, and every move or use of its result gets
+// the compiler's own counted s_waitcnt: correct by construction; the pin AHEAD rows later is where the wait lands.
+template <typename TIO> struct SafeLd;
+template <> struct SafeLd<float> {
+    static __device__ __forceinline__ uint32_t ld(gcptr p) { return gload_here<uint32_t>(p); }
+    static __device__ __forceinline__ float cvt(uint32_t r) { return __uint_as_float(r); }
+};
+template <> struct SafeLd<bf16_t> {
+    static __device__ __forceinline__ uint32_t ld(gcptr p) { return (uint32_t)gload_here<uint16_t>(p); }
+    static __device__ __forceinline__ float cvt(uint32_t r) { return __uint_as_float(r << 16); }
+};
+template <> struct SafeLd<f16_t> {
+    static __device__ __forceinline__ uint32_t ld(gcptr p) { return (uint32_t)gload_here<uint16_t>(p); }
+    static __device__ __forceinline__ float cvt(uint32_t r) { return (float)__builtin_bit_cast(_Float16, (uint16_t)r); }
+};
+template <int A> __device__ __forceinline__ void pin_raw(uint32_t (&v)[A])
+{
+#pragma unroll
+    for (int i = 0; i < A; ++i) asm volatile("" : "+v"(v[i]));
+}
+
 // a pair of horizontally adjacent output pixels: converted once, stored as two elements (the lanes of a wave write 128
 // contiguous bytes per instruction)
 template <typename TIO> struct PixSt;

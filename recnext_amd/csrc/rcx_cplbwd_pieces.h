@@ -23,30 +23,6 @@ template <int NP> __device__ __forceinline__ void fma_at(f32x2 (&row)[NP], int i
     else row[i >> 1].x = fmaf(a, b, row[i >> 1].x);
 }
 
-// Loads the compiler counts itself.  The forward kernels issue their x rows from inline asm and wait for them by hand; that is only
-// sound while the register allocator never copies a destination register between the load and the wait (it believes the value is
-// there), and in these kernels it does (v_mov_b64 of two in-flight registers right behind the loads: measured, wrong gradients).
-// An ordered (relaxed, wavefront-scope atomic) load stays where it is written as well, and every move or use of its result gets
-// the compiler's own counted s_waitcnt: correct by construction; the pin AHEAD rows later is where the wait lands.
-template <typename TIO> struct SafeLd;
-template <> struct SafeLd<float> {
-    static __device__ __forceinline__ uint32_t ld(gcptr p) { return gload_here<uint32_t>(p); }
-    static __device__ __forceinline__ float cvt(uint32_t r) { return __uint_as_float(r); }
-};
-template <> struct SafeLd<bf16_t> {
-    static __device__ __forceinline__ uint32_t ld(gcptr p) { return (uint32_t)gload_here<uint16_t>(p); }
-    static __device__ __forceinline__ float cvt(uint32_t r) { return __uint_as_float(r << 16); }
-};
-template <> struct SafeLd<f16_t> {
-    static __device__ __forceinline__ uint32_t ld(gcptr p) { return (uint32_t)gload_here<uint16_t>(p); }
-    static __device__ __forceinline__ float cvt(uint32_t r) { return (float)__builtin_bit_cast(_Float16, (uint16_t)r); }
-};
-template <int A> __device__ __forceinline__ void pin_raw(uint32_t (&v)[A])
-{
-#pragma unroll
-    for (int i = 0; i < A; ++i) asm volatile("" : "+v"(v[i]));
-}
-
 // weight-gradient accumulators of one stride-1 5x5 conv: E[u] = tap pairs (0,1)(2,3)(4,-) from even columns, O[u] = (-,0)(1,2)(3,4)
 struct WAcc {
     f32x2 E[5][3], O[5][3];

@@ -59,6 +59,11 @@ int cpl14_describe(int N, int C, int mode, int dtype, char* buf, int len);
 hipError_t cpl14_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s,
                          float* saved = nullptr, const size_t* f_off = nullptr, const size_t* c_off = nullptr);
 
+// one step, channel per lane: y = conv5(x + resize(coarse)) + bias on the 14x14 plane (RecAttn2d's fused kernel; rcx_cpl14.hip)
+bool upadd_cpl14_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int x_dt, int c_dt, int out_dt);
+hipError_t upadd_cpl14(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int mode, int x_dt, int c_dt,
+                       hipStream_t s);
+
 bool cpl7b_applicable(int N, int C, int H, int W, int level, int k, int dtype);
 int cpl7b_describe(int N, int C, int mode, char* buf, int len);
 hipError_t cpl7b_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s,
