@@ -331,3 +331,17 @@ def test_fused_backward_matches_the_per_step_backward(shape, mode, dtype, monkey
     for name, a1, a0, t in (("gx", gx1.float(), gx0.float(), tol), ("gw", gw1, gw0, 3e-5), ("gb", gb1, gb0, 3e-5)):
         assert torch.isfinite(a1).all(), name
         assert float((a1 - a0).abs().max()) < t * max(1.0, float(a0.abs().max())), (name, float((a1 - a0).abs().max()), float(a0.abs().max()))
+
+
+def test_adjoint_pieces_against_host_loops(tmp_path):
+    """tools/cplbwd_probe.hip: the register-plane pieces of the fused backward (tap-pair weight gradients for both strides, the
+    stride-2 adjoint, the resize adjoint) each against plain double-precision loops on the host, at 4x4, 7x7 and 14x14."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cplbwd_probe")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", os.path.join(root, "tools", "cplbwd_probe.hip"),
+                    "-o", exe], check=True, timeout=600)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-500:]
