@@ -19,6 +19,7 @@ from recnext_amd import ops
 
 SHAPES = {
     "m3": [(256, 64, 56, 56, 4), (256, 128, 28, 28, 3), (256, 256, 14, 14, 2), (256, 512, 7, 7, 1)],
+    "m3_b128": [(128, 64, 56, 56, 4), (128, 128, 28, 28, 3), (128, 256, 14, 14, 2), (128, 512, 7, 7, 1)],   # the training batch: inference forward beside bench_backward.py
     "m1": [(256, 48, 56, 56, 4), (256, 96, 28, 28, 3), (256, 192, 14, 14, 2), (256, 384, 7, 7, 1)],
     "m5": [(256, 80, 56, 56, 4), (256, 160, 28, 28, 3), (256, 320, 14, 14, 2), (256, 640, 7, 7, 1)],
     "m3_512": [(32, 64, 128, 128, 4), (32, 128, 64, 64, 3), (32, 256, 32, 32, 2), (32, 512, 16, 16, 1)],
