@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RCX_ABI_VERSION 2
+#define RCX_ABI_VERSION 3
 
 enum { RCX_DTYPE_F32 = 0, RCX_DTYPE_BF16 = 1, RCX_DTYPE_F16 = 2 };   /* F16: the reference's autocast dtype (engine.py:48) */
 enum { RCX_MODE_BILINEAR = 0, RCX_MODE_NEAREST = 1 };   /* F.interpolate(mode=...), model/recnext.py:33 */
@@ -76,6 +76,25 @@ size_t rcx_recconv2d_fwd_workspace_bytes(int N, int C, int H, int W, int level, 
 int rcx_recconv2d_fwd(const void* x, void* y, const float* wpack, const float* bpack,
                       void* workspace, size_t workspace_bytes,
                       int N, int C, int H, int W, int level, int k, int mode, int dtype, void* stream);
+
+/*
+ * The same forward for 16-bit activations whose taps may be rounded to the activations' type -- which is every case the reference
+ * itself can run in 16 bits: model.bfloat16() / .half() (the parameters already have that type, the rounding is exact) and
+ * torch.autocast (engine.py:48: the conv casts its weight).  It allows the schedules that run the 5 x 5 convs as banded 4 x 4 x 4
+ * products on the matrix cores: operands in the activations' type, float32 accumulation, and the input of the final conv,
+ * x + resize(C_1), rounded once (the reference's 16-bit run rounds after the resize, after the add and after every conv).  Where no
+ * such schedule exists for the shape this is rcx_recconv2d_fwd.  Results: within north_star's 1e-2 of the float32 forward, not within
+ * half an ulp of it as rcx_recconv2d_fwd's are.
+ *   mxpack : rcx_recconv2d_mxpack_bytes(C, level, k) bytes written by rcx_pack_recconv_mx from wpack (same life cycle as wpack: rebuilt
+ *            when a parameter changes); NULL selects rcx_recconv2d_fwd.  k = 5 only (0 bytes otherwise).
+ *   rcx_recconv2d_fwd_plan_mx : the schedule this call would use (cf. rcx_recconv2d_fwd_plan).
+ */
+size_t rcx_recconv2d_mxpack_bytes(int C, int level, int k);
+int rcx_pack_recconv_mx(const float* wpack, void* mxpack, int C, int level, int k, int dtype, void* stream);
+const char* rcx_recconv2d_fwd_plan_mx(int N, int C, int H, int W, int level, int k, int mode, int dtype);
+int rcx_recconv2d_fwd_mx(const void* x, void* y, const float* wpack, const float* bpack, const void* mxpack,
+                         void* workspace, size_t workspace_bytes,
+                         int N, int C, int H, int W, int level, int k, int mode, int dtype, void* stream);
 
 /*
  * Training (engine.py:48-64): a forward that keeps the fp32 pyramid F_1..F_L, C_1..C_L in `saved`, and the backward pass.

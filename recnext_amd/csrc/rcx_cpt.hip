@@ -39,6 +39,27 @@ int cpt_describe(int N, int C, int H, int mode, int dtype, char* buf, int len)
                     T == 4 ? cpt::Geo<4, 2, 0, float>::LDS_BYTES : cpt::Geo<2, 1, 0, float>::LDS_BYTES);
 }
 
+// Matrix-core variant (rcx_cpt_kernel.h, MX): the 56x56 / level 4 block with bf16 or float16 activations.  RCX_CPT_MX=0: off (A/B).
+bool cpt_mx_applicable(int N, int C, int H, int W, int level, int k, int dtype)
+{
+    (void)N;
+    const char* v = getenv("RCX_CPT_MX");
+    if (v && *v == '0') return false;
+    return cpt::enabled() && k == 5 && C >= 1 && (dtype == 1 || dtype == 2) && H == 56 && W == 56 && level == 4;
+}
+
+int cpt_mx_describe(int N, int C, int mode, int dtype, char* buf, int len)
+{
+    using G = cpt::Geo<4, 2, 0, bf16_t, true>;
+    return snprintf(buf, len, "cpt_mx(k_recconv_cpt<4, 2, %d, %d, %s, MX>,cb=%d,nt=%d,units=%d,lds=%d)", mode, C == 64 ? 128 : 0, dtype == 2 ? "f16" : "bf16",
+                    G::CB, G::NT, N * ((C + G::CB - 1) / G::CB), G::LDS_BYTES);
+}
+
+hipError_t cpt_mx_recconv(const void* x, void* y, const float* wpack, const float* bpack, const void* mxpack, int N, int C, int mode, int dtype, hipStream_t s)
+{
+    return cpt::launch_mx(x, y, wpack, bpack, mxpack, N, C, mode, dtype, s);
+}
+
 hipError_t cpt_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int H, int mode, int dtype, hipStream_t s,
                        float* saved, const size_t* f_off, const size_t* c_off)
 {

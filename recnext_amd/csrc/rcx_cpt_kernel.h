@@ -40,6 +40,12 @@ using lanes::vtab;
 using lanes::VT;
 
 #define CPT_FENCE __builtin_amdgcn_sched_barrier(0)
+#ifndef RCX_MX_AHEAD1
+#define RCX_MX_AHEAD1 2                    /* matrix-core variant: input rows requested ahead in pass 1 / pass 2 */
+#endif
+#ifndef RCX_MX_AHEAD2
+#define RCX_MX_AHEAD2 2
+#endif
 #ifndef RCX_CPT_PF
 #define RCX_CPT_PF 0                       /* wide-load L2 prefetch ahead of pass 1: measured slower, see pass 1 */
 #endif
@@ -194,6 +200,11 @@ template <typename T16, int PIXB> struct RowSt16 {
             if constexpr (std::is_same<T16, f16_t>::value) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p[j]) : "v"(a[j].x), "v"(a[j].y));
             else asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p[j]) : "v"(a[j].x), "v"(a[j].y));
         }
+        st_packed(p, vo, rs, rb, pix);
+    }
+    // the row already converted: seven registers of two pixels each
+    static __device__ __forceinline__ void st_packed(const uint32_t (&p)[7], unsigned vo, i32x4 rs, int rb, int pix)
+    {
         int t, t2;
         if constexpr (PIXB > 0 && PIXB * 13 <= 4095) {
             (void)pix; (void)t2;
@@ -254,6 +265,124 @@ __device__ __forceinline__ void pin_row(uint32_t (&v)[18])
     asm volatile("s_waitcnt vmcnt(%18)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
                  "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]),
                  "+v"(v[17]) : "n"(PENDING));
+}
+
+// ================= matrix-core variant (MX; 16-bit activations, round 3) =================
+// The two level-0 passes as 4 x 4 x 4 products on the matrix cores (v_mfma_f32_4x4x4_16b_bf16 / _f16: 16 independent blocks per
+// instruction, a block = four consecutive lanes).  Block = channel.  D[i][j] = sum_k A[i][k] B[k][j] with
+//   B[k][j]  the DATA: lane (channel, j) holds four horizontally adjacent pixels k of ITS tile j (two registers of two 16-bit values),
+//   A[i][k]  the TAPS as a banded Toeplitz block: lane (channel, i) holds row i, A[i][k] = w[tap row][column(k) - column(i) + 2] or 0,
+//   D[i][j]  four adjacent outputs i of tile j in the four result registers of lane (channel, j)
+// (maps measured with exact integer data, tools/ubench/mfma444.hip).  So a lane still owns its tile and its channel, and the four
+// lanes of a block are the four tiles of one tile row.  Three lane maps of the same wave (16 channels x those four tiles):
+//   M  lane = 4 * channel + tile column   what the matrix instruction wants
+//   A  lane = 16 * tile column + channel  what memory wants: 16 consecutive lanes = 32 contiguous bytes of one pixel (with map M every
+//      lane of a quad is in another tile, 1792 bytes apart, and a 2-byte load instruction touches 64 sectors instead of 4: the first
+//      build's passes took twice the vector kernel's time); x is loaded, x + resize(C1) formed and y stored in this map
+//   O  the vector kernel's own map (32 channels x 2 tiles) for everything between the passes, which is unchanged
+// Packed operand registers go A -> M (and packed results M -> A) through ds_bpermute_b32 (the LDS crossbar, no LDS memory, not a DPP
+// instruction): 10 per input row and 7 per output row against 40 matrix instructions.  One input row of 20 columns (-2 .. 17) = five
+// K blocks; an output block of four columns takes two of them per tap row (stride 1: 20 of 32 Toeplitz entries are taps) or three
+// (stride 2: 20 of 48).  Accumulation is float32; the operands are the activations' own 16-bit type, so the taps are rounded to
+// it (exact when the module's parameters already have that type, which is the only case the reference itself can run:
+// model/recnext.py:21-22 under .bfloat16() / autocast), and pass 2's conv input x + resize(C1) is rounded once (the reference's
+// bf16 run rounds after the resize, after the add and after the conv).  0 * inf = NaN: a non-finite pixel reaches every output
+// of the blocks that read its K block (up to five columns away instead of two).
+#define CPT_OUT20(v) CPT_OUT18(v), "=&v"(v[18]), "=&v"(v[19])
+#define CPT_ROW_IMM20(OP) CPT_ROW_IMM(OP) CPT_LI(OP, 18, "vr", "t", 2) CPT_LI(OP, 19, "vr", "t", 3)
+#define CPT_ROW_GEN20(OP)                                                                                                            \
+    CPT_ROW_GEN(OP) "s_add_i32 %[t2], %[t], %[pix]\n\ts_add_i32 %[t2], %[t2], %[pix]\n\t" CPT_LG(OP, 18, "vr", "t2")                 \
+    "s_add_i32 %[t2], %[t2], %[pix]\n\t" CPT_LG(OP, 19, "vr", "t2")
+#define CPT_OUT20_ALL(v) CPT_OUT20(v)
+
+// columns -2, -1 (vl), 0 .. 13 (vm), 14 .. 17 (vr)
+template <typename TIO, int PIXB>
+__device__ __forceinline__ void row_load20(uint32_t (&v)[20], unsigned vl, unsigned vm, unsigned vr, i32x4 rs, int rb, int pix)
+{
+    static_assert(sizeof(TIO) == 2, "the matrix-core passes take 16-bit activations");
+    int t, t2;
+    if constexpr (PIXB > 0 && PIXB * 13 <= 4095) {
+        (void)pix; (void)t2;
+        if constexpr (std::is_same<TIO, f16_t>::value)
+            asm volatile(CPT_ROW_IMM20(CPT_LDH) : CPT_OUT20(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+        else
+            asm volatile(CPT_ROW_IMM20(CPT_LD16) : CPT_OUT20(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+    } else {
+        if constexpr (std::is_same<TIO, f16_t>::value)
+            asm volatile(CPT_ROW_GEN20(CPT_LDH) : CPT_OUT20(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+        else
+            asm volatile(CPT_ROW_GEN20(CPT_LD16) : CPT_OUT20(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+    }
+}
+
+template <int PENDING>
+__device__ __forceinline__ void pin_row20(uint32_t (&v)[20])
+{
+    asm volatile("s_waitcnt vmcnt(%20)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                 "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]),
+                 "+v"(v[17]), "+v"(v[18]), "+v"(v[19]) : "n"(PENDING));
+}
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
+template <int A> __device__ __forceinline__ void pin(f32x4 (&v)[A]) {
+#pragma unroll
+    for (int i = 0; i < A; ++i) pin(v[i]);
+}
+
+// D = A B + C, sixteen 4 x 4 x 4 blocks (8 passes of the matrix pipe; 7.4 cycles back to back on independent accumulators)
+template <typename TIO> __device__ __forceinline__ f32x4 mx444(u32x2 a, u32x2 b, f32x4 c)
+{
+    if constexpr (std::is_same<TIO, f16_t>::value) return __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+// two float32 -> one register of two TIO, low half = the first (RNE, NaN stays NaN): v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32.
+// NOT inline asm: the matrix instructions write their results passes after they issue and nothing interlocks a vector instruction
+// that touches those registers meanwhile -- the compiler pads such neighbours itself, but it does not look inside an asm statement
+// (first build: a conversion in asm reused two registers of an accumulator whose last product was still in flight and lost its result
+// to the late write; tile rows 11 / 12, columns 0 and 1).  No asm VALU instruction may touch a register the matrix pipe reads or writes.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <typename TIO> __device__ __forceinline__ uint32_t pk16(float lo, float hi)
+{
+    if constexpr (std::is_same<TIO, f16_t>::value) return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2_t));
+    else return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2_t));
+}
+// two loaded elements as they stand in their registers (bf16: upper half, the D16-hi load; float16: lower half, zero-extended) -> one
+// register, low half = the first: one v_perm_b32 (bytes 0-3 of the selector address the second source, 4-7 the first)
+template <typename TIO> __device__ __forceinline__ uint32_t pack_raw(uint32_t lo, uint32_t hi)
+{
+    if constexpr (std::is_same<TIO, f16_t>::value) return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+    else return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
+
+// The taps of one conv as the A operands of this lane: row i = lane & 3 of every Toeplitz block, NKB blocks per tap row.
+// stride 1 (NKB = 2): output column 4m + i, K block kb = input columns 4(m + kb) - 2 + k  ->  tap v = 4 kb + k - i
+// stride 2 (NKB = 3): output column 4m + i, K block kb = input columns 8m + 4 kb - 2 + k   ->  tap v = 4 kb + k - 2 i   (0 outside 0 .. 4)
+// They come ready-made from the matrix pack (rcx_pack_recconv_mx, k_pack_mx in rcx_generic.hip: built once per parameter version like the float32
+// pack): [conv][tap row][K block slot 0..2][i][channel] of four 16-bit values = one 8-byte load per operand, no selects in here.
+constexpr int MXP_SLOTS = 3;                                // K block slots per tap row in the matrix pack (stride-1 convs use two)
+template <typename TIO, int STRIDE> struct MxTaps {
+    static constexpr int NKB = STRIDE == 1 ? 2 : 3;
+    u32x2 a[5][NKB];
+    float bias;
+};
+template <typename TIO, int STRIDE>
+__device__ __forceinline__ void load_mxtaps(MxTaps<TIO, STRIDE>& t, __amdgpu_buffer_rsrc_t msrc, const float* __restrict__ bpack, int conv, int C, int c, int has_bias, int i)
+{
+    const int voff = (i * C + c) * 8;
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+#pragma unroll
+        for (int kb = 0; kb < MxTaps<TIO, STRIDE>::NKB; ++kb) {
+            const int soff = ((conv * 5 + u) * MXP_SLOTS + kb) * 4 * C * 8;
+            t.a[u][kb] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(msrc, voff, soff, 0));
+        }
+    t.bias = has_bias ? bpack[(size_t)conv * C + c] : 0.f;
 }
 
 // the 25 taps of one conv for this lane's channel as three register pairs per tap row: (w0,w1) (w2,w3) (w4,0)
@@ -390,13 +519,14 @@ constexpr Rel rel2(int mode, int par, int c)
     return Rel{(c & 1) ? (c - 1) / 2 : c / 2, (c & 1) ? 0.75f : 0.25f};
 }
 
-template <int T_, int HALVES, int MODE, typename TIO>
+template <int T_, int HALVES, int MODE, typename TIO, bool MX_ = false>
 struct Geo {
     static constexpr int T = T_;
     static constexpr int NL = T == 4 ? 4 : 3;
     static constexpr int NW = T * T / HALVES;
     static constexpr int NT = NW * 64;
-    static constexpr int PIXF = 64 / HALVES;
+    static constexpr int CB = 64 / HALVES;                 // channels of a workgroup's block
+    static constexpr int PIXF = CB;                        // floats between two pixels of an LDS plane
     static constexpr int NWORK = T * T;
     static constexpr int P0 = 14 * T, P1 = 7 * T, P2 = plane_size(T, 2), P3 = plane_size(T, 3), P4 = plane_size(T, 4);
     // LDS, in pixels: zero row | guard | L1 | guard | L2 | L3 | L4
@@ -412,13 +542,17 @@ struct Geo {
 // IMG2 (T = 2 only): the two half-waves are two IMAGES (n, n + 1) of the same tile and the same 32 channels -- whole 32-channel
 // blocks for the channel counts that are not multiples of 64 (RecNeXt-M1: 96, M5: 160); geometry and parities stay uniform.
 // TRAIN: the training-forward instantiation (saves the pyramid); the inference instantiations carry none of that code.
-template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool IMG2 = false, bool TRAIN = false>
+// MX: the matrix-core instantiation (16-bit activations whose taps may be rounded to the same type; 56x56 / level 4): passes 1 and 2 as
+// 4 x 4 x 4 products, a wave = 16 channels x the four tiles of one tile row; everything between the passes is the code below unchanged.
+template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool IMG2 = false, bool TRAIN = false, bool MX = false>
 __global__ __launch_bounds__(T * T / HALVES * 64, T == 4 ? 1 : 2)
 void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack,
-                   int N, int C, int has_bias, SavedPyr sv)
+                   int N, int C, int has_bias, SavedPyr sv, const void* __restrict__ mxpack)
 {
-    using G = Geo<T, HALVES, MODE, TIO>;
+    using G = Geo<T, HALVES, MODE, TIO, MX>;
+    static_assert(!MX || (T == 4 && HALVES == 2 && !IMG2 && !TRAIN && sizeof(TIO) == 2), "matrix-core variant: 56x56, inference, 16-bit activations");
     constexpr int NL = G::NL, PIXF = G::PIXF, NWORK = G::NWORK, P0 = G::P0, P1 = G::P1, P2 = G::P2, P3 = G::P3, P4 = G::P4;
+    constexpr int NCOL = MX ? 20 : 18;                             // columns of a level-0 input row held by a lane
     constexpr int ESZ = (int)sizeof(TIO);
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -427,7 +561,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     // over the 8 XCDs; each XCD gets a contiguous run of units, so the channel blocks of one image (the two halves of its
     // 128-byte lines) pass through the same L2 at about the same time.
     static_assert(!IMG2 || HALVES == 1, "image halves use the one-tile-per-wave geometry");
-    constexpr int CHB = IMG2 ? 32 : PIXF;                          // channels per block
+    constexpr int CHB = IMG2 ? 32 : G::CB;                         // channels per block
     const int nb = (C + CHB - 1) / CHB;
     const int NU = IMG2 ? (N + 1) / 2 : N;                          // image units
     const unsigned total = (unsigned)NU * (unsigned)nb, GD = gridDim.x;
@@ -449,10 +583,15 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int h = HALVES == 2 ? (lane >> 5) : 0;
-    const int ch = lane & (PIXF - 1);
+    const int ch = lane & (G::CB - 1);
     const int tr = T == 4 ? (w >> 1) : (w >> 1);
     const int tcb = w & 1;
     const int tc = HALVES == 2 ? tcb + 2 * h : tcb;                      // per lane (HALVES == 2) / uniform
+    // MX: the passes' two lane maps of this wave's 16 channels (w & 1) x the four tiles of tile row tr (see "matrix-core variant")
+    const int chA = (w & 1) * 16 + (lane & 15), tcA = lane >> 4;         // A: memory
+    const int chM = (w & 1) * 16 + (lane >> 2), tcM = lane & 3;          // M: matrix operands and results
+    const int permAM = 4 * (16 * (lane & 3) + (lane >> 2));              // ds_bpermute address: lane (M) reads its value from lane (A)
+    const int permMA = 4 * (4 * (lane & 15) + (lane >> 4));              // ... and lane (A) from lane (M)
     const int q = tr * T + tc;                                          // this tile-lane's worker id
     const bool ledge = tc == 0, redge = tc == T - 1;
     const int ih = IMG2 ? (lane >> 5) : 0;                         // IMG2: this lane's image within the pair
@@ -491,31 +630,86 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     }
     const unsigned OOB = 0x80000000u;
     const unsigned imgoff = (unsigned)(ih * P0 * P0 * pix);            // IMG2: the second image of the pair (past the last image: out of range, reads 0)
-    const unsigned voffM = (IMG2 && n + ih >= N) ? OOB : (unsigned)((14 * tc) * pix + cc * ESZ) + imgoff;
-    const unsigned voffL = (ledge || voffM == OOB) ? OOB : voffM - 2u * (unsigned)pix;      // columns -2, -1 of the tile
-    const unsigned voffR = (redge || voffM == OOB) ? OOB : voffM + 14u * (unsigned)pix;     // columns 14, 15
-    // row r (tile-local, -2 .. 15), all 18 columns; rows outside the image are redirected to a valid row (loaded, not used)
-    auto load_row = [&](uint32_t (&raw)[18], int r) {
+    // the lane's tile column, channel and edge flags for global memory: map A in the matrix-core variant
+    const int tcG = MX ? tcA : tc;
+    const int cG = MX ? cb * CHB + chA : c;
+    const bool cvalidG = MX ? cG < C : cvalid;
+    const int ccG = cvalidG ? cG : C - 1;
+    const bool ledgeG = tcG == 0, redgeG = tcG == T - 1;
+    const unsigned voffM = (IMG2 && n + ih >= N) ? OOB : (unsigned)((14 * tcG) * pix + ccG * ESZ) + imgoff;
+    const unsigned voffL = (ledgeG || voffM == OOB) ? OOB : voffM - 2u * (unsigned)pix;      // columns -2, -1 of the tile
+    const unsigned voffR = (redgeG || voffM == OOB) ? OOB : voffM + 14u * (unsigned)pix;     // columns 14, 15 (MX: 14 .. 17)
+    // row r (tile-local, -2 .. 15), all 18 (MX: 20) columns; rows outside the image are redirected to a valid row (loaded, not used)
+    auto load_row = [&](uint32_t (&raw)[NCOL], int r) {
         int ar = 14 * tr + r;
         ar = ar < 0 ? 0 : (ar > P0 - 1 ? P0 - 1 : ar);
         const int rb = __builtin_amdgcn_readfirstlane(ar * (P0 * pix));     // uniform by construction; the asm below needs it in an SGPR
-        row_load<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
+        if constexpr (MX) row_load20<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
+        else row_load<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
     };
     auto row_valid = [&](int r) -> bool { const int ar = 14 * tr + r; return ar >= 0 && ar < P0; };   // uniform
 
     // pass 1's first rows are requested before the taps, the LDS clearing's tail and the barrier: their HBM latency runs behind those
-    constexpr int AHEAD1 = RCX_CPT_PF > 0 ? 2 : 3, R01 = -2, NR1 = 17;
-    uint32_t raw1[NR1][18];
-    if constexpr (RCX_CPT_PF == 0) sfor<AHEAD1>([&](auto rc) { load_row(raw1[decltype(rc)::value], R01 + decltype(rc)::value); });
+    constexpr int AHEAD1 = (RCX_CPT_PF > 0 || MX) ? RCX_MX_AHEAD1 : 3, R01 = -2, NR1 = 17;
+    uint32_t raw1[NR1][NCOL];
+    if constexpr (RCX_CPT_PF == 0 || MX) sfor<AHEAD1>([&](auto rc) { load_row(raw1[decltype(rc)::value], R01 + decltype(rc)::value); });
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, (NL + 2) * 25 * C * 4, 0x00020000);
     Taps td;
-    load_taps(td, wsrc, bpack, 0, C, cc, has_bias);
+    MxTaps<TIO, 2> ad;                                       // MX: the down conv as Toeplitz blocks (pass 1); td is loaded after the pass
+    const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc((void*)(MX ? mxpack : (const void*)wpack), 0, (NL + 2) * 5 * MXP_SLOTS * 4 * C * 8, 0x00020000);
+    const int cM = cb * CHB + chM, ccM = cM < C ? cM : C - 1;       // map M: the channel whose taps and results this lane holds
+    if constexpr (MX) load_mxtaps(ad, msrc, bpack, 0, C, ccM, has_bias, lane & 3);
+    else load_taps(td, wsrc, bpack, 0, C, cc, has_bias);
     __syncthreads();
     CPT_STAMP(1);
 
     // ================= pass 1: F1 tile = down(x), rows -2 .. 14 of the tile, input-row stationary (tap pairs) =================
     float f1[7][7];                                          // this lane's F1 tile stays in registers until T1 is formed
-    {
+    if constexpr (MX) {
+        // Matrix cores: an input row is five K blocks of four columns (two v_perm_b32 each); output block m (F1 columns 4m .. 4m+3,
+        // column 7 is not an output) takes the K blocks 2m, 2m+1, 2m+2 of every input row that one of its five tap rows reaches.
+        constexpr int AHEAD = AHEAD1, R0 = R01, NR = NR1;
+        uint32_t (&raw)[NR][NCOL] = raw1;
+        f32x4 facc[3][2];
+        const f32x4 b4 = f32x4{ad.bias, ad.bias, ad.bias, ad.bias};
+        sfor<NR>([&](auto rc) {
+            constexpr int ri = decltype(rc)::value, r = R0 + ri;
+            if constexpr (ri + AHEAD < NR) load_row(raw[ri + AHEAD], r + AHEAD);
+            constexpr int NY = [] { int k = 0; for (int j = 1; j <= AHEAD; ++j) k += (ri + j < NR ? NCOL : 0); return k > 63 ? 63 : k; }();
+            pin_row20<NY>(raw[ri]);
+            u32x2 B[5];                                          // packed in map A, handed to map M
+#pragma unroll
+            for (int kb = 0; kb < 5; ++kb)
+                B[kb] = u32x2{(uint32_t)__builtin_amdgcn_ds_bpermute(permAM, (int)pack_raw<TIO>(raw[ri][4 * kb], raw[ri][4 * kb + 1])),
+                              (uint32_t)__builtin_amdgcn_ds_bpermute(permAM, (int)pack_raw<TIO>(raw[ri][4 * kb + 2], raw[ri][4 * kb + 3]))};
+            const bool rv = row_valid(r);
+#pragma unroll
+            for (int o = 0; o < 7; ++o) {
+                const int u = r - 2 * o + 2;
+                if (u < 0 || u > 4) continue;
+                f32x4(&a)[2] = facc[o % 3];
+                if (rv) {
+                    // u == 0, first K block: the first product of output row o carries the initial value (the bias) as its addend
+#pragma unroll
+                    for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) a[m] = mx444<TIO>(ad.a[u][kb], B[2 * m + kb], (u == 0 && kb == 0) ? b4 : a[m]);
+                } else if (u == 0) {
+                    a[0] = b4;
+                    a[1] = b4;
+                }
+                if (u == 4) {                                    // F1 row o of tile (tr, tcM), channel chM -> LDS (T1 is formed from there)
+                    float* dst = lds + chM + (G::O1 + (7 * tr + o) * P1 + 7 * tcM) * PIXF;
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) dst[i * PIXF] = i < 4 ? a[0][i] : a[1][i - 4];
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 7; ++o) if (r - 2 * o + 2 >= 0 && r - 2 * o + 2 < 4) pin(facc[o % 3]);
+            CPT_FENCE;
+        });
+        load_taps(td, wsrc, bpack, 0, C, cc, has_bias);      // the ladder below runs on the vector pipe in float32
+    } else {
         constexpr int AHEAD = AHEAD1, R0 = R01, NR = NR1;
         const f32x2 b0 = f32x2{td.bias, 0.f};
         uint32_t (&raw)[NR][18] = raw1;
@@ -709,6 +903,13 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             cx = cx < 0 ? 0 : (cx > P2 - 1 ? P2 - 1 : cx);
             cofs[k] = cx * PIXF;
         }
+        if constexpr (MX) {                                   // pass 1 left F1 in LDS (its lane map is not this one)
+            const float* src = L1 + ((7 * tr) * P1 + 7 * tc) * PIXF;
+#pragma unroll
+            for (int r = 0; r < 7; ++r)
+#pragma unroll
+                for (int cI = 0; cI < 7; ++cI) f1[r][cI] = src[(r * P1 + cI) * PIXF];
+        }
         const int cpar = __builtin_amdgcn_readfirstlane(d0 & 1);
         auto form = [&](auto parc) {
             constexpr int PAR = decltype(parc)::value;
@@ -803,23 +1004,30 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         }
     }
     Taps tf;
-    load_taps(tf, wsrc, bpack, 1 + NL, C, cc, has_bias);
+    MxTaps<TIO, 1> af;                                       // MX: the final conv as Toeplitz blocks
+    if constexpr (MX) { load_mxtaps(af, msrc, bpack, 1 + NL, C, ccM, has_bias, lane & 3); tf.bias = af.bias; }
+    else load_taps(tf, wsrc, bpack, 1 + NL, C, cc, has_bias);
     __syncthreads();
     CPT_STAMP(7);
 
     // ================= pass 2: y tile = conv(x + resize(C1)), input rows -2 .. 15, five accumulator rows in flight =================
     {
-        constexpr int AHEAD = 2, R0 = -2, NR = 18;
+        constexpr int AHEAD = MX ? RCX_MX_AHEAD2 : 2, R0 = -2, NR = 18;
         // C1 columns -2 .. 8 of the tile: the two on each side may lie outside the plane (clamped: ATen's border rule)
-        const int cb0 = 7 * tc;
-        const int cL0 = (ledge ? 0 : cb0 - 2) * PIXF, cL1 = (ledge ? 0 : cb0 - 1) * PIXF;
-        const int cR0 = (redge ? P1 - 1 : cb0 + 7) * PIXF, cR1 = (redge ? P1 - 1 : cb0 + 8) * PIXF;
+        // (this pass reads C1 and x and writes y in the global-memory lane map: tcG, ledgeG ... = map A in the matrix-core variant)
+        const int cb0 = 7 * tcG;
+        const int cL0 = (ledgeG ? 0 : cb0 - 2) * PIXF, cL1 = (ledgeG ? 0 : cb0 - 1) * PIXF;
+        const int cR0 = (redgeG ? P1 - 1 : cb0 + 7) * PIXF, cR1 = (redgeG ? P1 - 1 : cb0 + 8) * PIXF;
+        const float lmaskG = ledgeG ? 0.f : 1.f, rmaskG = redgeG ? 0.f : 1.f;
+        const float* const L1G = (MX ? lds + chA : L) + G::O1 * PIXF;
         // horizontal weights; the pairs that lie outside the image (columns -2, -1 at the left edge, 14, 15 at the right) are zeroed here
         const f32x2 wq = MODE == 1 ? splat(0.f) : splat(0.25f), wt = MODE == 1 ? splat(1.f) : splat(0.75f);
-        uint32_t raw[NR][18];
+        uint32_t raw[NR][NCOL];
         f32x2 H[2][9];
-        f32x2 acc[5][7];
+        f32x2 acc[MX ? 1 : 5][7];
+        f32x4 accm[MX ? 5 : 1][4];                            // MX: five output rows in flight, four blocks of four columns (14, 15 are not outputs)
         const f32x2 bf = splat(tf.bias);
+        const f32x4 bf4 = f32x4{tf.bias, tf.bias, tf.bias, tf.bias};
         i32x4 ysrc;                                           // y image as a raw buffer; lanes past the last channel store out of range (dropped)
         {
             const unsigned long long a = (unsigned long long)(reinterpret_cast<char*>(y) + (size_t)n * P0 * P0 * pix);
@@ -828,12 +1036,12 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             ysrc.z = (IMG2 && n + 1 < N ? 2 : 1) * P0 * P0 * pix;
             ysrc.w = 0x00020000;
         }
-        const unsigned yoff = cvalid ? (unsigned)((14 * tc) * pix + c * ESZ) + imgoff : OOB;
+        const unsigned yoff = cvalidG ? (unsigned)((14 * tcG) * pix + cG * ESZ) + imgoff : OOB;
         // H[i]: C1 row i (tile-local, -2 .. 8; clamped into the plane) resized horizontally to the 18 columns -2 .. 15
         auto build_H = [&](f32x2 (&Hs)[9], int i) {
             int ar = 7 * tr + i;
             ar = ar < 0 ? 0 : (ar > P1 - 1 ? P1 - 1 : ar);
-            const float* rp = L1 + ar * (P1 * PIXF);
+            const float* rp = L1G + ar * (P1 * PIXF);
             float cv[11];
             cv[0] = rp[cL0];
             cv[1] = rp[cL1];
@@ -852,8 +1060,8 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                 const float mid = ((j + 1) & 1) ? P[(j + 1) >> 1].y : P[(j + 1) >> 1].x;
                 Hs[j] = pfma(splat(mid), wt, e);
             });
-            Hs[0] = Hs[0] * splat(lmask);
-            Hs[8] = Hs[8] * splat(rmask);
+            Hs[0] = Hs[0] * splat(lmaskG);
+            Hs[8] = Hs[8] * splat(rmaskG);
         };
         sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], R0 + decltype(rc)::value); });
         build_H(H[0], -2);
@@ -873,7 +1081,52 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             // end of the iterations in between (14 stores each; iteration i stores a row for 4 <= i <= 17); the counter holds 63
             constexpr int NLD = NR - 1 - ri < AHEAD ? NR - 1 - ri : AHEAD;
             constexpr int NST = (ri - 1 >= 4 && ri - 1 <= 17 ? 1 : 0) + (AHEAD >= 2 && ri - 2 >= 4 && ri - 2 <= 17 ? 1 : 0) + (AHEAD >= 3 && ri - 3 >= 4 && ri - 3 <= 17 ? 1 : 0);
-            pin_row<(18 * NLD + 14 * NST > 63 ? 63 : 18 * NLD + 14 * NST)>(raw[ri]);
+            if constexpr (MX) pin_row20<(NCOL * NLD + 14 * NST > 63 ? 63 : NCOL * NLD + 14 * NST)>(raw[ri]);
+            else pin_row<(18 * NLD + 14 * NST > 63 ? 63 : 18 * NLD + 14 * NST)>(raw[ri]);
+            if constexpr (MX) {
+              if (row_valid(t)) {
+                // T0 row = x + resize(C1), columns -2 .. 17 (16, 17: x alone -- they only meet zero Toeplitz entries), rounded once to the
+                // activations' type as five K blocks; output block m takes the K blocks m and m + 1 of each of its five input rows
+                f32x2 row[10];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const f32x2 xv = f32x2{raw_f32<TIO>(raw[ri][2 * k]), raw_f32<TIO>(raw[ri][2 * k + 1])};
+                    if (MODE == 1) row[k] = xv + H[(i0 + 2) & 1][k];
+                    else row[k] = pfma(splat(lam), H[(i1 + 2) & 1][k], pfma(splat(1.f - lam), H[(i0 + 2) & 1][k], xv));
+                }
+                row[9] = f32x2{raw_f32<TIO>(raw[ri][18]), raw_f32<TIO>(raw[ri][19])};
+                u32x2 B[5];                                      // rounded and packed in map A, handed to map M
+#pragma unroll
+                for (int kb = 0; kb < 5; ++kb)
+                    B[kb] = u32x2{(uint32_t)__builtin_amdgcn_ds_bpermute(permAM, (int)pk16<TIO>(row[2 * kb].x, row[2 * kb].y)),
+                                  (uint32_t)__builtin_amdgcn_ds_bpermute(permAM, (int)pk16<TIO>(row[2 * kb + 1].x, row[2 * kb + 1].y))};
+                CPT_FENCE;
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const int o = t - u + 2;
+                    if (o < 0 || o > 13) continue;
+                    f32x4(&a)[4] = accm[o % 5];
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) a[m] = mx444<TIO>(af.a[u][kb], B[m + kb], (u == 0 && kb == 0) ? bf4 : a[m]);     // u == 0: output row t + 2 enters the window
+                }
+              } else if constexpr (t + 2 >= 0 && t + 2 <= 13) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) accm[(t + 2) % 5][m] = bf4;
+              }
+              if constexpr (t - 2 >= 0 && t - 2 <= 13) {
+                constexpr int o = t - 2;
+                uint32_t p7[7];                               // converted by compiler-visible instructions (pk16): they read matrix results
+#pragma unroll
+                for (int j = 0; j < 7; ++j)                   // ... in map M, stored from map A
+                    p7[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(permMA, (int)pk16<TIO>(accm[o % 5][j >> 1][2 * (j & 1)], accm[o % 5][j >> 1][2 * (j & 1) + 1]));
+                const int yrb = __builtin_amdgcn_readfirstlane((14 * tr + o) * (P0 * pix));
+                RowSt<TIO, PIXB>::st_packed(p7, yoff, ysrc, yrb, pix);
+              }
+#pragma unroll
+              for (int o = 0; o < 14; ++o) if (o > t - 2 && o <= t + 2) pin(accm[o % 5]);
+            } else {
             if (row_valid(t)) {
                 f32x2 row[9], odd[8];
 #pragma unroll
@@ -912,6 +1165,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             }
 #pragma unroll
             for (int o = 0; o < 14; ++o) if (o > t - 2 && o <= t + 2) pin(acc[o % 5]);
+            }
             pin(H[0]);
             pin(H[1]);
             CPT_FENCE;
@@ -930,15 +1184,15 @@ static inline bool enabled()
     return !(v && *v == '0') && !(l && *l == '0');
 }
 
-template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool IMG2 = false, bool TRAIN = false>
-static hipError_t launch(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv)
+template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool IMG2 = false, bool TRAIN = false, bool MX = false>
+static hipError_t launch(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv, const void* mxpack = nullptr)
 {
-    using G = Geo<T, HALVES, MODE, TIO>;
-    if constexpr (!TRAIN && MODE == 0 && !IMG2) {             // training forward: bilinear only (what RecConv2d trains with), whole-block variants
+    using G = Geo<T, HALVES, MODE, TIO, MX>;
+    if constexpr (!TRAIN && MODE == 0 && !IMG2 && !MX) {      // training forward: bilinear only (what RecConv2d trains with), whole-block variants
         if (sv.base) return launch<T, HALVES, MODE, PIXB, TIO, IMG2, true>(x, y, wpack, bpack, N, C, s, sv);
     }
     if (!TRAIN && sv.base) return hipErrorInvalidConfiguration;
-    auto kfn = k_recconv_cpt<T, HALVES, MODE, PIXB, TIO, IMG2, TRAIN>;
+    auto kfn = k_recconv_cpt<T, HALVES, MODE, PIXB, TIO, IMG2, TRAIN, MX>;
     static bool attr_set = false;                              // once per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
@@ -951,12 +1205,13 @@ static hipError_t launch(const void* x, void* y, const float* wpack, const float
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
         cus = v;
     }
-    const unsigned total = IMG2 ? (unsigned)(((N + 1) / 2) * ((C + 31) / 32)) : (unsigned)(N * ((C + G::PIXF - 1) / G::PIXF));
+    const unsigned total = IMG2 ? (unsigned)(((N + 1) / 2) * ((C + 31) / 32)) : (unsigned)(N * ((C + G::CB - 1) / G::CB));
     unsigned cap = (unsigned)cus * (T == 4 ? 1u : 2u);         // workgroups resident at once (LDS: one / two per CU)
     if (const char* e = getenv("RCX_CPT_GRID")) { const int g = atoi(e); if (g > 0) cap = (unsigned)g; }    // A/B knob
     cap &= ~7u;
     const unsigned grid = total <= cap || cap == 0 ? total : cap;
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(G::NT), G::LDS_BYTES, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
+    if (MX && !mxpack) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(G::NT), G::LDS_BYTES, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv, mxpack);
     return hipGetLastError();
 }
 
@@ -970,6 +1225,22 @@ static hipError_t launch_c(const void* x, void* y, const float* wpack, const flo
         if (C % 64 != 0) return launch<T, HALVES, MODE, 0, TIO, true>(x, y, wpack, bpack, N, C, s, sv);      // whole 32-channel blocks, image pairs
     }
     return launch<T, HALVES, MODE, 0, TIO>(x, y, wpack, bpack, N, C, s, sv);
+}
+
+// matrix-core variant (56x56 / level 4, bf16 or float16 activations; rcx_cpt.hip decides when it applies)
+template <int MODE, typename TIO>
+static hipError_t launch_mx_c(const void* x, void* y, const float* wpack, const float* bpack, const void* mxpack, int N, int C, hipStream_t s)
+{
+    const SavedPyr sv{};
+    if (C == 64) return launch<4, 2, MODE, 64 * (int)sizeof(TIO), TIO, false, false, true>(x, y, wpack, bpack, N, C, s, sv, mxpack);
+    return launch<4, 2, MODE, 0, TIO, false, false, true>(x, y, wpack, bpack, N, C, s, sv, mxpack);
+}
+template <int DEFER = 0>                                   // a template only so that the eight instantiations are made where it is called (rcx_cpt.hip)
+static hipError_t launch_mx(const void* x, void* y, const float* wpack, const float* bpack, const void* mxpack, int N, int C, int mode, int dtype, hipStream_t s)
+{
+    if (dtype == 1) return mode == 1 ? launch_mx_c<1, bf16_t>(x, y, wpack, bpack, mxpack, N, C, s) : launch_mx_c<0, bf16_t>(x, y, wpack, bpack, mxpack, N, C, s);
+    if (dtype == 2) return mode == 1 ? launch_mx_c<1, f16_t>(x, y, wpack, bpack, mxpack, N, C, s) : launch_mx_c<0, f16_t>(x, y, wpack, bpack, mxpack, N, C, s);
+    return hipErrorInvalidConfiguration;
 }
 
 template <int T, int HALVES>

@@ -8,6 +8,7 @@
 // adjacent outputs for a vector of V channels so the window is read once per row instead of once
 // per tap.  NHWC puts channels on consecutive lanes: every wave-load is a run of whole pixels.
 // The fused single-launch schedules live in rcx_plane.hip; rcx_api.hip picks between them.
+#include <type_traits>
 #include "rcx_common.h"
 #include "rcx_launch.h"
 
@@ -317,6 +318,43 @@ hipError_t pack_params(const PackPtrs& P, float* wpack, float* wflip, float* bpa
     if (dt == 0) hipLaunchKernelGGL(k_pack_params<float>, grid, block, 0, s, P, wpack, wflip, bpack, C, k * k);
     else if (dt == 2) hipLaunchKernelGGL(k_pack_params<f16_t>, grid, block, 0, s, P, wpack, wflip, bpack, C, k * k);
     else hipLaunchKernelGGL(k_pack_params<bf16_t>, grid, block, 0, s, P, wpack, wflip, bpack, C, k * k);
+    return hipGetLastError();
+}
+
+// The matrix pack (round 3): the 5 x 5 taps of every conv of a block as the A operands of the 4 x 4 x 4 matrix products
+// (rcx_cpt_kernel.h, "matrix-core variant"): banded Toeplitz blocks, row i of a block = four 16-bit values
+//   conv 0 (the shared stride-2 conv): slot kb = 0..2, entry k:  w[u][4 kb + k - 2 i]
+//   convs 1.. (stride 1)             : slot kb = 0..1, entry k:  w[u][4 kb + k - i]     (slot 2 is zero)
+// or 0 where that tap index is outside 0 .. 4; laid out [conv][tap row u][slot][i][channel] x 8 bytes.  Source: the float32 pack, so a
+// folded output affine (RecConv2d.fold_output_affine) is already in the taps; they are rounded to the activations' type here.
+template <typename T16>
+__global__ void k_pack_mx(const float* __restrict__ wpack, uint2* __restrict__ dst, int C, int count)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = count * 5 * 3 * 4 * C;
+    if (idx >= total) return;
+    const int c = idx % C, i = (idx / C) % 4, kb = (idx / (4 * C)) % 3, u = (idx / (12 * C)) % 5, j = idx / (60 * C);
+    const int stride = j == 0 ? 2 : 1;
+    uint16_t e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int v = 4 * kb + k - stride * i;
+        const bool on = v >= 0 && v <= 4 && (stride == 2 || kb < 2);
+        const float w = on ? wpack[((size_t)(j * 25 + u * 5 + v)) * C + c] : 0.f;
+        if constexpr (std::is_same<T16, f16_t>::value) e[k] = __builtin_bit_cast(uint16_t, (f16_t)w);
+        else e[k] = f32_to_bf16(w);
+    }
+    dst[idx] = make_uint2((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16));
+}
+
+size_t mxpack_bytes(int count, int C) { return (size_t)count * 5 * 3 * 4 * C * 8; }
+
+hipError_t pack_mx(const float* wpack, void* mxpack, int count, int C, int dt, hipStream_t s)
+{
+    const int n = count * 5 * 3 * 4 * C;
+    if (dt == 2) hipLaunchKernelGGL(k_pack_mx<f16_t>, dim3((n + 255) / 256), dim3(256), 0, s, wpack, (uint2*)mxpack, C, count);
+    else if (dt == 1) hipLaunchKernelGGL(k_pack_mx<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, s, wpack, (uint2*)mxpack, C, count);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -30,6 +30,9 @@ hipError_t pack_bias(const void* b, float* dst, int C, int dt, hipStream_t s);
 struct PackPtrs { const void* w[10]; const void* b[10]; };         // RCX_MAX_LEVEL + 2 convs
 hipError_t pack_params(const PackPtrs& P, float* wpack, float* wflip, float* bpack, int count, int C, int k, int dt, hipStream_t s);
 hipError_t unpack_grads(const float* gwpack, const PackPtrs& P, int count, int C, int k, hipStream_t s);
+// the taps as Toeplitz blocks for the matrix-core schedules (k = 5; dt = the activations' 16-bit type)
+size_t mxpack_bytes(int count, int C);
+hipError_t pack_mx(const float* wpack, void* mxpack, int count, int C, int dt, hipStream_t s);
 
 // rcx_plane.hip -- fused single-launch schedule (k=5, C%8==0, pyramid fits in LDS)
 bool plane_applicable(int N, int C, int H, int W, int level, int k, int dtype);
@@ -95,6 +98,10 @@ int cpt_describe(int N, int C, int H, int mode, int dtype, char* buf, int len);
 bool cpt_train_applicable(int N, int C, int H, int W, int level, int k, int mode, int dtype);
 hipError_t cpt_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int H, int mode, int dtype, hipStream_t s,
                        float* saved = nullptr, const size_t* f_off = nullptr, const size_t* c_off = nullptr);
+// the same block with its two level-0 passes on the matrix cores (16-bit activations, taps rounded to their type: rcx_recconv2d_fwd_mx)
+bool cpt_mx_applicable(int N, int C, int H, int W, int level, int k, int dtype);
+int cpt_mx_describe(int N, int C, int mode, int dtype, char* buf, int len);
+hipError_t cpt_mx_recconv(const void* x, void* y, const float* wpack, const float* bpack, const void* mxpack, int N, int C, int mode, int dtype, hipStream_t s);
 
 // rcx_down.hip -- register-resident depthwise 7x7 stride-2 conv with channel multiplier 2 (Downsample) on the 7*2^k planes
 bool down_lanes_applicable(int N, int Cin, int H, int W, int k, int stride, int dtype);

@@ -130,8 +130,27 @@ def recconv2d_plan(n, c, h, w, level, k, mode, dtype):
     return _lib.load().rcx_recconv2d_fwd_plan(n, c, h, w, level, k, _lib.MODES[mode], _DT[dtype]).decode()
 
 
-def recconv2d_forward(x, wpack, bpack, level, k, mode="bilinear"):
-    """RecConv2d.forward (model/recnext.py:24-34) on the HIP kernels. Returns a channels_last tensor like x."""
+def pack_recconv_mx(wpack, level, c, k, dtype):
+    """The taps of a block as the matrix-core schedules want them (rcx_pack_recconv_mx): banded Toeplitz blocks in `dtype` (bfloat16 or
+    float16), built from the float32 pack.  None where no such pack exists (k != 5)."""
+    lib = _lib.load()
+    nbytes = lib.rcx_recconv2d_mxpack_bytes(c, level, k)
+    if not nbytes:
+        return None
+    mx = torch.empty(nbytes, dtype=torch.uint8, device=wpack.device)
+    with torch.cuda.device(wpack.device):
+        rc = lib.rcx_pack_recconv_mx(wpack.data_ptr(), mx.data_ptr(), c, level, k, _DT[dtype], _stream(wpack.device))
+    _lib.check(rc, "rcx_pack_recconv_mx")
+    return mx
+
+
+def recconv2d_plan_mx(n, c, h, w, level, k, mode, dtype):
+    return _lib.load().rcx_recconv2d_fwd_plan_mx(n, c, h, w, level, k, _lib.MODES[mode], _DT[dtype]).decode()
+
+
+def recconv2d_forward(x, wpack, bpack, level, k, mode="bilinear", mxpack=None):
+    """RecConv2d.forward (model/recnext.py:24-34) on the HIP kernels. Returns a channels_last tensor like x.
+    mxpack (pack_recconv_mx, in x's 16-bit dtype): the taps may be rounded to x's dtype -- rcx_recconv2d_fwd_mx."""
     x = _nhwc(x)
     n, c, h, w = x.shape
     if mode not in _lib.MODES:
@@ -144,10 +163,16 @@ def recconv2d_forward(x, wpack, bpack, level, k, mode="bilinear"):
     nbytes = lib.rcx_recconv2d_fwd_workspace_bytes(n, c, h, w, level, k, dt)    # 0 on the fused schedules: nothing to allocate
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     with torch.cuda.device(x.device):
-        rc = lib.rcx_recconv2d_fwd(x.data_ptr(), y.data_ptr(), wpack.data_ptr(),
-                                   bpack.data_ptr() if bpack is not None else None,
-                                   ws.data_ptr() if ws is not None else None, nbytes, n, c, h, w, level, k, _lib.MODES[mode], dt,
-                                   _stream(x.device))
+        if mxpack is not None and dt != _lib.DTYPE_F32:
+            rc = lib.rcx_recconv2d_fwd_mx(x.data_ptr(), y.data_ptr(), wpack.data_ptr(),
+                                          bpack.data_ptr() if bpack is not None else None, mxpack.data_ptr(),
+                                          ws.data_ptr() if ws is not None else None, nbytes, n, c, h, w, level, k, _lib.MODES[mode], dt,
+                                          _stream(x.device))
+        else:
+            rc = lib.rcx_recconv2d_fwd(x.data_ptr(), y.data_ptr(), wpack.data_ptr(),
+                                       bpack.data_ptr() if bpack is not None else None,
+                                       ws.data_ptr() if ws is not None else None, nbytes, n, c, h, w, level, k, _lib.MODES[mode], dt,
+                                       _stream(x.device))
     _lib.check(rc, "rcx_recconv2d_fwd")
     return y
 

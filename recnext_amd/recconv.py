@@ -37,6 +37,8 @@ class RecConv2d(nn.Module):
         self._pack_key = None
         self._pack = None
         self._wflip = None                                  # the pack with every k x k flipped (the backward's taps)
+        self._mx_key = None
+        self._mx = None                                     # the taps as Toeplitz blocks in a 16-bit type (matrix-core schedules)
         # Optional per-channel affine applied to the block's OUTPUT (y*scale + shift), folded into
         # convs[level] when the packs are built: used to absorb the eval-mode BatchNorm that follows the
         # token mixer in MetaNeXtBlock (model/recnext.py:153,158) -- SURVEY.md section 8f row 2.
@@ -109,7 +111,24 @@ class RecConv2d(nn.Module):
                 _warn_eval_with_grad()
             return _RecConv2dFn.apply(x, self, *plist)
         wpack, bpack = self.packed_params()
-        return ops.recconv2d_forward(x, wpack, bpack, self.level, self.kernel_size, self.mode)
+        return ops.recconv2d_forward(x, wpack, bpack, self.level, self.kernel_size, self.mode, mxpack=self.packed_mx(x.dtype))
+
+    def packed_mx(self, dtype):
+        """The taps as the matrix-core schedules want them, or None where the float32 vector kernels must run.
+
+        They apply when the taps may be rounded to the activations' 16-bit type, i.e. in exactly the situations in which the
+        reference can run the block in 16 bits at all (nn.Conv2d refuses mixed dtypes): the parameters have the activations' type
+        (``model.bfloat16()`` / ``.half()`` -- the rounding is then exact) or autocast is on (the conv casts its weight,
+        engine.py:48).  float32 parameters with 16-bit activations outside autocast -- which only this module accepts -- keep
+        the exact float32 taps on the vector pipe.  Call after packed_params() (same cache key)."""
+        if dtype not in (torch.bfloat16, torch.float16) or self.kernel_size != 5:
+            return None
+        if self.down.weight.dtype != dtype and not torch.is_autocast_enabled():
+            return None
+        if getattr(self, "_mx_key", None) != (self._pack_key, dtype):
+            self._mx = ops.pack_recconv_mx(self._pack[0], self.level, self.in_channels, self.kernel_size, dtype)
+            self._mx_key = (self._pack_key, dtype)
+        return self._mx
 
     def extra_repr(self):
         return (f"{self.in_channels}, kernel_size={self.kernel_size}, level={self.level}, mode={self.mode!r}, "

@@ -206,9 +206,16 @@ def gen_recattn(refa, utils, out):
             y = mod(x)
             d = mod.down[0](x)                      # stride-2 depthwise (+folded BN)
             a = mod.down[1](d)                      # linear attention output
+            # the bf16 targets (round 3): the float32 module on bf16-rounded inputs, and the reference's OWN bf16 run of the same
+            # inputs -- its distance from the float32 result is the yardstick for the HIP path's bf16 error (BASELINE config 4)
+            xr = bf16_round(x)
+            y_r = mod(xr)
+            import copy
+            y_b = copy.deepcopy(mod).bfloat16()(xr.bfloat16()).float()
         la = mod.down[1]
         rec = {
             "x": np32(x), "y": np32(y), "y_unfused": np32(y_unfused), "down_out": np32(d), "attn_out": np32(a),
+            "y_bf16in_f32": np32(y_r), "y_bf16": np32(y_b),
             "w_down": np32(mod.down[0].weight), "b_down": np32(mod.down[0].bias),
             "w_conv": np32(mod.conv.weight), "b_conv": np32(mod.conv.bias),
             "w_qk": np32(la.qk.weight), "b_qk": np32(la.qk.bias),

@@ -85,10 +85,10 @@ def test_tiny_model_logits_gpu_with_hip_token_mixers(fam):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,batch", [("recnext_m0", 2), ("recnext_a0", 2), ("recnext_a3", 4), ("recnext_m3", 2)])
+@pytest.mark.parametrize("name,batch", [("recnext_m0", 2), ("recnext_a0", 2), ("recnext_a3", 4), ("recnext_m3", 2), ("recnext_m1", 2), ("recnext_m5", 2)])
 def test_full_model_hip_vs_eager_gpu(name, batch):
     """Whole registered model at 224: HIP token mixers vs the ATen restatement, same weights, fp32 and bf16.
-    recnext_a3 is BASELINE config 4, recnext_m3 the headline model."""
+    recnext_a3 is BASELINE config 4, recnext_m3 the headline model, recnext_m1 / recnext_m5 configs 2 and 3 (per GPU)."""
     dev = torch.device("cuda:0")
     fam = models.CONFIGS[name]["family"]
     torch.manual_seed(0)

@@ -363,6 +363,14 @@ FULL = [
     ("M3 stage3", 256, 512, 7, 7, 1),
     ("M5 stage0", 128, 80, 56, 56, 4),
     ("M3@512 stage0", 16, 64, 128, 128, 4),
+    # BASELINE config 3's per-GPU workload (RecNeXt-M5, 256 images per GPU; model/recnext.py:406) and config 2's other stages (M1, :376)
+    ("M5 cfg3 stage0", 256, 80, 56, 56, 4),
+    ("M5 cfg3 stage1", 256, 160, 28, 28, 3),
+    ("M5 cfg3 stage2", 256, 320, 14, 14, 2),
+    ("M5 cfg3 stage3", 256, 640, 7, 7, 1),
+    ("M1 cfg2 stage0", 256, 48, 56, 56, 4),
+    ("M1 cfg2 stage2", 256, 192, 14, 14, 2),
+    ("M1 cfg2 stage3", 256, 384, 7, 7, 1),
 ]
 
 
@@ -511,7 +519,18 @@ def test_linear_attention_core(case, dtype):
     if dtype == torch.float32:
         assert np.abs(got - ref).max() < 2e-4
     else:
-        assert np.allclose(got, ref, atol=3e-2, rtol=3e-2)      # the qk GEMM output and pe are rounded to bf16 on the way in
+        # the qk GEMM output and pe are rounded to bf16 on the way in, exactly as the reference's bf16 run rounds them; the yardstick is
+        # that chain (q/k activation, the two products, normaliser, + pe in bf16 PyTorch operators on the same rounded inputs)
+        import torch.nn.functional as F
+        s_ = (h * w) ** -0.5
+        qf = (F.elu(qpre) + 1.0).view(b, h * w, heads, c // heads).permute(0, 2, 3, 1)      # (b, heads, d, n), model/recattn.py:17-19
+        kf = (F.elu(kpre) + 1.0).view(b, h * w, heads, c // heads).permute(0, 2, 3, 1)
+        vf = dd.permute(0, 2, 3, 1).reshape(b, h * w, heads, c // heads).permute(0, 2, 3, 1)
+        kv = (kf * s_) @ (vf.transpose(-2, -1) * s_)                                         # :23
+        z = 1.0 / (qf.transpose(-2, -1) @ kf.mean(dim=-1, keepdim=True) + 1e-6)              # :24
+        o = (qf.transpose(-2, -1) @ kv * z).transpose(-2, -1).reshape(b, c, h, w) + pe       # :25-28
+        ref_bf16 = o.float().cpu().numpy()
+        _assert_bf16_no_worse_than_reference(got, ref.astype(np.float32), ref_bf16, "x".join(map(str, case)))
 
 
 @pytest.mark.parametrize("name", recattn_cases())
@@ -530,6 +549,24 @@ def test_recattn2d_module_matches_reference_golden(name):
     with torch.no_grad():
         y = mod(x)
     assert float((y.cpu() - torch.from_numpy(d["y"])).abs().max()) < 2e-4
+    # bf16 (north_star: 1e-2): against the float32 reference on the bf16-rounded input, with the reference's OWN bf16 run of the same
+    # input (fixture y_bf16, tests/golden/make_golden.py) as the yardstick where that run itself is outside 1e-2
+    xr = torch.from_numpy(bf16_round_np(d["x"])).to(dev()).bfloat16().contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        yb = mod.bfloat16()(xr).float().cpu().numpy()
+    want, ref_bf16 = d["y_bf16in_f32"], d["y_bf16"]
+    _assert_bf16_no_worse_than_reference(yb, want, ref_bf16, name)
+
+
+def _assert_bf16_no_worse_than_reference(got, want, ref_bf16, label):
+    """err_hip <= max(1e-2 (1 + |ref|), 1.25 err_reference_bf16): element-wise north_star tolerance, relaxed only as far as the
+    reference's own bf16 run of the same inputs is from the float32 result (max and mean)."""
+    err, err_ref = np.abs(got - want), np.abs(ref_bf16 - want)
+    tol = BF16_ATOL + BF16_RTOL * np.abs(want)
+    print(f"{label}: bf16 max|err| hip {err.max():.3e} (reference's own bf16 run {err_ref.max():.3e}), mean hip {err.mean():.3e} "
+          f"(reference {err_ref.mean():.3e}), worst err/tol hip {(err / tol).max():.2f} (reference {(err_ref / tol).max():.2f})")
+    assert (err <= np.maximum(tol, 1.25 * err_ref.max())).all(), (float(err.max()), float(err_ref.max()))
+    assert err.mean() <= max(1e-3 * (1.0 + float(np.abs(want).mean())), 1.25 * float(err_ref.mean()))
 
 
 # ---- BASELINE config 4: the four token mixers of RecNeXt-A3 at 224x224, batch 256 (model/recattn.py:403, :163-171) ----
@@ -575,9 +612,12 @@ def test_recattn2d_full_size_properties(case, dtype):
     scale = float(want.abs().max())
     if dtype == torch.float32:
         assert float((got - want).abs().max()) < 1e-3 * max(1.0, scale)
-    else:       # bf16: the qk GEMM, pe and the attention output are rounded to bf16 between the kernels (as in the reference)
-        assert float((got - want).abs().max()) < 3e-2 * max(1.0, scale)
-        assert float((got - want).abs().mean()) < 3e-3 * max(1.0, scale)
+    else:       # bf16: the qk GEMM, pe and the attention output are rounded to bf16 between the kernels (as in the reference, which
+        # rounds after EVERY operator): the yardstick is the reference chain's own bf16 run of the same three images
+        import copy
+        with torch.no_grad():
+            ref_bf16 = copy.deepcopy(ref).bfloat16()(x[idx].cpu().contiguous()).float()
+        _assert_bf16_no_worse_than_reference(got.numpy(), want.numpy(), ref_bf16.numpy(), case[0])
 
 
 # ---- register-resident single-step kernels (rcx_upadd.hip) on the 7*2^k planes ----

@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--mode", default="bilinear")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--taps", default="io", choices=["io", "fp32"],
+                    help="io: the module's parameters have the activations' dtype (model.bfloat16(): the matrix-core schedules apply); "
+                         "fp32: float32 parameters with 16-bit activations (exact taps, vector kernels)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     rows = []
@@ -60,6 +63,9 @@ def main():
                 eb = 4 if dtype == torch.float32 else 2
                 torch.manual_seed(0)
                 mod = recnext_amd.RecConv2d(c, kernel_size=5, level=level, mode=args.mode).to(dev).eval()
+                mx = args.taps == "io" and dtype != torch.float32
+                if mx:
+                    mod = mod.to(dtype)
                 x = torch.randn(n, c, h, w, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
                 with torch.no_grad():
                     for _ in range(3):
@@ -68,7 +74,8 @@ def main():
                     med, mn = time_fn(lambda: mod(x), args.iters)
                     alg = 2 * n * c * h * w * eb + (level + 2) * c * 25 * eb
                     row = {"set": sname, "shape": [n, c, h, w], "level": level, "dtype": dname,
-                           "plan": ops.recconv2d_plan(n, c, h, w, level, 5, args.mode, dtype),
+                           "taps": "io" if mx else "fp32",
+                           "plan": (ops.recconv2d_plan_mx if mx else ops.recconv2d_plan)(n, c, h, w, level, 5, args.mode, dtype),
                            "ms": med, "ms_min": mn, "alg_GBs": alg / med / 1e6, "frac_8TBs": alg / med / 1e6 / 8000}
                     if args.eager:
                         from oracle.torch_eager import EagerRecConv2d

@@ -1,7 +1,7 @@
 // Stand-alone timing / phase-stamp harness for rcx_cpt.hip (development tool; no torch, no library): compiles the kernel file
 // itself, launches it on random data, prints the HIP-event time per launch and, with -DRCX_STAMPS, the phase timeline.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize [-DRCX_STAMPS] [-D...] tools/cpt_bench.hip -o tools/cpt_bench
-//   tools/cpt_bench [H=56] [C=64] [N=256] [dtype: 1=bf16 0=f32] [iters=20]
+//   tools/cpt_bench [H=56] [C=64] [N=256] [dtype: 1=bf16 0=f32] [iters=20] [mx: 1 = the matrix-core variant (56x56, bf16)]
 #include "../recnext_amd/csrc/rcx_cpt.hip"
 #include "../recnext_amd/csrc/rcx_cpt2.hip"
 
@@ -17,6 +17,7 @@ int main(int argc, char** argv)
 {
     const int H = argc > 1 ? atoi(argv[1]) : 56, C = argc > 2 ? atoi(argv[2]) : 64, N = argc > 3 ? atoi(argv[3]) : 256;
     const int dt = argc > 4 ? atoi(argv[4]) : 1, iters = argc > 5 ? atoi(argv[5]) : 20;
+    const int mx = argc > 6 ? atoi(argv[6]) : 0;
     const int level = H == 56 ? 4 : 3, esz = dt ? 2 : 4;
     const size_t elems = (size_t)N * C * H * H;
     std::vector<unsigned short> hx16(dt ? elems : 0);
@@ -37,24 +38,39 @@ int main(int argc, char** argv)
     CK(hipMalloc(&st, nst * 8)); CK(hipMemset(st, 0, nst * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(rcx::cpt::g_cpt_stamps), &st, sizeof(st)));
 #endif
+    // the matrix pack built on the host (k_pack_mx's layout: [conv][u][slot][i][C] x four bf16)
+    void* mxp = nullptr;
+    if (mx) {
+        std::vector<unsigned short> hm((size_t)(level + 2) * 5 * 3 * 4 * C * 4, 0);
+        for (int j = 0; j < level + 2; ++j) for (int u = 0; u < 5; ++u) for (int kb = 0; kb < 3; ++kb) for (int i = 0; i < 4; ++i) for (int c = 0; c < C; ++c)
+            for (int k = 0; k < 4; ++k) {
+                const int st = j == 0 ? 2 : 1, v = 4 * kb + k - st * i;
+                float wv = (v >= 0 && v <= 4 && (st == 2 || kb < 2)) ? hw[(size_t)(j * 25 + u * 5 + v) * C + c] : 0.f;
+                unsigned bits; memcpy(&bits, &wv, 4);
+                bits += 0x7FFF + ((bits >> 16) & 1);
+                hm[((((size_t)(j * 5 + u) * 3 + kb) * 4 + i) * C + c) * 4 + k] = (unsigned short)(bits >> 16);
+            }
+        CK(hipMalloc(&mxp, hm.size() * 2)); CK(hipMemcpy(mxp, hm.data(), hm.size() * 2, hipMemcpyHostToDevice));
+    }
+    auto run = [&](hipStream_t st_) { return mx ? rcx::cpt_mx_recconv(x, y, w, nullptr, mxp, N, C, 0, dt, st_) : rcx::cpt_recconv(x, y, w, nullptr, N, C, H, 0, dt, st_); };
     hipStream_t s; CK(hipStreamCreate(&s));
-    for (int i = 0; i < 3; ++i) CK(rcx::cpt_recconv(x, y, w, nullptr, N, C, H, 0, dt, s));
+    for (int i = 0; i < 3; ++i) CK(run(s));
     CK(hipStreamSynchronize(s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<float> ts;
     for (int r = 0; r < 5; ++r) {
         CK(hipEventRecord(e0, s));
-        for (int i = 0; i < iters; ++i) CK(rcx::cpt_recconv(x, y, w, nullptr, N, C, H, 0, dt, s));
+        for (int i = 0; i < iters; ++i) CK(run(s));
         CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms / iters * 1000.f);
     }
     std::sort(ts.begin(), ts.end());
     const double bytes = 2.0 * elems * esz + (double)(level + 2) * 25 * C * esz;
-    printf("H=%d C=%d N=%d %s: %.2f us per launch (min %.2f)  %.0f GB/s algorithmic = %.3f of 8 TB/s\n", H, C, N, dt ? "bf16" : "f32", ts[2], ts[0],
+    printf("%sH=%d C=%d N=%d %s: %.2f us per launch (min %.2f)  %.0f GB/s algorithmic = %.3f of 8 TB/s\n", mx ? "matrix cores " : "", H, C, N, dt ? "bf16" : "f32", ts[2], ts[0],
            bytes / ts[2] / 1e3, bytes / ts[2] / 1e3 / 8000.0);
 #ifdef RCX_STAMPS
     CK(hipMemset(st, 0, nst * 8)); CK(hipDeviceSynchronize());
-    CK(rcx::cpt_recconv(x, y, w, nullptr, N, C, H, 0, dt, s)); CK(hipStreamSynchronize(s));
+    CK(run(s)); CK(hipStreamSynchronize(s));
     std::vector<unsigned long long> h(nst);
     CK(hipMemcpy(h.data(), st, nst * 8, hipMemcpyDeviceToHost));
     const char* names[9] = {"start", "LDS zeroed, taps", "pass 1 done", "barrier", "down ladder", "up pieces", "T1 formed", "C1 done", "pass 2 done"};
