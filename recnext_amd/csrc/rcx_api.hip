@@ -282,7 +282,7 @@ namespace {
 bool use_mx(int N, int C, int H, int W, int level, int k, int dtype)
 {
     if (lanes_off() || getenv("RCX_FORCE_SPLIT")) return false;
-    return rcx::cpt_mx_applicable(N, C, H, W, level, k, dtype);
+    return rcx::cpt_mx_applicable(N, C, H, W, level, k, dtype) || rcx::cpl14mx_applicable(N, C, H, W, level, k, dtype);
 }
 }  // namespace
 
@@ -305,7 +305,10 @@ const char* rcx_recconv2d_fwd_plan_mx(int N, int C, int H, int W, int level, int
 {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0) return "invalid";
     static thread_local char desc[256];
-    if (use_mx(N, C, H, W, level, k, dtype) && rcx::cpt_mx_describe(N, C, mode == RCX_MODE_NEAREST ? 1 : 0, dtype, desc, (int)sizeof(desc)) > 0) return desc;
+    if (use_mx(N, C, H, W, level, k, dtype)) {
+        const int md = mode == RCX_MODE_NEAREST ? 1 : 0;
+        if ((H == 14 ? rcx::cpl14mx_describe(N, C, md, dtype, desc, (int)sizeof(desc)) : rcx::cpt_mx_describe(N, C, md, dtype, desc, (int)sizeof(desc))) > 0) return desc;
+    }
     return rcx_recconv2d_fwd_plan(N, C, H, W, level, k, mode, dtype);
 }
 
@@ -318,7 +321,9 @@ int rcx_recconv2d_fwd_mx(const void* x, void* y, const float* wpack, const float
         if (!wpack) return fail(RCX_ERR_BAD_ARG, "null weight pack");
         if (x == y) return fail(RCX_ERR_BAD_ARG, "y must not alias x");
         if (mode != RCX_MODE_BILINEAR && mode != RCX_MODE_NEAREST) return fail(RCX_ERR_BAD_ARG, "unknown mode %d", mode);
-        hipError_t e = rcx::cpt_mx_recconv(x, y, wpack, bpack, mxpack, N, C, mode == RCX_MODE_NEAREST ? 1 : 0, dtype, (hipStream_t)stream);
+        const int md = mode == RCX_MODE_NEAREST ? 1 : 0;
+        hipError_t e = H == 14 ? rcx::cpl14mx_recconv(x, y, mxpack, bpack, N, C, md, dtype, (hipStream_t)stream)
+                               : rcx::cpt_mx_recconv(x, y, wpack, bpack, mxpack, N, C, md, dtype, (hipStream_t)stream);
         return e == hipSuccess ? 0 : hip_fail(e, "matrix-core schedule");
     }
     return rcx_recconv2d_fwd(x, y, wpack, bpack, workspace, workspace_bytes, N, C, H, W, level, k, mode, dtype, stream);

@@ -540,10 +540,17 @@ static hipError_t launch(const void* x, void* y, const float* wpack, const float
 // x through LDS: 16-bit I/O and whole 64-channel blocks.  OFF by default (RCX_CPL14_LDS=1 switches it on for A/B runs): measured
 // 19.96 us against 19.27 us for the register / AGPR-stash form at 256 x 256 x 14 x 14 bf16 (profiles/r02c_cpl14_lds_variant.txt) --
 // the kernel is bound by its ~5.3 k instructions at one wave per SIMD, not by the latency of its x loads.
+// It is an A/B variant: only the diagnostic library (make diag: -DRCX_AB_VARIANTS) carries it (round 3: the shipped library has the one
+// form that is used, and its asm-hazard scan -- part of `make all` -- reported this variant's f16 / nearest instantiation).
 static inline bool use_xl(int C, int esz)
 {
+#ifdef RCX_AB_VARIANTS
     const char* v = getenv("RCX_CPL14_LDS");
     return esz == 2 && C % 64 == 0 && v && *v == '1';
+#else
+    (void)C; (void)esz;
+    return false;
+#endif
 }
 
 template <int MODE, int CT, typename TIO>
@@ -557,9 +564,11 @@ static hipError_t launch_xl(const void* x, void* y, const float* wpack, const fl
 template <int MODE, typename TIO>
 static hipError_t launch_c(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv)
 {
+#ifdef RCX_AB_VARIANTS
     if constexpr (sizeof(TIO) == 2) {
         if (use_xl(C, 2)) return C == 256 ? launch_xl<MODE, 256, TIO>(x, y, wpack, bpack, N, C, s, sv) : launch_xl<MODE, 0, TIO>(x, y, wpack, bpack, N, C, s, sv);
     }
+#endif
     if (C == 256) return launch<MODE, 256, TIO>(x, y, wpack, bpack, N, C, s, sv);          // RecNeXt-M3/M4 stage 2: immediates instead of scalar adds
     return launch<MODE, 0, TIO>(x, y, wpack, bpack, N, C, s, sv);
 }

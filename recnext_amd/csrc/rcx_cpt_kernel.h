@@ -40,8 +40,23 @@ using lanes::vtab;
 using lanes::VT;
 
 #define CPT_FENCE __builtin_amdgcn_sched_barrier(0)
+#ifndef RCX_ABL
+#define RCX_ABL 0                          /* tools/mx_bench.hip: timing-only ablations of the matrix-core passes (results are wrong) */
+#endif
+#define ABL_NOPERM (RCX_ABL & 1)           /* no ds_bpermute */
+#define ABL_NOMFMA (RCX_ABL & 2)           /* one matrix instruction per K block instead of all */
+#define ABL_NOBAR (RCX_ABL & 4)            /* no per-step barrier */
+#define ABL_NOTR (RCX_ABL & 8)             /* no transposing / row reads from the stage */
+#define ABL_NOSTAGE (RCX_ABL & 16)         /* no global loads and LDS writes of the staging */
+#define ABL_NOSTORE (RCX_ABL & 32)         /* no y stores */
+#ifndef RCX_MX_STAGE
+#define RCX_MX_STAGE 0                     /* matrix-core variant, how x reaches the lanes: bit 0 / bit 1 = pass 1 / pass 2 through the band-synchronous LDS
+                                              staging (wide loads, transposing reads); 0 = element loads in lane map A.  Measured: profiles/r03_mx_*.txt */
+#endif
+#define MX_STAGE1 (RCX_MX_STAGE & 1)
+#define MX_STAGE2 (RCX_MX_STAGE & 2)
 #ifndef RCX_MX_AHEAD1
-#define RCX_MX_AHEAD1 2                    /* matrix-core variant: input rows requested ahead in pass 1 / pass 2 */
+#define RCX_MX_AHEAD1 5                    /* matrix-core variant: steps (rows of the four bands) in flight in registers, pass 1 / pass 2 */
 #endif
 #ifndef RCX_MX_AHEAD2
 #define RCX_MX_AHEAD2 2
@@ -323,6 +338,33 @@ __device__ __forceinline__ void pin_row20(uint32_t (&v)[20])
                  "+v"(v[17]), "+v"(v[18]), "+v"(v[19]) : "n"(PENDING));
 }
 
+// two 16-byte loads per lane in one statement (same rules as row_load) and their counted wait
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wide_load2(u32x4& a, u32x4& b, unsigned va, unsigned vb, i32x4 rs, int rb)
+{
+    int t;
+    asm volatile("s_add_i32 %[t], %[rb], 0\n\tbuffer_load_dwordx4 %[a], %[va], %[rs], %[t] offen\n\tbuffer_load_dwordx4 %[b], %[vb], %[rs], %[t] offen"
+                 : [a] "=&v"(a), [b] "=&v"(b), [t] "=&s"(t) : [va] "v"(va), [vb] "v"(vb), [rs] "s"(rs), [rb] "s"(rb) : "scc");
+}
+template <int PENDING> __device__ __forceinline__ void pin_wide2(u32x4& a, u32x4& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(PENDING)); }
+
+// twenty horizontally adjacent pixels of this lane's channel from an LDS image [pixel][channel] of 16-bit values (64 bytes per pixel):
+// loads and their wait in ONE statement, so no register is ever in flight outside it.  bf16 arrives in float32 position
+// (ds_read_u16_d16_hi), float16 zero-extended -- exactly what row_load20 leaves.
+#define CPT_DS20(OP)                                                                                                                  \
+    OP " %0, %20\n\t" OP " %1, %20 offset:64\n\t" OP " %2, %20 offset:128\n\t" OP " %3, %20 offset:192\n\t" OP " %4, %20 offset:256\n\t"     \
+    OP " %5, %20 offset:320\n\t" OP " %6, %20 offset:384\n\t" OP " %7, %20 offset:448\n\t" OP " %8, %20 offset:512\n\t"                     \
+    OP " %9, %20 offset:576\n\t" OP " %10, %20 offset:640\n\t" OP " %11, %20 offset:704\n\t" OP " %12, %20 offset:768\n\t"                  \
+    OP " %13, %20 offset:832\n\t" OP " %14, %20 offset:896\n\t" OP " %15, %20 offset:960\n\t" OP " %16, %20 offset:1024\n\t"                \
+    OP " %17, %20 offset:1088\n\t" OP " %18, %20 offset:1152\n\t" OP " %19, %20 offset:1216\n\ts_waitcnt lgkmcnt(0)"
+template <typename TIO>
+__device__ __forceinline__ void lds_row20(uint32_t (&v)[20], unsigned addr)
+{
+    static_assert(sizeof(TIO) == 2, "16-bit activations");
+    if constexpr (std::is_same<TIO, f16_t>::value) asm volatile(CPT_DS20("ds_read_u16") : CPT_OUT20(v) : "v"(addr) : "memory");
+    else asm volatile(CPT_DS20("ds_read_u16_d16_hi") : CPT_OUT20(v) : "v"(addr) : "memory");
+}
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -536,7 +578,15 @@ struct Geo {
     static constexpr int O3 = O2 + P2 * P2;
     static constexpr int O4 = O3 + P3 * P3;
     static constexpr int NPIX = O4 + (NL >= 4 ? P4 * P4 : 0);
-    static constexpr int LDS_BYTES = NPIX * PIXF * 4;
+    // MX: the streaming passes stage rows of x behind the level-1 plane -- over the planes of the levels below, which are dead during
+    // both passes -- and use the CU's whole LDS.  One staged row of a band: 68 pixels (columns -4 .. 63; -4 .. -1 stay zero and 56 .. 63
+    // are written as zeros: the conv's padding) x 32 channels x 2 bytes, + 32 bytes so that the two bands a transposing read's
+    // 32-lane half touches fall on different banks.
+    static constexpr int XBAND = 68 * CB * 2 + 32;
+    static constexpr int XSTAGE = 4 * XBAND;
+    static constexpr int XOFF = O2 * PIXF * 4;              // byte offset of the staging area
+    static constexpr int LDS_BYTES = MX_ ? 160 * 1024 : NPIX * PIXF * 4;
+    static_assert(!MX_ || XOFF + 2 * XSTAGE <= 160 * 1024, "staging area does not fit");
 };
 
 // IMG2 (T = 2 only): the two half-waves are two IMAGES (n, n + 1) of the same tile and the same 32 channels -- whole 32-channel
@@ -581,7 +631,9 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     const int n = IMG2 ? 2 * nu : nu;                              // first (only) image of the unit
 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
+    int lane_ = tid & 63;
+    if constexpr (MX) asm volatile("" : "+v"(lane_));            // per unit: what derives from the lane index is recomputed, not kept live across units
+    const int lane = lane_;
     const int h = HALVES == 2 ? (lane >> 5) : 0;
     const int ch = lane & (G::CB - 1);
     const int tr = T == 4 ? (w >> 1) : (w >> 1);
@@ -648,11 +700,35 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         else row_load<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
     };
     auto row_valid = [&](int r) -> bool { const int ar = 14 * tr + r; return ar >= 0 && ar < P0; };   // uniform
+    // MX, both passes: the band-synchronous staging of x rows (see pass 1).  Loader role of this wave: band w >> 1, two 1 KB pieces per step
+    char* const xst = reinterpret_cast<char*>(lds) + G::XOFF;
+    const int bandL = w >> 1;
+    const int colL = 32 * (w & 1) + (lane >> 2);              // piece 0: 16 columns from colL (4 lanes of 16 bytes per pixel), piece 1: from colL + 16
+    const unsigned qoffL = (unsigned)((cb * CHB) * ESZ + (lane & 3) * 16);
+    const unsigned vla = (unsigned)(colL * pix) + qoffL, vlb = colL + 16 < P0 ? (unsigned)((colL + 16) * pix) + qoffL : OOB;
+    const int wrA = bandL * G::XBAND + (colL + 4) * (G::CB * 2) + (lane & 3) * 16, wrB = wrA + 16 * (G::CB * 2);
+    auto sfetch = [&](u32x4& a, u32x4& b, int sI) {          // step sI: rows 14 j + sI - 2; rows outside the image read zeros
+        const int ar = 14 * bandL + sI - 2;                   // uniform
+        const bool ok = ar >= 0 && ar < P0;
+        const int rb = __builtin_amdgcn_readfirstlane((ok ? ar : 0) * (P0 * pix));
+        wide_load2(a, b, ok ? vla : OOB, ok ? vlb : OOB, rsrc, rb);
+    };
+    auto sstore = [&](const u32x4& a, const u32x4& b, int sI) {
+        char* st = xst + (sI & 1) * G::XSTAGE;
+        *reinterpret_cast<u32x4*>(st + wrA) = a;
+        *reinterpret_cast<u32x4*>(st + wrB) = b;
+    };
+    auto zero_pads = [&]() {                                  // columns -4 .. -1 of both stages (the ladder has written over this area)
+        for (int i = tid; i < 2 * 4 * 4 * 4; i += G::NT) {   // stage, band, pad pixel, 16-byte quarter
+            const int q = i & 3, pp = (i >> 2) & 3, bnd = (i >> 4) & 3, sg = i >> 6;
+            *reinterpret_cast<u32x4*>(xst + sg * G::XSTAGE + bnd * G::XBAND + pp * (G::CB * 2) + q * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+    };
 
     // pass 1's first rows are requested before the taps, the LDS clearing's tail and the barrier: their HBM latency runs behind those
-    constexpr int AHEAD1 = (RCX_CPT_PF > 0 || MX) ? RCX_MX_AHEAD1 : 3, R01 = -2, NR1 = 17;
+    constexpr int AHEAD1 = RCX_CPT_PF > 0 ? 2 : 3, R01 = -2, NR1 = 17;
     uint32_t raw1[NR1][NCOL];
-    if constexpr (RCX_CPT_PF == 0 || MX) sfor<AHEAD1>([&](auto rc) { load_row(raw1[decltype(rc)::value], R01 + decltype(rc)::value); });
+    if constexpr (RCX_CPT_PF == 0 && !(MX && MX_STAGE1)) sfor<AHEAD1>([&](auto rc) { load_row(raw1[decltype(rc)::value], R01 + decltype(rc)::value); });
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, (NL + 2) * 25 * C * 4, 0x00020000);
     Taps td;
     MxTaps<TIO, 2> ad;                                       // MX: the down conv as Toeplitz blocks (pass 1); td is loaded after the pass
@@ -665,9 +741,10 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
 
     // ================= pass 1: F1 tile = down(x), rows -2 .. 14 of the tile, input-row stationary (tap pairs) =================
     float f1[7][7];                                          // this lane's F1 tile stays in registers until T1 is formed
-    if constexpr (MX) {
-        // Matrix cores: an input row is five K blocks of four columns (two v_perm_b32 each); output block m (F1 columns 4m .. 4m+3,
-        // column 7 is not an output) takes the K blocks 2m, 2m+1, 2m+2 of every input row that one of its five tap rows reaches.
+    if constexpr (MX && !MX_STAGE1) {
+        // Matrix cores, element loads in lane map A (wave = tile row tr x 16 channels, the four lanes of a matrix block = the four tile
+        // columns): an input row is five K blocks of four columns (two v_perm_b32 each, then ds_bpermute_b32 into map M); output block m
+        // (F1 columns 4m .. 4m+3, column 7 is not an output) takes the K blocks 2m, 2m+1, 2m+2 of every input row one of its tap rows reaches
         constexpr int AHEAD = AHEAD1, R0 = R01, NR = NR1;
         uint32_t (&raw)[NR][NCOL] = raw1;
         f32x4 facc[3][2];
@@ -707,6 +784,68 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
 #pragma unroll
             for (int o = 0; o < 7; ++o) if (r - 2 * o + 2 >= 0 && r - 2 * o + 2 < 4) pin(facc[o % 3]);
             CPT_FENCE;
+        });
+        load_taps(td, wsrc, bpack, 0, C, cc, has_bias);      // the ladder below runs on the vector pipe in float32
+    } else if constexpr (MX) {
+        // Matrix cores, band-synchronous streaming.  The four lanes of a matrix block are the four BANDS of the plane (tile rows
+        // j = 0 .. 3: rows 14 j + r), a wave = (tile column tcw = w >> 1) x 16 channels (w & 1), and all eight waves walk r = -2 .. 14
+        // together.  Per step every wave fetches two 1 KB pieces of the four rows 14 j + r (16 bytes per lane: whole 64-byte
+        // half-lines, each pixel once -- the element loads of the first build touched 32 bytes per cache-line access and made this
+        // pass L1-tag bound at twice the vector kernel's time), AH steps ahead into registers, and drops them into a two-stage LDS
+        // image [band][pixel][channel]; a K block of four columns x 16 channels x 4 bands then is ONE ds_read_b64_tr_b16 (the
+        // transposing read hands lane 16 j + c the four pixels of channel c of band j) and two ds_bpermute_b32 into the matrix
+        // instruction's lane order 4 c + j.  Rows and columns outside the image are zeros in the image (out-of-range loads / pad pixels).
+        constexpr int AH = RCX_MX_AHEAD1, NR = NR1;          // steps in flight in registers, steps
+        u32x4 xa[AH + 1], xb[AH + 1];
+        auto fetch = [&](auto sc) { sfetch(xa[decltype(sc)::value % (AH + 1)], xb[decltype(sc)::value % (AH + 1)], decltype(sc)::value); };
+        auto stage = [&](auto sc) {                              // registers -> LDS stage s & 1 (younger loads in flight: the rows behind it)
+            constexpr int sI = decltype(sc)::value;
+            constexpr int NY = 2 * ((NR - 1 - sI) < AH ? (NR - 1 - sI) : AH);
+            pin_wide2<NY>(xa[sI % (AH + 1)], xb[sI % (AH + 1)]);
+            sstore(xa[sI % (AH + 1)], xb[sI % (AH + 1)], sI);
+        };
+        zero_pads();
+        sfor<AH + 1>([&](auto sc) { fetch(sc); });
+        stage(IC<0>{});
+        __syncthreads();
+        // reader role: K block kb of band j = pixels 14 tcw - 2 + 4 kb .. + 3 (image index + 4), channels 16 (w & 1) .. + 15; lane 4 q + p of a
+        // 16-lane group supplies row q, 8-byte chunk p
+        const int tcw = w >> 1;
+        const int rdA = (lane >> 4) * G::XBAND + (14 * tcw + 2 + ((lane >> 2) & 3)) * (G::CB * 2) + (w & 1) * 32 + (lane & 3) * 8;
+        f32x4 facc[3][2];
+        const f32x4 b4 = f32x4{ad.bias, ad.bias, ad.bias, ad.bias};
+        sfor<NR>([&](auto rc) {
+            constexpr int ri = decltype(rc)::value, r = R01 + ri;
+            if constexpr (!ABL_NOSTAGE) {
+            if constexpr (ri + 1 + AH < NR) fetch(IC<ri + 1 + AH>{});
+            if constexpr (ri + 1 < NR) stage(IC<ri + 1>{});      // next step's rows into the other stage
+            }
+            const char* st = xst + (ri & 1) * G::XSTAGE + rdA;
+            u32x2 B[5];
+#pragma unroll
+            for (int kb = 0; kb < 5; ++kb) {
+                u32x2 v = u32x2{(uint32_t)(lane + kb), (uint32_t)(ri + kb)};
+                if constexpr (!ABL_NOTR) v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + kb * 4 * (G::CB * 2))));
+                if constexpr (ABL_NOPERM) B[kb] = v;
+                else B[kb] = u32x2{(uint32_t)__builtin_amdgcn_ds_bpermute(permAM, (int)v.x), (uint32_t)__builtin_amdgcn_ds_bpermute(permAM, (int)v.y)};
+            }
+#pragma unroll
+            for (int o = 0; o < 7; ++o) {
+                const int u = r - 2 * o + 2;
+                if (u < 0 || u > 4) continue;
+                f32x4(&a)[2] = facc[o % 3];
+                // u == 0, first K block: the first product of output row o carries the initial value (the bias) as its addend
+#pragma unroll
+                for (int kb = 0; kb < (ABL_NOMFMA ? 1 : 3); ++kb)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) a[m] = mx444<TIO>(ad.a[u][kb], B[2 * m + kb], (u == 0 && kb == 0) ? b4 : a[m]);
+                if (u == 4) {                                    // F1 row o of tile (band tcM, tile column tcw), channel chM -> LDS
+                    float* dst = lds + chM + (G::O1 + (7 * tcM + o) * P1 + 7 * tcw) * PIXF;
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) dst[i * PIXF] = i < 4 ? a[0][i] : a[1][i - 4];
+                }
+            }
+            if constexpr (!ABL_NOBAR) __syncthreads();           // the other stage is complete; this one may be refilled
         });
         load_taps(td, wsrc, bpack, 0, C, cc, has_bias);      // the ladder below runs on the vector pipe in float32
     } else {
@@ -1012,7 +1151,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
 
     // ================= pass 2: y tile = conv(x + resize(C1)), input rows -2 .. 15, five accumulator rows in flight =================
     {
-        constexpr int AHEAD = MX ? RCX_MX_AHEAD2 : 2, R0 = -2, NR = 18;
+        constexpr int AHEAD = 2, R0 = -2, NR = 18;
         // C1 columns -2 .. 8 of the tile: the two on each side may lie outside the plane (clamped: ATen's border rule)
         // (this pass reads C1 and x and writes y in the global-memory lane map: tcG, ledgeG ... = map A in the matrix-core variant)
         const int cb0 = 7 * tcG;
@@ -1063,12 +1202,43 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             Hs[0] = Hs[0] * splat(lmaskG);
             Hs[8] = Hs[8] * splat(rmaskG);
         };
-        sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], R0 + decltype(rc)::value); });
+        // MX: x comes through the band-synchronous staging of pass 1 (this wave's band is its tile row tr; step = row t + 2 of every band);
+        // a lane then reads the 20 pixels of its tile and channel from the staged row (LDS, no cache-line tags, no halo re-reads)
+        constexpr int AH = RCX_MX_AHEAD2;
+        u32x4 xa[MX ? AH + 1 : 1], xb[MX ? AH + 1 : 1];
+        auto fetch = [&](auto sc) { sfetch(xa[decltype(sc)::value % (AH + 1)], xb[decltype(sc)::value % (AH + 1)], decltype(sc)::value); };
+        auto stage = [&](auto sc) {
+            constexpr int sI = decltype(sc)::value;
+            // younger memory operations: the loads of the steps behind it and the output rows stored since step sI was requested
+            // (in iteration sI - 1 - AH, or before the loop): iterations i = 4 .. 17 end with 14 stores
+            constexpr int NY = [] {
+                int k = 0;
+                for (int j = sI + 1; j <= sI + AH && j < NR; ++j) k += 2;
+                for (int i = (sI - 1 - AH < 0 ? 0 : sI - 1 - AH); i <= sI - 2; ++i) if (i >= 4 && i <= 17) k += 14;
+                return k > 63 ? 63 : k;
+            }();
+            pin_wide2<NY>(xa[sI % (AH + 1)], xb[sI % (AH + 1)]);
+            sstore(xa[sI % (AH + 1)], xb[sI % (AH + 1)], sI);
+        };
+        const unsigned rdL = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(xst + tr * G::XBAND + (14 * tcA + 2) * (G::CB * 2) + chA * 2);
+        if constexpr (MX && MX_STAGE2) {
+            zero_pads();
+            sfor<AH + 1>([&](auto sc) { fetch(sc); });
+            stage(IC<0>{});
+            __syncthreads();
+        } else sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], R0 + decltype(rc)::value); });
         build_H(H[0], -2);
         build_H(H[1], -1);
         sfor<NR>([&](auto rc) {
             constexpr int ri = decltype(rc)::value, t = R0 + ri;
-            if constexpr (ri + AHEAD < NR) load_row(raw[ri + AHEAD], t + AHEAD);
+            if constexpr (MX && MX_STAGE2) {
+                if constexpr (!ABL_NOSTAGE) {
+                if constexpr (ri + 1 + AH < NR) fetch(IC<ri + 1 + AH>{});
+                if constexpr (ri + 1 < NR) stage(IC<ri + 1>{});
+                }
+                if constexpr (ABL_NOTR) { for (int k = 0; k < 20; ++k) raw[ri][k] = (uint32_t)(lane + k + ri) << 16; }
+                else lds_row20<TIO>(raw[ri], rdL + (ri & 1) * G::XSTAGE);
+            } else if constexpr (ri + AHEAD < NR) load_row(raw[ri + AHEAD], t + AHEAD);
             // vertical source rows (tile origin is even): t even -> (t/2 - 1, t/2) weight 0.75; t odd -> ((t-1)/2, (t+1)/2) weight 0.25
             constexpr int te = (t + 2) & 1;                  // parity of t (t + 2 >= 0)
             constexpr int i0 = MODE == 1 ? ((t + 2) >> 1) - 1 : (te ? (t - 1) / 2 : t / 2 - 1);
@@ -1081,8 +1251,8 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             // end of the iterations in between (14 stores each; iteration i stores a row for 4 <= i <= 17); the counter holds 63
             constexpr int NLD = NR - 1 - ri < AHEAD ? NR - 1 - ri : AHEAD;
             constexpr int NST = (ri - 1 >= 4 && ri - 1 <= 17 ? 1 : 0) + (AHEAD >= 2 && ri - 2 >= 4 && ri - 2 <= 17 ? 1 : 0) + (AHEAD >= 3 && ri - 3 >= 4 && ri - 3 <= 17 ? 1 : 0);
-            if constexpr (MX) pin_row20<(NCOL * NLD + 14 * NST > 63 ? 63 : NCOL * NLD + 14 * NST)>(raw[ri]);
-            else pin_row<(18 * NLD + 14 * NST > 63 ? 63 : 18 * NLD + 14 * NST)>(raw[ri]);
+            if constexpr (MX && !MX_STAGE2) pin_row20<(NCOL * NLD + 14 * NST > 63 ? 63 : NCOL * NLD + 14 * NST)>(raw[ri]);
+            if constexpr (!MX) pin_row<(18 * NLD + 14 * NST > 63 ? 63 : 18 * NLD + 14 * NST)>(raw[ri]);
             if constexpr (MX) {
               if (row_valid(t)) {
                 // T0 row = x + resize(C1), columns -2 .. 17 (16, 17: x alone -- they only meet zero Toeplitz entries), rounded once to the
@@ -1098,6 +1268,8 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                 u32x2 B[5];                                      // rounded and packed in map A, handed to map M
 #pragma unroll
                 for (int kb = 0; kb < 5; ++kb)
+                    if constexpr (ABL_NOPERM) B[kb] = u32x2{pk16<TIO>(row[2 * kb].x, row[2 * kb].y), pk16<TIO>(row[2 * kb + 1].x, row[2 * kb + 1].y)};
+                    else
                     B[kb] = u32x2{(uint32_t)__builtin_amdgcn_ds_bpermute(permAM, (int)pk16<TIO>(row[2 * kb].x, row[2 * kb].y)),
                                   (uint32_t)__builtin_amdgcn_ds_bpermute(permAM, (int)pk16<TIO>(row[2 * kb + 1].x, row[2 * kb + 1].y))};
                 CPT_FENCE;
@@ -1107,9 +1279,9 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                     if (o < 0 || o > 13) continue;
                     f32x4(&a)[4] = accm[o % 5];
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
+                    for (int kb = 0; kb < (ABL_NOMFMA ? 1 : 2); ++kb)
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) a[m] = mx444<TIO>(af.a[u][kb], B[m + kb], (u == 0 && kb == 0) ? bf4 : a[m]);     // u == 0: output row t + 2 enters the window
+                        for (int m = 0; m < (ABL_NOMFMA ? 1 : 4); ++m) a[m] = mx444<TIO>(af.a[u][kb], B[m + kb], (u == 0 && kb == 0) ? bf4 : a[m]);     // u == 0: output row t + 2 enters the window
                 }
               } else if constexpr (t + 2 >= 0 && t + 2 <= 13) {
 #pragma unroll
@@ -1120,9 +1292,11 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                 uint32_t p7[7];                               // converted by compiler-visible instructions (pk16): they read matrix results
 #pragma unroll
                 for (int j = 0; j < 7; ++j)                   // ... in map M, stored from map A
-                    p7[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(permMA, (int)pk16<TIO>(accm[o % 5][j >> 1][2 * (j & 1)], accm[o % 5][j >> 1][2 * (j & 1) + 1]));
+                    p7[j] = ABL_NOPERM ? pk16<TIO>(accm[o % 5][j >> 1][2 * (j & 1)], accm[o % 5][j >> 1][2 * (j & 1) + 1])
+                                       : (uint32_t)__builtin_amdgcn_ds_bpermute(permMA, (int)pk16<TIO>(accm[o % 5][j >> 1][2 * (j & 1)], accm[o % 5][j >> 1][2 * (j & 1) + 1]));
                 const int yrb = __builtin_amdgcn_readfirstlane((14 * tr + o) * (P0 * pix));
-                RowSt<TIO, PIXB>::st_packed(p7, yoff, ysrc, yrb, pix);
+                if constexpr (ABL_NOSTORE) { if (p7[0] == 0x12345678u && p7[3] == 77u) RowSt<TIO, PIXB>::st_packed(p7, yoff, ysrc, yrb, pix); }
+                else RowSt<TIO, PIXB>::st_packed(p7, yoff, ysrc, yrb, pix);
               }
 #pragma unroll
               for (int o = 0; o < 14; ++o) if (o > t - 2 && o <= t + 2) pin(accm[o % 5]);
@@ -1169,6 +1343,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             pin(H[0]);
             pin(H[1]);
             CPT_FENCE;
+            if constexpr (MX && MX_STAGE2 && !ABL_NOBAR) __syncthreads();    // the other stage is complete; this one may be refilled
         });
     }
     CPT_STAMP(8);

@@ -103,6 +103,11 @@ bool cpt_mx_applicable(int N, int C, int H, int W, int level, int k, int dtype);
 int cpt_mx_describe(int N, int C, int mode, int dtype, char* buf, int len);
 hipError_t cpt_mx_recconv(const void* x, void* y, const float* wpack, const float* bpack, const void* mxpack, int N, int C, int mode, int dtype, hipStream_t s);
 
+// matrix-core kernel of the 14x14 / level 2 block (rcx_cpl14mx.hip): 16-bit activations, any channel count
+bool cpl14mx_applicable(int N, int C, int H, int W, int level, int k, int dtype);
+int cpl14mx_describe(int N, int C, int mode, int dtype, char* buf, int len);
+hipError_t cpl14mx_recconv(const void* x, void* y, const void* mxpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s);
+
 // rcx_down.hip -- register-resident depthwise 7x7 stride-2 conv with channel multiplier 2 (Downsample) on the 7*2^k planes
 bool down_lanes_applicable(int N, int Cin, int H, int W, int k, int stride, int dtype);
 hipError_t down_lanes(const void* x, void* y, const float* w, const float* b, int N, int Cin, int H, int W, int k, int stride, int dtype, hipStream_t s);

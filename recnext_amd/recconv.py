@@ -11,10 +11,19 @@ Forward and backward accept float32, bfloat16 or float16 CUDA tensors (logical N
 storage is consumed zero-copy, anything else is converted once) and returns a channels_last tensor
 of the same shape and dtype.  All arithmetic is float32 inside the kernels.  There is no CPU path.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from . import ops
+
+
+# The matrix-core schedules (rcx_recconv2d_fwd_mx: 56x56 / level 4 and 14x14 / level 2 blocks with 16-bit activations and taps) are
+# parity-green at north_star's 1e-2 but, as measured in round 3 (DESIGN.md, profiles/r03_mfma4x4x4.txt), only 0 - 4 % faster than the
+# float32 vector kernels, whose results are within half an ulp of the float32 forward: they are opt-in.  RCX_MX=1 turns them on for
+# every module; ``module.matrix_cores = True`` for one.
+MATRIX_CORES_DEFAULT = os.environ.get("RCX_MX", "0") not in ("", "0")
 
 
 class RecConv2d(nn.Module):
@@ -39,6 +48,8 @@ class RecConv2d(nn.Module):
         self._wflip = None                                  # the pack with every k x k flipped (the backward's taps)
         self._mx_key = None
         self._mx = None                                     # the taps as Toeplitz blocks in a 16-bit type (matrix-core schedules)
+        # None: follow MATRIX_CORES_DEFAULT (environment RCX_MX at import time); True / False: this module's own choice
+        self.matrix_cores = None
         # Optional per-channel affine applied to the block's OUTPUT (y*scale + shift), folded into
         # convs[level] when the packs are built: used to absorb the eval-mode BatchNorm that follows the
         # token mixer in MetaNeXtBlock (model/recnext.py:153,158) -- SURVEY.md section 8f row 2.
@@ -121,11 +132,14 @@ class RecConv2d(nn.Module):
         (``model.bfloat16()`` / ``.half()`` -- the rounding is then exact) or autocast is on (the conv casts its weight,
         engine.py:48).  float32 parameters with 16-bit activations outside autocast -- which only this module accepts -- keep
         the exact float32 taps on the vector pipe.  Call after packed_params() (same cache key)."""
+        mc = getattr(self, "matrix_cores", None)
+        if not (mc if mc is not None else MATRIX_CORES_DEFAULT):
+            return None
         if dtype not in (torch.bfloat16, torch.float16) or self.kernel_size != 5:
             return None
         if self.down.weight.dtype != dtype and not torch.is_autocast_enabled():
             return None
-        if getattr(self, "_mx_key", None) != (self._pack_key, dtype):
+        if getattr(self, "_mx_key", None) != (self._pack_key, dtype):           # getattr: modules pickled before round 3
             self._mx = ops.pack_recconv_mx(self._pack[0], self.level, self.in_channels, self.kernel_size, dtype)
             self._mx_key = (self._pack_key, dtype)
         return self._mx

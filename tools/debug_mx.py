@@ -27,6 +27,7 @@ def check(n, c, h, level, dtype, mode="bilinear", bias=False, seed=0):
     with torch.no_grad():
         y_vec = mod(x).float().cpu().numpy()                   # float32 parameters: vector kernels, exact taps
         mm = mod.to(dtype)
+        mm.matrix_cores = True
         y_mx = mm(x).float().cpu().numpy()
         y_mx2 = mm(x).float().cpu().numpy()
     plan = ops.recconv2d_plan_mx(n, c, h, h, level, 5, mode, dtype)
@@ -55,6 +56,7 @@ def bench(n, c, h, level, dtype, iters=30):
     for name, m in (("vector", mod), ("matrix", None)):
         if m is None:
             m = mod.to(dtype)
+            m.matrix_cores = True
         with torch.no_grad():
             for _ in range(5):
                 m(x)
@@ -82,7 +84,15 @@ if __name__ == "__main__":
     ok &= check(2, 48, 56, 4, torch.bfloat16, bias=True)
     ok &= check(3, 80, 56, 4, torch.bfloat16)
     ok &= check(9, 64, 56, 4, torch.bfloat16, seed=3)
+    ok &= check(4, 256, 14, 2, torch.bfloat16)
+    ok &= check(5, 256, 14, 2, torch.bfloat16, mode="nearest")
+    ok &= check(3, 320, 14, 2, torch.float16)
+    ok &= check(7, 24, 14, 2, torch.bfloat16, bias=True)
+    ok &= check(2, 200, 14, 2, torch.bfloat16, seed=5)
     print("ALL OK" if ok else "FAILURES")
-    bench(256, 64, 56, 4, torch.bfloat16)
-    bench(256, 64, 56, 4, torch.float16)
-    bench(256, 80, 56, 4, torch.bfloat16)
+    if "--bench" in sys.argv:
+        bench(256, 64, 56, 4, torch.bfloat16)
+        bench(256, 256, 14, 2, torch.bfloat16)
+        bench(256, 256, 14, 2, torch.float16)
+        bench(256, 320, 14, 2, torch.bfloat16)
+        bench(128, 256, 14, 2, torch.bfloat16)
