@@ -31,6 +31,40 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+VALU_PEAK_TFS = 157.3          # float32 vector peak (same table): the secondary ceiling of SURVEY 8d
+
+
+def measure_copy_ceiling(torch, device, gib=1.0, reps=5):
+    """The copy ceiling of THIS device ("state both the nominal and the measured copy ceiling"): a device-to-device copy of
+    1 GiB, read + written bytes over its HIP-event time, best of `reps` after one warm-up.  Runs before the timed region."""
+    n = int(gib * (1 << 30)) // 2
+    a = torch.empty(n, dtype=torch.bfloat16, device=device).normal_()
+    b = torch.empty_like(a)
+    best = 0.0
+    for i in range(reps + 1):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        b.copy_(a)
+        e.record()
+        torch.cuda.synchronize(device)
+        if i:
+            best = max(best, 2 * a.numel() * 2 / (s.elapsed_time(e) * 1e-3) / 1e9)
+    del a, b
+    torch.cuda.empty_cache()
+    return best
+
+
+def recconv_flops(n, c, h, w, level, k):
+    """Algorithmic flops of one RecConv2d forward: 2 k^2 C (sum_{l>=1} H_l W_l + sum_{l>=0} H_l W_l) for the stride-2 ladder
+    and the level + 1 stride-1 convs, + 8 per resized element (bilinear) + 1 per added element."""
+    hs, ws = [h], [w]
+    for _ in range(level):
+        hs.append((hs[-1] + 1) // 2)
+        ws.append((ws[-1] + 1) // 2)
+    areas = [a * b for a, b in zip(hs, ws)]
+    conv = 2 * k * k * c * (sum(areas[1:]) + sum(areas))
+    resize_add = 9 * c * sum(areas[:-1])
+    return n * (conv + resize_add)
 
 
 def parse_args():
@@ -128,8 +162,14 @@ def kernel_name(plan, elem_bytes):
         return f"rcx::lanes::{kern}, {t}>"
     if plan.startswith("cpt(k_recconv_cpt"):
         kern = plan[len("cpt("):plan.index(">")]
-        img2 = kern.endswith(", IMG2")                                       # last template argument: image-pair variant
-        return f"rcx::cpt::{kern[:-6] if img2 else kern}, {t}, {'true' if img2 else 'false'}>"
+        img2 = kern.endswith(", IMG2")                                       # template arguments after the type: image pairs, training, matrix cores
+        return f"rcx::cpt::{kern[:-6] if img2 else kern}, {t}, {'true' if img2 else 'false'}, false, false>"
+    if plan.startswith("cpt_mx(k_recconv_cpt"):
+        kern = plan[len("cpt_mx("):plan.index(">")].rsplit(", ", 2)[0]        # "... <4, 2, mode, pixb, bf16, MX" -> up to the pitch
+        return f"rcx::cpt::{kern}, {'_Float16' if ', f16,' in plan else 'unsigned short'}, false, false, true>"
+    if plan.startswith("cpl14_mx(k_recconv_mx14"):
+        mode = plan[len("cpl14_mx(k_recconv_mx14<"):].split(",")[0]
+        return f"rcx::mx14::k_recconv_mx14<{mode}, {'_Float16' if ', f16>' in plan else 'unsigned short'}>"
     if plan.startswith("cpl(k_recconv_cpl"):
         kern = plan[len("cpl("):plan.index(">")]
         ns = "cpl" if kern.startswith("k_recconv_cpl7<") else "cpl14"       # rcx_cpl.hip (round 1) / rcx_cpl14.hip
@@ -267,6 +307,7 @@ def main():
 
     from recnext_amd.speed import tune_gemms
     gemm_tuned = tune_gemms(net, x)                       # before the warm-up steps, outside the timed region
+    copy_gbs = measure_copy_ceiling(torch, device) if rank == 0 else None
     with torch.no_grad():
         for _ in range(args.warmup):
             net(x)
@@ -286,10 +327,15 @@ def main():
     if rank == 0:
         images = world * args.batch * args.steps
         value = images / elapsed
-        plan_of = lambda n, c, h, w, level, k: ops.recconv2d_plan(n, c, h, w, level, k, "bilinear", dtype)
+        from recnext_amd import recconv as _rc
+        mx_on = _rc.MATRIX_CORES_DEFAULT and dtype != torch.float32         # RCX_MX=1: the matrix-core schedules where they exist
+        plan_of = lambda n, c, h, w, level, k: (ops.recconv2d_plan_mx if mx_on else ops.recconv2d_plan)(n, c, h, w, level, k, "bilinear", dtype)
         per_shape, per_kernel = timers.summarize(elem, plan_of)
         dom = per_kernel[0]                                   # the kernel instantiation with the most time in the step
         traffic, traffic_source = load_traffic(dom["kernel"])
+        dom_shape = next(rr for rr in per_shape if kernel_name(rr["plan"], elem) == dom["kernel"])
+        dom_flops = recconv_flops(dom_shape["N"], dom_shape["C"], dom_shape["H"], dom_shape["W"], dom_shape["level"], dom_shape["k"])
+        dom_tfs = dom_flops / (dom["avg_launch_ms"] * 1e-3) / 1e12
         mixer_ms_per_step = sum(rr["total_ms"] for rr in per_shape) / args.steps
         mixer_bytes = models.token_mixer_algorithmic_bytes(args.model, args.resolution, elem) * args.batch \
             if models.CONFIGS[args.model]["family"] == "m" else None
@@ -307,6 +353,11 @@ def main():
                        "parallelism": f"dp{world} (batch-sharded replicas, no collective in the timed region)"},
             "roofline": {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         # the measured copy ceiling of this device beside the nominal peak, and the vector-ALU ceiling
+                         "peak_measured": copy_gbs, "frac_of_measured": dom["achieved_GBs"] / copy_gbs if copy_gbs else None,
+                         "valu": {"flops_per_launch": dom_flops, "achieved_TFs": dom_tfs, "peak_TFs": VALU_PEAK_TFS, "frac": dom_tfs / VALU_PEAK_TFS,
+                                  "note": "algorithmic float32 flops of the block (2 k^2 C (sum_l>=1 + sum_l>=0 H_l W_l) + 9 per resized-and-added "
+                                          "element) against the vector peak; the matrix-core schedules do the same flops on the other pipe"},
                          "kernel": dom["kernel"], "shapes": dom["shapes"], "avg_launch_ms": dom["avg_launch_ms"],
                          "algorithmic_bytes_per_launch": dom["algorithmic_bytes"] / dom["launches"],
                          "launches_timed": dom["launches"],

@@ -43,6 +43,9 @@ enum {
 
 int rcx_abi_version(void);
 const char* rcx_last_error(void);
+/* The RCX_* environment switches (A/B measurement knobs) are read once, at the first call that consults one; this
+ * re-reads them.  For tests and A/B tools that flip a switch inside one process; not to be called while another thread is in the library. */
+void rcx_reload_options(void);
 
 /* Description of the kernel schedule rcx_recconv2d_fwd would use for this problem, e.g. "generic" or
  * "plane(cb=16,band8,nt=512,lds=157760)"; thread-local storage, valid until the next call on this thread. */

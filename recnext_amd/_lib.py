@@ -22,6 +22,7 @@ _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 SIGNATURES = {
     "rcx_abi_version": (_i, []),
     "rcx_last_error": (ctypes.c_char_p, []),
+    "rcx_reload_options": (None, []),
     "rcx_recconv2d_fwd_plan": (ctypes.c_char_p, [_i] * 8),
     "rcx_pack_dw_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "rcx_pack_bias": (_i, [_vp, _vp, _i, _i, _vp]),

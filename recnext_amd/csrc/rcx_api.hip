@@ -1,11 +1,48 @@
 // C ABI of librecnext_amd.so (include/recnext_amd.h): argument checking, schedule selection,
 // error reporting.  No allocation, no synchronisation, no retained pointers.
 #include "../../include/recnext_amd.h"
+#include "rcx_opts.h"
 #include "rcx_launch.h"
 
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+
+#include <mutex>
+#include <string>
+
+// ---- the RCX_* switches, read once (rcx_opts.h)
+namespace rcx {
+namespace opt {
+namespace {
+const char* const kNames[COUNT] = {
+    "RCX_FORCE_SPLIT", "RCX_FORCE_GENERIC", "RCX_LANES", "RCX_LANES_WAVES", "RCX_LANES_NI", "RCX_WGRAD_CPL", "RCX_CPT", "RCX_CPT_GRID", "RCX_CPT_MX",
+    "RCX_CPL", "RCX_CPL7", "RCX_CPL14", "RCX_CPL14_LDS", "RCX_CPL14_MX", "RCX_UPADD_CPL", "RCX_ATTN_MFMA", "RCX_ATTN_SCALAR", "RCX_TRAIN_FUSED",
+    "RCX_BWD_SPLIT", "RCX_BWD_NESTED", "RCX_BWD_FUSED", "RCX_PLANE_LPP", "RCX_PLANE_B2", "RCX_PLANE_NT", "RCX_PLANE_ABLATE", "RCX_LANES_ABLATE"};
+std::string g_val[COUNT];
+bool g_set[COUNT];
+std::once_flag g_once;
+void read_all()
+{
+    for (int i = 0; i < COUNT; ++i) {
+        const char* v = getenv(kNames[i]);
+        g_set[i] = v != nullptr;
+        g_val[i] = v ? v : "";
+    }
+}
+}  // namespace
+const char* value(Id id)
+{
+    std::call_once(g_once, read_all);
+    return g_set[id] ? g_val[id].c_str() : nullptr;
+}
+void reload()
+{
+    std::call_once(g_once, read_all);
+    read_all();
+}
+}  // namespace opt
+}  // namespace rcx
 
 namespace {
 
@@ -69,7 +106,7 @@ int check_common(const void* x, const void* y, int N, int C, int H, int W, int k
 // one-launch-per-ladder-step schedule (used by tests to cover both, and for A/B timing).
 bool use_plane(int N, int C, int H, int W, int level, int k, int dtype)
 {
-    const char* f = getenv("RCX_FORCE_GENERIC");
+    const char* f = rcx::opt::value(rcx::opt::FORCE_GENERIC);
     if (f && *f && *f != '0') return false;
     return rcx::plane_applicable(N, C, H, W, level, k, dtype);
 }
@@ -79,10 +116,10 @@ bool use_plane(int N, int C, int H, int W, int level, int k, int dtype)
 //   y = conv_L(x + resize(C_1)) (step kernel).  F_1 and C_1 live in the caller's workspace.
 bool use_split(int N, int C, int H, int W, int level, int k, int dtype)
 {
-    const char* f = getenv("RCX_FORCE_GENERIC");
+    const char* f = rcx::opt::value(rcx::opt::FORCE_GENERIC);
     if (f && *f && *f != '0') return false;
     if (level < 1 || k != 5 || H != W || (H & 1)) return false;
-    const char* force = getenv("RCX_FORCE_SPLIT");                  // A/B knob: three launches even where one fused kernel exists
+    const char* force = rcx::opt::value(rcx::opt::FORCE_SPLIT);                  // A/B knob: three launches even where one fused kernel exists
     if (rcx::lanes_applicable(N, C, H, W, level, k, dtype) && !(force && *force == '1')) return false;
     return rcx::down5_lanes_applicable(N, C, H, W, k, 2, dtype, RCX_DTYPE_F32) &&
            rcx::lanes_applicable(N, C, H / 2, W / 2, level - 1, k, RCX_DTYPE_F32) &&
@@ -94,14 +131,14 @@ size_t split_bytes(int N, int C, int H, int W) { return 2 * align256(sizeof(floa
 // the register-resident schedule takes precedence where it applies (RCX_LANES=0 switches it off)
 bool use_lanes(int N, int C, int H, int W, int level, int k, int dtype)
 {
-    const char* f = getenv("RCX_FORCE_GENERIC");
+    const char* f = rcx::opt::value(rcx::opt::FORCE_GENERIC);
     if (f && *f && *f != '0') return false;
     return rcx::lanes_applicable(N, C, H, W, level, k, dtype);
 }
 
 bool lanes_off()
 {
-    const char* f = getenv("RCX_FORCE_GENERIC");
+    const char* f = rcx::opt::value(rcx::opt::FORCE_GENERIC);
     return f && *f && *f != '0';
 }
 
@@ -138,13 +175,15 @@ extern "C" {
 
 int rcx_abi_version(void) { return RCX_ABI_VERSION; }
 
+void rcx_reload_options(void) { rcx::opt::reload(); }
+
 const char* rcx_last_error(void) { return g_err; }
 
 const char* rcx_recconv2d_fwd_plan(int N, int C, int H, int W, int level, int k, int mode, int dtype)
 {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0) return "invalid";
     static thread_local char desc[256];
-    if (!(getenv("RCX_FORCE_SPLIT") && use_split(N, C, H, W, level, k, dtype)) && use_lanes(N, C, H, W, level, k, dtype) && rcx::lanes_describe(N, C, H, W, level, k, mode == RCX_MODE_NEAREST ? 1 : 0, dtype, desc, (int)sizeof(desc)) > 0) return desc;
+    if (!(rcx::opt::value(rcx::opt::FORCE_SPLIT) && use_split(N, C, H, W, level, k, dtype)) && use_lanes(N, C, H, W, level, k, dtype) && rcx::lanes_describe(N, C, H, W, level, k, mode == RCX_MODE_NEAREST ? 1 : 0, dtype, desc, (int)sizeof(desc)) > 0) return desc;
     if (use_split(N, C, H, W, level, k, dtype)) {
         char inner[128];
         rcx::lanes_describe(N, C, H / 2, W / 2, level - 1, k, mode == RCX_MODE_NEAREST ? 1 : 0, RCX_DTYPE_F32, inner, (int)sizeof(inner));
@@ -203,7 +242,7 @@ int rcx_pack_bias(const void* b, float* dst, int C, int dtype, void* stream)
 size_t rcx_recconv2d_fwd_workspace_bytes(int N, int C, int H, int W, int level, int k, int dtype)
 {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0) return 0;
-    if (getenv("RCX_FORCE_SPLIT") && use_split(N, C, H, W, level, k, dtype)) return split_bytes(N, C, H, W);
+    if (rcx::opt::value(rcx::opt::FORCE_SPLIT) && use_split(N, C, H, W, level, k, dtype)) return split_bytes(N, C, H, W);
     if (use_lanes(N, C, H, W, level, k, dtype)) return 0;          // registers only
     if (use_split(N, C, H, W, level, k, dtype)) return split_bytes(N, C, H, W);
     if (use_plane(N, C, H, W, level, k, dtype)) return 0;          // the fused schedule keeps every intermediate in LDS
@@ -219,7 +258,7 @@ int rcx_recconv2d_fwd(const void* x, void* y, const float* wpack, const float* b
     if (x == y) return fail(RCX_ERR_BAD_ARG, "y must not alias x");
     if (level < 0 || level > RCX_MAX_LEVEL) return fail(RCX_ERR_BAD_ARG, "level %d outside [0,%d]", level, RCX_MAX_LEVEL);
     if (mode != RCX_MODE_BILINEAR && mode != RCX_MODE_NEAREST) return fail(RCX_ERR_BAD_ARG, "unknown mode %d", mode);
-    if (!(getenv("RCX_FORCE_SPLIT") && use_split(N, C, H, W, level, k, dtype)) && use_lanes(N, C, H, W, level, k, dtype)) {
+    if (!(rcx::opt::value(rcx::opt::FORCE_SPLIT) && use_split(N, C, H, W, level, k, dtype)) && use_lanes(N, C, H, W, level, k, dtype)) {
         hipError_t le = rcx::lanes_recconv(x, y, wpack, bpack, N, C, H, W, level, k, mode, dtype, (hipStream_t)stream);
         return le == hipSuccess ? 0 : hip_fail(le, "lanes schedule");
     }
@@ -281,7 +320,7 @@ int rcx_recconv2d_fwd(const void* x, void* y, const float* wpack, const float* b
 namespace {
 bool use_mx(int N, int C, int H, int W, int level, int k, int dtype)
 {
-    if (lanes_off() || getenv("RCX_FORCE_SPLIT")) return false;
+    if (lanes_off() || rcx::opt::value(rcx::opt::FORCE_SPLIT)) return false;
     return rcx::cpt_mx_applicable(N, C, H, W, level, k, dtype) || rcx::cpl14mx_applicable(N, C, H, W, level, k, dtype);
 }
 }  // namespace
@@ -389,8 +428,8 @@ int rcx_recconv2d_fwd_train(const void* x, void* y, const float* wpack, const fl
     // the blocks of RecNeXt at 224x224 (channel-per-lane kernels): the inference kernel itself leaves the pyramid behind --
     // one launch instead of 2 * level + 1 (RCX_TRAIN_FUSED=0: the per-step schedule, for A/B runs)
     {
-        const char* tf = getenv("RCX_TRAIN_FUSED");
-        const bool fused_ok = !(tf && *tf == '0') && !lanes_off() && !(getenv("RCX_FORCE_SPLIT"));
+        const char* tf = rcx::opt::value(rcx::opt::TRAIN_FUSED);
+        const bool fused_ok = !(tf && *tf == '0') && !lanes_off() && !(rcx::opt::value(rcx::opt::FORCE_SPLIT));
         const int md = mode == RCX_MODE_NEAREST ? 1 : 0;
         if (fused_ok && rcx::cpt_train_applicable(N, C, H, W, level, k, md, dtype)) {
             hipError_t fe = rcx::cpt_recconv(x, y, wpack, bpack, N, C, H, md, dtype, s, (float*)saved, L.f_off, L.c_off);
@@ -486,7 +525,7 @@ int rcx_recconv2d_bwd(const void* x, const float* gy, const float* wpack, const 
     int m = 0;
     if (level >= 3 && !lanes_off() && L.h[level - 2] == 14 && L.w[level - 2] == 14 &&
         rcx::cplbwd_applicable(N, C, 14, 14, 2, k, RCX_DTYPE_F32)) {
-        const char* nv = getenv("RCX_BWD_NESTED");
+        const char* nv = rcx::opt::value(rcx::opt::BWD_NESTED);
         if (!(nv && *nv == '0')) m = level - 2;
     }
     // up recursion (:31-33), finest level first in the backward direction
@@ -544,7 +583,7 @@ int rcx_dwconv2d_mult2_fwd(const void* x, void* y, const float* w_kkc, const flo
     if (int rc = check_common(x, y, N, Cin, H, W, k, dtype)) return rc;
     if (!w_kkc) return fail(RCX_ERR_BAD_ARG, "null weight");
     if (stride != 1 && stride != 2) return fail(RCX_ERR_UNSUPPORTED, "stride %d not supported (1 or 2)", stride);
-    const char* f = getenv("RCX_FORCE_GENERIC");
+    const char* f = rcx::opt::value(rcx::opt::FORCE_GENERIC);
     hipError_t e;
     if (!(f && *f && *f != '0') && rcx::down_lanes_applicable(N, Cin, H, W, k, stride, dtype))
         e = rcx::down_lanes(x, y, w_kkc, bias, N, Cin, H, W, k, stride, dtype, (hipStream_t)stream);

@@ -11,6 +11,7 @@
 // Layout: all five tensors are (B, n, C) = NHWC; head h owns channels [h*D, (h+1)*D), D = C / heads.  G = 4 output columns per
 // thread when D % 4 == 0 (D <= 64), else G = 1 (D <= 32).
 #include <stdlib.h>
+#include "rcx_opts.h"
 
 #include "rcx_common.h"
 #include "rcx_launch.h"
@@ -861,7 +862,7 @@ hipError_t linattn_core_bwd(const void* qpre, const void* kpre, const void* v, c
 {
     const dim3 grid((unsigned)(B * heads)), block(LA_NT);
     {
-        const char* m = getenv("RCX_ATTN_MFMA");                     // A/B knob: 0 = the vector-pipe kernel
+        const char* m = rcx::opt::value(rcx::opt::ATTN_MFMA);                     // A/B knob: 0 = the vector-pipe kernel
         if (C / heads == 32 && dtype != 0 && !(m && *m == '0')) {
             if (dtype == 1) hipLaunchKernelGGL((k_linattn_bwd_mfma<bf16_t>), grid, dim3(LM_NW * 64), 0, s, (const bf16_t*)qpre, (const bf16_t*)kpre, (const bf16_t*)v, (const bf16_t*)gout, (bf16_t*)gq, (bf16_t*)gk, (bf16_t*)gv, n, C, heads);
             else hipLaunchKernelGGL((k_linattn_bwd_mfma<f16_t>), grid, dim3(LM_NW * 64), 0, s, (const f16_t*)qpre, (const f16_t*)kpre, (const f16_t*)v, (const f16_t*)gout, (f16_t*)gq, (f16_t*)gk, (f16_t*)gv, n, C, heads);
@@ -883,7 +884,7 @@ hipError_t linattn_core(const void* qpre, const void* kpre, const void* v, const
     const dim3 grid((unsigned)(B * heads)), block(LA_NT);
     const bool wide = ((C / heads) % 4) == 0;
     {
-        const char* m = getenv("RCX_ATTN_MFMA");                     // A/B knob: 0 = the vector-pipe kernels for every head dimension
+        const char* m = rcx::opt::value(rcx::opt::ATTN_MFMA);                     // A/B knob: 0 = the vector-pipe kernels for every head dimension
         // Measured (batch 256, bf16): 784 tokens 88 -> 61 us with 4 waves per head; 196 / 49 / 16 tokens no faster than the vector-pipe kernel
         // (36 / 23 / 31 against 36 / 20 / 20 us: too few tokens per head to amortise the partial-sum exchange) -- so only the long sequences
         if (C / heads == 32 && dtype != 0 && n >= 512 && !(m && *m == '0')) {
@@ -894,7 +895,7 @@ hipError_t linattn_core(const void* qpre, const void* kpre, const void* v, const
     }
 #define RCX_LA_LAUNCH(T, G) hipLaunchKernelGGL((k_linattn_core<T, G>), grid, block, 0, s, (const T*)qpre, (const T*)kpre, (const T*)v, \
                                                (const T*)pe, (T*)out, n, C, heads)
-    const char* old = getenv("RCX_ATTN_SCALAR");                 // A/B knob: the untiled kernel for every head dimension
+    const char* old = rcx::opt::value(rcx::opt::ATTN_SCALAR);                 // A/B knob: the untiled kernel for every head dimension
     const bool tiled = wide && !(old && *old == '1');
     if (tiled) {
 #define RCX_LA4(T, DM) hipLaunchKernelGGL((k_linattn_core4<T, DM>), grid, block, 0, s, (const T*)qpre, (const T*)kpre, (const T*)v, (const T*)pe, (T*)out, n, C, heads)

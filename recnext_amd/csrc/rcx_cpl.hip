@@ -6,6 +6,7 @@
 // resolved at compile time (border taps are simply not issued: 841 instead of 1225 FMAs for the 7x7 conv); the 7x7 conv
 // runs two columns per v_pk_fma_f32.  Same arithmetic as the lanes kernels (float32 throughout, one final rounding).
 #include <hip/hip_runtime.h>
+#include "rcx_opts.h"
 #include <stdlib.h>
 
 #include "rcx_common.h"
@@ -144,7 +145,7 @@ void k_recconv_cpl7(const TIO* __restrict__ x, TIO* __restrict__ y, const float*
 
 static inline bool enabled()
 {
-    const char* v = getenv("RCX_CPL");
+    const char* v = rcx::opt::value(rcx::opt::CPL);
     return !(v && *v == '0');
 }
 

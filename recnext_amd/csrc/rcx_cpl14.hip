@@ -19,6 +19,7 @@
 // immediate, no vector address arithmetic.  Same arithmetic as the other schedules: float32 throughout, one rounding at the
 // final store.
 #include "rcx_cpl14_pieces.h"
+#include "rcx_opts.h"
 
 namespace rcx {
 namespace cpl14 {
@@ -524,8 +525,8 @@ static hipError_t launch_up_c(const void* x, const void* coarse, void* y, const 
 // back to the lanes kernel, RCX_LANES=0 / RCX_FORCE_GENERIC=1 switch every register-resident schedule off
 static inline bool enabled()
 {
-    const char* v = getenv("RCX_CPL14");
-    const char* l = getenv("RCX_LANES");
+    const char* v = rcx::opt::value(rcx::opt::CPL14);
+    const char* l = rcx::opt::value(rcx::opt::LANES);
     return !(v && *v == '0') && !(l && *l == '0');
 }
 
@@ -545,7 +546,7 @@ static hipError_t launch(const void* x, void* y, const float* wpack, const float
 static inline bool use_xl(int C, int esz)
 {
 #ifdef RCX_AB_VARIANTS
-    const char* v = getenv("RCX_CPL14_LDS");
+    const char* v = rcx::opt::value(rcx::opt::CPL14_LDS);
     return esz == 2 && C % 64 == 0 && v && *v == '1';
 #else
     (void)C; (void)esz;
@@ -594,8 +595,8 @@ static hipError_t launch7_c(const void* x, void* y, const float* wpack, const fl
 bool cpl7b_applicable(int N, int C, int H, int W, int level, int k, int dtype)
 {
     (void)N;
-    const char* v = getenv("RCX_CPL7");
-    const char* all = getenv("RCX_CPL");                          // RCX_CPL=0: no channel-per-lane kernel on 7x7 (the lanes kernel instead)
+    const char* v = rcx::opt::value(rcx::opt::CPL7);
+    const char* all = rcx::opt::value(rcx::opt::CPL);                          // RCX_CPL=0: no channel-per-lane kernel on 7x7 (the lanes kernel instead)
     return cpl14::enabled() && !(v && *v == 'o') && !(all && *all == '0') && H == 7 && W == 7 && level == 1 && k == 5 && C >= 1 && (dtype == 0 || dtype == 1 || dtype == 2);
 }
 
@@ -619,7 +620,7 @@ hipError_t cpl7b_recconv(const void* x, void* y, const float* wpack, const float
 bool upadd_cpl14_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int x_dt, int c_dt, int out_dt)
 {
     (void)N;
-    const char* v = getenv("RCX_UPADD_CPL");
+    const char* v = rcx::opt::value(rcx::opt::UPADD_CPL);
     return cpl14::enabled() && !(v && *v == '0') && H == 14 && W == 14 && Hc == 7 && Wc == 7 && k == 5 && C >= 1 && out_dt == x_dt &&
            (x_dt == 0 || x_dt == 1 || x_dt == 2) && (c_dt == x_dt || c_dt == 0);
 }

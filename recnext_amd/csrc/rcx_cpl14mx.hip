@@ -20,6 +20,7 @@
 // Against the vector kernel (k_recconv_cpl14: 3 780 FMA instructions of 4 677 vector instructions per wave, 18.6 us at 256 x 256):
 // ~ 850 matrix instructions + ~ 1 500 vector instructions.
 #include "rcx_cpt_kernel.h"
+#include "rcx_opts.h"
 
 namespace rcx {
 namespace mx14 {
@@ -331,9 +332,9 @@ static hipError_t launch(const void* x, void* y, const void* mxpack, const float
 // RCX_CPL14_MX=0: off (A/B)
 bool cpl14mx_applicable(int N, int C, int H, int W, int level, int k, int dtype)
 {
-    const char* v = getenv("RCX_CPL14_MX");
+    const char* v = rcx::opt::value(rcx::opt::CPL14_MX);
     if (v && *v == '0') return false;
-    const char* l = getenv("RCX_LANES");
+    const char* l = rcx::opt::value(rcx::opt::LANES);
     if (l && *l == '0') return false;
     // 32-bit byte offsets inside the activation buffer
     // C % 8: 16-byte loads of eight channels; 32-bit byte offsets inside the activation buffer

@@ -19,6 +19,7 @@
 // Same arithmetic as the per-step backward (float32 throughout, one rounding at the gx store); the summation ORDER differs, so
 // results agree with it to float32 rounding, not bit for bit -- both are checked against autograd (tests/test_backward_gpu.py).
 #include "rcx_cplbwd_pieces.h"
+#include "rcx_opts.h"
 
 namespace rcx {
 namespace cplbwd {
@@ -380,7 +381,7 @@ template <int MODE, int CT, typename TIO>
 static hipError_t launch14(const BwdArgs& A, hipStream_t s)
 {
     const unsigned planes = (unsigned)(A.N * ((A.C + 63) / 64));
-    const char* v = getenv("RCX_BWD_SPLIT");                                // A/B switch: 0 = one wave per plane always
+    const char* v = rcx::opt::value(rcx::opt::BWD_SPLIT);                                // A/B switch: 0 = one wave per plane always
     // two waves per plane while that still fits the chip's 1024 SIMDs in one round (and the split grid keeps whole XCD rounds)
     BwdArgs B = A;
     B.split = !(v && *v == '0') && planes * 2 <= 1024 && planes % 8 == 0;
@@ -413,7 +414,7 @@ static hipError_t launch7_c(const BwdArgs& A, hipStream_t s)
 // the fused backward applies where the fused training forward does, and needs one partial row per image in a 512-row slot
 bool cplbwd_applicable(int N, int C, int H, int W, int level, int k, int dtype)
 {
-    const char* v = getenv("RCX_BWD_FUSED");
+    const char* v = rcx::opt::value(rcx::opt::BWD_FUSED);
     if (v && *v == '0') return false;
     if (N > 512) return false;
     return cpl7b_applicable(N, C, H, W, level, k, dtype) || cpl14_applicable(N, C, H, W, level, k, dtype);

@@ -11,6 +11,7 @@
 // column tile) add their 26 sums per channel through LDS in a fixed order and leave ONE partial row per (image, 14-row band):
 // deterministic, summed over the batch by the same second stage as everything else (k_wgrad_reduce_jobs).
 #include "rcx_cplbwd_pieces.h"
+#include "rcx_opts.h"
 
 namespace rcx {
 namespace cplwgrad {
@@ -361,7 +362,7 @@ static hipError_t launch2_h(const void* a, const float* g, float* partial, int N
 // rows of `partial` the kernel leaves: one per (image, 14-row band)
 bool wgrad_cpl_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int stride, bool has_coarse)
 {
-    const char* v = getenv("RCX_WGRAD_CPL");
+    const char* v = rcx::opt::value(rcx::opt::WGRAD_CPL);
     if (v && *v == '0') return false;
     return k == 5 && stride == 1 && H == W && (H == 56 || H == 28) && (!has_coarse || (Hc * 2 == H && Wc * 2 == W)) && C >= 1 &&
            N * (H / 14) <= 512;
@@ -369,7 +370,7 @@ bool wgrad_cpl_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int
 
 bool wgrad2_cpl_applicable(int N, int C, int H, int W, int Ho, int Wo, int k, int stride, bool has_coarse)
 {
-    const char* v = getenv("RCX_WGRAD_CPL");
+    const char* v = rcx::opt::value(rcx::opt::WGRAD_CPL);
     if (v && *v == '0') return false;
     return !has_coarse && k == 5 && stride == 2 && H == W && (H == 56 || H == 28) && Ho * 2 == H && Wo * 2 == W && C >= 1 &&
            N * (H / 28) <= 512;
@@ -385,7 +386,7 @@ hipError_t wgrad2_cpl(const void* a, int a_dt, const float* g, float* partial, i
 // the Downsample conv (7x7, stride 2, channel multiplier 2): C = OUTPUT channels; rows of `partial`: N * (H / 28), each (49 + 1) * C
 bool wgrad2m_cpl_applicable(int N, int Cout, int H, int W, int k)
 {
-    const char* v = getenv("RCX_WGRAD_CPL");
+    const char* v = rcx::opt::value(rcx::opt::WGRAD_CPL);
     if (v && *v == '0') return false;
     return k == 7 && H == W && (H == 56 || H == 28) && Cout >= 2 && Cout % 2 == 0 && N * (H / 28) <= 512;
 }

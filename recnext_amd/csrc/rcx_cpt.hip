@@ -1,6 +1,7 @@
 // Public side of the channel-per-lane tiled RecConv2d kernels (rcx_cpt_kernel.h) and the 56x56 / level 4 instantiations; the
 // 28x28 / level 3 ones are compiled in rcx_cpt2.hip (two translation units so that they build in parallel).
 #include "rcx_cpt_kernel.h"
+#include "rcx_opts.h"
 
 namespace rcx {
 namespace cpt {
@@ -17,7 +18,7 @@ bool cpt_applicable(int N, int C, int H, int W, int level, int k, int dtype)
     if (!cpt::enabled() || k != 5 || C < 1 || !(dtype == 0 || dtype == 1 || dtype == 2)) return false;
     if (H == 56 && W == 56 && level == 4) return true;
     if (H == 28 && W == 28 && level == 3) {
-        const char* v = getenv("RCX_CPT");
+        const char* v = rcx::opt::value(rcx::opt::CPT);
         return C % 64 == 0 || (v && *v == 'a');
     }
     return false;
@@ -43,7 +44,7 @@ int cpt_describe(int N, int C, int H, int mode, int dtype, char* buf, int len)
 bool cpt_mx_applicable(int N, int C, int H, int W, int level, int k, int dtype)
 {
     (void)N;
-    const char* v = getenv("RCX_CPT_MX");
+    const char* v = rcx::opt::value(rcx::opt::CPT_MX);
     if (v && *v == '0') return false;
     return cpt::enabled() && k == 5 && C >= 1 && (dtype == 1 || dtype == 2) && H == 56 && W == 56 && level == 4;
 }

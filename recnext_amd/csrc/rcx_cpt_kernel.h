@@ -23,6 +23,7 @@
 // pixel, 0.25 v + 0.75 v instead of ATen's v -- one ulp); the 4 -> 7 step uses ATen's float formulas (rcx_common.h).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "rcx_opts.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -1354,8 +1355,8 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
 
 static inline bool enabled()
 {
-    const char* v = getenv("RCX_CPT");
-    const char* l = getenv("RCX_LANES");
+    const char* v = rcx::opt::value(rcx::opt::CPT);
+    const char* l = rcx::opt::value(rcx::opt::LANES);
     return !(v && *v == '0') && !(l && *l == '0');
 }
 
@@ -1382,7 +1383,7 @@ static hipError_t launch(const void* x, void* y, const float* wpack, const float
     }
     const unsigned total = IMG2 ? (unsigned)(((N + 1) / 2) * ((C + 31) / 32)) : (unsigned)(N * ((C + G::CB - 1) / G::CB));
     unsigned cap = (unsigned)cus * (T == 4 ? 1u : 2u);         // workgroups resident at once (LDS: one / two per CU)
-    if (const char* e = getenv("RCX_CPT_GRID")) { const int g = atoi(e); if (g > 0) cap = (unsigned)g; }    // A/B knob
+    if (const char* e = rcx::opt::value(rcx::opt::CPT_GRID)) { const int g = atoi(e); if (g > 0) cap = (unsigned)g; }    // A/B knob
     cap &= ~7u;
     const unsigned grid = total <= cap || cap == 0 ? total : cap;
     if (MX && !mxpack) return hipErrorInvalidValue;

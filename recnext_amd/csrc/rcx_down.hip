@@ -6,6 +6,7 @@
 // seven window rows stream through registers.  x enters in 4-row bands through a 2-slot LDS ring (coalesced 16-byte
 // global accesses), finished output row pairs leave through a second small ring.  One barrier per band.
 #include "rcx_lanes.h"
+#include "rcx_opts.h"
 #include "rcx_launch.h"
 
 namespace rcx {
@@ -254,16 +255,16 @@ struct DownPlan {
     DownArgs args;
 };
 
-static int env_int_d(const char* name, int dflt)
+static int env_int_d(rcx::opt::Id id, int dflt)
 {
-    const char* v = getenv(name);
+    const char* v = rcx::opt::value(id);
     return v && *v ? atoi(v) : dflt;
 }
 
 static DownPlan plan_down(int N, int Cin, int H, int W, int k, int stride, int dtype)
 {
     DownPlan p{};
-    if (env_int_d("RCX_LANES", 1) == 0) return p;
+    if (env_int_d(rcx::opt::LANES, 1) == 0) return p;
     if (k != 7 || stride != 2 || H != W) return p;
     int lpc;
     if (W == 56 || W == 128 || W == 64 || W == 32) lpc = 16;

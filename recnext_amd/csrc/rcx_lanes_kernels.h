@@ -2,6 +2,7 @@
 // rcx_lanes16.hip: 16 * 2^k planes -- two translation units so that they compile in parallel).
 #pragma once
 #include "rcx_lanes.h"
+#include "rcx_opts.h"
 #include "rcx_launch.h"
 
 #ifndef RCX_LSTAMP
@@ -525,16 +526,16 @@ struct LanesPlan {
     LanesArgs args;
 };
 
-static inline int env_int(const char* name, int dflt)
+static inline int env_int(rcx::opt::Id id, int dflt)
 {
-    const char* v = getenv(name);
+    const char* v = rcx::opt::value(id);
     return v && *v ? atoi(v) : dflt;
 }
 
 static inline LanesPlan plan(int N, int C, int H, int W, int level, int k, int dtype)
 {
     LanesPlan p{};
-    if (env_int("RCX_LANES", 1) == 0) return p;
+    if (env_int(rcx::opt::LANES, 1) == 0) return p;
     if (k != 5 || H != W) return p;
     if (dtype > 1) return p;                       // float16 I/O: the channel-per-lane kernels and the generic schedule (rcx_api.hip)
     int natural = -1, lpc = 8;
@@ -550,7 +551,7 @@ static inline LanesPlan plan(int N, int C, int H, int W, int level, int k, int d
     const int cpw = 64 / lpc;
     const bool banded = W >= 28 && W != 16;
     const int sr = 4;
-    int waves = env_int("RCX_LANES_WAVES", W == 7 || lpc == 16 ? 8 : 4);
+    int waves = env_int(rcx::opt::LANES_WAVES, W == 7 || lpc == 16 ? 8 : 4);
     if (waves != 8 && waves != 4 && waves != 2 && waves != 1) waves = 8;
     while (waves > 1 && C % (waves * cpw) != 0) waves >>= 1;
     if (W % 16 == 0 && waves < 4) return p;                  // the 16-family is instantiated for 8 and 4 waves only
@@ -563,7 +564,7 @@ static inline LanesPlan plan(int N, int C, int H, int W, int level, int k, int d
     p.w0 = W; p.level = level; p.lpc = lpc; p.waves = waves;
     p.args.N = N; p.args.C = C; p.args.nblk = C / cbw;
     // enough workgroups to fill 256 CUs a few times over, the rest of the batch looped inside (taps staged once)
-    int ni = env_int("RCX_LANES_NI", 0);
+    int ni = env_int(rcx::opt::LANES_NI, 0);
     if (ni <= 0) {
         ni = 1;
         while ((long)p.args.nblk * ((N + 2 * ni - 1) / (2 * ni)) >= 2048 && ni < 4) ni *= 2;
@@ -580,7 +581,7 @@ static hipError_t launch_w(const void* x, void* y, const float* wpack, const flo
     RCX_SET_LDS_ONCE(kfn, p.lds);
     LanesArgs a = p.args;
     a.has_bias = bpack != nullptr;
-    a.ablate = env_int("RCX_LANES_ABLATE", 0);
+    a.ablate = env_int(rcx::opt::LANES_ABLATE, 0);
     const unsigned grid = (unsigned)(a.nblk * (((a.N + a.ni - 1) / a.ni + 7) / 8 * 8));
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), p.lds, s, (const TIO*)x, (TIO*)y, wpack, bpack, a);
     return hipGetLastError();

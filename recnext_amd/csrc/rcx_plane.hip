@@ -21,6 +21,7 @@
 //            D bands ahead are issued before the current band is convolved (register FIFO with
 //            static slots), which is what keeps HBM latency off the critical path at 1-2 waves/SIMD.
 #include "rcx_common.h"
+#include "rcx_opts.h"
 #include "rcx_launch.h"
 
 #include <cstdio>
@@ -735,9 +736,9 @@ struct PlanePlan {
 
 static inline int down_size5(int h) { return (h + 2 * PL_P - PL_K) / 2 + 1; }
 
-static int env_int(const char* name, int dflt)
+static int env_int(rcx::opt::Id id, int dflt)
 {
-    const char* v = getenv(name);
+    const char* v = rcx::opt::value(id);
     return v && *v ? atoi(v) : dflt;
 }
 
@@ -828,8 +829,8 @@ PlanePlan plan_plane(int N, int C, int H, int W, int level, int k, int dtype)
     if ((long long)H * W * C >= (1LL << 30)) return none; // per-image element offsets are 32-bit in the kernels
     const size_t LDS_CU = 160 * 1024;
     const int cpl = dtype == 1 ? 4 : 2;                    // channel pairs per 16-byte chunk
-    const int force_lpp = env_int("RCX_PLANE_LPP", 0), force_b2 = env_int("RCX_PLANE_B2", 0);
-    const int force_nt = env_int("RCX_PLANE_NT", 0);
+    const int force_lpp = env_int(rcx::opt::PLANE_LPP, 0), force_b2 = env_int(rcx::opt::PLANE_B2, 0);
+    const int force_nt = env_int(rcx::opt::PLANE_NT, 0);
     static const int lpps[] = {32, 16, 8, 4};
     constexpr int WHOLE = 1 << 20;
 
@@ -879,7 +880,7 @@ static hipError_t launch_plane_t(const void* x, void* y, const float* wpack, con
     a.has_bias = bpack != nullptr;
     a.mode = mode;
 #ifdef RCX_STAMPS
-    a.ablate = env_int("RCX_PLANE_ABLATE", 0);
+    a.ablate = env_int(rcx::opt::PLANE_ABLATE, 0);
 #else
     a.ablate = 0;
 #endif

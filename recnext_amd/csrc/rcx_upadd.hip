@@ -8,6 +8,7 @@
 // Both stream x through an LDS ring in 4-row bands (coalesced 16-byte global accesses, one barrier per band) and keep the
 // five live window rows in registers; the up-add kernel also rings the four coarse rows a band needs.
 #include "rcx_lanes.h"
+#include "rcx_opts.h"
 #include "rcx_launch.h"
 
 namespace rcx {
@@ -451,7 +452,7 @@ struct StepPlan {
 static StepPlan plan_step(int N, int C, int H, int W, int min_bytes_per_channel)
 {
     StepPlan p{};
-    const char* off = getenv("RCX_LANES");
+    const char* off = rcx::opt::value(rcx::opt::LANES);
     if (off && *off == '0') return p;
     if (H != W) return p;
     int lpc;

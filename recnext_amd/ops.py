@@ -126,6 +126,11 @@ def unpack_recconv_grads(gwpack, count, c, k):
     return out
 
 
+def reload_options():
+    """Re-read the RCX_* environment switches (the library reads them once): for tests and A/B tools that flip one inside a process."""
+    _lib.load().rcx_reload_options()
+
+
 def recconv2d_plan(n, c, h, w, level, k, mode, dtype):
     return _lib.load().rcx_recconv2d_fwd_plan(n, c, h, w, level, k, _lib.MODES[mode], _DT[dtype]).decode()
 

@@ -39,14 +39,20 @@ class LinearAttention(nn.Module):
         b, c, h, w = x.shape
         n = h * w
         s = n ** -0.5
-        if x.is_cuda and c % 4 == 0 and self.head_dim <= 64 and x.dtype in ops._DT:
+        # the HIP core's own rule for the head size (rcx_linear_attention_fwd): any D <= 32, or a multiple of 4 up to 64
+        hd_ok = self.head_dim <= 32 or (self.head_dim <= 64 and self.head_dim % 4 == 0)
+        if x.is_cuda and c % 4 == 0 and hd_ok and x.dtype in ops._DT:
             # GPU (training step): the projection as two GEMMs + the module's BatchNorm, then everything after it -- activation,
-            # k v^T, normaliser, + pe -- in one HIP kernel with a HIP backward (rcx_linear_attention_fwd / _bwd)
-            qkpre = self._qk_gpu(x)                             # (b, 2c, h, w), channels_last storage
+            # k v^T, normaliser, + pe -- in one HIP kernel with a HIP backward (rcx_linear_attention_fwd / _bwd).  Under autocast the
+            # GEMMs answer in the autocast type while x stays float32: the core takes one type, x's
+            qkpre = self._qk_gpu(x).to(x.dtype)                 # (b, 2c, h, w), channels_last storage
             tok = qkpre.permute(0, 2, 3, 1).reshape(b, n, 2 * c)
             qpre, kpre = tok[..., :c].contiguous(), tok[..., c:].contiguous()
-            pe = _conv_norm_train(self.pe, x, 1)
+            pe = _conv_norm_train(self.pe, x, 1).to(x.dtype)
             return ops.LinearAttentionCoreFn.apply(qpre, kpre, x.contiguous(memory_format=torch.channels_last), pe, self.num_heads)
+        # What is left runs the reference's formulation (model/recattn.py:16-28 / :39-51) on PyTorch operators: CPU tensors (the
+        # parameter-count and golden tests of the model skeleton run there) and head sizes the HIP core does not take.  It is the
+        # reference's own code path, not a fallback OF the HIP path: RecConv2d, whose whole body is the product, raises instead.
         if x.is_cuda:
             qk = F.elu(self._qk_gpu(x)) + 1.0
         else:
@@ -90,12 +96,15 @@ def _folded(m):
     """(weight, bias) of a ConvNorm in eval mode or of its fused nn.Conv2d."""
     if isinstance(m, nn.Conv2d):
         return m.weight, m.bias
+    # in float32 whatever the parameters' type: a module in bfloat16 would otherwise round the scale, the product and the shift again
+    # (measured on RecNeXt-A3's mixers, round 3: 1.4 x the mean error of the reference's own bfloat16 run; the reference folds in float32,
+    # utils.py:227-234, before any cast)
     conv, norm = m.conv, m.norm
-    s = norm.weight / torch.sqrt(norm.running_var + norm.eps)
-    b = norm.bias - s * norm.running_mean
+    s = norm.weight.float() / torch.sqrt(norm.running_var.float() + norm.eps)
+    b = norm.bias.float() - s * norm.running_mean.float()
     if conv.bias is not None:
-        b = b + s * conv.bias
-    return conv.weight * s[:, None, None, None], b
+        b = b + s * conv.bias.float()
+    return conv.weight.float() * s[:, None, None, None], b
 
 
 class RecAttn2d(nn.Module):
@@ -129,7 +138,7 @@ class RecAttn2d(nn.Module):
                 wqk, bqk = _folded(la.qk)                       # (2C, C/2, 1, 1): rows [0,C) = q from channels [0,C/2), rows [C,2C) = k
                 wpe, bpe = _folded(la.pe)
                 c = wqk.shape[0] // 2
-                dt = wd.dtype
+                dt = self.conv.conv.weight.dtype if not isinstance(self.conv, nn.Conv2d) else self.conv.weight.dtype     # the GEMM operands' type
                 zeros = lambda b_, n_: torch.zeros(n_, device=wd.device) if b_ is None else b_.float()
                 self._pack = (ops.pack_dw_weight(wd.float()), None if bd is None else ops.pack_bias(bd.float()),
                               ops.pack_dw_weight(wc.float()), None if bc is None else ops.pack_bias(bc.float()),

@@ -7,9 +7,8 @@ input created once on the device, T0 seconds of warm-up, then iterate with a dev
 iteration until T1 seconds have accumulated; print ``name device images/s @ batch size B``.
 Additions: ``--dtype`` (the reference runs fp32 only) and channels_last storage, which is what the HIP
 token mixers consume zero-copy; ``--gpus N`` (one rank per GPU on batch shards, whole-job images/s;
-recnext_amd.launch starts the ranks); ``--impl ref`` / ``--device cpu`` time the REFERENCE's operator chain
-instead (the baseline leg of bench.py -- measurement only; the product path itself has no CPU mode and
-``--impl hip --device cpu`` is an error).
+recnext_amd.launch starts the ranks).  The product has no CPU mode and exactly one implementation: timing the REFERENCE's operator
+chain (on the GPU or on the host cores) is tools/speed_ref.py, outside this package, on the same loop (``throughput`` below).
 """
 import argparse
 import os
@@ -113,47 +112,30 @@ def throughput(name, model, device, batch_size, resolution=224, dtype=torch.bflo
     return rate
 
 
-def _reference_net(name, device, dtype):
-    """--impl ref: the reference's operator chain as the token mixers.  It lives with the benchmark's baseline leg (bench.py at
-    the repository root), not in this package: the product has exactly one implementation."""
-    import importlib.util
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("_rcx_bench", os.path.join(root, "bench.py"))
-    bench = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(bench)
-    return bench.reference_model(name, device, dtype)
-
-
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="recnext_m1", type=str)
     ap.add_argument("--resolution", default=224, type=int)
     ap.add_argument("--batch-size", default=2048, type=int)
     ap.add_argument("--dtype", default="bf16", choices=sorted(DTYPES))
-    ap.add_argument("--impl", default="hip", choices=["hip", "ref"], help="hip: this repository's kernels; ref: the reference's ATen operator chain")
-    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"])
     ap.add_argument("--gpus", default=1, type=int, help="ranks (one per GPU); --batch-size is per GPU")
-    ap.add_argument("--threads", default=0, type=int, help="--device cpu: torch thread count (0 = leave)")
     ap.add_argument("--t0", default=T0, type=float)
     ap.add_argument("--t1", default=T1, type=float)
     args = ap.parse_args(argv)
-    if args.impl == "hip" and args.device == "cpu":
-        ap.error("the HIP token mixers have no CPU path; use --impl ref --device cpu for the reference's CPU baseline")
+    if not torch.cuda.is_available():
+        ap.error("the HIP token mixers have no CPU path (tools/speed_ref.py --device cpu times the reference's CPU baseline)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         import sys
         from . import launch              # children are fresh processes; this parent has not touched the GPU
         raise SystemExit(launch.spawn_ranks(args.gpus, os.path.abspath(__file__), list(argv if argv is not None else sys.argv[1:])))
     from . import dist as rdist
-    ranks = rdist.init(args.device)
+    ranks = rdist.init("cuda")
     device = str(ranks.device)
     dtype = DTYPES[args.dtype]
-    if args.device == "cpu" and args.threads:
-        torch.set_num_threads(args.threads)
-    net = _reference_net(args.model, device, dtype) if args.impl == "ref" else build_inference_model(args.model, device, dtype)
+    net = build_inference_model(args.model, device, dtype)
     rdist.barrier(ranks)
     with torch.no_grad():                 # speed_gpu.py:40 switches autograd off for the whole process; scoped here
-        rate = throughput(args.model if args.impl == "hip" else args.model + "[ref]", net, device, args.batch_size, args.resolution,
-                          dtype, args.t0, args.t1, ranks=ranks)
+        rate = throughput(args.model, net, device, args.batch_size, args.resolution, dtype, args.t0, args.t1, ranks=ranks)
     rdist.finish(ranks)
     return rate
 

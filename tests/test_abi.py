@@ -5,6 +5,8 @@ import re
 
 import pytest
 
+from tests.util import rcx_env
+
 import recnext_amd
 from recnext_amd import _lib
 
@@ -52,33 +54,21 @@ def test_abi_version_and_argument_errors_without_gpu():
     assert lib.rcx_recconv2d_fwd_plan(256, 128, 28, 28, 3, 5, 1, 0).startswith(b"cpt(k_recconv_cpt<2, 1, 1, 512>")
     assert lib.rcx_recconv2d_fwd_plan(256, 48, 56, 56, 4, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<4, 2, 0, 0>")          # run-time pixel pitch
     assert lib.rcx_recconv2d_fwd_plan(256, 96, 28, 28, 3, 5, 0, 1).startswith(b"lanes(k_recconv_lanes_banded<28, 3, 8, 0,")   # ragged 64-channel blocks: banded
-    os.environ["RCX_CPT"] = "all"
-    try:
+    with rcx_env(RCX_CPT="all"):
         assert lib.rcx_recconv2d_fwd_plan(256, 96, 28, 28, 3, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<2, 1, 0, 0, IMG2>,cb=32")   # image-pair variant
-    finally:
-        del os.environ["RCX_CPT"]
-    os.environ["RCX_CPT"] = "0"
-    try:
+    with rcx_env(RCX_CPT="0"):
         assert lib.rcx_recconv2d_fwd_plan(256, 64, 56, 56, 4, 5, 0, 1).startswith(b"lanes(k_recconv_lanes_banded<56, 4, 16, 0,")
-    finally:
-        del os.environ["RCX_CPT"]
     assert lib.rcx_recconv2d_fwd_plan(256, 256, 14, 14, 2, 5, 1, 0).startswith(b"cpl(k_recconv_cpl14<1, 256>")       # channel per lane
     assert lib.rcx_recconv2d_fwd_plan(256, 192, 14, 14, 2, 5, 0, 1).startswith(b"cpl(k_recconv_cpl14<0, 0>")          # any channel count
-    os.environ["RCX_CPL14"] = "0"
-    try:
+    with rcx_env(RCX_CPL14="0"):
         assert lib.rcx_recconv2d_fwd_plan(256, 256, 14, 14, 2, 5, 1, 0).startswith(b"lanes(k_recconv_lanes<14, 2, 8, 1,")
-    finally:
-        del os.environ["RCX_CPL14"]
     assert lib.rcx_recconv2d_fwd_plan(32, 64, 32, 32, 2, 5, 0, 1).startswith(b"lanes(k_recconv_lanes_banded<32, 2, 16, 0,")
     assert lib.rcx_recconv2d_fwd_plan(32, 64, 24, 40, 2, 5, 0, 1).startswith(b"plane(")          # neither 7*2^k nor 16*2^k
     assert lib.rcx_recconv2d_fwd_plan(256, 512, 7, 7, 1, 5, 0, 1).startswith(b"cpl(k_recconv_cpl7b<0, 512>")     # channel per lane
     assert lib.rcx_recconv2d_fwd_plan(2, 40, 7, 7, 1, 5, 0, 1).startswith(b"cpl(k_recconv_cpl7b<0, 0>")          # any channel count
-    os.environ["RCX_CPL7"] = "old"
-    try:
+    with rcx_env(RCX_CPL7="old"):
         assert lib.rcx_recconv2d_fwd_plan(256, 512, 7, 7, 1, 5, 0, 1).startswith(b"cpl(k_recconv_cpl7<0>")       # round 1's version
         assert lib.rcx_recconv2d_fwd_plan(2, 40, 7, 7, 1, 5, 0, 1).startswith(b"lanes(k_recconv_lanes<7, 1, 8, 0,")   # C % 64 != 0
-    finally:
-        del os.environ["RCX_CPL7"]
     assert lib.rcx_recconv2d_fwd_plan(1, 8, 7, 7, 1, 3, 0, 0) == b"generic"
     assert lib.rcx_recconv2d_fwd(one, one, one, None, None, 0, 1, 8, 7, 7, 0, 5, 0, 0, None) == -1      # alias
     assert lib.rcx_dwconv2d_fwd(one, two, one, None, 1, 8, 7, 7, 5, 3, 0, 0, None) == -2                # stride 3

@@ -5,6 +5,8 @@ import sys
 
 import pytest
 
+from tests.util import rcx_env
+
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
@@ -39,13 +41,8 @@ def test_random_backward_configurations_fused_against_per_step():
         gy = torch.randn(n, c, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
         _, saved = ops.recconv2d_forward_train(x, wpack, bpack, level, 5, mode)
         gx1, gw1, gb1 = ops.recconv2d_backward(x, gy, wpack, saved, level, 5, mode, need_bias=True)
-        for k in knobs:
-            os.environ[k] = "0"
-        try:
+        with rcx_env(**{k: "0" for k in knobs}):
             gx0, gw0, gb0 = ops.recconv2d_backward(x, gy, wpack, saved, level, 5, mode, need_bias=True)
-        finally:
-            for k in knobs:
-                del os.environ[k]
         tol = 3e-5 if dtype == torch.float32 else 1e-2
         tag = (it, n, c, hw, level, mode, str(dtype))
         for name, a1, a0, t in (("gx", gx1.float(), gx0.float(), tol), ("gw", gw1, gw0, 3e-5), ("gb", gb1, gb0, 3e-5)):

@@ -14,7 +14,7 @@ import torch
 import recnext_amd
 from recnext_amd import ops
 from oracle import c_oracle
-from tests.util import bf16_round_np, load_recconv, recattn_cases, recconv_cases
+from tests.util import bf16_round_np, load_recconv, rcx_env, recattn_cases, recconv_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -644,11 +644,8 @@ def test_upadd_step_kernel(mode, case, dts):
     else:
         assert np.allclose(got, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
     # same numbers as the generic schedule up to float reassociation
-    os.environ["RCX_FORCE_GENERIC"] = "1"
-    try:
+    with rcx_env(RCX_FORCE_GENERIC="1"):
         yg = ops.upadd_dwconv(t(x).to(xdt), t(cs).to(cdt), ops.pack_dw_weight(t(wt)), ops.pack_bias(t(b)), k=5, mode=mode)
-    finally:
-        del os.environ["RCX_FORCE_GENERIC"]
     assert np.allclose(yg.float().cpu().numpy(), got, atol=1e-2 if xdt == torch.bfloat16 else 1e-4, rtol=1e-2)
 
 

@@ -41,3 +41,28 @@ def bf16_round_np(a):
     u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
     r = ((u >> 16) & 1) + 0x7FFF
     return ((u + r) & 0xFFFF0000).astype(np.uint32).view(np.float32)
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def rcx_env(**switches):
+    """Set RCX_* environment switches (value None: unset) for the body and make the library re-read them on both sides."""
+    from recnext_amd import ops
+    old = {k: os.environ.get(k) for k in switches}
+    try:
+        for k, v in switches.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        ops.reload_options()
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        ops.reload_options()
