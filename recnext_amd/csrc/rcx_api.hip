@@ -8,42 +8,6 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include <mutex>
-#include <string>
-
-// ---- the RCX_* switches, read once (rcx_opts.h)
-namespace rcx {
-namespace opt {
-namespace {
-const char* const kNames[COUNT] = {
-    "RCX_FORCE_SPLIT", "RCX_FORCE_GENERIC", "RCX_LANES", "RCX_LANES_WAVES", "RCX_LANES_NI", "RCX_WGRAD_CPL", "RCX_CPT", "RCX_CPT_GRID", "RCX_CPT_MX",
-    "RCX_CPL", "RCX_CPL7", "RCX_CPL14", "RCX_CPL14_LDS", "RCX_CPL14_MX", "RCX_UPADD_CPL", "RCX_ATTN_MFMA", "RCX_ATTN_SCALAR", "RCX_TRAIN_FUSED",
-    "RCX_BWD_SPLIT", "RCX_BWD_NESTED", "RCX_BWD_FUSED", "RCX_PLANE_LPP", "RCX_PLANE_B2", "RCX_PLANE_NT", "RCX_PLANE_ABLATE", "RCX_LANES_ABLATE"};
-std::string g_val[COUNT];
-bool g_set[COUNT];
-std::once_flag g_once;
-void read_all()
-{
-    for (int i = 0; i < COUNT; ++i) {
-        const char* v = getenv(kNames[i]);
-        g_set[i] = v != nullptr;
-        g_val[i] = v ? v : "";
-    }
-}
-}  // namespace
-const char* value(Id id)
-{
-    std::call_once(g_once, read_all);
-    return g_set[id] ? g_val[id].c_str() : nullptr;
-}
-void reload()
-{
-    std::call_once(g_once, read_all);
-    read_all();
-}
-}  // namespace opt
-}  // namespace rcx
-
 namespace {
 
 thread_local char g_err[512] = "";

@@ -595,8 +595,12 @@ struct Geo {
 // TRAIN: the training-forward instantiation (saves the pyramid); the inference instantiations carry none of that code.
 // MX: the matrix-core instantiation (16-bit activations whose taps may be rounded to the same type; 56x56 / level 4): passes 1 and 2 as
 // 4 x 4 x 4 products, a wave = 16 channels x the four tiles of one tile row; everything between the passes is the code below unchanged.
+// HALVES = 4 (T = 4; round 3): a wave = 16 channels x the four tiles of one tile row (the quarters of the wave are the tile columns), a
+// workgroup = four waves = 16 channels of an image with 69 KB of LDS -- TWO workgroups per CU, which run different units and so are
+// in different phases: one's barrier-bound small-plane phases and load waits fill with the other's passes (a 32-channel workgroup
+// alone on its CU serialises ~105 k cycles of phases that each leave most of the CU idle).
 template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool IMG2 = false, bool TRAIN = false, bool MX = false>
-__global__ __launch_bounds__(T * T / HALVES * 64, T == 4 ? 1 : 2)
+__global__ __launch_bounds__(T * T / HALVES * 64, (T == 4 && HALVES == 2) ? 1 : 2)
 void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack,
                    int N, int C, int has_bias, SavedPyr sv, const void* __restrict__ mxpack)
 {
@@ -612,6 +616,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     // over the 8 XCDs; each XCD gets a contiguous run of units, so the channel blocks of one image (the two halves of its
     // 128-byte lines) pass through the same L2 at about the same time.
     static_assert(!IMG2 || HALVES == 1, "image halves use the one-tile-per-wave geometry");
+    static_assert(HALVES != 4 || (T == 4 && !TRAIN && !MX), "quarter-wave tiles: the 56x56 inference kernel");
     constexpr int CHB = IMG2 ? 32 : G::CB;                         // channels per block
     const int nb = (C + CHB - 1) / CHB;
     const int NU = IMG2 ? (N + 1) / 2 : N;                          // image units
@@ -633,13 +638,13 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane_ = tid & 63;
-    if constexpr (MX) asm volatile("" : "+v"(lane_));            // per unit: what derives from the lane index is recomputed, not kept live across units
+    if constexpr (MX || HALVES == 4) asm volatile("" : "+v"(lane_));   // per unit: what derives from the lane index is recomputed, not kept live across units
     const int lane = lane_;
-    const int h = HALVES == 2 ? (lane >> 5) : 0;
+    const int h = HALVES == 4 ? (lane >> 4) : (HALVES == 2 ? (lane >> 5) : 0);
     const int ch = lane & (G::CB - 1);
-    const int tr = T == 4 ? (w >> 1) : (w >> 1);
+    const int tr = HALVES == 4 ? w : (w >> 1);
     const int tcb = w & 1;
-    const int tc = HALVES == 2 ? tcb + 2 * h : tcb;                      // per lane (HALVES == 2) / uniform
+    const int tc = HALVES == 4 ? h : (HALVES == 2 ? tcb + 2 * h : tcb);  // per lane (HALVES >= 2) / uniform
     // MX: the passes' two lane maps of this wave's 16 channels (w & 1) x the four tiles of tile row tr (see "matrix-core variant")
     const int chA = (w & 1) * 16 + (lane & 15), tcA = lane >> 4;         // A: memory
     const int chM = (w & 1) * 16 + (lane >> 2), tcM = lane & 3;          // M: matrix operands and results
@@ -1050,7 +1055,41 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
 #pragma unroll
                 for (int cI = 0; cI < 7; ++cI) f1[r][cI] = src[(r * P1 + cI) * PIXF];
         }
-        const int cpar = __builtin_amdgcn_readfirstlane(d0 & 1);
+        // HALVES = 4: the four tile columns of a wave have both parities -- the same sums with per-lane weights and selected neighbours
+        auto form_lane = [&]() {
+            const bool par = (d0 & 1) != 0;
+            const float le = MODE == 1 ? 0.f : (par ? 0.25f : 0.75f), lo = MODE == 1 ? 0.f : (par ? 0.75f : 0.25f);
+#pragma unroll
+            for (int r = 0; r < 7; ++r) {
+                const int dr = 7 * tr + r;                      // uniform
+                int i0, i1;
+                float lam;
+                if (MODE == 1) { i0 = i1 = dr >> 1; lam = 0.f; }
+                else if (dr & 1) { i0 = (dr - 1) >> 1; i1 = i0 + 1; lam = 0.25f; }
+                else { i0 = (dr >> 1) - 1; i1 = i0 + 1; lam = 0.75f; }
+                i0 = i0 < 0 ? 0 : (i0 > P2 - 1 ? P2 - 1 : i0);
+                i1 = i1 < 0 ? 0 : (i1 > P2 - 1 ? P2 - 1 : i1);
+                const float* r0 = L2 + i0 * (P2 * PIXF);
+                const float* r1 = L2 + i1 * (P2 * PIXF);
+                float V[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) V[k] = MODE == 1 ? r0[cofs[k]] : fmaf(lam, r1[cofs[k]], (1.f - lam) * r0[cofs[k]]);
+#pragma unroll
+                for (int cI = 0; cI < 7; ++cI) {
+                    float up;
+                    if (cI & 1) {                                // rel2: par 0 -> (m, m+1; 0.25), par 1 -> (m-1, m; 0.75), m = (cI + 1) / 2
+                        const int m = (cI + 1) / 2;
+                        const float a0 = par ? V[m - 1] : V[m], a1 = par ? V[m] : V[m + 1];
+                        up = MODE == 1 ? (par ? V[m] : V[m - 1]) : fmaf(lo, a1, (1.f - lo) * a0);
+                    } else {                                     // rel2: (m, m+1), weight 0.75 (par 0) / 0.25 (par 1), m = cI / 2
+                        const int m = cI / 2;
+                        up = MODE == 1 ? V[m] : fmaf(le, V[m + 1], (1.f - le) * V[m]);
+                    }
+                    f1[r][cI] += up;
+                }
+            }
+        };
+        const int cpar = HALVES == 4 ? 0 : __builtin_amdgcn_readfirstlane(d0 & 1);
         auto form = [&](auto parc) {
             constexpr int PAR = decltype(parc)::value;
 #pragma unroll
@@ -1076,7 +1115,8 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                 });
             }
         };
-        if (cpar) form(IC<1>{}); else form(IC<0>{});
+        if constexpr (HALVES == 4) form_lane();
+        else if (cpar) form(IC<1>{}); else form(IC<0>{});
         float* dst = L1 + ((7 * tr) * P1 + 7 * tc) * PIXF;
 #pragma unroll
         for (int r = 0; r < 7; ++r)
@@ -1364,7 +1404,7 @@ template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool IMG2 = false
 static hipError_t launch(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv, const void* mxpack = nullptr)
 {
     using G = Geo<T, HALVES, MODE, TIO, MX>;
-    if constexpr (!TRAIN && MODE == 0 && !IMG2 && !MX) {      // training forward: bilinear only (what RecConv2d trains with), whole-block variants
+    if constexpr (!TRAIN && MODE == 0 && !IMG2 && !MX && HALVES != 4) {      // training forward: bilinear only (what RecConv2d trains with), whole-block variants
         if (sv.base) return launch<T, HALVES, MODE, PIXB, TIO, IMG2, true>(x, y, wpack, bpack, N, C, s, sv);
     }
     if (!TRAIN && sv.base) return hipErrorInvalidConfiguration;
@@ -1382,7 +1422,7 @@ static hipError_t launch(const void* x, void* y, const float* wpack, const float
         cus = v;
     }
     const unsigned total = IMG2 ? (unsigned)(((N + 1) / 2) * ((C + 31) / 32)) : (unsigned)(N * ((C + G::CB - 1) / G::CB));
-    unsigned cap = (unsigned)cus * (T == 4 ? 1u : 2u);         // workgroups resident at once (LDS: one / two per CU)
+    unsigned cap = (unsigned)cus * ((T == 4 && HALVES == 2) ? 1u : 2u);   // workgroups resident at once (LDS: one / two per CU)
     if (const char* e = rcx::opt::value(rcx::opt::CPT_GRID)) { const int g = atoi(e); if (g > 0) cap = (unsigned)g; }    // A/B knob
     cap &= ~7u;
     const unsigned grid = total <= cap || cap == 0 ? total : cap;
@@ -1418,6 +1458,9 @@ static hipError_t launch_mx(const void* x, void* y, const float* wpack, const fl
     if (dtype == 2) return mode == 1 ? launch_mx_c<1, f16_t>(x, y, wpack, bpack, mxpack, N, C, s) : launch_mx_c<0, f16_t>(x, y, wpack, bpack, mxpack, N, C, s);
     return hipErrorInvalidConfiguration;
 }
+
+// RCX_CPT_CB=16: the 56x56 block with 16-channel workgroups, two per CU (HALVES = 4); =32: the 32-channel workgroups (HALVES = 2)
+static inline bool cb16() { const char* v = rcx::opt::value(rcx::opt::CPT_CB); return !(v && v[0] == '3'); }
 
 template <int T, int HALVES>
 static hipError_t launch_md(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s, const SavedPyr& sv)

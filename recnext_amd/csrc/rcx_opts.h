@@ -1,21 +1,61 @@
 // The RCX_* environment switches (A/B measurement knobs; none changes results beyond the stated tolerances).  They are read ONCE, at the
 // first call that asks for one, into process-wide storage -- a launch no longer pays ~35 getenv() walks of the environment --
-// and again only when rcx_reload_options() is called (tests and A/B tools flip a switch and reload).
+// and again only when rcx_reload_options() is called (tests and A/B tools flip a switch and reload).  Header-only (inline functions with
+// one shared table per process), so the stand-alone harnesses under tools/ that compile a single kernel file link without rcx_api.hip.
 #pragma once
+#include <stdlib.h>
+#include <mutex>
+#include <string>
 
 namespace rcx {
 namespace opt {
 
 enum Id {
     FORCE_SPLIT, FORCE_GENERIC, LANES, LANES_WAVES, LANES_NI, WGRAD_CPL, CPT, CPT_GRID, CPT_MX, CPL, CPL7, CPL14, CPL14_LDS, CPL14_MX, UPADD_CPL,
-    ATTN_MFMA, ATTN_SCALAR, TRAIN_FUSED, BWD_SPLIT, BWD_NESTED, BWD_FUSED, PLANE_LPP, PLANE_B2, PLANE_NT, PLANE_ABLATE, LANES_ABLATE, COUNT
+    ATTN_MFMA, ATTN_SCALAR, TRAIN_FUSED, BWD_SPLIT, BWD_NESTED, BWD_FUSED, PLANE_LPP, PLANE_B2, PLANE_NT, PLANE_ABLATE, LANES_ABLATE, CPT_CB, COUNT
 };
 
+namespace detail {
+inline const char* name_of(int i)
+{
+    static const char* const k[COUNT] = {
+        "RCX_FORCE_SPLIT", "RCX_FORCE_GENERIC", "RCX_LANES", "RCX_LANES_WAVES", "RCX_LANES_NI", "RCX_WGRAD_CPL", "RCX_CPT", "RCX_CPT_GRID", "RCX_CPT_MX",
+        "RCX_CPL", "RCX_CPL7", "RCX_CPL14", "RCX_CPL14_LDS", "RCX_CPL14_MX", "RCX_UPADD_CPL", "RCX_ATTN_MFMA", "RCX_ATTN_SCALAR", "RCX_TRAIN_FUSED",
+        "RCX_BWD_SPLIT", "RCX_BWD_NESTED", "RCX_BWD_FUSED", "RCX_PLANE_LPP", "RCX_PLANE_B2", "RCX_PLANE_NT", "RCX_PLANE_ABLATE", "RCX_LANES_ABLATE",
+        "RCX_CPT_CB"};
+    return k[i];
+}
+struct Table {
+    std::string val[COUNT];
+    bool set[COUNT];
+    std::once_flag once;
+    void read()
+    {
+        for (int i = 0; i < COUNT; ++i) {
+            const char* v = getenv(name_of(i));
+            set[i] = v != nullptr;
+            val[i] = v ? v : "";
+        }
+    }
+};
+inline Table& table() { static Table t; return t; }
+}  // namespace detail
+
 // the variable's value as of the last (re)load, or nullptr when it is not set; the pointer stays valid until the next reload
-const char* value(Id id);
+inline const char* value(Id id)
+{
+    detail::Table& t = detail::table();
+    std::call_once(t.once, [&] { t.read(); });
+    return t.set[id] ? t.val[id].c_str() : nullptr;
+}
 inline bool is_zero(Id id) { const char* v = value(id); return v && *v == '0'; }      // "RCX_X=0": switched off
 inline bool is_on(Id id) { const char* v = value(id); return v && *v && *v != '0'; }  // set to anything but "" / "0..."
-void reload();
+inline void reload()
+{
+    detail::Table& t = detail::table();
+    std::call_once(t.once, [&] { t.read(); });
+    t.read();
+}
 
 }  // namespace opt
 }  // namespace rcx
