@@ -51,7 +51,7 @@ void rcx_reload_options(void);
  * "plane(cb=16,band8,nt=512,lds=157760)"; thread-local storage, valid until the next call on this thread. */
 const char* rcx_recconv2d_fwd_plan(int N, int C, int H, int W, int level, int k, int mode, int dtype);
 
-/* Repack one depthwise weight (C,1,k,k) [dtype f32|bf16] -> float32 (k,k,C).
+/* Repack one depthwise weight (C,1,k,k) [dtype f32|bf16|f16] -> float32 (k,k,C).
  * Replaces nothing in the reference (layout plumbing for nn.Conv2d(groups=C).weight, model/recnext.py:21-22). */
 int rcx_pack_dw_weight(const void* w_ckk, float* dst_kkc, int C, int k, int dtype, void* stream);
 /* All parameters of one RecConv2d block in one launch: w[j] (C,1,k,k) and b[j] (C) [dtype f32|bf16|f16], j = 0 .. count-1 in pack
@@ -63,7 +63,7 @@ int rcx_pack_recconv_params(const void* const* w, const void* const* b, float* w
                             int count, int C, int k, int dtype, void* stream);
 /* The inverse layout change for the gradients: gwpack (count,k,k,C) float32 -> gw[j] (C,1,k,k) float32 contiguous, one launch. */
 int rcx_unpack_recconv_grads(const float* gwpack, void* const* gw, int count, int C, int k, void* stream);
-/* Convert one bias vector (C) [dtype f32|bf16] -> float32 (C). */
+/* Convert one bias vector (C) [dtype f32|bf16|f16] -> float32 (C). */
 int rcx_pack_bias(const void* b, float* dst, int C, int dtype, void* stream);
 
 /* Scratch bytes rcx_recconv2d_fwd needs for this problem (may be 0). */
@@ -101,7 +101,8 @@ int rcx_recconv2d_fwd_mx(const void* x, void* y, const float* wpack, const float
 
 /*
  * Training (engine.py:48-64): a forward that keeps the fp32 pyramid F_1..F_L, C_1..C_L in `saved`, and the backward pass.
- *   rcx_recconv2d_fwd_train   same contract as rcx_recconv2d_fwd (always the per-level schedule); `saved` must hold
+ *   rcx_recconv2d_fwd_train   same contract as rcx_recconv2d_fwd (the blocks of RecNeXt at 224x224 run their inference launch, which then also
+ *                             writes the pyramid; other shapes the per-level schedule); `saved` must hold
  *                             rcx_recconv2d_train_saved_bytes() and stay untouched until rcx_recconv2d_bwd has run.
  *   rcx_recconv2d_bwd         gy: N x H x W x C float32 (dL/dy);  gx: N x H x W x C of `dtype` (dL/dx);
  *                             wpack_flipped: wpack with every k x k tap block rotated by 180 degrees (transpose convs);

@@ -32,7 +32,7 @@ bool cpt_train_applicable(int N, int C, int H, int W, int level, int k, int mode
 
 int cpt_describe(int N, int C, int H, int mode, int dtype, char* buf, int len)
 {
-    const int T = H / 14, halves = T == 4 ? (cpt::cb16() ? 4 : 2) : 1, pixf = 64 / halves;
+    const int T = H / 14, halves = T == 4 ? (cpt::cb16(N, C) ? 4 : 2) : 1, pixf = 64 / halves;
     const int pixb = C == (T == 4 ? 64 : 128) ? C * (dtype == 0 ? 4 : 2) : 0;
     const bool img2 = T == 2 && C % 64 != 0;
     const int total = img2 ? ((N + 1) / 2) * ((C + 31) / 32) : N * ((C + pixf - 1) / pixf);
@@ -68,7 +68,7 @@ hipError_t cpt_recconv(const void* x, void* y, const float* wpack, const float* 
     sv.base = saved;
     if (saved)
         for (int l = 1; l <= (H == 56 ? 4 : 3); ++l) { sv.f_off[l] = f_off[l]; sv.c_off[l] = c_off[l]; }
-    if (H == 56) return (!saved && cpt::cb16()) ? cpt::launch_md<4, 4>(x, y, wpack, bpack, N, C, mode, dtype, s, sv)
+    if (H == 56) return (!saved && cpt::cb16(N, C)) ? cpt::launch_md<4, 4>(x, y, wpack, bpack, N, C, mode, dtype, s, sv)
                                                : cpt::launch_md<4, 2>(x, y, wpack, bpack, N, C, mode, dtype, s, sv);
     return cpt::launch_t2(x, y, wpack, bpack, N, C, mode, dtype, s, sv);
 }

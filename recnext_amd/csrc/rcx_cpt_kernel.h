@@ -598,7 +598,7 @@ struct Geo {
 // HALVES = 4 (T = 4; round 3): a wave = 16 channels x the four tiles of one tile row (the quarters of the wave are the tile columns), a
 // workgroup = four waves = 16 channels of an image with 69 KB of LDS -- TWO workgroups per CU, which run different units and so are
 // in different phases: one's barrier-bound small-plane phases and load waits fill with the other's passes (a 32-channel workgroup
-// alone on its CU serialises ~105 k cycles of phases that each leave most of the CU idle).
+// alone on its CU serialises ~105 k cycles of phases that each leave most of the CU idle).  Used where cb16() says so.
 template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool IMG2 = false, bool TRAIN = false, bool MX = false>
 __global__ __launch_bounds__(T * T / HALVES * 64, (T == 4 && HALVES == 2) ? 1 : 2)
 void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack,
@@ -1409,17 +1409,14 @@ static hipError_t launch(const void* x, void* y, const float* wpack, const float
     }
     if (!TRAIN && sv.base) return hipErrorInvalidConfiguration;
     auto kfn = k_recconv_cpt<T, HALVES, MODE, PIXB, TIO, IMG2, TRAIN, MX>;
-    static bool attr_set = false;                              // once per instantiation
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    static int cus = 0;
+    RCX_SET_LDS_ONCE(kfn, G::LDS_BYTES);                       // once per instantiation and device
+    static std::atomic<int> cus_cache{0};
+    int cus = cus_cache.load(std::memory_order_relaxed);
     if (!cus) {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
         cus = v;
+        cus_cache.store(v, std::memory_order_relaxed);
     }
     const unsigned total = IMG2 ? (unsigned)(((N + 1) / 2) * ((C + 31) / 32)) : (unsigned)(N * ((C + G::CB - 1) / G::CB));
     unsigned cap = (unsigned)cus * ((T == 4 && HALVES == 2) ? 1u : 2u);   // workgroups resident at once (LDS: one / two per CU)
@@ -1459,8 +1456,18 @@ static hipError_t launch_mx(const void* x, void* y, const float* wpack, const fl
     return hipErrorInvalidConfiguration;
 }
 
-// RCX_CPT_CB=16: the 56x56 block with 16-channel workgroups, two per CU (HALVES = 4); =32: the 32-channel workgroups (HALVES = 2)
-static inline bool cb16() { const char* v = rcx::opt::value(rcx::opt::CPT_CB); return !(v && v[0] == '3'); }
+// The 56x56 block with 16-channel workgroups, two per CU (HALVES = 4), or with 32-channel workgroups (HALVES = 2).  Measured INSIDE the
+// models (bench.py per-kernel event times, batch 256, bf16; profiles/r03_cpt_cb16.txt): 64 channels 108.1 us with 32-channel blocks, 117.5
+// with 16 (32-byte runs per cache-line access); 48 channels (RecNeXt-M1) 111.6 -> 92.5 us and 80 channels (M5) 175.6 -> 157.2 us with
+// 16 (no half-empty last block); few units (3 images x 48 channels) 53.7 -> 37.2 us.  So: 16 where the channel count is not a multiple
+// of 32 or where 32-channel units would not fill the chip; RCX_CPT_CB=16 / 32 pins either (A/B).
+static inline bool cb16(int N, int C)
+{
+    const char* v = rcx::opt::value(rcx::opt::CPT_CB);
+    if (v && v[0] == '1') return true;
+    if (v && v[0] == '3') return false;
+    return C % 32 != 0 || (long long)N * ((C + 31) / 32) < 256;
+}
 
 template <int T, int HALVES>
 static hipError_t launch_md(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s, const SavedPyr& sv)

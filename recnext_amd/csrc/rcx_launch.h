@@ -3,15 +3,20 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
-// Raise a kernel's dynamic-LDS limit once per kernel instantiation (the static lives in the expanding template function), not per
-// launch; a later launch that needs more raises it again.
+// Raise a kernel's dynamic-LDS limit once per kernel instantiation AND DEVICE (the attribute belongs to the device's copy of the
+// function; the statics live in the expanding template function), not per launch; a later launch that needs more raises it again.
+// Atomics: two host threads may launch the same kernel; the worst case is one redundant hipFuncSetAttribute call.
+#include <atomic>
+#define RCX_MAX_DEVICES 64
 #define RCX_SET_LDS_ONCE(kfn, bytes)                                                                                              \
     do {                                                                                                                          \
-        static size_t rcx_lds_set_ = 0;                                                                                           \
-        if ((size_t)(bytes) > 64 * 1024 && (size_t)(bytes) > rcx_lds_set_) {                                                      \
+        static std::atomic<size_t> rcx_lds_set_[RCX_MAX_DEVICES];                                                                 \
+        int rcx_dev_ = 0;                                                                                                         \
+        if (hipGetDevice(&rcx_dev_) != hipSuccess || rcx_dev_ < 0 || rcx_dev_ >= RCX_MAX_DEVICES) rcx_dev_ = RCX_MAX_DEVICES - 1; \
+        if ((size_t)(bytes) > 64 * 1024 && (size_t)(bytes) > rcx_lds_set_[rcx_dev_].load(std::memory_order_acquire)) {            \
             hipError_t rcx_e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
             if (rcx_e_ != hipSuccess) return rcx_e_;                                                                              \
-            rcx_lds_set_ = (size_t)(bytes);                                                                                       \
+            if (rcx_dev_ != RCX_MAX_DEVICES - 1) rcx_lds_set_[rcx_dev_].store((size_t)(bytes), std::memory_order_release);        \
         }                                                                                                                         \
     } while (0)
 

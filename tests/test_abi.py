@@ -50,11 +50,14 @@ def test_abi_version_and_argument_errors_without_gpu():
     assert lib.rcx_recconv2d_fwd_workspace_bytes(1, 8, 7, 7, 1, 3, 0) > 0
     assert lib.rcx_recconv2d_fwd(one, two, one, None, None, 0, 1, 8, 7, 7, 1, 3, 0, 0, None) == -3      # workspace
     assert lib.rcx_recconv2d_fwd_workspace_bytes(256, 64, 56, 56, 4, 5, 1) == 0
-    assert lib.rcx_recconv2d_fwd_plan(256, 64, 56, 56, 4, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<4, 4, 0, 128>,cb=16")  # tiled channel per lane, 16-channel workgroups
-    with rcx_env(RCX_CPT_CB="32"):                                                                                          # round 2's 32-channel workgroups (A/B)
-        assert lib.rcx_recconv2d_fwd_plan(256, 64, 56, 56, 4, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<4, 2, 0, 128>,cb=32")
+    assert lib.rcx_recconv2d_fwd_plan(256, 64, 56, 56, 4, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<4, 2, 0, 128>,cb=32")  # tiled channel per lane
+    assert lib.rcx_recconv2d_fwd_plan(2, 64, 56, 56, 4, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<4, 4, 0, 128>,cb=16")    # few units: 16-channel workgroups, two per CU
+    with rcx_env(RCX_CPT_CB="16"):
+        assert lib.rcx_recconv2d_fwd_plan(256, 64, 56, 56, 4, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<4, 4, 0, 128>,cb=16")
     assert lib.rcx_recconv2d_fwd_plan(256, 128, 28, 28, 3, 5, 1, 0).startswith(b"cpt(k_recconv_cpt<2, 1, 1, 512>")
-    assert lib.rcx_recconv2d_fwd_plan(256, 48, 56, 56, 4, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<4, 4, 0, 0>")          # run-time pixel pitch
+    assert lib.rcx_recconv2d_fwd_plan(256, 48, 56, 56, 4, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<4, 4, 0, 0>,cb=16")    # run-time pixel pitch; ragged 32-blocks: 16
+    with rcx_env(RCX_CPT_CB="32"):
+        assert lib.rcx_recconv2d_fwd_plan(256, 48, 56, 56, 4, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<4, 2, 0, 0>,cb=32")
     assert lib.rcx_recconv2d_fwd_plan(256, 96, 28, 28, 3, 5, 0, 1).startswith(b"lanes(k_recconv_lanes_banded<28, 3, 8, 0,")   # ragged 64-channel blocks: banded
     with rcx_env(RCX_CPT="all"):
         assert lib.rcx_recconv2d_fwd_plan(256, 96, 28, 28, 3, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<2, 1, 0, 0, IMG2>,cb=32")   # image-pair variant

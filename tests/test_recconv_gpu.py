@@ -193,15 +193,17 @@ def test_channel_per_lane_14x14_kernel_against_oracle_and_lanes_kernel(mode, bia
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("shape", [(3, 64), (2, 80), (5, 8), (2, 48)], ids=lambda v: "x".join(map(str, v)))
 def test_56_block_with_16_and_32_channel_workgroups_is_the_same_function(mode, dtype, shape):
-    """Round 3: the 56x56 / level 4 block runs as 16-channel workgroups, two per CU (k_recconv_cpt<4, 4, ...>); round 2's 32-channel
-    workgroups stay behind RCX_CPT_CB=32.  Same arithmetic in the same order per (channel, tile): bit-identical outputs."""
+    """Round 3: the 56x56 / level 4 block also runs as 16-channel workgroups, two per CU (k_recconv_cpt<4, 4, ...>: chosen for channel
+    counts that are not multiples of 32 and for few units) beside round 2's 32-channel workgroups.  Same arithmetic in the same order per
+    (channel, tile): bit-identical outputs."""
     n, c = shape
     torch.manual_seed(n * 100 + c)
     mod = recnext_amd.RecConv2d(c, kernel_size=5, level=4, mode=mode, bias=True).to(dev()).eval()
     x = torch.randn(n, c, 56, 56, device=dev()).to(dtype).contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
-        assert ops.recconv2d_plan(n, c, 56, 56, 4, 5, mode, dtype).startswith("cpt(k_recconv_cpt<4, 4,")
-        y16 = mod(x)
+        with rcx_env(RCX_CPT_CB="16"):
+            assert ops.recconv2d_plan(n, c, 56, 56, 4, 5, mode, dtype).startswith("cpt(k_recconv_cpt<4, 4,")
+            y16 = mod(x)
         with rcx_env(RCX_CPT_CB="32"):
             assert ops.recconv2d_plan(n, c, 56, 56, 4, 5, mode, dtype).startswith("cpt(k_recconv_cpt<4, 2,")
             y32 = mod(x)
