@@ -18,7 +18,11 @@
 // Numerics: float32 accumulation; the conv INPUTS are rounded to the activations' type (x is exact; F1, F2, F1 + resize(C2) and
 // x + resize(C1) once each) -- fewer roundings than the reference's own 16-bit run, which rounds after every operator (:27-34).
 // Against the vector kernel (k_recconv_cpl14: 3 780 FMA instructions of 4 677 vector instructions per wave, 18.6 us at 256 x 256):
-// ~ 850 matrix instructions + ~ 1 500 vector instructions.
+// ~ 800 matrix instructions + ~ 1 900 vector instructions, 19.0 us -- one dependent chain per SIMD either way.
+// A band-split variant (the four lanes of a block = four row bands of ONE plane, every plane in the wave's LDS image as 8-byte K blocks,
+// no barrier, 4 096 one-wave workgroups) was built and measured in round 3 and is not kept: a wave alone took 6.6 us instead of 14 (as
+// designed), the full problem 36.6 us -- 27 KB of LDS per wave leave 1.5 waves per SIMD, and every level is an LDS write -> read ->
+// matrix -> convert -> write chain that nothing hides (profiles/r03_mx14b_band_split.txt).
 #include "rcx_cpt_kernel.h"
 #include "rcx_opts.h"
 
