@@ -162,17 +162,16 @@ def kernel_name(plan, elem_bytes):
         return f"rcx::lanes::{kern}, {t}>"
     if plan.startswith("cpt(k_recconv_cpt"):
         kern = plan[len("cpt("):plan.index(">")]
-        img2 = kern.endswith(", IMG2")                                       # template arguments after the type: image pairs, training, matrix cores
-        return f"rcx::cpt::{kern[:-6] if img2 else kern}, {t}, {'true' if img2 else 'false'}, false, false>"
+        return f"rcx::cpt::{kern}, {t}, false, false>"                 # template arguments after the type: training, matrix cores
     if plan.startswith("cpt_mx(k_recconv_cpt"):
         kern = plan[len("cpt_mx("):plan.index(">")].rsplit(", ", 2)[0]        # "... <4, 2, mode, pixb, bf16, MX" -> up to the pitch
-        return f"rcx::cpt::{kern}, {'_Float16' if ', f16,' in plan else 'unsigned short'}, false, false, true>"
+        return f"rcx::cpt::{kern}, {'_Float16' if ', f16,' in plan else 'unsigned short'}, false, true>"
     if plan.startswith("cpl14_mx(k_recconv_mx14"):
         mode = plan[len("cpl14_mx(k_recconv_mx14<"):].split(",")[0]
         return f"rcx::mx14::k_recconv_mx14<{mode}, {'_Float16' if ', f16>' in plan else 'unsigned short'}>"
     if plan.startswith("cpl(k_recconv_cpl"):
         kern = plan[len("cpl("):plan.index(">")]
-        ns = "cpl" if kern.startswith("k_recconv_cpl7<") else "cpl14"       # rcx_cpl.hip (round 1) / rcx_cpl14.hip
+        ns = "cpl14"                                                          # rcx_cpl14.hip
         if kern.startswith("k_recconv_cpl14<"):                              # last template argument: x through LDS (A/B variant)
             xl = kern.endswith(", XL")
             return f"rcx::{ns}::{kern[:-4] if xl else kern}, {t}, {'true' if xl else 'false'}>"

@@ -591,13 +591,12 @@ static hipError_t launch7_c(const void* x, void* y, const float* wpack, const fl
 
 }  // namespace cpl14
 
-// the 7x7 / level 1 block on the pieces of this file (RCX_CPL7=old keeps rcx_cpl.hip's first version for A/B runs)
+// the 7x7 / level 1 block on the pieces of this file (round 1's first version, rcx_cpl.hip, left the tree in round 3: profiles/r01*, r02a_*)
 bool cpl7b_applicable(int N, int C, int H, int W, int level, int k, int dtype)
 {
     (void)N;
-    const char* v = rcx::opt::value(rcx::opt::CPL7);
     const char* all = rcx::opt::value(rcx::opt::CPL);                          // RCX_CPL=0: no channel-per-lane kernel on 7x7 (the lanes kernel instead)
-    return cpl14::enabled() && !(v && *v == 'o') && !(all && *all == '0') && H == 7 && W == 7 && level == 1 && k == 5 && C >= 1 && (dtype == 0 || dtype == 1 || dtype == 2);
+    return cpl14::enabled() && !(all && *all == '0') && H == 7 && W == 7 && level == 1 && k == 5 && C >= 1 && (dtype == 0 || dtype == 1 || dtype == 2);
 }
 
 int cpl7b_describe(int N, int C, int mode, char* buf, int len)

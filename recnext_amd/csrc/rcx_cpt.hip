@@ -8,19 +8,26 @@ namespace cpt {
 hipError_t launch_t2(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s, const SavedPyr& sv);
 }  // namespace cpt
 
-// A/B switches read per call like the other schedules' (tests flip them inside one process): RCX_CPT=0 gives both blocks back to
-// the banded lanes kernels; RCX_CPT=all also takes the 28x28 block with channel counts that are not multiples of 64 (image-pair
-// variant, IMG2) -- off by default: measured slower than the banded kernel there (256 x 96: 51.7 vs 46.4 us, 256 x 160: 73.7 vs
-// 70.6 us, profiles/r02c_cpt_img2_variant.txt): a workgroup's latency does not shrink with the channel count.
+// RCX_CPT=0 gives both blocks back to the banded lanes kernels.  The 28x28 block with a channel count that is not a multiple of 64
+// (RecNeXt-M0/M1/M2/M5) stays on the banded kernel by default; RCX_CPT=32 puts it on 32-channel workgroups (k_recconv_cpt<2, 2, ...>, four
+// per CU).  Measured (profiles/r03_cpt_28_ragged.txt, bf16, us, 32-channel workgroups / banded): 256 x 112 (1 024 units) 51.9 / 57.4,
+// 256 x 96 (768) 45.3 / 46.9 (inside RecNeXt-M1: 46.7 / 47.0), 256 x 80 46.8 / 46.9, 128 x 160 (640) 41.7 / 42.6 -- but with fewer units a
+// unit's own ~37 us of phases is the floor (128 x 96: 37.8 / 28.9, 64 x 160: 37.3 / 27.8) and with more the second round runs on a fraction
+// of the chip (256 x 160: 63.0 / 67.3 alone, 75.6 / 68.7 inside RecNeXt-M5; 512 x 96: 84.0 / 79.3).  A rule on the unit count would pick a
+// different summation order for a batch and for its shards (the two kernels agree to float32 round-off, not bit for bit), and "a batch
+// shard gives the same rows"  is kept exact: the choice never depends on N.
+static bool cpt28_ragged(int N, int C)
+{
+    (void)N; (void)C;
+    const char* v = rcx::opt::value(rcx::opt::CPT);
+    return v && *v == '3';
+}
+
 bool cpt_applicable(int N, int C, int H, int W, int level, int k, int dtype)
 {
-    (void)N;
     if (!cpt::enabled() || k != 5 || C < 1 || !(dtype == 0 || dtype == 1 || dtype == 2)) return false;
     if (H == 56 && W == 56 && level == 4) return true;
-    if (H == 28 && W == 28 && level == 3) {
-        const char* v = rcx::opt::value(rcx::opt::CPT);
-        return C % 64 == 0 || (v && *v == 'a');
-    }
+    if (H == 28 && W == 28 && level == 3) return C % 64 == 0 || cpt28_ragged(N, C);
     return false;
 }
 
@@ -32,12 +39,12 @@ bool cpt_train_applicable(int N, int C, int H, int W, int level, int k, int mode
 
 int cpt_describe(int N, int C, int H, int mode, int dtype, char* buf, int len)
 {
-    const int T = H / 14, halves = T == 4 ? (cpt::cb16(N, C) ? 4 : 2) : 1, pixf = 64 / halves;
+    const int T = H / 14, halves = T == 4 ? (cpt::cb16(N, C) ? 4 : 2) : (C % 64 != 0 ? 2 : 1), pixf = 64 / halves;
     const int pixb = C == (T == 4 ? 64 : 128) ? C * (dtype == 0 ? 4 : 2) : 0;
-    const bool img2 = T == 2 && C % 64 != 0;
-    const int total = img2 ? ((N + 1) / 2) * ((C + 31) / 32) : N * ((C + pixf - 1) / pixf);
-    return snprintf(buf, len, "cpt(k_recconv_cpt<%d, %d, %d, %d%s>,cb=%d,nt=%d,units=%d,lds=%d)", T, halves, mode, pixb, img2 ? ", IMG2" : "", img2 ? 32 : pixf, T * T / halves * 64, total,
-                    T == 4 ? (halves == 4 ? cpt::Geo<4, 4, 0, float>::LDS_BYTES : cpt::Geo<4, 2, 0, float>::LDS_BYTES) : cpt::Geo<2, 1, 0, float>::LDS_BYTES);
+    const int total = N * ((C + pixf - 1) / pixf);
+    return snprintf(buf, len, "cpt(k_recconv_cpt<%d, %d, %d, %d>,cb=%d,nt=%d,units=%d,lds=%d)", T, halves, mode, pixb, pixf, T * T / halves * 64, total,
+                    T == 4 ? (halves == 4 ? cpt::Geo<4, 4, 0, float>::LDS_BYTES : cpt::Geo<4, 2, 0, float>::LDS_BYTES)
+                           : (halves == 2 ? cpt::Geo<2, 2, 0, float>::LDS_BYTES : cpt::Geo<2, 1, 0, float>::LDS_BYTES));
 }
 
 // Matrix-core variant (rcx_cpt_kernel.h, MX): the 56x56 / level 4 block with bf16 or float16 activations.  RCX_CPT_MX=0: off (A/B).

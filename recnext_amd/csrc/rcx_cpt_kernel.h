@@ -590,8 +590,9 @@ struct Geo {
     static_assert(!MX_ || XOFF + 2 * XSTAGE <= 160 * 1024, "staging area does not fit");
 };
 
-// IMG2 (T = 2 only): the two half-waves are two IMAGES (n, n + 1) of the same tile and the same 32 channels -- whole 32-channel
-// blocks for the channel counts that are not multiples of 64 (RecNeXt-M1: 96, M5: 160); geometry and parities stay uniform.
+// T = 2, HALVES = 2 (round 3): a wave = 32 channels x the two tiles of one tile row, a workgroup = two waves = 32 channels of an image with
+// 35.7 KB of LDS, four per CU -- for the channel counts that are not multiples of 64 (RecNeXt-M1: 96, M5: 160); it replaces round 2's
+// image-pair variant (two half-waves = two images; slower than the banded kernel, profiles/r02c_cpt_img2_variant.txt).
 // TRAIN: the training-forward instantiation (saves the pyramid); the inference instantiations carry none of that code.
 // MX: the matrix-core instantiation (16-bit activations whose taps may be rounded to the same type; 56x56 / level 4): passes 1 and 2 as
 // 4 x 4 x 4 products, a wave = 16 channels x the four tiles of one tile row; everything between the passes is the code below unchanged.
@@ -599,13 +600,13 @@ struct Geo {
 // workgroup = four waves = 16 channels of an image with 69 KB of LDS -- TWO workgroups per CU, which run different units and so are
 // in different phases: one's barrier-bound small-plane phases and load waits fill with the other's passes (a 32-channel workgroup
 // alone on its CU serialises ~105 k cycles of phases that each leave most of the CU idle).  Used where cb16() says so.
-template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool IMG2 = false, bool TRAIN = false, bool MX = false>
-__global__ __launch_bounds__(T * T / HALVES * 64, (T == 4 && HALVES == 2) ? 1 : 2)
+template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool TRAIN = false, bool MX = false>
+__global__ __launch_bounds__(T * T / HALVES * 64, (T == 4 && HALVES == 2) ? 1 : 2)          // 256 registers either way: 8 waves per CU
 void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack,
                    int N, int C, int has_bias, SavedPyr sv, const void* __restrict__ mxpack)
 {
     using G = Geo<T, HALVES, MODE, TIO, MX>;
-    static_assert(!MX || (T == 4 && HALVES == 2 && !IMG2 && !TRAIN && sizeof(TIO) == 2), "matrix-core variant: 56x56, inference, 16-bit activations");
+    static_assert(!MX || (T == 4 && HALVES == 2 && !TRAIN && sizeof(TIO) == 2), "matrix-core variant: 56x56, inference, 16-bit activations");
     constexpr int NL = G::NL, PIXF = G::PIXF, NWORK = G::NWORK, P0 = G::P0, P1 = G::P1, P2 = G::P2, P3 = G::P3, P4 = G::P4;
     constexpr int NCOL = MX ? 20 : 18;                             // columns of a level-0 input row held by a lane
     constexpr int ESZ = (int)sizeof(TIO);
@@ -615,12 +616,11 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     // channel block) -- no relaunch gap between the rounds, LDS zeroed once.  XCD-aware order: workgroups are dealt round-robin
     // over the 8 XCDs; each XCD gets a contiguous run of units, so the channel blocks of one image (the two halves of its
     // 128-byte lines) pass through the same L2 at about the same time.
-    static_assert(!IMG2 || HALVES == 1, "image halves use the one-tile-per-wave geometry");
     static_assert(HALVES != 4 || (T == 4 && !TRAIN && !MX), "quarter-wave tiles: the 56x56 inference kernel");
-    constexpr int CHB = IMG2 ? 32 : G::CB;                         // channels per block
+    static_assert(!(T == 2 && HALVES == 2) || (!TRAIN && !MX), "two tiles per wave at 28x28: inference");
+    constexpr int CHB = G::CB;                                     // channels per block
     const int nb = (C + CHB - 1) / CHB;
-    const int NU = IMG2 ? (N + 1) / 2 : N;                          // image units
-    const unsigned total = (unsigned)NU * (unsigned)nb, GD = gridDim.x;
+    const unsigned total = (unsigned)N * (unsigned)nb, GD = gridDim.x;
     const bool xcd = (total & 7u) == 0 && (GD & 7u) == 0;
     const int tid = (int)threadIdx.x;
   for (unsigned it = 0;; ++it) {
@@ -633,18 +633,18 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         unit = blockIdx.x + it * GD;
         if (unit >= total) break;
     }
-    const int nu = (int)(unit / (unsigned)nb), cb = (int)(unit - (unsigned)nu * (unsigned)nb);
-    const int n = IMG2 ? 2 * nu : nu;                              // first (only) image of the unit
+    const int n = (int)(unit / (unsigned)nb), cb = (int)(unit - (unsigned)n * (unsigned)nb);
 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane_ = tid & 63;
-    if constexpr (MX || HALVES == 4) asm volatile("" : "+v"(lane_));   // per unit: what derives from the lane index is recomputed, not kept live across units
+    if constexpr (MX || HALVES == 4 || (T == 2 && HALVES == 2)) asm volatile("" : "+v"(lane_));   // per unit: what derives from the lane index is recomputed, not kept live across units
     const int lane = lane_;
+    constexpr int WPR = T / HALVES;                              // waves per tile row (a wave holds HALVES tiles of one tile row)
     const int h = HALVES == 4 ? (lane >> 4) : (HALVES == 2 ? (lane >> 5) : 0);
     const int ch = lane & (G::CB - 1);
-    const int tr = HALVES == 4 ? w : (w >> 1);
-    const int tcb = w & 1;
-    const int tc = HALVES == 4 ? h : (HALVES == 2 ? tcb + 2 * h : tcb);  // per lane (HALVES >= 2) / uniform
+    const int tr = w / WPR;
+    const int tcb = w % WPR;
+    const int tc = tcb + WPR * h;                                        // per lane (HALVES >= 2) / uniform
     // MX: the passes' two lane maps of this wave's 16 channels (w & 1) x the four tiles of tile row tr (see "matrix-core variant")
     const int chA = (w & 1) * 16 + (lane & 15), tcA = lane >> 4;         // A: memory
     const int chM = (w & 1) * 16 + (lane >> 2), tcM = lane & 3;          // M: matrix operands and results
@@ -652,14 +652,13 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     const int permMA = 4 * (4 * (lane & 15) + (lane >> 4));              // ... and lane (A) from lane (M)
     const int q = tr * T + tc;                                          // this tile-lane's worker id
     const bool ledge = tc == 0, redge = tc == T - 1;
-    const int ih = IMG2 ? (lane >> 5) : 0;                         // IMG2: this lane's image within the pair
-    const int c = cb * CHB + (IMG2 ? (lane & 31) : ch);
-    const bool cvalid = c < C && n + ih < N;
+    const int c = cb * CHB + ch;
+    const bool cvalid = c < C;
     const int cc = cvalid ? c : C - 1;
     const int pix = C * ESZ;                                            // bytes between horizontally adjacent pixels
     // training forward: this lane's element (row, col) of the saved plane at byte offset `off` (P x P pixels per image)
     auto sv_ptr = [&](unsigned long long off, int P, int row, int col) -> float* {
-        return reinterpret_cast<float*>(reinterpret_cast<char*>(sv.base) + off) + (((size_t)(n + ih) * P + row) * P + col) * C + c;
+        return reinterpret_cast<float*>(reinterpret_cast<char*>(sv.base) + off) + (((size_t)n * P + row) * P + col) * C + c;
     };
     const bool svon = TRAIN && sv.base != nullptr && cvalid;
 
@@ -683,20 +682,19 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         const unsigned long long a = (unsigned long long)ximg;
         rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
         rsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
-        rsrc.z = (IMG2 && n + 1 < N ? 2 : 1) * P0 * P0 * pix;
+        rsrc.z = P0 * P0 * pix;
         rsrc.w = 0x00020000;
     }
     const unsigned OOB = 0x80000000u;
-    const unsigned imgoff = (unsigned)(ih * P0 * P0 * pix);            // IMG2: the second image of the pair (past the last image: out of range, reads 0)
     // the lane's tile column, channel and edge flags for global memory: map A in the matrix-core variant
     const int tcG = MX ? tcA : tc;
     const int cG = MX ? cb * CHB + chA : c;
     const bool cvalidG = MX ? cG < C : cvalid;
     const int ccG = cvalidG ? cG : C - 1;
     const bool ledgeG = tcG == 0, redgeG = tcG == T - 1;
-    const unsigned voffM = (IMG2 && n + ih >= N) ? OOB : (unsigned)((14 * tcG) * pix + ccG * ESZ) + imgoff;
-    const unsigned voffL = (ledgeG || voffM == OOB) ? OOB : voffM - 2u * (unsigned)pix;      // columns -2, -1 of the tile
-    const unsigned voffR = (redgeG || voffM == OOB) ? OOB : voffM + 14u * (unsigned)pix;     // columns 14, 15 (MX: 14 .. 17)
+    const unsigned voffM = (unsigned)((14 * tcG) * pix + ccG * ESZ);
+    const unsigned voffL = ledgeG ? OOB : voffM - 2u * (unsigned)pix;      // columns -2, -1 of the tile
+    const unsigned voffR = redgeG ? OOB : voffM + 14u * (unsigned)pix;     // columns 14, 15 (MX: 14 .. 17)
     // row r (tile-local, -2 .. 15), all 18 (MX: 20) columns; rows outside the image are redirected to a valid row (loaded, not used)
     auto load_row = [&](uint32_t (&raw)[NCOL], int r) {
         int ar = 14 * tr + r;
@@ -1089,7 +1087,8 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                 }
             }
         };
-        const int cpar = HALVES == 4 ? 0 : __builtin_amdgcn_readfirstlane(d0 & 1);
+        constexpr bool LANE_PARITY = HALVES > 1 && WPR == 1;      // the tiles of a wave are neighbours: both column parities in one wave
+        const int cpar = LANE_PARITY ? 0 : __builtin_amdgcn_readfirstlane(d0 & 1);
         auto form = [&](auto parc) {
             constexpr int PAR = decltype(parc)::value;
 #pragma unroll
@@ -1115,7 +1114,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                 });
             }
         };
-        if constexpr (HALVES == 4) form_lane();
+        if constexpr (LANE_PARITY) form_lane();
         else if (cpar) form(IC<1>{}); else form(IC<0>{});
         float* dst = L1 + ((7 * tr) * P1 + 7 * tc) * PIXF;
 #pragma unroll
@@ -1213,10 +1212,10 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             const unsigned long long a = (unsigned long long)(reinterpret_cast<char*>(y) + (size_t)n * P0 * P0 * pix);
             ysrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
             ysrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
-            ysrc.z = (IMG2 && n + 1 < N ? 2 : 1) * P0 * P0 * pix;
+            ysrc.z = P0 * P0 * pix;
             ysrc.w = 0x00020000;
         }
-        const unsigned yoff = cvalidG ? (unsigned)((14 * tcG) * pix + cG * ESZ) + imgoff : OOB;
+        const unsigned yoff = cvalidG ? (unsigned)((14 * tcG) * pix + cG * ESZ) : OOB;
         // H[i]: C1 row i (tile-local, -2 .. 8; clamped into the plane) resized horizontally to the 18 columns -2 .. 15
         auto build_H = [&](f32x2 (&Hs)[9], int i) {
             int ar = 7 * tr + i;
@@ -1400,15 +1399,15 @@ static inline bool enabled()
     return !(v && *v == '0') && !(l && *l == '0');
 }
 
-template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool IMG2 = false, bool TRAIN = false, bool MX = false>
+template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool TRAIN = false, bool MX = false>
 static hipError_t launch(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv, const void* mxpack = nullptr)
 {
     using G = Geo<T, HALVES, MODE, TIO, MX>;
-    if constexpr (!TRAIN && MODE == 0 && !IMG2 && !MX && HALVES != 4) {      // training forward: bilinear only (what RecConv2d trains with), whole-block variants
-        if (sv.base) return launch<T, HALVES, MODE, PIXB, TIO, IMG2, true>(x, y, wpack, bpack, N, C, s, sv);
+    if constexpr (!TRAIN && MODE == 0 && !MX && HALVES != 4 && !(T == 2 && HALVES == 2)) {      // training forward: bilinear only (what RecConv2d trains with), whole-block variants
+        if (sv.base) return launch<T, HALVES, MODE, PIXB, TIO, true>(x, y, wpack, bpack, N, C, s, sv);
     }
     if (!TRAIN && sv.base) return hipErrorInvalidConfiguration;
-    auto kfn = k_recconv_cpt<T, HALVES, MODE, PIXB, TIO, IMG2, TRAIN, MX>;
+    auto kfn = k_recconv_cpt<T, HALVES, MODE, PIXB, TIO, TRAIN, MX>;
     RCX_SET_LDS_ONCE(kfn, G::LDS_BYTES);                       // once per instantiation and device
     static std::atomic<int> cus_cache{0};
     int cus = cus_cache.load(std::memory_order_relaxed);
@@ -1418,8 +1417,11 @@ static hipError_t launch(const void* x, void* y, const float* wpack, const float
         cus = v;
         cus_cache.store(v, std::memory_order_relaxed);
     }
-    const unsigned total = IMG2 ? (unsigned)(((N + 1) / 2) * ((C + 31) / 32)) : (unsigned)(N * ((C + G::CB - 1) / G::CB));
-    unsigned cap = (unsigned)cus * ((T == 4 && HALVES == 2) ? 1u : 2u);   // workgroups resident at once (LDS: one / two per CU)
+    const unsigned total = (unsigned)(N * ((C + G::CB - 1) / G::CB));
+    // workgroups resident at once: 8 waves per CU (256 registers each) and 160 KB of LDS
+    constexpr unsigned PER_CU = (T == 4 && HALVES == 2) ? 1u : ((T == 2 && HALVES == 2) ? 4u : 2u);
+    static_assert(PER_CU * G::LDS_BYTES <= 160 * 1024 && PER_CU * G::NW <= 8, "residency");
+    unsigned cap = (unsigned)cus * PER_CU;
     if (const char* e = rcx::opt::value(rcx::opt::CPT_GRID)) { const int g = atoi(e); if (g > 0) cap = (unsigned)g; }    // A/B knob
     cap &= ~7u;
     const unsigned grid = total <= cap || cap == 0 ? total : cap;
@@ -1434,8 +1436,10 @@ static hipError_t launch_c(const void* x, void* y, const float* wpack, const flo
 {
     constexpr int CM3 = T == 4 ? 64 : 128;
     if (C == CM3) return launch<T, HALVES, MODE, CM3 * (int)sizeof(TIO), TIO>(x, y, wpack, bpack, N, C, s, sv);
-    if constexpr (T == 2) {
-        if (C % 64 != 0) return launch<T, HALVES, MODE, 0, TIO, true>(x, y, wpack, bpack, N, C, s, sv);      // whole 32-channel blocks, image pairs
+    if constexpr (T == 2 && HALVES == 1) {
+        // channel counts that are not multiples of 64 (RecNeXt-M1: 96, M5: 160, M0: 80): 32-channel workgroups of two waves, a wave = the two
+        // tiles of a tile row, four workgroups per CU (round 3)
+        if (C % 64 != 0 && !sv.base) return launch<2, 2, MODE, 0, TIO>(x, y, wpack, bpack, N, C, s, sv);
     }
     return launch<T, HALVES, MODE, 0, TIO>(x, y, wpack, bpack, N, C, s, sv);
 }
@@ -1445,8 +1449,8 @@ template <int MODE, typename TIO>
 static hipError_t launch_mx_c(const void* x, void* y, const float* wpack, const float* bpack, const void* mxpack, int N, int C, hipStream_t s)
 {
     const SavedPyr sv{};
-    if (C == 64) return launch<4, 2, MODE, 64 * (int)sizeof(TIO), TIO, false, false, true>(x, y, wpack, bpack, N, C, s, sv, mxpack);
-    return launch<4, 2, MODE, 0, TIO, false, false, true>(x, y, wpack, bpack, N, C, s, sv, mxpack);
+    if (C == 64) return launch<4, 2, MODE, 64 * (int)sizeof(TIO), TIO, false, true>(x, y, wpack, bpack, N, C, s, sv, mxpack);
+    return launch<4, 2, MODE, 0, TIO, false, true>(x, y, wpack, bpack, N, C, s, sv, mxpack);
 }
 template <int DEFER = 0>                                   // a template only so that the eight instantiations are made where it is called (rcx_cpt.hip)
 static hipError_t launch_mx(const void* x, void* y, const float* wpack, const float* bpack, const void* mxpack, int N, int C, int mode, int dtype, hipStream_t s)

@@ -74,7 +74,6 @@ int lanes_describe(int N, int C, int H, int W, int level, int k, int mode, int d
     if (cpl7b_applicable(N, C, H, W, level, k, dtype)) return cpl7b_describe(N, C, mode, buf, len);
     const lanes::LanesPlan p = lanes::plan(N, C, H, W, level, k, dtype);
     if (!p.ok) return 0;
-    if (cpl7_applicable(N, C, H, W, level, k, dtype)) return cpl7_describe(N, C, mode, buf, len);
     // kernel=<template arguments>: W0, LEVEL, lanes per channel, mode, waves[, band rows] -- the name rocprofv3 reports
     char kern[64];
     if (p.banded) snprintf(kern, sizeof(kern), "k_recconv_lanes_banded<%d, %d, %d, %d, %d, %d>", p.w0, p.level, p.lpc, mode, p.waves, p.sr);
@@ -90,7 +89,6 @@ hipError_t lanes_recconv(const void* x, void* y, const float* wpack, const float
     if (cpl7b_applicable(N, C, H, W, level, k, dtype)) return cpl7b_recconv(x, y, wpack, bpack, N, C, mode, dtype, s);
     const lanes::LanesPlan p = lanes::plan(N, C, H, W, level, k, dtype);
     if (!p.ok) return hipErrorInvalidConfiguration;
-    if (cpl7_applicable(N, C, H, W, level, k, dtype)) return cpl7_recconv(x, y, wpack, bpack, N, C, mode, dtype, s);
     if (p.w0 % 16 == 0) return lanes16_recconv(x, y, wpack, bpack, N, C, H, W, level, k, mode, dtype, s);
     if (dtype == 1) return mode == 1 ? lanes::launch_m<1, bf16_t>(x, y, wpack, bpack, p, s) : lanes::launch_m<0, bf16_t>(x, y, wpack, bpack, p, s);
     return mode == 1 ? lanes::launch_m<1, float>(x, y, wpack, bpack, p, s) : lanes::launch_m<0, float>(x, y, wpack, bpack, p, s);

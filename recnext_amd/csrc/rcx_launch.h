@@ -55,10 +55,6 @@ hipError_t lanes_recconv(const void* x, void* y, const float* wpack, const float
 hipError_t lanes16_recconv(const void* x, void* y, const float* wpack, const float* bpack,
                            int N, int C, int H, int W, int level, int k, int mode, int dtype, hipStream_t s);
 
-// channel-per-lane kernel of the 7x7 / level 1 block (rcx_cpl.hip)
-bool cpl7_applicable(int N, int C, int H, int W, int level, int k, int dtype);
-int cpl7_describe(int N, int C, int mode, char* buf, int len);
-hipError_t cpl7_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s);
 
 // channel-per-lane kernel of the 14x14 / level 2 block (rcx_cpl14.hip): any channel count
 bool cpl14_applicable(int N, int C, int H, int W, int level, int k, int dtype);

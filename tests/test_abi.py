@@ -58,9 +58,13 @@ def test_abi_version_and_argument_errors_without_gpu():
     assert lib.rcx_recconv2d_fwd_plan(256, 48, 56, 56, 4, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<4, 4, 0, 0>,cb=16")    # run-time pixel pitch; ragged 32-blocks: 16
     with rcx_env(RCX_CPT_CB="32"):
         assert lib.rcx_recconv2d_fwd_plan(256, 48, 56, 56, 4, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<4, 2, 0, 0>,cb=32")
-    assert lib.rcx_recconv2d_fwd_plan(256, 96, 28, 28, 3, 5, 0, 1).startswith(b"lanes(k_recconv_lanes_banded<28, 3, 8, 0,")   # ragged 64-channel blocks: banded
-    with rcx_env(RCX_CPT="all"):
-        assert lib.rcx_recconv2d_fwd_plan(256, 96, 28, 28, 3, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<2, 1, 0, 0, IMG2>,cb=32")   # image-pair variant
+    # channel counts that are not multiples of 64: the banded kernel whatever the batch (a shard must give the same rows as the batch);
+    # RCX_CPT=32: 32-channel workgroups, two tiles per wave (round 3)
+    assert lib.rcx_recconv2d_fwd_plan(256, 96, 28, 28, 3, 5, 0, 1).startswith(b"lanes(k_recconv_lanes_banded<28, 3, 8, 0,")
+    assert lib.rcx_recconv2d_fwd_plan(4, 96, 28, 28, 3, 5, 0, 1).startswith(b"lanes(k_recconv_lanes_banded<28, 3, 8, 0,")
+    with rcx_env(RCX_CPT="32"):
+        assert lib.rcx_recconv2d_fwd_plan(256, 96, 28, 28, 3, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<2, 2, 0, 0>,cb=32,nt=128,units=768")
+        assert lib.rcx_recconv2d_fwd_plan(4, 96, 28, 28, 3, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<2, 2, 0, 0>,cb=32,nt=128,units=12")
     with rcx_env(RCX_CPT="0"):
         assert lib.rcx_recconv2d_fwd_plan(256, 64, 56, 56, 4, 5, 0, 1).startswith(b"lanes(k_recconv_lanes_banded<56, 4, 16, 0,")
     assert lib.rcx_recconv2d_fwd_plan(256, 256, 14, 14, 2, 5, 1, 0).startswith(b"cpl(k_recconv_cpl14<1, 256>")       # channel per lane
@@ -71,8 +75,7 @@ def test_abi_version_and_argument_errors_without_gpu():
     assert lib.rcx_recconv2d_fwd_plan(32, 64, 24, 40, 2, 5, 0, 1).startswith(b"plane(")          # neither 7*2^k nor 16*2^k
     assert lib.rcx_recconv2d_fwd_plan(256, 512, 7, 7, 1, 5, 0, 1).startswith(b"cpl(k_recconv_cpl7b<0, 512>")     # channel per lane
     assert lib.rcx_recconv2d_fwd_plan(2, 40, 7, 7, 1, 5, 0, 1).startswith(b"cpl(k_recconv_cpl7b<0, 0>")          # any channel count
-    with rcx_env(RCX_CPL7="old"):
-        assert lib.rcx_recconv2d_fwd_plan(256, 512, 7, 7, 1, 5, 0, 1).startswith(b"cpl(k_recconv_cpl7<0>")       # round 1's version
+    with rcx_env(RCX_CPL="0"):
         assert lib.rcx_recconv2d_fwd_plan(2, 40, 7, 7, 1, 5, 0, 1).startswith(b"lanes(k_recconv_lanes<7, 1, 8, 0,")   # C % 64 != 0
     assert lib.rcx_recconv2d_fwd_plan(1, 8, 7, 7, 1, 3, 0, 0) == b"generic"
     assert lib.rcx_recconv2d_fwd(one, one, one, None, None, 0, 1, 8, 7, 7, 0, 5, 0, 0, None) == -1      # alias

@@ -131,8 +131,8 @@ def test_sweep_against_c_oracle(case):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("c", [128, 512, 40])
 def test_channel_per_lane_kernel_against_oracle_and_lanes_kernel(mode, bias, dtype, c, monkeypatch):
-    """The 7x7 / level 1 block has two register-resident kernels (rcx_cpl.hip, rcx_lanes.hip): both against the oracle and
-    against each other (the lanes kernel pairs taps in another order: float32 rounding differences only)."""
+    """The 7x7 / level 1 block has two register-resident kernels (rcx_cpl14.hip's k_recconv_cpl7b, rcx_lanes.hip): both against the
+    oracle and against each other (the lanes kernel pairs taps in another order: float32 rounding differences only)."""
     n, level, k = 5, 1, 5
     rng = np.random.default_rng(zlib.crc32(repr((mode, bias, str(dtype), c)).encode()))
     x, wd, wc, bd, bc = _rand_case(rng, n, c, 7, 7, level, k, bias)
@@ -141,12 +141,6 @@ def test_channel_per_lane_kernel_against_oracle_and_lanes_kernel(mode, bias, dty
     ref = c_oracle.recconv2d(x, wd, wc, bd, bc, level, mode)
     assert ops.recconv2d_plan(n, c, 7, 7, level, k, mode, dtype).startswith("cpl(k_recconv_cpl7b<")
     got = _run_hip(x, wd, wc, bd, bc, level, k, mode, dtype)
-    if c % 64 == 0:                                   # round 1's channel-per-lane kernel (whole waves only), kept for A/B runs
-        monkeypatch.setenv("RCX_CPL7", "old")
-        assert ops.recconv2d_plan(n, c, 7, 7, level, k, mode, dtype).startswith("cpl(k_recconv_cpl7<")
-        old = _run_hip(x, wd, wc, bd, bc, level, k, mode, dtype)
-        assert np.allclose(old, got, atol=2e-5 if dtype == torch.float32 else 1e-2, rtol=1e-2)
-        monkeypatch.delenv("RCX_CPL7")
     monkeypatch.setenv("RCX_CPL", "0")
     assert ops.recconv2d_plan(n, c, 7, 7, level, k, mode, dtype).startswith("lanes(")
     other = _run_hip(x, wd, wc, bd, bc, level, k, mode, dtype)
@@ -218,8 +212,9 @@ def test_56_block_with_16_and_32_channel_workgroups_is_the_same_function(mode, d
 def test_tiled_channel_per_lane_kernel_against_oracle_and_lanes_kernel(mode, bias, dtype, shape, monkeypatch):
     """The 56x56 / level 4 and 28x28 / level 3 blocks on rcx_cpt.hip (a lane owns one channel of one 14x14 tile, the planes of
     level >= 1 in LDS) against the oracle: whole channel blocks (64, 128), ragged last blocks (48, 80, 8, 96, 160, 40), both
-    resize modes, bias; the ragged 28x28 cases run the image-pair variant (odd batches: the second image of the last pair is
-    out of range).  The banded lanes kernel it replaces must agree with it to float32 round-off."""
+    resize modes, bias; the 28x28 cases whose channel count is not a multiple of 64 run the 32-channel workgroups (two tiles per
+    wave, k_recconv_cpt<2, 2, ...>; 72 and 40 leave a ragged 32-block).  The banded lanes kernel it replaces must agree with it to
+    float32 round-off."""
     n, c, hw, level = shape
     k = 5
     rng = np.random.default_rng(zlib.crc32(repr((mode, bias, str(dtype), shape)).encode()))
@@ -227,8 +222,10 @@ def test_tiled_channel_per_lane_kernel_against_oracle_and_lanes_kernel(mode, bia
     if dtype == torch.bfloat16:
         x = bf16_round_np(x)
     ref = c_oracle.recconv2d(x, wd, wc, bd, bc, level, mode)
-    monkeypatch.setenv("RCX_CPT", "all")               # also the image-pair variant (28x28, C % 64 != 0), off by default
-    assert ops.recconv2d_plan(n, c, hw, hw, level, k, mode, dtype).startswith("cpt(k_recconv_cpt<")
+    monkeypatch.setenv("RCX_CPT", "32")                # 28x28, C % 64 != 0: the 32-channel workgroups whatever the unit count
+    plan = ops.recconv2d_plan(n, c, hw, hw, level, k, mode, dtype)
+    assert plan.startswith("cpt(k_recconv_cpt<")
+    assert plan.startswith("cpt(k_recconv_cpt<2, 2,") == (hw == 28 and c % 64 != 0)
     got = _run_hip(x, wd, wc, bd, bc, level, k, mode, dtype)
     if dtype == torch.float32:
         assert np.abs(got - ref).max() < F32_TIGHT

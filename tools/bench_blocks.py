@@ -22,6 +22,10 @@ SHAPES = {
     "m3_b128": [(128, 64, 56, 56, 4), (128, 128, 28, 28, 3), (128, 256, 14, 14, 2), (128, 512, 7, 7, 1)],   # the training batch: inference forward beside bench_backward.py
     "m1": [(256, 48, 56, 56, 4), (256, 96, 28, 28, 3), (256, 192, 14, 14, 2), (256, 384, 7, 7, 1)],
     "m5": [(256, 80, 56, 56, 4), (256, 160, 28, 28, 3), (256, 320, 14, 14, 2), (256, 640, 7, 7, 1)],
+    # the 28x28 block with channel counts that are not multiples of 64 (M0: 80, M1: 96, M2: 112, M5: 160), several batch sizes: the policy
+    # of rcx_cpt.hip::cpt28_ragged (RCX_CPT=32 / 64 force one side)
+    "ragged28": [(256, 80, 28, 28, 3), (256, 96, 28, 28, 3), (256, 112, 28, 28, 3), (256, 160, 28, 28, 3), (128, 96, 28, 28, 3), (128, 160, 28, 28, 3),
+                 (64, 160, 28, 28, 3), (512, 96, 28, 28, 3)],
     "m3_512": [(32, 64, 128, 128, 4), (32, 128, 64, 64, 3), (32, 256, 32, 32, 2), (32, 512, 16, 16, 1)],
     # RecNeXt-M3 backbone on a COCO batch (detection/configs/_base_/datasets/coco_instance.py:9-12: 800 x 1344 padded, 2 images per GPU)
     "m3_coco": [(2, 64, 200, 336, 4), (2, 128, 100, 168, 3), (2, 256, 50, 84, 2), (2, 512, 25, 42, 1)],
@@ -42,6 +46,26 @@ def time_fn(fn, iters, rounds=3):
     return best[len(best) // 2], best[0]
 
 
+def time_fresh(fn, x, iters):
+    """As inside a model: x is WRITTEN by another kernel right before every launch (dirty lines in the producer's L2, nothing of it clean
+    in the consumer's), and only the launch itself is bracketed.  Stand-alone loops over a read-only x rank some variants the other way
+    round (profiles/r03_cpt_cb16.txt, r03_cpt_28_ragged.txt)."""
+    x0 = x.clone()
+    other = torch.empty(256 * 1024 * 1024 // 4, device=x.device)             # 256 MB: what a model's other kernels leave in the caches
+    ts = []
+    for _ in range(iters):
+        other.add_(1.0)
+        x.copy_(x0)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        ts.append((s, e))
+    torch.cuda.synchronize()
+    v = sorted(a.elapsed_time(b) for a, b in ts)
+    return v[len(v) // 2], v[0]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sets", default="m3")
@@ -53,6 +77,7 @@ def main():
     ap.add_argument("--taps", default="io", choices=["io", "fp32"],
                     help="io: the module's parameters have the activations' dtype (model.bfloat16(): the matrix-core schedules apply); "
                          "fp32: float32 parameters with 16-bit activations (exact taps, vector kernels)")
+    ap.add_argument("--fresh", action="store_true", help="x rewritten (and 256 MB of other traffic) before every launch, each launch bracketed alone")
     ap.add_argument("--mx", action="store_true", help="with --taps io: allow the matrix-core schedules (RecConv2d.matrix_cores)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -73,9 +98,9 @@ def main():
                     for _ in range(3):
                         mod(x)
                     torch.cuda.synchronize()
-                    med, mn = time_fn(lambda: mod(x), args.iters)
+                    med, mn = time_fresh(lambda: mod(x), x, args.iters) if args.fresh else time_fn(lambda: mod(x), args.iters)
                     alg = 2 * n * c * h * w * eb + (level + 2) * c * 25 * eb
-                    row = {"set": sname, "shape": [n, c, h, w], "level": level, "dtype": dname,
+                    row = {"set": sname, "shape": [n, c, h, w], "level": level, "dtype": dname, "timing": "fresh" if args.fresh else "loop",
                            "taps": "io" if mx else "fp32",
                            "plan": (ops.recconv2d_plan_mx if mx and args.mx else ops.recconv2d_plan)(n, c, h, w, level, 5, args.mode, dtype),
                            "ms": med, "ms_min": mn, "alg_GBs": alg / med / 1e6, "frac_8TBs": alg / med / 1e6 / 8000}

@@ -34,7 +34,7 @@ int main(int argc, char** argv)
     CK(hipMemcpyToSymbol(HIP_SYMBOL(rcx::cpt::g_cpt_stamps), &st, sizeof(st)));
 #endif
     const rcx::cpt::SavedPyr sv{};
-    auto run = [&](hipStream_t s) { return rcx::cpt::launch<4, 2, 0, 128, rcx::bf16_t, false, false, true>(x, y, w, nullptr, N, C, s, sv, mxp); };
+    auto run = [&](hipStream_t s) { return rcx::cpt::launch<4, 2, 0, 128, rcx::bf16_t, false, true>(x, y, w, nullptr, N, C, s, sv, mxp); };
     hipStream_t s; CK(hipStreamCreate(&s));
     for (int i = 0; i < 3; ++i) CK(run(s));
     CK(hipStreamSynchronize(s));
