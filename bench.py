@@ -82,13 +82,19 @@ def parse_args():
 
 
 class MixerTimers:
-    """HIP events around every token-mixer call (recorded on the stream the kernels are launched on): RecConv2d is one kernel
-    launch; RecAttn2d (A family) is a unit of four HIP kernels and two GEMMs and is reported as such."""
+    """HIP events around token-mixer calls (recorded on the stream the kernels are launched on): RecConv2d is one kernel
+    launch; RecAttn2d (A family) is a unit of four HIP kernels and two GEMMs and is reported as such.
+
+    Every event pair costs the stream ~2.5 us (the marker packets keep the next kernel from starting early): 40 pairs a step are
+    2.7 % of RecNeXt-M3's step (tools/graph_probe.py: 63.8 k img/s without any, 62.1 k with all).  So the warm-up steps bracket
+    EVERY mixer (the per-kernel table, and which kernel dominates), and the timed region brackets only the dominant kernel's
+    launches (`only`), which is what the roofline object is computed from."""
 
     def __init__(self, net, torch, RecConv2d):
         self.torch = torch
         self.records = []          # (module_key, start, end)
         self.enabled = False
+        self.only = None           # None: every mixer; else the set of (C, H, W, level, k) keys whose launches are bracketed
         self.keys = {}
         for name, m in net.named_modules():
             if isinstance(m, RecConv2d):
@@ -97,14 +103,18 @@ class MixerTimers:
                 m.register_forward_hook(self._post)
         self._open = {}
 
+    @staticmethod
+    def shape_key(m, shape):
+        return (shape[1], shape[2], shape[3], getattr(m, "level", None), m.kernel_size)
+
     def _pre(self, m, args):
-        if self.enabled:
+        if self.enabled and (self.only is None or self.shape_key(m, args[0].shape) in self.only):
             e = self.torch.cuda.Event(enable_timing=True)
             e.record()
             self._open[m] = (e, tuple(args[0].shape))
 
     def _post(self, m, args, out):
-        if self.enabled:
+        if m in self._open:
             e = self.torch.cuda.Event(enable_timing=True)
             e.record()
             s, shape = self._open.pop(m)
@@ -114,8 +124,8 @@ class MixerTimers:
         """Per block shape, and per kernel instantiation (what rocprofv3 --stats aggregates by)."""
         by_shape = {}
         for m, shape, s, e in self.records:
-            n, c, h, w = shape
-            key = (c, h, w, getattr(m, "level", None), m.kernel_size)
+            n = shape[0]
+            key = self.shape_key(m, shape)
             ent = by_shape.setdefault(key, {"ms": 0.0, "calls": 0, "N": n})
             ent["ms"] += s.elapsed_time(e)
             ent["calls"] += 1
@@ -307,10 +317,24 @@ def main():
     from recnext_amd.speed import tune_gemms
     gemm_tuned = tune_gemms(net, x)                       # before the warm-up steps, outside the timed region
     copy_gbs = measure_copy_ceiling(torch, device) if rank == 0 else None
+    mx_on = False
+    plan_of = None
     with torch.no_grad():
-        for _ in range(args.warmup):
+        # warm-up: the first step builds the packs and sets the kernels' attributes; the others are bracketed mixer by mixer
+        for i in range(args.warmup):
+            timers.enabled = i > 0
             net(x)
         timers.enabled = False
+        torch.cuda.synchronize(device)
+        from recnext_amd import recconv as _rc
+        mx_on = _rc.MATRIX_CORES_DEFAULT and dtype != torch.float32         # RCX_MX=1: the matrix-core schedules where they exist
+        plan_of = lambda n, c, h, w, level, k: (ops.recconv2d_plan_mx if mx_on else ops.recconv2d_plan)(n, c, h, w, level, k, "bilinear", dtype)
+        survey_steps = max(args.warmup - 1, 0)
+        survey = timers.summarize(elem, plan_of) if survey_steps else None
+        if survey:                                            # timed region: only the launches of the kernel with the most time in a step
+            dom_name = survey[1][0]["kernel"]
+            timers.only = {(rr["C"], rr["H"], rr["W"], rr["level"], rr["k"]) for rr in survey[0] if kernel_name(rr["plan"], elem) == dom_name}
+        timers.records = []
         rdist.barrier(r)
         timers.enabled = True
         t0 = time.perf_counter()
@@ -326,16 +350,15 @@ def main():
     if rank == 0:
         images = world * args.batch * args.steps
         value = images / elapsed
-        from recnext_amd import recconv as _rc
-        mx_on = _rc.MATRIX_CORES_DEFAULT and dtype != torch.float32         # RCX_MX=1: the matrix-core schedules where they exist
-        plan_of = lambda n, c, h, w, level, k: (ops.recconv2d_plan_mx if mx_on else ops.recconv2d_plan)(n, c, h, w, level, k, "bilinear", dtype)
-        per_shape, per_kernel = timers.summarize(elem, plan_of)
-        dom = per_kernel[0]                                   # the kernel instantiation with the most time in the step
+        timed_shapes, timed_kernels = timers.summarize(elem, plan_of)
+        dom = timed_kernels[0]                                # the kernel instantiation with the most time in the step, bracketed in the timed region
+        per_shape, per_kernel = survey if survey else (timed_shapes, timed_kernels)
+        table_steps = survey_steps if survey else args.steps
         traffic, traffic_source = load_traffic(dom["kernel"])
-        dom_shape = next(rr for rr in per_shape if kernel_name(rr["plan"], elem) == dom["kernel"])
+        dom_shape = next(rr for rr in timed_shapes if kernel_name(rr["plan"], elem) == dom["kernel"])
         dom_flops = recconv_flops(dom_shape["N"], dom_shape["C"], dom_shape["H"], dom_shape["W"], dom_shape["level"], dom_shape["k"])
         dom_tfs = dom_flops / (dom["avg_launch_ms"] * 1e-3) / 1e12
-        mixer_ms_per_step = sum(rr["total_ms"] for rr in per_shape) / args.steps
+        mixer_ms_per_step = sum(rr["total_ms"] for rr in per_shape) / table_steps
         mixer_bytes = models.token_mixer_algorithmic_bytes(args.model, args.resolution, elem) * args.batch \
             if models.CONFIGS[args.model]["family"] == "m" else None
         rnd = lambda d: {k: (round(v, 5) if isinstance(v, float) else v) for k, v in d.items()}
@@ -360,9 +383,11 @@ def main():
                          "kernel": dom["kernel"], "shapes": dom["shapes"], "avg_launch_ms": dom["avg_launch_ms"],
                          "algorithmic_bytes_per_launch": dom["algorithmic_bytes"] / dom["launches"],
                          "launches_timed": dom["launches"],
-                         "note": "HIP events on the launch stream around each launch inside the timed region; "
+                         "note": "HIP events on the launch stream around each launch of this kernel inside the timed region; "
                                  "algorithmic bytes = 2*N*C*H*W*b + (level+2)*C*k*k*b per launch (SURVEY 8d)"},
-            "token_mixers": {"ms_per_step": mixer_ms_per_step, "share_of_step": mixer_ms_per_step / (elapsed / args.steps * 1e3),
+            "token_mixers": {"measured_over": (f"the last {survey_steps} warm-up steps (every mixer bracketed; the timed region brackets only the "
+                                               "dominant kernel, an event pair costs the stream ~2.5 us)") if survey else "the timed region",
+                             "ms_per_step": mixer_ms_per_step, "share_of_step": mixer_ms_per_step / (elapsed / args.steps * 1e3),
                              "algorithmic_bytes_per_step": mixer_bytes,
                              "achieved_GBs": (mixer_bytes / (mixer_ms_per_step * 1e-3) / 1e9) if mixer_bytes else None,
                              "frac_of_hbm_peak": (mixer_bytes / (mixer_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if mixer_bytes else None,

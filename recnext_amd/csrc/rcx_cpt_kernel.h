@@ -62,6 +62,12 @@ using lanes::VT;
 #ifndef RCX_MX_AHEAD2
 #define RCX_MX_AHEAD2 2
 #endif
+#ifndef RCX_CPT_AHEAD1
+#define RCX_CPT_AHEAD1 3                   /* rows of x in flight in front of the row being used, pass 1 / pass 2 (tools/cpt_one.hip sweeps them) */
+#endif
+#ifndef RCX_CPT_AHEAD2
+#define RCX_CPT_AHEAD2 2
+#endif
 #ifndef RCX_CPT_PF
 #define RCX_CPT_PF 0                       /* wide-load L2 prefetch ahead of pass 1: measured slower, see pass 1 */
 #endif
@@ -730,7 +736,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     };
 
     // pass 1's first rows are requested before the taps, the LDS clearing's tail and the barrier: their HBM latency runs behind those
-    constexpr int AHEAD1 = RCX_CPT_PF > 0 ? 2 : 3, R01 = -2, NR1 = 17;
+    constexpr int AHEAD1 = RCX_CPT_PF > 0 ? 2 : RCX_CPT_AHEAD1, R01 = -2, NR1 = 17;
     uint32_t raw1[NR1][NCOL];
     if constexpr (RCX_CPT_PF == 0 && !(MX && MX_STAGE1)) sfor<AHEAD1>([&](auto rc) { load_row(raw1[decltype(rc)::value], R01 + decltype(rc)::value); });
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, (NL + 2) * 25 * C * 4, 0x00020000);
@@ -1191,7 +1197,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
 
     // ================= pass 2: y tile = conv(x + resize(C1)), input rows -2 .. 15, five accumulator rows in flight =================
     {
-        constexpr int AHEAD = 2, R0 = -2, NR = 18;
+        constexpr int AHEAD = RCX_CPT_AHEAD2, R0 = -2, NR = 18;
         // C1 columns -2 .. 8 of the tile: the two on each side may lie outside the plane (clamped: ATen's border rule)
         // (this pass reads C1 and x and writes y in the global-memory lane map: tcG, ledgeG ... = map A in the matrix-core variant)
         const int cb0 = 7 * tcG;
@@ -1290,7 +1296,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             // younger memory operations at this point: the rows requested since (18 loads each) and the output rows stored at the
             // end of the iterations in between (14 stores each; iteration i stores a row for 4 <= i <= 17); the counter holds 63
             constexpr int NLD = NR - 1 - ri < AHEAD ? NR - 1 - ri : AHEAD;
-            constexpr int NST = (ri - 1 >= 4 && ri - 1 <= 17 ? 1 : 0) + (AHEAD >= 2 && ri - 2 >= 4 && ri - 2 <= 17 ? 1 : 0) + (AHEAD >= 3 && ri - 3 >= 4 && ri - 3 <= 17 ? 1 : 0);
+            constexpr int NST = [] { int k = 0; for (int j = 1; j <= AHEAD; ++j) k += (ri - j >= 4 && ri - j <= 17) ? 1 : 0; return k; }();
             if constexpr (MX && !MX_STAGE2) pin_row20<(NCOL * NLD + 14 * NST > 63 ? 63 : NCOL * NLD + 14 * NST)>(raw[ri]);
             if constexpr (!MX) pin_row<(18 * NLD + 14 * NST > 63 ? 63 : 18 * NLD + 14 * NST)>(raw[ri]);
             if constexpr (MX) {

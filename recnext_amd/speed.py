@@ -80,15 +80,19 @@ def tune_gemms(model, inputs):
         tn.tuning_enable(False)
 
 
-def throughput(name, model, device, batch_size, resolution=224, dtype=torch.bfloat16, t0=T0, t1=T1, ranks=None, quiet=False):
+def throughput(name, model, device, batch_size, resolution=224, dtype=torch.bfloat16, t0=T0, t1=T1, ranks=None, quiet=False, graph=False):
     """speed_gpu.py:11-27.  With `ranks` (recnext_amd.dist.Ranks, world > 1) every rank runs the loop on its own shard of
-    `batch_size` images per GPU and rank 0 reports the whole-job rate (sum over ranks)."""
+    `batch_size` images per GPU and rank 0 reports the whole-job rate (sum over ranks).  `graph`: the same forward replayed as one
+    HIP graph (recnext_amd.graph.GraphedInference) -- what small batches, bound by the host's launches, want."""
     cuda = torch.device(device).type == "cuda"
     sync = torch.cuda.synchronize if cuda else (lambda: None)
     inputs = synthetic_batch(batch_size, resolution, device, dtype, seed=ranks.rank if ranks else 0)
     if cuda:
         torch.cuda.empty_cache()
         tune_gemms(model, inputs)
+    if graph:
+        from .graph import GraphedInference
+        model = GraphedInference(model)
     sync()
     start = time.time()
     model(inputs)
@@ -119,6 +123,7 @@ def main(argv=None):
     ap.add_argument("--batch-size", default=2048, type=int)
     ap.add_argument("--dtype", default="bf16", choices=sorted(DTYPES))
     ap.add_argument("--gpus", default=1, type=int, help="ranks (one per GPU); --batch-size is per GPU")
+    ap.add_argument("--graph", action="store_true", help="replay the forward as one HIP graph (small batches are bound by the host's launches)")
     ap.add_argument("--t0", default=T0, type=float)
     ap.add_argument("--t1", default=T1, type=float)
     args = ap.parse_args(argv)
@@ -135,7 +140,7 @@ def main(argv=None):
     net = build_inference_model(args.model, device, dtype)
     rdist.barrier(ranks)
     with torch.no_grad():                 # speed_gpu.py:40 switches autograd off for the whole process; scoped here
-        rate = throughput(args.model, net, device, args.batch_size, args.resolution, dtype, args.t0, args.t1, ranks=ranks)
+        rate = throughput(args.model, net, device, args.batch_size, args.resolution, dtype, args.t0, args.t1, ranks=ranks, graph=args.graph)
     rdist.finish(ranks)
     return rate
 
