@@ -135,7 +135,7 @@ class MixerTimers:
             avg_ms = ent["ms"] / ent["calls"]
             if level is None:                 # RecAttn2d: compulsory bytes of its depthwise pieces, 3.5 * S per block
                 alg = int(3.5 * n * c * h * w * elem_bytes)
-                plan = "recattn2d(k_down5_lanes + qk GEMMs + pe conv + k_linattn_core4 + k_upadd_lanes)"
+                plan = "recattn2d(conv5 stride 2 + qk GEMMs + pe conv + k_linattn_core4 + conv5(x + resize))"
             else:
                 alg = 2 * n * c * h * w * elem_bytes + (level + 2) * c * k * k * elem_bytes
                 plan = plan_of(n, c, h, w, level, k)
@@ -321,15 +321,16 @@ def main():
     plan_of = None
     with torch.no_grad():
         # warm-up: the first step builds the packs and sets the kernels' attributes; the others are bracketed mixer by mixer
+        skip = 1 if args.warmup < 4 else 2                     # lazy one-time work (packs, kernel attributes, library solution look-ups) is over by then
         for i in range(args.warmup):
-            timers.enabled = i > 0
+            timers.enabled = i >= skip
             net(x)
         timers.enabled = False
         torch.cuda.synchronize(device)
         from recnext_amd import recconv as _rc
         mx_on = _rc.MATRIX_CORES_DEFAULT and dtype != torch.float32         # RCX_MX=1: the matrix-core schedules where they exist
         plan_of = lambda n, c, h, w, level, k: (ops.recconv2d_plan_mx if mx_on else ops.recconv2d_plan)(n, c, h, w, level, k, "bilinear", dtype)
-        survey_steps = max(args.warmup - 1, 0)
+        survey_steps = max(args.warmup - skip, 0)
         survey = timers.summarize(elem, plan_of) if survey_steps else None
         if survey:                                            # timed region: only the launches of the kernel with the most time in a step
             dom_name = survey[1][0]["kernel"]
@@ -356,8 +357,11 @@ def main():
         table_steps = survey_steps if survey else args.steps
         traffic, traffic_source = load_traffic(dom["kernel"])
         dom_shape = next(rr for rr in timed_shapes if kernel_name(rr["plan"], elem) == dom["kernel"])
-        dom_flops = recconv_flops(dom_shape["N"], dom_shape["C"], dom_shape["H"], dom_shape["W"], dom_shape["level"], dom_shape["k"])
-        dom_tfs = dom_flops / (dom["avg_launch_ms"] * 1e-3) / 1e12
+        if dom_shape["level"] is None:                        # RecAttn2d (A family): a unit of several launches, no single-kernel flop count
+            dom_flops = dom_tfs = None
+        else:
+            dom_flops = recconv_flops(dom_shape["N"], dom_shape["C"], dom_shape["H"], dom_shape["W"], dom_shape["level"], dom_shape["k"])
+            dom_tfs = dom_flops / (dom["avg_launch_ms"] * 1e-3) / 1e12
         mixer_ms_per_step = sum(rr["total_ms"] for rr in per_shape) / table_steps
         mixer_bytes = models.token_mixer_algorithmic_bytes(args.model, args.resolution, elem) * args.batch \
             if models.CONFIGS[args.model]["family"] == "m" else None
@@ -377,7 +381,8 @@ def main():
                          "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          # the measured copy ceiling of this device beside the nominal peak, and the vector-ALU ceiling
                          "peak_measured": copy_gbs, "frac_of_measured": dom["achieved_GBs"] / copy_gbs if copy_gbs else None,
-                         "valu": {"flops_per_launch": dom_flops, "achieved_TFs": dom_tfs, "peak_TFs": VALU_PEAK_TFS, "frac": dom_tfs / VALU_PEAK_TFS,
+                         "valu": None if dom_flops is None else
+                                 {"flops_per_launch": dom_flops, "achieved_TFs": dom_tfs, "peak_TFs": VALU_PEAK_TFS, "frac": dom_tfs / VALU_PEAK_TFS,
                                   "note": "algorithmic float32 flops of the block (2 k^2 C (sum_l>=1 + sum_l>=0 H_l W_l) + 9 per resized-and-added "
                                           "element) against the vector peak; the matrix-core schedules do the same flops on the other pipe"},
                          "kernel": dom["kernel"], "shapes": dom["shapes"], "avg_launch_ms": dom["avg_launch_ms"],

@@ -142,6 +142,10 @@ int rcx_dwconv2d_mult2_fwd(const void* x, void* y, const float* w_kkc, const flo
  *   x: N x H x W x C (x_dtype); coarse: N x Hc x Wc x C (coarse_dtype) or NULL (then y = dwconv_k(x));
  *   y: N x H x W x C (out_dtype).
  */
+/* Which kernel rcx_upadd_dwconv_fwd would run ("upadd_cpt(k_upadd_cpt<mode, pitch>,...)", "upadd_cpl14(...)", "upadd_lanes(...)",
+ * "conv5_lanes(...)", "generic"); has_coarse = 0 for the plain conv (coarse == NULL).  Thread-local storage, valid until the next call. */
+const char* rcx_upadd_dwconv_fwd_plan(int N, int C, int H, int W, int Hc, int Wc, int k, int mode,
+                                      int x_dtype, int coarse_dtype, int out_dtype, int has_coarse);
 int rcx_upadd_dwconv_fwd(const void* x, const void* coarse, void* y, const float* w_kkc, const float* bias,
                          int N, int C, int H, int W, int Hc, int Wc, int k, int mode,
                          int x_dtype, int coarse_dtype, int out_dtype, void* stream);

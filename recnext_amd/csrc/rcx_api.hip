@@ -107,10 +107,25 @@ bool lanes_off()
 }
 
 // one ladder rung / one up-recursion step: the register-resident kernel where it applies, else the generic one
+// RCX_UPADD_CPT=all: the tiled single-step kernels (rcx_upcpt.hip) also where the lanes kernels keep a ragged channel count (tests)
+bool upcpt_everywhere()
+{
+    const char* v = rcx::opt::value(rcx::opt::UPADD_CPT);
+    return v && *v == 'a';
+}
+
 hipError_t step_dwconv(const void* x, void* y, const float* w, const float* b, int N, int C, int H, int W, int k, int stride,
                        int in_dt, int out_dt, hipStream_t s)
 {
-    if (!lanes_off() && rcx::down5_lanes_applicable(N, C, H, W, k, stride, in_dt, out_dt))
+    // stride-2 conv5: the register-resident lanes kernel where it has a plan (the 7 * 2^k / 16 * 2^k squares: it already runs at the
+    // copy ceiling there, 256 x 64 x 56 x 56 24.7 us against 26.1), the tiled channel-per-lane kernel (rcx_upcpt.hip) on every other
+    // even plane whose width is a multiple of 14 (112 x 112: 15.1 us against 50.8; 200 x 336: 84.8 against 218).  Never a function of N.
+    const bool lanes_ok = !lanes_off() && rcx::down5_lanes_applicable(N, C, H, W, k, stride, in_dt, out_dt);
+    if (lanes_ok && !upcpt_everywhere())
+        return rcx::down5_lanes(x, y, w, b, N, C, H, W, in_dt, out_dt, s);
+    if (!lanes_off() && rcx::down5_cpt_applicable(N, C, H, W, k, stride, in_dt, out_dt))
+        return rcx::down5_cpt(x, y, w, b, N, C, H, W, in_dt, out_dt, s);
+    if (lanes_ok)
         return rcx::down5_lanes(x, y, w, b, N, C, H, W, in_dt, out_dt, s);
     if (!lanes_off() && stride == 1 && rcx::conv5_lanes_applicable(N, C, H, W, k, in_dt, out_dt))
         return rcx::conv5_lanes(x, y, w, b, N, C, H, W, in_dt, s);
@@ -122,7 +137,13 @@ hipError_t step_upadd(const void* x, const void* coarse, void* y, const float* w
 {
     if (coarse && !lanes_off() && rcx::upadd_cpl14_applicable(N, C, H, W, Hc, Wc, k, x_dt, c_dt, out_dt))
         return rcx::upadd_cpl14(x, coarse, y, w, b, N, C, mode, x_dt, c_dt, s);
-    if (coarse && !lanes_off() && rcx::upadd_lanes_applicable(N, C, H, W, Hc, Wc, k, x_dt, c_dt, out_dt))
+    // tiled channel-per-lane kernel (rcx_upcpt.hip): whole 64-channel waves, or wherever the register-resident lanes kernel has no plan
+    // (float16, planes that are not 7 * 2^k / 16 * 2^k squares); ragged channel blocks on a lanes plane stay with the lanes kernel
+    // (256 x 96 x 28 x 28: 24 - 26 us against 28 - 52).  Never a function of N.
+    const bool lanes_ok = coarse && !lanes_off() && rcx::upadd_lanes_applicable(N, C, H, W, Hc, Wc, k, x_dt, c_dt, out_dt);
+    if (coarse && !lanes_off() && (C % 64 == 0 || !lanes_ok || upcpt_everywhere()) && rcx::upadd_cpt_applicable(N, C, H, W, Hc, Wc, k, x_dt, c_dt, out_dt))
+        return rcx::upadd_cpt(x, coarse, y, w, b, N, C, H, W, mode, x_dt, c_dt, s);
+    if (lanes_ok)
         return rcx::upadd_lanes(x, coarse, y, w, b, N, C, H, W, mode, x_dt, c_dt, s);
     if (!coarse && !lanes_off() && rcx::conv5_lanes_applicable(N, C, H, W, k, x_dt, out_dt))
         return rcx::conv5_lanes(x, y, w, b, N, C, H, W, x_dt, s);
@@ -234,12 +255,12 @@ int rcx_recconv2d_fwd(const void* x, void* y, const float* wpack, const float* b
         float* f1 = (float*)workspace;
         float* c1 = (float*)((char*)workspace + need / 2);
         const size_t wsz = (size_t)k * k * C;
-        hipError_t e = rcx::down5_lanes(x, f1, wpack, bpack, N, C, H, W, dtype, RCX_DTYPE_F32, s);
+        hipError_t e = step_dwconv(x, f1, wpack, bpack, N, C, H, W, k, 2, dtype, RCX_DTYPE_F32, s);
         if (e != hipSuccess) return hip_fail(e, "split schedule: down");
         e = rcx::lanes_recconv(f1, c1, wpack, bpack, N, C, H / 2, W / 2, level - 1, k, mode, RCX_DTYPE_F32, s);
         if (e != hipSuccess) return hip_fail(e, "split schedule: inner block");
-        e = rcx::upadd_lanes(x, c1, y, wpack + (size_t)(1 + level) * wsz, bpack ? bpack + (size_t)(1 + level) * C : nullptr,
-                             N, C, H, W, mode, dtype, RCX_DTYPE_F32, s);
+        e = step_upadd(x, c1, y, wpack + (size_t)(1 + level) * wsz, bpack ? bpack + (size_t)(1 + level) * C : nullptr,
+                       N, C, H, W, H / 2, W / 2, k, mode, dtype, RCX_DTYPE_F32, dtype, s);
         return e == hipSuccess ? 0 : hip_fail(e, "split schedule: final conv");
     }
     if (use_plane(N, C, H, W, level, k, dtype)) {
@@ -260,22 +281,22 @@ int rcx_recconv2d_fwd(const void* x, void* y, const float* wpack, const float* b
     // down ladder, shared weight (model/recnext.py:27-29); F_l kept in float32
     for (int l = 1; l <= level; ++l) {
         const void* src = l == 1 ? x : (const void*)F_(l - 1);
-        e = rcx::generic_dwconv(src, F_(l), W_(0), B_(0), N, C, L.h[l - 1], L.w[l - 1], k, 2,
-                                l == 1 ? dtype : RCX_DTYPE_F32, RCX_DTYPE_F32, s);
+        e = step_dwconv(src, F_(l), W_(0), B_(0), N, C, L.h[l - 1], L.w[l - 1], k, 2,          // the best single-step kernel each plane has
+                        l == 1 ? dtype : RCX_DTYPE_F32, RCX_DTYPE_F32, s);
         if (e != hipSuccess) return hip_fail(e, "down ladder");
     }
     // up recursion, coarsest first (model/recnext.py:31-33): C_l = conv_j(F_l + resize(C_{l+1}))
     for (int l = level, j = 0; l >= 1; --l, ++j) {
         const float* coarse = l == level ? nullptr : Cb(l + 1);
-        e = rcx::generic_upadd_dwconv(F_(l), coarse, Cb(l), W_(1 + j), B_(1 + j), N, C, L.h[l], L.w[l],
-                                      l == level ? 0 : L.h[l + 1], l == level ? 0 : L.w[l + 1], k, mode,
-                                      RCX_DTYPE_F32, RCX_DTYPE_F32, RCX_DTYPE_F32, s);
+        e = step_upadd(F_(l), coarse, Cb(l), W_(1 + j), B_(1 + j), N, C, L.h[l], L.w[l],
+                       l == level ? 0 : L.h[l + 1], l == level ? 0 : L.w[l + 1], k, mode,
+                       RCX_DTYPE_F32, RCX_DTYPE_F32, RCX_DTYPE_F32, s);
         if (e != hipSuccess) return hip_fail(e, "up recursion");
     }
     // final conv (model/recnext.py:34)
-    e = rcx::generic_upadd_dwconv(x, level >= 1 ? Cb(1) : nullptr, y, W_(1 + level), B_(1 + level), N, C, H, W,
-                                  level >= 1 ? L.h[1] : 0, level >= 1 ? L.w[1] : 0, k, mode,
-                                  dtype, RCX_DTYPE_F32, dtype, s);
+    e = step_upadd(x, level >= 1 ? Cb(1) : nullptr, y, W_(1 + level), B_(1 + level), N, C, H, W,
+                   level >= 1 ? L.h[1] : 0, level >= 1 ? L.w[1] : 0, k, mode,
+                   dtype, RCX_DTYPE_F32, dtype, s);
     if (e != hipSuccess) return hip_fail(e, "final conv");
     return 0;
 }
@@ -554,6 +575,20 @@ int rcx_dwconv2d_mult2_fwd(const void* x, void* y, const float* w_kkc, const flo
     else
         e = rcx::generic_dwconv_mult2(x, y, w_kkc, bias, N, Cin, H, W, k, stride, dtype, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_dwconv2d_mult2_fwd");
+}
+
+const char* rcx_upadd_dwconv_fwd_plan(int N, int C, int H, int W, int Hc, int Wc, int k, int mode, int x_dtype, int coarse_dtype, int out_dtype, int has_coarse)
+{
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || (k & 1) == 0) return "invalid";
+    static thread_local char desc[160];
+    const bool lanes = !lanes_off();
+    if (has_coarse && lanes && rcx::upadd_cpl14_applicable(N, C, H, W, Hc, Wc, k, x_dtype, coarse_dtype, out_dtype)) return "upadd_cpl14(k_upadd_cpl14)";
+    const bool lanes_ok = has_coarse && lanes && rcx::upadd_lanes_applicable(N, C, H, W, Hc, Wc, k, x_dtype, coarse_dtype, out_dtype);
+    if (has_coarse && lanes && (C % 64 == 0 || !lanes_ok || upcpt_everywhere()) && rcx::upadd_cpt_applicable(N, C, H, W, Hc, Wc, k, x_dtype, coarse_dtype, out_dtype) &&
+        rcx::upadd_cpt_describe(N, C, H, W, mode == RCX_MODE_NEAREST ? 1 : 0, x_dtype, desc, (int)sizeof(desc)) > 0) return desc;
+    if (lanes_ok) return "upadd_lanes(k_upadd_lanes)";
+    if (!has_coarse && lanes && rcx::conv5_lanes_applicable(N, C, H, W, k, x_dtype, out_dtype)) return "conv5_lanes(k_upadd_lanes)";
+    return "generic";
 }
 
 int rcx_upadd_dwconv_fwd(const void* x, const void* coarse, void* y, const float* w_kkc, const float* bias,

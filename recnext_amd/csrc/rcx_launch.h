@@ -64,6 +64,13 @@ hipError_t cpl14_recconv(const void* x, void* y, const float* wpack, const float
                          float* saved = nullptr, const size_t* f_off = nullptr, const size_t* c_off = nullptr);
 
 // one step, channel per lane: y = conv5(x + resize(coarse)) + bias on the 14x14 plane (RecAttn2d's fused kernel; rcx_cpl14.hip)
+// rcx_upcpt.hip -- conv5(x + resize2x(coarse)) on any plane whose width is a multiple of 14: channel per lane, tiled, no LDS (round 3)
+bool upadd_cpt_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int x_dt, int c_dt, int out_dt);
+int upadd_cpt_describe(int N, int C, int H, int W, int mode, int x_dt, char* buf, int len);
+hipError_t upadd_cpt(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int H, int W, int mode,
+                     int x_dt, int c_dt, hipStream_t s);
+bool down5_cpt_applicable(int N, int C, int H, int W, int k, int stride, int in_dt, int out_dt);
+hipError_t down5_cpt(const void* x, void* y, const float* w, const float* b, int N, int C, int H, int W, int in_dt, int out_dt, hipStream_t s);
 bool upadd_cpl14_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int x_dt, int c_dt, int out_dt);
 hipError_t upadd_cpl14(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int mode, int x_dt, int c_dt,
                        hipStream_t s);

@@ -1,0 +1,498 @@
+// Single steps of the recursion on planes of ANY height and a width that is a multiple of 14, channel per lane (round 3):
+//
+//   k_upadd_cpt   y = conv5(x + resize2x(coarse))   -- the last line of RecConv2d.forward (model/recnext.py:31-34) and of
+//                                                      RecAttn2d.forward (model/recattn.py:67) as one launch
+//
+// It is pass 2 of k_recconv_cpt (rcx_cpt_kernel.h) made a kernel of its own: a wave = 64 channels of one 14 x 14 tile, a lane = one
+// channel; x streams one row at a time from global memory into registers through the same hand-issued row statements (18 columns with
+// the halo, out-of-image columns = out-of-range offsets that read 0), the conv is input-row stationary on v_pk_fma_f32 with five
+// accumulator rows in flight, a row of 14 outputs leaves as one statement.  What the fused kernel reads from its LDS planes -- the rows
+// of the coarse plane, 11 columns per tile -- comes from global memory here, one row every second input row, hand-issued like x (the
+// coarse plane is a quarter of x and stays in L2).  No LDS, no barrier, nothing shared between waves: any plane whose width is a
+// multiple of 14 (56, 28, 112; the 200 x 336, 100 x 168, 50 x 84 stages of a COCO input), any even height (rows past the plane are
+// loaded from a valid row and not used, their stores go out of range), any channel count (lanes past the last channel load channel
+// C - 1 and store out of range).
+//
+// Every wave issues the SAME sequence of memory instructions whatever its tile (skipped rows still load, stores of absent rows are
+// dropped by the hardware), so the s_waitcnt counts are exact compile-time numbers: `Sched` replays the issue order at compile time.
+#include "rcx_cpt_kernel.h"
+#include "rcx_opts.h"
+
+namespace rcx {
+namespace upcpt {
+
+using namespace cpt;
+
+constexpr int NR = 18;            // input rows of a tile: -2 .. 15
+constexpr int NCR = 11;           // coarse columns of a tile: -2 .. 8
+
+// the order in which a wave issues its vector-memory instructions (identical for every wave), replayed at compile time
+// AHEAD = x rows in flight in front of the row being used
+template <int MODE, int NSTORE, int AHEAD> struct Sched {
+    static constexpr int c_last = MODE == 0 ? 8 : 7;                                     // last coarse row a tile needs
+    static constexpr bool is_build(int ri) { return MODE == 0 ? (ri & 1) == 1 : ((ri & 1) == 0 && ri >= 2); }
+    static constexpr int build_row(int ri) { return MODE == 0 ? (ri - 1) / 2 : (ri - 2) / 2; }
+    // kind 0: coarse rows -2, -1 (prologue); 1: the coarse row built in iteration ri; 2: x row ri.  Result: memory instructions issued
+    // after the awaited one and before the wait = the largest count the wait may leave outstanding.
+    static constexpr int pending(int kind, int ri_target)
+    {
+        int seq = 0, xend[NR + AHEAD + 1] = {}, cend[16] = {};
+        for (int i = -2; i <= 0; ++i) { seq += NCR; cend[i + 2] = seq; }
+        for (int r = 0; r < AHEAD; ++r) { seq += 18; xend[r] = seq; }
+        if (kind == 0) return seq - cend[1];
+        for (int ri = 0; ri < NR; ++ri) {
+            if (ri + AHEAD < NR) { seq += 18; xend[ri + AHEAD] = seq; }
+            if (is_build(ri)) {
+                const int ib = build_row(ri);
+                if (kind == 1 && ri == ri_target) return seq - cend[ib + 2];
+                if (ib + 1 <= c_last) { seq += NCR; cend[ib + 3] = seq; }                // requested right after row ib was consumed
+            }
+            if (kind == 2 && ri == ri_target) return seq - xend[ri];
+            if (ri - 4 >= 0 && ri - 4 <= 13) seq += NSTORE;                              // output row t - 2 leaves at the end of the iteration
+        }
+        return 0;
+    }
+    static constexpr int cap(int v) { return v > 63 ? 63 : v; }
+};
+
+// one row of the coarse plane: columns -2 .. 8 of the tile (the outer two on each side clamped into the plane by the offsets)
+#define UPC_OUT11(v) "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10])
+#define UPC_L(OP, d) OP " %" #d ", %[vo], %[rs], %[t] offen\n\t"
+#define UPC_ROW(OP)                                                                                                                  \
+    "s_add_i32 %[t], %[rb], %[l0]\n\t" UPC_L(OP, 0) "s_add_i32 %[t], %[rb], %[l1]\n\t" UPC_L(OP, 1)                                    \
+    "s_add_i32 %[t], %[rb], 0\n\t" UPC_L(OP, 2) "s_add_i32 %[t], %[t], %[pix]\n\t" UPC_L(OP, 3) "s_add_i32 %[t], %[t], %[pix]\n\t" UPC_L(OP, 4) \
+    "s_add_i32 %[t], %[t], %[pix]\n\t" UPC_L(OP, 5) "s_add_i32 %[t], %[t], %[pix]\n\t" UPC_L(OP, 6) "s_add_i32 %[t], %[t], %[pix]\n\t" UPC_L(OP, 7) \
+    "s_add_i32 %[t], %[t], %[pix]\n\t" UPC_L(OP, 8) "s_add_i32 %[t], %[rb], %[r0]\n\t" UPC_L(OP, 9) "s_add_i32 %[t], %[rb], %[r1]\n\t" UPC_L(OP, 10)
+template <typename TC>
+__device__ __forceinline__ void coarse_row_load(uint32_t (&v)[NCR], unsigned vo, i32x4 rs, int rb, int l0, int l1, int r0, int r1, int pix)
+{
+    int t;
+    if constexpr (std::is_same<TC, f16_t>::value)
+        asm volatile(UPC_ROW(CPT_LDH) : UPC_OUT11(v), [t] "=&s"(t) : [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [l0] "s"(l0), [l1] "s"(l1), [r0] "s"(r0), [r1] "s"(r1), [pix] "s"(pix) : "scc");
+    else if constexpr (sizeof(TC) == 2)
+        asm volatile(UPC_ROW(CPT_LD16) : UPC_OUT11(v), [t] "=&s"(t) : [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [l0] "s"(l0), [l1] "s"(l1), [r0] "s"(r0), [r1] "s"(r1), [pix] "s"(pix) : "scc");
+    else
+        asm volatile(UPC_ROW(CPT_LD32) : UPC_OUT11(v), [t] "=&s"(t) : [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [l0] "s"(l0), [l1] "s"(l1), [r0] "s"(r0), [r1] "s"(r1), [pix] "s"(pix) : "scc");
+}
+template <int PENDING> __device__ __forceinline__ void pin_coarse(uint32_t (&v)[NCR])
+{
+    asm volatile("s_waitcnt vmcnt(%11)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                 "+v"(v[9]), "+v"(v[10]) : "n"(PENDING));
+}
+
+// MODE 0 bilinear (exact 2x: weights 1/4, 3/4, clamped borders = ATen's align_corners=False arithmetic), 1 nearest.
+// PIXB = bytes per pixel of x and y when known at compile time (64 or 128 channels of a 16-bit type), 0 = run time.
+template <int MODE, int PIXB, typename TIO, typename TC>
+__global__ __launch_bounds__(256, 2) void k_upadd_cpt(const TIO* __restrict__ x, const TC* __restrict__ coarse, TIO* __restrict__ y,
+                                                      const float* __restrict__ w, const float* __restrict__ bias, int N, int C, int H, int W, int has_bias)
+{
+    constexpr int ESZ = (int)sizeof(TIO), CSZ = (int)sizeof(TC), NST = 14;
+    // float16 converts every element into a second register: one row less in flight keeps the kernel inside 256 registers (a spilled
+    // row register would be stored before its load has landed)
+    constexpr int AHEAD = std::is_same<TIO, f16_t>::value ? 1 : 2;
+    using S = Sched<MODE, NST, AHEAD>;
+    const int nb = (C + 63) / 64, TR = (H + 13) / 14, TCn = W / 14, Hc = H / 2, Wc = W / 2;
+    const int pix = PIXB ? PIXB : C * ESZ, pixc = C * CSZ;
+    const unsigned total = (unsigned)N * nb * TR * TCn;
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (unit >= total) return;
+    // tile column fastest: the four waves of a workgroup are horizontal neighbours (their halo columns are each other's interiors)
+    const int tc = (int)(unit % (unsigned)TCn);
+    unsigned q = unit / (unsigned)TCn;
+    const int tr = (int)(q % (unsigned)TR);
+    q /= (unsigned)TR;
+    const int cb = (int)(q % (unsigned)nb), n = (int)(q / (unsigned)nb);
+    const int c = cb * 64 + lane;
+    const bool cvalid = c < C;
+    const int cc = cvalid ? c : C - 1;
+    const bool ledge = tc == 0, redge = tc == TCn - 1;
+    const unsigned OOB = 0x80000000u;
+
+    // the coarse rows -2, -1, 0 first (they are needed first), then the first rows of x, then the taps
+    i32x4 csrc, rsrc, ysrc;
+    {
+        const unsigned long long a = (unsigned long long)(reinterpret_cast<const char*>(coarse) + (size_t)n * Hc * Wc * pixc);
+        csrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        csrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+        csrc.z = Hc * Wc * pixc;
+        csrc.w = 0x00020000;
+        const unsigned long long ax = (unsigned long long)(reinterpret_cast<const char*>(x) + (size_t)n * H * W * pix);
+        rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ax);
+        rsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(ax >> 32) & 0xffff);
+        rsrc.z = H * W * pix;
+        rsrc.w = 0x00020000;
+        const unsigned long long ay = (unsigned long long)(reinterpret_cast<char*>(y) + (size_t)n * H * W * pix);
+        ysrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ay);
+        ysrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(ay >> 32) & 0xffff);
+        ysrc.z = H * W * pix;
+        ysrc.w = 0x00020000;
+    }
+    const unsigned cvo = (unsigned)(cc * CSZ);
+    const int cb0 = 7 * tc;
+    // scalar column offsets of the clamped outer coarse columns, relative to column cb0 of the row
+    const int l0 = __builtin_amdgcn_readfirstlane(ledge ? 0 : -2 * pixc), l1 = __builtin_amdgcn_readfirstlane(ledge ? 0 : -pixc);
+    const int r0 = __builtin_amdgcn_readfirstlane((redge ? 6 : 7) * pixc), r1 = __builtin_amdgcn_readfirstlane((redge ? 6 : 8) * pixc);
+    auto load_coarse = [&](uint32_t (&dst)[NCR], int i) {        // tile-local coarse row i, clamped into the plane (ATen's border rule)
+        int ar = 7 * tr + i;
+        ar = ar < 0 ? 0 : (ar > Hc - 1 ? Hc - 1 : ar);
+        const int rb = __builtin_amdgcn_readfirstlane((ar * Wc + cb0) * pixc);
+        coarse_row_load<TC>(dst, cvo, csrc, rb, l0, l1, r0, r1, pixc);
+    };
+    const float lmask = ledge ? 0.f : 1.f, rmask = redge ? 0.f : 1.f;
+    const f32x2 wq = MODE == 1 ? splat(0.f) : splat(0.25f), wt = MODE == 1 ? splat(1.f) : splat(0.75f);
+    // H row: a coarse row resized horizontally to the 18 columns -2 .. 15 (pairs outside the image zeroed)
+    auto build_H = [&](f32x2 (&Hs)[9], const uint32_t (&cr)[NCR]) {
+        float cv[NCR];
+#pragma unroll
+        for (int k = 0; k < NCR; ++k) cv[k] = raw_f32<TC>(cr[k]);
+        f32x2 P[6], Pq[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) { P[m] = f32x2{cv[2 * m], m < 5 ? cv[2 * m + 1] : 0.f}; Pq[m] = P[m] * wq; }
+        sfor<9>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const f32x2 e = f32x2{(j & 1) ? Pq[j >> 1].y : Pq[j >> 1].x, (j & 1) ? Pq[(j >> 1) + 1].y : Pq[(j >> 1) + 1].x};
+            const float mid = ((j + 1) & 1) ? P[(j + 1) >> 1].y : P[(j + 1) >> 1].x;
+            Hs[j] = pfma(splat(mid), wt, e);
+        });
+        Hs[0] = Hs[0] * splat(lmask);
+        Hs[8] = Hs[8] * splat(rmask);
+    };
+
+    const unsigned voffM = (unsigned)((14 * tc) * pix + cc * ESZ);
+    const unsigned voffL = ledge ? OOB : voffM - 2u * (unsigned)pix;
+    const unsigned voffR = redge ? OOB : voffM + 14u * (unsigned)pix;
+    auto load_row = [&](uint32_t (&raw)[18], int r) {            // rows outside the plane: a valid row is loaded and not used
+        int ar = 14 * tr + r;
+        ar = ar < 0 ? 0 : (ar > H - 1 ? H - 1 : ar);
+        const int rb = __builtin_amdgcn_readfirstlane(ar * (W * pix));
+        row_load<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
+    };
+    auto row_valid = [&](int r) -> bool { const int ar = 14 * tr + r; return ar >= 0 && ar < H; };       // uniform
+
+    uint32_t raw[NR][18];
+    f32x2 Hh[2][9];
+    f32x2 acc[5][7];
+    uint32_t craw[NCR];
+    {
+        // prologue, in the order Sched replays: coarse rows -2, -1, 0, then x rows -2, -1, then (compiler-counted) the taps
+        uint32_t cm2[NCR], cm1[NCR];
+        load_coarse(cm2, -2);
+        load_coarse(cm1, -1);
+        load_coarse(craw, 0);
+        sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], -2 + decltype(rc)::value); });
+        pin_coarse<S::cap(S::pending(0, 0))>(cm1);                // rows -2 and -1 have landed (memory operations complete in order)
+        pin_coarse<S::cap(S::pending(0, 0))>(cm2);
+        build_H(Hh[0], cm2);
+        build_H(Hh[1], cm1);
+    }
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 25 * C * 4, 0x00020000);
+    Taps tf;
+    load_taps(tf, wsrc, bias, 0, C, cc, has_bias);
+    // the taps land HERE, on every path: left to the compiler, their loads sink to the first use inside the conditional row bodies, and
+    // its own count of outstanding loads (which knows nothing of the hand-issued ones) then drains the row prefetch in every iteration
+#pragma unroll
+    for (int u = 0; u < 5; ++u) { pin(tf.p[u][0]); pin(tf.p[u][1]); pin(tf.p[u][2]); }
+    f32x2 bf = splat(tf.bias);
+    pin(bf);                                                     // a real register pair: no half of it is ever borrowed from a row in flight
+    const unsigned yoff = cvalid ? (unsigned)((14 * tc) * pix + c * ESZ) : OOB;
+
+    sfor<NR>([&](auto rc) {
+        constexpr int ri = decltype(rc)::value, t = ri - 2;
+        if constexpr (ri + AHEAD < NR) load_row(raw[ri + AHEAD], t + AHEAD);
+        // vertical source rows (tile origin is even): t even -> (t/2 - 1, t/2) weight 0.75 on the second; t odd -> ((t-1)/2, (t+1)/2), 0.25
+        constexpr int te = (t + 2) & 1;
+        constexpr int i0 = MODE == 1 ? ((t + 2) >> 1) - 1 : (te ? (t - 1) / 2 : t / 2 - 1);
+        constexpr int i1 = MODE == 1 ? i0 : i0 + 1;
+        constexpr float lam = MODE == 1 ? 0.f : (te ? 0.25f : 0.75f);
+        if constexpr (S::is_build(ri)) {
+            constexpr int ib = S::build_row(ri);
+            static_assert(ib == (MODE == 0 ? i1 : i0), "the row built here is the one this iteration is the first to use");
+            pin_coarse<S::cap(S::pending(1, ri))>(craw);
+            build_H(Hh[(ib + 2) & 1], craw);
+            if constexpr (ib + 1 <= S::c_last) load_coarse(craw, ib + 1);
+        }
+        pin_row<S::cap(S::pending(2, ri))>(raw[ri]);
+        if (row_valid(t)) {
+            f32x2 row[9], odd[8];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const f32x2 xv = f32x2{raw_f32<TIO>(raw[ri][2 * k]), raw_f32<TIO>(raw[ri][2 * k + 1])};
+                if (MODE == 1) row[k] = xv + Hh[(i0 + 2) & 1][k];
+                else row[k] = pfma(splat(lam), Hh[(i1 + 2) & 1][k], pfma(splat(1.f - lam), Hh[(i0 + 2) & 1][k], xv));
+            }
+            // the two columns left of the image and right of it are zero padding of the conv INPUT: x read 0 there and H was zeroed
+#pragma unroll
+            for (int j = 0; j < 8; ++j) odd[j] = shift1(row[j], row[j + 1]);
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int o = t - u + 2;
+                if (o < 0 || o > 13) continue;
+                f32x2(&a)[7] = acc[o % 5];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) a[j] = pfma(row[j], splat(tf.at(u, 0)), u == 0 ? bf : a[j]);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) a[j] = pfma(odd[j], splat(tf.at(u, 1)), a[j]);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) a[j] = pfma(row[j + 1], splat(tf.at(u, 2)), a[j]);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) a[j] = pfma(odd[j + 1], splat(tf.at(u, 3)), a[j]);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) a[j] = pfma(row[j + 2], splat(tf.at(u, 4)), a[j]);
+            }
+        } else if constexpr (t + 2 >= 0 && t + 2 <= 13) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc[(t + 2) % 5][j] = bf;
+        }
+        if constexpr (t - 2 >= 0 && t - 2 <= 13) {
+            constexpr int o = t - 2;
+            const int arow = 14 * tr + o;
+            const int yrb = __builtin_amdgcn_readfirstlane((arow < H ? arow : 0) * (W * pix));
+            RowSt<TIO, PIXB>::st(acc[o % 5], arow < H ? yoff : OOB, ysrc, yrb, pix);     // rows past the plane: dropped, but issued (Sched counts them)
+        }
+#pragma unroll
+        for (int o = 0; o < 14; ++o) if (o > t - 2 && o <= t + 2) pin(acc[o % 5]);
+        pin(Hh[0]);
+        pin(Hh[1]);
+        CPT_FENCE;
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+//   k_down5_cpt   y = conv5, stride 2 (x)   -- one step of the down ladder (model/recnext.py:27-29) / RecAttn2d's `down` conv
+//                                              (model/recattn.py:61) on any even plane whose width is a multiple of 14
+// Pass 1 of k_recconv_cpt as a kernel of its own: a wave = 64 channels of one 14 x 14 input tile = 7 x 7 outputs, input rows -2 .. 14
+// stream through registers, input-row stationary with the taps paired ((w0, w1), (w2, w3), (w4, 0): the even / odd partial sums of an
+// output share a register pair and are added at the end), an output row of 7 pixels leaves as one statement.
+constexpr int NR1 = 17;           // input rows of a tile: -2 .. 14
+
+template <int AHEAD> struct SchedDown {
+    static constexpr int pending(int ri_target)
+    {
+        int seq = 0, xend[NR1 + AHEAD + 1] = {};
+        for (int r = 0; r < AHEAD; ++r) { seq += 18; xend[r] = seq; }
+        for (int ri = 0; ri < NR1; ++ri) {
+            if (ri + AHEAD < NR1) { seq += 18; xend[ri + AHEAD] = seq; }
+            if (ri == ri_target) return seq - xend[ri];
+            if (ri >= 4 && (ri & 1) == 0) seq += 7;               // output row (ri - 4) / 2 leaves at the end of the iteration
+        }
+        return 0;
+    }
+    static constexpr int cap(int v) { return v > 63 ? 63 : v; }
+};
+
+// one output row: 7 pixels, pitch `pix` bytes; vo out of range -> dropped (but issued)
+#define DN_S(OP, d) OP " %[p" #d "], %[vo], %[rs], %[t] offen\n\t"
+#define DN_N "s_add_i32 %[t], %[t], %[pix]\n\t"
+template <typename TO> struct DownSt;
+template <> struct DownSt<float> {
+    static __device__ __forceinline__ void st(const float (&v)[7], unsigned vo, i32x4 rs, int rb, int pix)
+    {
+        int t;
+        asm volatile("s_add_i32 %[t], %[rb], 0\n\t" DN_S("buffer_store_dword", 0) DN_N DN_S("buffer_store_dword", 1) DN_N DN_S("buffer_store_dword", 2) DN_N
+                     DN_S("buffer_store_dword", 3) DN_N DN_S("buffer_store_dword", 4) DN_N DN_S("buffer_store_dword", 5) DN_N DN_S("buffer_store_dword", 6)
+                     : [t] "=&s"(t)
+                     : [p0] "v"(v[0]), [p1] "v"(v[1]), [p2] "v"(v[2]), [p3] "v"(v[3]), [p4] "v"(v[4]), [p5] "v"(v[5]), [p6] "v"(v[6]),
+                       [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc", "memory");
+    }
+};
+template <typename T16> struct DownSt16 {
+    static __device__ __forceinline__ void st(const float (&v)[7], unsigned vo, i32x4 rs, int rb, int pix)
+    {
+        uint32_t p[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = pk16<T16>(v[2 * j], j < 3 ? v[2 * j + 1] : 0.f);
+        int t;
+        asm volatile("s_add_i32 %[t], %[rb], 0\n\t" DN_S("buffer_store_short", 0) DN_N DN_S("buffer_store_short_d16_hi", 0) DN_N DN_S("buffer_store_short", 1) DN_N
+                     DN_S("buffer_store_short_d16_hi", 1) DN_N DN_S("buffer_store_short", 2) DN_N DN_S("buffer_store_short_d16_hi", 2) DN_N DN_S("buffer_store_short", 3)
+                     : [t] "=&s"(t)
+                     : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc", "memory");
+    }
+};
+template <> struct DownSt<bf16_t> : DownSt16<bf16_t> {};
+template <> struct DownSt<f16_t> : DownSt16<f16_t> {};
+
+template <int PIXB, typename TIO, typename TO>
+__global__ __launch_bounds__(256, 2) void k_down5_cpt(const TIO* __restrict__ x, TO* __restrict__ y, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      int N, int C, int H, int W, int has_bias)
+{
+    constexpr int ESZ = (int)sizeof(TIO), OSZ = (int)sizeof(TO), AHEAD = 3;
+    using S = SchedDown<AHEAD>;
+    const int nb = (C + 63) / 64, TR = (H + 13) / 14, TCn = W / 14, Ho = H / 2, Wo = W / 2;
+    const int pix = PIXB ? PIXB : C * ESZ, pixo = C * OSZ;
+    const unsigned total = (unsigned)N * nb * TR * TCn;
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (unit >= total) return;
+    const int tc = (int)(unit % (unsigned)TCn);
+    unsigned q = unit / (unsigned)TCn;
+    const int tr = (int)(q % (unsigned)TR);
+    q /= (unsigned)TR;
+    const int cb = (int)(q % (unsigned)nb), n = (int)(q / (unsigned)nb);
+    const int c = cb * 64 + lane;
+    const bool cvalid = c < C;
+    const int cc = cvalid ? c : C - 1;
+    const bool ledge = tc == 0, redge = tc == TCn - 1;
+    const unsigned OOB = 0x80000000u;
+    i32x4 rsrc, ysrc;
+    {
+        const unsigned long long ax = (unsigned long long)(reinterpret_cast<const char*>(x) + (size_t)n * H * W * pix);
+        rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ax);
+        rsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(ax >> 32) & 0xffff);
+        rsrc.z = H * W * pix;
+        rsrc.w = 0x00020000;
+        const unsigned long long ay = (unsigned long long)(reinterpret_cast<char*>(y) + (size_t)n * Ho * Wo * pixo);
+        ysrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ay);
+        ysrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(ay >> 32) & 0xffff);
+        ysrc.z = Ho * Wo * pixo;
+        ysrc.w = 0x00020000;
+    }
+    const unsigned voffM = (unsigned)((14 * tc) * pix + cc * ESZ);
+    const unsigned voffL = ledge ? OOB : voffM - 2u * (unsigned)pix;
+    const unsigned voffR = redge ? OOB : voffM + 14u * (unsigned)pix;
+    auto load_row = [&](uint32_t (&raw)[18], int r) {
+        int ar = 14 * tr + r;
+        ar = ar < 0 ? 0 : (ar > H - 1 ? H - 1 : ar);
+        const int rb = __builtin_amdgcn_readfirstlane(ar * (W * pix));
+        row_load<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
+    };
+    auto row_valid = [&](int r) -> bool { const int ar = 14 * tr + r; return ar >= 0 && ar < H; };
+    uint32_t raw[NR1][18];
+    sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], -2 + decltype(rc)::value); });
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 25 * C * 4, 0x00020000);
+    Taps td;
+    load_taps(td, wsrc, bias, 0, C, cc, has_bias);
+#pragma unroll
+    for (int u = 0; u < 5; ++u) { pin(td.p[u][0]); pin(td.p[u][1]); pin(td.p[u][2]); }       // landed here, on every path (see k_upadd_cpt)
+    f32x2 b0 = f32x2{td.bias, 0.f};
+    pin(b0);
+    const unsigned yoff = cvalid ? (unsigned)((7 * tc) * pixo + c * OSZ) : OOB;
+    f32x2 facc[3][7];
+    sfor<NR1>([&](auto rc) {
+        constexpr int ri = decltype(rc)::value, r = ri - 2;
+        if constexpr (ri + AHEAD < NR1) load_row(raw[ri + AHEAD], r + AHEAD);
+        pin_row<S::cap(S::pending(ri))>(raw[ri]);
+        f32x2 xr[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) xr[k] = f32x2{raw_f32<TIO>(raw[ri][2 * k]), raw_f32<TIO>(raw[ri][2 * k + 1])};
+        const bool rv = row_valid(r);
+#pragma unroll
+        for (int o = 0; o < 7; ++o) {
+            const int u = r - 2 * o + 2;
+            if (u < 0 || u > 4) continue;
+            f32x2(&a)[7] = facc[o % 3];
+            if (rv) {
+#pragma unroll
+                for (int i = 0; i < 7; ++i) a[i] = pfma(xr[i], td.p[u][0], u == 0 ? b0 : a[i]);
+#pragma unroll
+                for (int i = 0; i < 7; ++i) a[i] = pfma(xr[i + 1], td.p[u][1], a[i]);
+#pragma unroll
+                for (int i = 0; i < 7; ++i) a[i].x = fmaf(xr[i + 2].x, td.p[u][2].x, a[i].x);
+            } else if (u == 0) {
+#pragma unroll
+                for (int i = 0; i < 7; ++i) a[i] = b0;
+            }
+            if (u == 4) {
+                float out[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) out[i] = a[i].x + a[i].y;
+                const int orow = 7 * tr + o;
+                const int yrb = __builtin_amdgcn_readfirstlane((orow < Ho ? orow : 0) * (Wo * pixo));
+                DownSt<TO>::st(out, orow < Ho ? yoff : OOB, ysrc, yrb, pixo);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 7; ++o) if (r - 2 * o + 2 >= 0 && r - 2 * o + 2 < 4) pin(facc[o % 3]);
+        CPT_FENCE;
+    });
+}
+
+template <typename TIO, typename TO>
+static hipError_t launch_down(const void* x, void* y, const float* w, const float* b, int N, int C, int H, int W, hipStream_t s)
+{
+    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / 14);
+    const dim3 grid((unsigned)((units + 3) / 4)), block(256);
+    const int hb = b != nullptr;
+    const int pixb = C * (int)sizeof(TIO);
+#define RCX_GO(PB) hipLaunchKernelGGL((k_down5_cpt<PB, TIO, TO>), grid, block, 0, s, (const TIO*)x, (TO*)y, w, b, N, C, H, W, hb)
+    if constexpr (sizeof(TIO) == 2) {
+        if (pixb == 128) { RCX_GO(128); return hipGetLastError(); }
+        if (pixb == 256) { RCX_GO(256); return hipGetLastError(); }
+    }
+    RCX_GO(0);
+#undef RCX_GO
+    return hipGetLastError();
+}
+
+static inline bool enabled()
+{
+    const char* v = rcx::opt::value(rcx::opt::UPADD_CPT);
+    const char* l = rcx::opt::value(rcx::opt::LANES);
+    return !(v && *v == '0') && !(l && *l == '0');
+}
+
+template <int MODE, typename TIO, typename TC>
+static hipError_t launch(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int H, int W, hipStream_t s)
+{
+    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / 14);
+    const dim3 grid((unsigned)((units + 3) / 4)), block(256);
+    const int hb = b != nullptr;
+    const int pixb = C * (int)sizeof(TIO);
+#define RCX_GO(PB) hipLaunchKernelGGL((k_upadd_cpt<MODE, PB, TIO, TC>), grid, block, 0, s, (const TIO*)x, (const TC*)coarse, (TIO*)y, w, b, N, C, H, W, hb)
+    if constexpr (sizeof(TIO) == 2) {
+        if (pixb == 128) { RCX_GO(128); return hipGetLastError(); }
+        if (pixb == 256) { RCX_GO(256); return hipGetLastError(); }
+    }
+    RCX_GO(0);
+#undef RCX_GO
+    return hipGetLastError();
+}
+
+}  // namespace upcpt
+
+// y = conv5(x + resize2x(coarse)): exact 2x planes whose width is a multiple of 14, at least one full tile high; the 14 x 14 plane has
+// its own whole-plane kernel (rcx_cpl14.hip)
+bool upadd_cpt_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int x_dt, int c_dt, int out_dt)
+{
+    if (!upcpt::enabled() || k != 5 || out_dt != x_dt || x_dt < 0 || x_dt > 2 || !(c_dt == x_dt || c_dt == 0)) return false;
+    if (N < 1 || C < 1 || Hc * 2 != H || Wc * 2 != W || W % 14 != 0 || H < 28 || W < 28) return false;
+    const long long img = (long long)H * W * C * 4;
+    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / 14);
+    return img < (1ll << 31) && units < (1ll << 31);
+}
+
+int upadd_cpt_describe(int N, int C, int H, int W, int mode, int x_dt, char* buf, int len)
+{
+    const int pixb = x_dt != 0 && (C == 64 || C == 128) ? C * 2 : 0;
+    return snprintf(buf, len, "upadd_cpt(k_upadd_cpt<%d, %d>,cb=64,nt=256,tiles=%lld)", mode, pixb,
+                    (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / 14));
+}
+
+hipError_t upadd_cpt(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int H, int W, int mode,
+                     int x_dt, int c_dt, hipStream_t s)
+{
+#define RCX_UP(TX, TC) (mode == 1 ? upcpt::launch<1, TX, TC>(x, coarse, y, w, b, N, C, H, W, s) : upcpt::launch<0, TX, TC>(x, coarse, y, w, b, N, C, H, W, s))
+    if (x_dt == 1) return c_dt == 1 ? RCX_UP(bf16_t, bf16_t) : RCX_UP(bf16_t, float);
+    if (x_dt == 2) return c_dt == 2 ? RCX_UP(f16_t, f16_t) : RCX_UP(f16_t, float);
+    return RCX_UP(float, float);
+#undef RCX_UP
+}
+
+// y = conv5 stride 2 (x): even planes whose width is a multiple of 14, at least one full tile
+bool down5_cpt_applicable(int N, int C, int H, int W, int k, int stride, int in_dt, int out_dt)
+{
+    if (!upcpt::enabled() || k != 5 || stride != 2 || in_dt < 0 || in_dt > 2 || !(out_dt == in_dt || out_dt == 0)) return false;
+    if (N < 1 || C < 1 || (H & 1) || W % 14 != 0 || H < 28 || W < 28) return false;
+    const long long img = (long long)H * W * C * 4;
+    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / 14);
+    return img < (1ll << 31) && units < (1ll << 31);
+}
+
+hipError_t down5_cpt(const void* x, void* y, const float* w, const float* b, int N, int C, int H, int W, int in_dt, int out_dt, hipStream_t s)
+{
+    if (in_dt == 1) return out_dt == 1 ? upcpt::launch_down<bf16_t, bf16_t>(x, y, w, b, N, C, H, W, s) : upcpt::launch_down<bf16_t, float>(x, y, w, b, N, C, H, W, s);
+    if (in_dt == 2) return out_dt == 2 ? upcpt::launch_down<f16_t, f16_t>(x, y, w, b, N, C, H, W, s) : upcpt::launch_down<f16_t, float>(x, y, w, b, N, C, H, W, s);
+    return upcpt::launch_down<float, float>(x, y, w, b, N, C, H, W, s);
+}
+
+}  // namespace rcx

@@ -198,6 +198,13 @@ def dwconv2d(x, w_kkc, bias=None, k=5, stride=1, out_dtype=None):
     return y
 
 
+def upadd_dwconv_plan(n, c, h, w, hc, wc, k, mode, x_dtype, coarse_dtype=None, out_dtype=None):
+    """Which kernel upadd_dwconv would run for these extents and types (rcx_upadd_dwconv_fwd_plan); coarse_dtype None = no coarse plane."""
+    return _lib.load().rcx_upadd_dwconv_fwd_plan(n, c, h, w, hc, wc, k, _lib.MODES[mode], _DT[x_dtype],
+                                                 _DT[coarse_dtype] if coarse_dtype is not None else _lib.DTYPE_F32,
+                                                 _DT[out_dtype or x_dtype], 1 if coarse_dtype is not None else 0).decode()
+
+
 def upadd_dwconv(x, coarse, w_kkc, bias=None, k=5, mode="nearest", out_dtype=None):
     """dwconv_k(x + resize(coarse -> size(x), mode)); coarse may be None."""
     x = _nhwc(x)

@@ -667,6 +667,89 @@ def test_upadd_step_kernel(mode, case, dts):
     assert np.allclose(yg.float().cpu().numpy(), got, atol=1e-2 if xdt == torch.bfloat16 else 1e-4, rtol=1e-2)
 
 
+# ---- the same step, channel per lane and tiled (rcx_upcpt.hip, round 3): any even height, any width that is a multiple of 14 ----
+UPCPT_CASES = [
+    # (N, C, H, W): square stage planes with the compile-time pixel pitches (64 / 128 channels), ragged 64-channel blocks (48, 96, 130, 24),
+    # non-square planes, a last tile row that is partly (30, 100) or by one row pair (200) outside the plane, one and three tile columns
+    (3, 64, 56, 56), (2, 128, 28, 28), (2, 48, 56, 56), (2, 96, 28, 28), (1, 130, 28, 56), (2, 24, 30, 42), (1, 64, 100, 168), (1, 16, 200, 28),
+    (1, 8, 50, 84), (5, 40, 28, 28),
+]
+
+
+@pytest.mark.parametrize("mode", ["bilinear", "nearest"])
+@pytest.mark.parametrize("bias", [False, True], ids=["nobias", "bias"])
+@pytest.mark.parametrize("case", UPCPT_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("dts", [("f32", "f32"), ("bf16", "f32"), ("bf16", "bf16"), ("f16", "f16"), ("f16", "f32")], ids=lambda d: "-".join(d))
+def test_upadd_tiled_channel_per_lane_kernel(mode, bias, case, dts):
+    n, c, h, w = case
+    DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+    xdt, cdt = DT[dts[0]], DT[dts[1]]
+    rng = np.random.default_rng(zlib.crc32(repr((mode, bias, case, dts)).encode()))
+    rnd = (lambda a: a.astype(np.float16).astype(np.float32)) if "f16" in dts else bf16_round_np
+    x = rnd(rng.standard_normal((n, c, h, w)).astype(np.float32))
+    cs = rnd(rng.standard_normal((n, c, h // 2, w // 2)).astype(np.float32))
+    wt = (rng.standard_normal((c, 1, 5, 5)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(c).astype(np.float32) if bias else None
+    ref = c_oracle.dwconv2d(c_oracle.add_resized(x, cs, mode), wt, b, 1)
+    t = lambda a: torch.from_numpy(a).to(dev())
+    run = lambda: ops.upadd_dwconv(t(x).to(xdt), t(cs).to(cdt), ops.pack_dw_weight(t(wt)), ops.pack_bias(t(b)) if bias else None, k=5, mode=mode)
+    with rcx_env(RCX_UPADD_CPT="all"):                     # also where the lanes kernel would keep a ragged channel count
+        plan = ops.upadd_dwconv_plan(n, c, h, w, h // 2, w // 2, 5, mode, xdt, cdt)
+        assert plan.startswith(f"upadd_cpt(k_upadd_cpt<{1 if mode == 'nearest' else 0}, "), plan
+        y = run()
+        assert torch.equal(run(), y)
+    if c % 64 == 0:                                        # the default rule: whole 64-channel waves always take the tiled kernel
+        assert ops.upadd_dwconv_plan(n, c, h, w, h // 2, w // 2, 5, mode, xdt, cdt).startswith("upadd_cpt(")
+    elif (c, h, w) == (96, 28, 28) and "f16" not in dts:   # ragged channel count on a plane the lanes kernel has a plan for
+        assert ops.upadd_dwconv_plan(n, c, h, w, h // 2, w // 2, 5, mode, xdt, cdt).startswith("upadd_lanes(")
+    assert y.dtype == xdt
+    got = y.float().cpu().numpy()
+    if xdt == torch.float32:
+        assert np.abs(got - ref).max() < F32_TIGHT
+    elif xdt == torch.float16:
+        assert np.allclose(got, ref, atol=2e-3, rtol=2e-3)
+    else:
+        assert np.allclose(got, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
+        assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 1e-5)          # one rounding, at the store
+    with rcx_env(RCX_UPADD_CPT="0"):                     # the kernels it replaces: the same numbers up to float32 reassociation
+        assert not ops.upadd_dwconv_plan(n, c, h, w, h // 2, w // 2, 5, mode, xdt, cdt).startswith("upadd_cpt(")
+        other = run().float().cpu().numpy()
+    assert np.allclose(other, got, atol={torch.float32: 1e-4, torch.bfloat16: 1e-2, torch.float16: 2e-3}[xdt], rtol=1e-2)
+
+
+@pytest.mark.parametrize("bias", [False, True], ids=["nobias", "bias"])
+@pytest.mark.parametrize("case", UPCPT_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("dts", [("f32", "f32"), ("bf16", "f32"), ("bf16", "bf16"), ("f16", "f16"), ("f16", "f32")], ids=lambda d: "-".join(d))
+def test_down5_tiled_channel_per_lane_kernel(bias, case, dts):
+    """k_down5_cpt (rcx_upcpt.hip): the stride-2 conv on the same planes as the kernel above, against the oracle and against the kernels
+    it replaces (RCX_UPADD_CPT=0: the lanes kernel on the 7 * 2^k squares, the generic kernel elsewhere)."""
+    n, c, h, w = case
+    DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+    xdt, odt = DT[dts[0]], DT[dts[1]]
+    rng = np.random.default_rng(zlib.crc32(repr(("down", bias, case, dts)).encode()))
+    rnd = (lambda a: a.astype(np.float16).astype(np.float32)) if "f16" in dts else bf16_round_np
+    x = rnd(rng.standard_normal((n, c, h, w)).astype(np.float32))
+    wt = (rng.standard_normal((c, 1, 5, 5)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(c).astype(np.float32) if bias else None
+    ref = c_oracle.dwconv2d(x, wt, b, 2)
+    t = lambda a: torch.from_numpy(a).to(dev())
+    run = lambda: ops.dwconv2d(t(x).to(xdt), ops.pack_dw_weight(t(wt)), ops.pack_bias(t(b)) if bias else None, k=5, stride=2, out_dtype=odt)
+    with rcx_env(RCX_UPADD_CPT="all"):                     # also where the lanes kernel would keep a ragged channel count
+        y = run()
+        assert y.dtype == odt and tuple(y.shape) == ref.shape and torch.equal(run(), y)
+    got = y.float().cpu().numpy()
+    if odt == torch.float32:
+        assert np.abs(got - ref).max() < F32_TIGHT
+    elif odt == torch.float16:
+        assert np.allclose(got, ref, atol=2e-3, rtol=2e-3)
+    else:
+        assert np.allclose(got, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
+        assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 1e-5)
+    with rcx_env(RCX_UPADD_CPT="0"):
+        other = run().float().cpu().numpy()
+    assert np.allclose(other, got, atol={torch.float32: 1e-4, torch.bfloat16: 1e-2, torch.float16: 2e-3}[odt], rtol=1e-2)
+
+
 @pytest.mark.parametrize("case", [(3, 64, 56), (2, 48, 56), (3, 96, 28), (5, 32, 28), (3, 256, 14), (2, 80, 14), (2, 64, 64), (2, 32, 32)],
                          ids=lambda c: "x".join(map(str, c)))
 @pytest.mark.parametrize("dts", [("f32", "f32"), ("bf16", "f32"), ("bf16", "bf16")], ids=lambda d: "-".join(d))

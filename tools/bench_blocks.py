@@ -26,6 +26,9 @@ SHAPES = {
     # of rcx_cpt.hip::cpt28_ragged (RCX_CPT=32 / 64 force one side)
     "ragged28": [(256, 80, 28, 28, 3), (256, 96, 28, 28, 3), (256, 112, 28, 28, 3), (256, 160, 28, 28, 3), (128, 96, 28, 28, 3), (128, 160, 28, 28, 3),
                  (64, 160, 28, 28, 3), (512, 96, 28, 28, 3)],
+    # RecNeXt-M3 at 448 x 448 (twice the training resolution): 112 x 112 / level 4 is the split schedule (conv5 stride 2 -> the fused 56 x 56 block ->
+    # conv5(x + resize)); its two outer steps are the tiled channel-per-lane kernels of rcx_upcpt.hip since round 3
+    "m3_448": [(64, 64, 112, 112, 4), (64, 128, 56, 56, 3), (64, 256, 28, 28, 2), (64, 512, 14, 14, 1)],
     "m3_512": [(32, 64, 128, 128, 4), (32, 128, 64, 64, 3), (32, 256, 32, 32, 2), (32, 512, 16, 16, 1)],
     # RecNeXt-M3 backbone on a COCO batch (detection/configs/_base_/datasets/coco_instance.py:9-12: 800 x 1344 padded, 2 images per GPU)
     "m3_coco": [(2, 64, 200, 336, 4), (2, 128, 100, 168, 3), (2, 256, 50, 84, 2), (2, 512, 25, 42, 1)],
