@@ -114,40 +114,62 @@ bool upcpt_everywhere()
     return v && *v == 'a';
 }
 
+// Which single-step kernel a plane gets.  Never a function of N: a batch and its shards must give the same rows bit for bit.
+enum StepKernel { STEP_GENERIC, STEP_LANES, STEP_CPT, STEP_CPL14, STEP_CONV5_LANES };
+
+// stride-2 conv5 (stride 1: the plain conv5): the register-resident lanes kernel where it has a plan (the 7 * 2^k / 16 * 2^k squares: it
+// already runs at the copy ceiling on 56 x 56 / 28 x 28, 256 x 64 x 56 x 56 24.7 us against 26.1), the tiled channel-per-lane kernel
+// (rcx_upcpt.hip) on every other even plane whose width is a multiple of 14 (112 x 112: 15.1 us against 50.8; 200 x 336: 84.8 against 218)
+// and on the 16 * 2^k squares in bfloat16 (16-wide tiles: 32 x 64 x 128 x 128 22.4 us against the lanes kernel's 39.9, 32 x 256 x 32 x 32
+// 12.1 against 16.2, 64 x 64 16.2 / 16.6).
+StepKernel pick_dwconv(int N, int C, int H, int W, int k, int stride, int in_dt, int out_dt)
+{
+    if (lanes_off()) return STEP_GENERIC;
+    const bool lanes_ok = rcx::down5_lanes_applicable(N, C, H, W, k, stride, in_dt, out_dt);
+    if (lanes_ok && !upcpt_everywhere() && !(W % 14 != 0 && C % 64 == 0)) return STEP_LANES;
+    if (rcx::down5_cpt_applicable(N, C, H, W, k, stride, in_dt, out_dt)) return STEP_CPT;
+    if (lanes_ok) return STEP_LANES;
+    if (stride == 1 && rcx::conv5_lanes_applicable(N, C, H, W, k, in_dt, out_dt)) return STEP_CONV5_LANES;
+    return STEP_GENERIC;
+}
+
+// conv5(x + resize(coarse)): the whole-plane kernel on 14 x 14; the tiled channel-per-lane kernel (rcx_upcpt.hip) for whole 64-channel
+// waves (256 x 64 x 56 x 56: 61 - 63 us against the lanes kernel's 74 - 76) and wherever the lanes kernel has no plan (float16, planes that
+// are not 7 * 2^k / 16 * 2^k squares: 32 x 64 x 200 x 336 168 - 176 us against the generic kernel's 860 - 1 413); ragged channel counts on a
+// lanes plane stay with the lanes kernel (256 x 96 x 28 x 28: 24 - 26 us against 28 - 52), and so do 16-wide tiles on a plane lower than
+// 64 rows, whose third tile row is mostly empty (32 x 256 x 32 x 32: 20 us against 14; 64 x 64: 31 against 35; 128 x 128: 47 - 52 against 85 - 91).
+StepKernel pick_upadd(int N, int C, int H, int W, int Hc, int Wc, int k, int x_dt, int c_dt, int out_dt, bool has_coarse)
+{
+    if (lanes_off()) return STEP_GENERIC;
+    if (!has_coarse) return rcx::conv5_lanes_applicable(N, C, H, W, k, x_dt, out_dt) ? STEP_CONV5_LANES : STEP_GENERIC;
+    if (rcx::upadd_cpl14_applicable(N, C, H, W, Hc, Wc, k, x_dt, c_dt, out_dt)) return STEP_CPL14;
+    const bool lanes_ok = rcx::upadd_lanes_applicable(N, C, H, W, Hc, Wc, k, x_dt, c_dt, out_dt);
+    const bool whole = C % 64 == 0 && !(W % 14 != 0 && H < 64);
+    if ((whole || !lanes_ok || upcpt_everywhere()) && rcx::upadd_cpt_applicable(N, C, H, W, Hc, Wc, k, x_dt, c_dt, out_dt)) return STEP_CPT;
+    return lanes_ok ? STEP_LANES : STEP_GENERIC;
+}
+
 hipError_t step_dwconv(const void* x, void* y, const float* w, const float* b, int N, int C, int H, int W, int k, int stride,
                        int in_dt, int out_dt, hipStream_t s)
 {
-    // stride-2 conv5: the register-resident lanes kernel where it has a plan (the 7 * 2^k / 16 * 2^k squares: it already runs at the
-    // copy ceiling there, 256 x 64 x 56 x 56 24.7 us against 26.1), the tiled channel-per-lane kernel (rcx_upcpt.hip) on every other
-    // even plane whose width is a multiple of 14 (112 x 112: 15.1 us against 50.8; 200 x 336: 84.8 against 218).  Never a function of N.
-    const bool lanes_ok = !lanes_off() && rcx::down5_lanes_applicable(N, C, H, W, k, stride, in_dt, out_dt);
-    if (lanes_ok && !upcpt_everywhere())
-        return rcx::down5_lanes(x, y, w, b, N, C, H, W, in_dt, out_dt, s);
-    if (!lanes_off() && rcx::down5_cpt_applicable(N, C, H, W, k, stride, in_dt, out_dt))
-        return rcx::down5_cpt(x, y, w, b, N, C, H, W, in_dt, out_dt, s);
-    if (lanes_ok)
-        return rcx::down5_lanes(x, y, w, b, N, C, H, W, in_dt, out_dt, s);
-    if (!lanes_off() && stride == 1 && rcx::conv5_lanes_applicable(N, C, H, W, k, in_dt, out_dt))
-        return rcx::conv5_lanes(x, y, w, b, N, C, H, W, in_dt, s);
-    return rcx::generic_dwconv(x, y, w, b, N, C, H, W, k, stride, in_dt, out_dt, s);
+    switch (pick_dwconv(N, C, H, W, k, stride, in_dt, out_dt)) {
+    case STEP_LANES: return rcx::down5_lanes(x, y, w, b, N, C, H, W, in_dt, out_dt, s);
+    case STEP_CPT: return rcx::down5_cpt(x, y, w, b, N, C, H, W, in_dt, out_dt, s);
+    case STEP_CONV5_LANES: return rcx::conv5_lanes(x, y, w, b, N, C, H, W, in_dt, s);
+    default: return rcx::generic_dwconv(x, y, w, b, N, C, H, W, k, stride, in_dt, out_dt, s);
+    }
 }
 
 hipError_t step_upadd(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int H, int W,
                       int Hc, int Wc, int k, int mode, int x_dt, int c_dt, int out_dt, hipStream_t s)
 {
-    if (coarse && !lanes_off() && rcx::upadd_cpl14_applicable(N, C, H, W, Hc, Wc, k, x_dt, c_dt, out_dt))
-        return rcx::upadd_cpl14(x, coarse, y, w, b, N, C, mode, x_dt, c_dt, s);
-    // tiled channel-per-lane kernel (rcx_upcpt.hip): whole 64-channel waves, or wherever the register-resident lanes kernel has no plan
-    // (float16, planes that are not 7 * 2^k / 16 * 2^k squares); ragged channel blocks on a lanes plane stay with the lanes kernel
-    // (256 x 96 x 28 x 28: 24 - 26 us against 28 - 52).  Never a function of N.
-    const bool lanes_ok = coarse && !lanes_off() && rcx::upadd_lanes_applicable(N, C, H, W, Hc, Wc, k, x_dt, c_dt, out_dt);
-    if (coarse && !lanes_off() && (C % 64 == 0 || !lanes_ok || upcpt_everywhere()) && rcx::upadd_cpt_applicable(N, C, H, W, Hc, Wc, k, x_dt, c_dt, out_dt))
-        return rcx::upadd_cpt(x, coarse, y, w, b, N, C, H, W, mode, x_dt, c_dt, s);
-    if (lanes_ok)
-        return rcx::upadd_lanes(x, coarse, y, w, b, N, C, H, W, mode, x_dt, c_dt, s);
-    if (!coarse && !lanes_off() && rcx::conv5_lanes_applicable(N, C, H, W, k, x_dt, out_dt))
-        return rcx::conv5_lanes(x, y, w, b, N, C, H, W, x_dt, s);
-    return rcx::generic_upadd_dwconv(x, coarse, y, w, b, N, C, H, W, Hc, Wc, k, mode, x_dt, c_dt, out_dt, s);
+    switch (pick_upadd(N, C, H, W, Hc, Wc, k, x_dt, c_dt, out_dt, coarse != nullptr)) {
+    case STEP_CPL14: return rcx::upadd_cpl14(x, coarse, y, w, b, N, C, mode, x_dt, c_dt, s);
+    case STEP_CPT: return rcx::upadd_cpt(x, coarse, y, w, b, N, C, H, W, mode, x_dt, c_dt, s);
+    case STEP_LANES: return rcx::upadd_lanes(x, coarse, y, w, b, N, C, H, W, mode, x_dt, c_dt, s);
+    case STEP_CONV5_LANES: return rcx::conv5_lanes(x, y, w, b, N, C, H, W, x_dt, s);
+    default: return rcx::generic_upadd_dwconv(x, coarse, y, w, b, N, C, H, W, Hc, Wc, k, mode, x_dt, c_dt, out_dt, s);
+    }
 }
 
 }  // namespace
@@ -172,7 +194,9 @@ const char* rcx_recconv2d_fwd_plan(int N, int C, int H, int W, int level, int k,
     if (use_split(N, C, H, W, level, k, dtype)) {
         char inner[128];
         rcx::lanes_describe(N, C, H / 2, W / 2, level - 1, k, mode == RCX_MODE_NEAREST ? 1 : 0, RCX_DTYPE_F32, inner, (int)sizeof(inner));
-        snprintf(desc, sizeof(desc), "split(k_down5_lanes + %s + k_upadd_lanes)", inner);
+        const bool dcpt = pick_dwconv(N, C, H, W, k, 2, dtype, RCX_DTYPE_F32) == STEP_CPT;
+        const bool ucpt = pick_upadd(N, C, H, W, H / 2, W / 2, k, dtype, RCX_DTYPE_F32, dtype, true) == STEP_CPT;
+        snprintf(desc, sizeof(desc), "split(%s + %s + %s)", dcpt ? "k_down5_cpt" : "k_down5_lanes", inner, ucpt ? "k_upadd_cpt" : "k_upadd_lanes");
         return desc;
     }
     if (!use_plane(N, C, H, W, level, k, dtype)) return "generic";
@@ -581,14 +605,13 @@ const char* rcx_upadd_dwconv_fwd_plan(int N, int C, int H, int W, int Hc, int Wc
 {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || (k & 1) == 0) return "invalid";
     static thread_local char desc[160];
-    const bool lanes = !lanes_off();
-    if (has_coarse && lanes && rcx::upadd_cpl14_applicable(N, C, H, W, Hc, Wc, k, x_dtype, coarse_dtype, out_dtype)) return "upadd_cpl14(k_upadd_cpl14)";
-    const bool lanes_ok = has_coarse && lanes && rcx::upadd_lanes_applicable(N, C, H, W, Hc, Wc, k, x_dtype, coarse_dtype, out_dtype);
-    if (has_coarse && lanes && (C % 64 == 0 || !lanes_ok || upcpt_everywhere()) && rcx::upadd_cpt_applicable(N, C, H, W, Hc, Wc, k, x_dtype, coarse_dtype, out_dtype) &&
-        rcx::upadd_cpt_describe(N, C, H, W, mode == RCX_MODE_NEAREST ? 1 : 0, x_dtype, desc, (int)sizeof(desc)) > 0) return desc;
-    if (lanes_ok) return "upadd_lanes(k_upadd_lanes)";
-    if (!has_coarse && lanes && rcx::conv5_lanes_applicable(N, C, H, W, k, x_dtype, out_dtype)) return "conv5_lanes(k_upadd_lanes)";
-    return "generic";
+    switch (pick_upadd(N, C, H, W, Hc, Wc, k, x_dtype, coarse_dtype, out_dtype, has_coarse != 0)) {
+    case STEP_CPL14: return "upadd_cpl14(k_upadd_cpl14)";
+    case STEP_CPT: return rcx::upadd_cpt_describe(N, C, H, W, mode == RCX_MODE_NEAREST ? 1 : 0, x_dtype, desc, (int)sizeof(desc)) > 0 ? desc : "upadd_cpt(k_upadd_cpt)";
+    case STEP_LANES: return "upadd_lanes(k_upadd_lanes)";
+    case STEP_CONV5_LANES: return "conv5_lanes(k_upadd_lanes)";
+    default: return "generic";
+    }
 }
 
 int rcx_upadd_dwconv_fwd(const void* x, const void* coarse, void* y, const float* w_kkc, const float* bias,

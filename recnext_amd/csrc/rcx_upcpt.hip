@@ -1,4 +1,5 @@
-// Single steps of the recursion on planes of ANY height and a width that is a multiple of 14, channel per lane (round 3):
+// Single steps of the recursion on planes of ANY even height and a width that is a multiple of 14 (or, 16-bit activations, of 16),
+// channel per lane (round 3):
 //
 //   k_upadd_cpt   y = conv5(x + resize2x(coarse))   -- the last line of RecConv2d.forward (model/recnext.py:31-34) and of
 //                                                      RecAttn2d.forward (model/recattn.py:67) as one launch
@@ -15,6 +16,9 @@
 //
 // Every wave issues the SAME sequence of memory instructions whatever its tile (skipped rows still load, stores of absent rows are
 // dropped by the hardware), so the s_waitcnt counts are exact compile-time numbers: `Sched` replays the issue order at compile time.
+//
+// TW = tile width: 14 (the 7 * 2^k planes, COCO stages) or 16 (the 16 * 2^k planes of 256 x 256 / 512 x 512 inputs; 16-bit activations
+// only: the 20-column row statements exist for the 2-byte loads).  Tiles are 14 rows high either way.
 #include "rcx_cpt_kernel.h"
 #include "rcx_opts.h"
 
@@ -23,12 +27,16 @@ namespace upcpt {
 
 using namespace cpt;
 
+// tile width of a plane: 14 where it divides the width, else 16 (bfloat16 activations: float16's extra conversion registers do not fit
+// beside the 16-wide tile's accumulators, float32 has no 20-column row statement), else 0 = not ours
+static inline int tile_width(int W, int x_dt) { return W % 14 == 0 ? 14 : ((W % 16 == 0 && x_dt == 1) ? 16 : 0); }
+
 constexpr int NR = 18;            // input rows of a tile: -2 .. 15
-constexpr int NCR = 11;           // coarse columns of a tile: -2 .. 8
 
 // the order in which a wave issues its vector-memory instructions (identical for every wave), replayed at compile time
 // AHEAD = x rows in flight in front of the row being used
-template <int MODE, int NSTORE, int AHEAD> struct Sched {
+template <int MODE, int TW, int AHEAD> struct Sched {
+    static constexpr int NCOL = TW + 4, NCR = TW / 2 + 4, NSTORE = TW;
     static constexpr int c_last = MODE == 0 ? 8 : 7;                                     // last coarse row a tile needs
     static constexpr bool is_build(int ri) { return MODE == 0 ? (ri & 1) == 1 : ((ri & 1) == 0 && ri >= 2); }
     static constexpr int build_row(int ri) { return MODE == 0 ? (ri - 1) / 2 : (ri - 2) / 2; }
@@ -38,10 +46,10 @@ template <int MODE, int NSTORE, int AHEAD> struct Sched {
     {
         int seq = 0, xend[NR + AHEAD + 1] = {}, cend[16] = {};
         for (int i = -2; i <= 0; ++i) { seq += NCR; cend[i + 2] = seq; }
-        for (int r = 0; r < AHEAD; ++r) { seq += 18; xend[r] = seq; }
+        for (int r = 0; r < AHEAD; ++r) { seq += NCOL; xend[r] = seq; }
         if (kind == 0) return seq - cend[1];
         for (int ri = 0; ri < NR; ++ri) {
-            if (ri + AHEAD < NR) { seq += 18; xend[ri + AHEAD] = seq; }
+            if (ri + AHEAD < NR) { seq += NCOL; xend[ri + AHEAD] = seq; }
             if (is_build(ri)) {
                 const int ib = build_row(ri);
                 if (kind == 1 && ri == ri_target) return seq - cend[ib + 2];
@@ -55,43 +63,134 @@ template <int MODE, int NSTORE, int AHEAD> struct Sched {
     static constexpr int cap(int v) { return v > 63 ? 63 : v; }
 };
 
-// one row of the coarse plane: columns -2 .. 8 of the tile (the outer two on each side clamped into the plane by the offsets)
+// one row of the coarse plane: columns -2 .. TW/2 + 1 of the tile (the outer two on each side clamped into the plane by the offsets)
 #define UPC_OUT11(v) "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10])
 #define UPC_L(OP, d) OP " %" #d ", %[vo], %[rs], %[t] offen\n\t"
-#define UPC_ROW(OP)                                                                                                                  \
+#define UPC_N "s_add_i32 %[t], %[t], %[pix]\n\t"
+#define UPC_ROW11(OP)                                                                                                                \
     "s_add_i32 %[t], %[rb], %[l0]\n\t" UPC_L(OP, 0) "s_add_i32 %[t], %[rb], %[l1]\n\t" UPC_L(OP, 1)                                    \
-    "s_add_i32 %[t], %[rb], 0\n\t" UPC_L(OP, 2) "s_add_i32 %[t], %[t], %[pix]\n\t" UPC_L(OP, 3) "s_add_i32 %[t], %[t], %[pix]\n\t" UPC_L(OP, 4) \
-    "s_add_i32 %[t], %[t], %[pix]\n\t" UPC_L(OP, 5) "s_add_i32 %[t], %[t], %[pix]\n\t" UPC_L(OP, 6) "s_add_i32 %[t], %[t], %[pix]\n\t" UPC_L(OP, 7) \
-    "s_add_i32 %[t], %[t], %[pix]\n\t" UPC_L(OP, 8) "s_add_i32 %[t], %[rb], %[r0]\n\t" UPC_L(OP, 9) "s_add_i32 %[t], %[rb], %[r1]\n\t" UPC_L(OP, 10)
+    "s_add_i32 %[t], %[rb], 0\n\t" UPC_L(OP, 2) UPC_N UPC_L(OP, 3) UPC_N UPC_L(OP, 4) UPC_N UPC_L(OP, 5) UPC_N UPC_L(OP, 6) UPC_N UPC_L(OP, 7) UPC_N UPC_L(OP, 8) \
+    "s_add_i32 %[t], %[rb], %[r0]\n\t" UPC_L(OP, 9) "s_add_i32 %[t], %[rb], %[r1]\n\t" UPC_L(OP, 10)
+#define UPC_ROW12(OP)                                                                                                                \
+    "s_add_i32 %[t], %[rb], %[l0]\n\t" UPC_L(OP, 0) "s_add_i32 %[t], %[rb], %[l1]\n\t" UPC_L(OP, 1)                                    \
+    "s_add_i32 %[t], %[rb], 0\n\t" UPC_L(OP, 2) UPC_N UPC_L(OP, 3) UPC_N UPC_L(OP, 4) UPC_N UPC_L(OP, 5) UPC_N UPC_L(OP, 6) UPC_N UPC_L(OP, 7) UPC_N UPC_L(OP, 8) UPC_N UPC_L(OP, 9) \
+    "s_add_i32 %[t], %[rb], %[r0]\n\t" UPC_L(OP, 10) "s_add_i32 %[t], %[rb], %[r1]\n\t" UPC_L(OP, 11)
+#define UPC_IN [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [l0] "s"(l0), [l1] "s"(l1), [r0] "s"(r0), [r1] "s"(r1), [pix] "s"(pix)
 template <typename TC>
-__device__ __forceinline__ void coarse_row_load(uint32_t (&v)[NCR], unsigned vo, i32x4 rs, int rb, int l0, int l1, int r0, int r1, int pix)
+__device__ __forceinline__ void coarse_row_load(uint32_t (&v)[11], unsigned vo, i32x4 rs, int rb, int l0, int l1, int r0, int r1, int pix)
 {
     int t;
-    if constexpr (std::is_same<TC, f16_t>::value)
-        asm volatile(UPC_ROW(CPT_LDH) : UPC_OUT11(v), [t] "=&s"(t) : [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [l0] "s"(l0), [l1] "s"(l1), [r0] "s"(r0), [r1] "s"(r1), [pix] "s"(pix) : "scc");
-    else if constexpr (sizeof(TC) == 2)
-        asm volatile(UPC_ROW(CPT_LD16) : UPC_OUT11(v), [t] "=&s"(t) : [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [l0] "s"(l0), [l1] "s"(l1), [r0] "s"(r0), [r1] "s"(r1), [pix] "s"(pix) : "scc");
-    else
-        asm volatile(UPC_ROW(CPT_LD32) : UPC_OUT11(v), [t] "=&s"(t) : [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [l0] "s"(l0), [l1] "s"(l1), [r0] "s"(r0), [r1] "s"(r1), [pix] "s"(pix) : "scc");
+    if constexpr (std::is_same<TC, f16_t>::value) asm volatile(UPC_ROW11(CPT_LDH) : UPC_OUT11(v), [t] "=&s"(t) : UPC_IN : "scc");
+    else if constexpr (sizeof(TC) == 2) asm volatile(UPC_ROW11(CPT_LD16) : UPC_OUT11(v), [t] "=&s"(t) : UPC_IN : "scc");
+    else asm volatile(UPC_ROW11(CPT_LD32) : UPC_OUT11(v), [t] "=&s"(t) : UPC_IN : "scc");
 }
-template <int PENDING> __device__ __forceinline__ void pin_coarse(uint32_t (&v)[NCR])
+template <typename TC>
+__device__ __forceinline__ void coarse_row_load(uint32_t (&v)[12], unsigned vo, i32x4 rs, int rb, int l0, int l1, int r0, int r1, int pix)
+{
+    int t;
+    if constexpr (std::is_same<TC, f16_t>::value) asm volatile(UPC_ROW12(CPT_LDH) : UPC_OUT11(v), "=&v"(v[11]), [t] "=&s"(t) : UPC_IN : "scc");
+    else if constexpr (sizeof(TC) == 2) asm volatile(UPC_ROW12(CPT_LD16) : UPC_OUT11(v), "=&v"(v[11]), [t] "=&s"(t) : UPC_IN : "scc");
+    else asm volatile(UPC_ROW12(CPT_LD32) : UPC_OUT11(v), "=&v"(v[11]), [t] "=&s"(t) : UPC_IN : "scc");
+}
+template <int PENDING> __device__ __forceinline__ void pin_coarse(uint32_t (&v)[11])
 {
     asm volatile("s_waitcnt vmcnt(%11)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
                  "+v"(v[9]), "+v"(v[10]) : "n"(PENDING));
 }
+template <int PENDING> __device__ __forceinline__ void pin_coarse(uint32_t (&v)[12])
+{
+    asm volatile("s_waitcnt vmcnt(%12)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                 "+v"(v[9]), "+v"(v[10]), "+v"(v[11]) : "n"(PENDING));
+}
+
+// ---- 16-wide tiles (16-bit activations): a row of 20 columns = -2, -1 (vl), 0 .. 15 (vm), 16, 17 (vr), and a row of 16 outputs
+#define UPW_ROW_IMM(OP)                                                                                                              \
+    "s_add_i32 %[t], %[rb], 0\n\t"                                                                                                  \
+    CPT_LI(OP, 0, "vl", "t", 0) CPT_LI(OP, 1, "vl", "t", 1)                                                                          \
+    CPT_LI(OP, 2, "vm", "t", 0) CPT_LI(OP, 3, "vm", "t", 1) CPT_LI(OP, 4, "vm", "t", 2) CPT_LI(OP, 5, "vm", "t", 3)                  \
+    CPT_LI(OP, 6, "vm", "t", 4) CPT_LI(OP, 7, "vm", "t", 5) CPT_LI(OP, 8, "vm", "t", 6) CPT_LI(OP, 9, "vm", "t", 7)                  \
+    CPT_LI(OP, 10, "vm", "t", 8) CPT_LI(OP, 11, "vm", "t", 9) CPT_LI(OP, 12, "vm", "t", 10) CPT_LI(OP, 13, "vm", "t", 11)            \
+    CPT_LI(OP, 14, "vm", "t", 12) CPT_LI(OP, 15, "vm", "t", 13) CPT_LI(OP, 16, "vm", "t", 14) CPT_LI(OP, 17, "vm", "t", 15)          \
+    CPT_LI(OP, 18, "vr", "t", 0) CPT_LI(OP, 19, "vr", "t", 1)
+#define UPW_ROW_GEN(OP)                                                                                                              \
+    "s_add_i32 %[t], %[rb], 0\n\ts_add_i32 %[t2], %[rb], %[pix]\n\t"                                                                \
+    CPT_LG(OP, 0, "vl", "t") CPT_LG(OP, 1, "vl", "t2") CPT_LG(OP, 18, "vr", "t") CPT_LG(OP, 19, "vr", "t2")                          \
+    CPT_LG(OP, 2, "vm", "t") CPT_LG(OP, 3, "vm", "t2")                                                                               \
+    CPT_LGN(OP, 4) CPT_LGN(OP, 5) CPT_LGN(OP, 6) CPT_LGN(OP, 7) CPT_LGN(OP, 8) CPT_LGN(OP, 9) CPT_LGN(OP, 10) CPT_LGN(OP, 11)         \
+    CPT_LGN(OP, 12) CPT_LGN(OP, 13) CPT_LGN(OP, 14) CPT_LGN(OP, 15) CPT_LGN(OP, 16) CPT_LGN(OP, 17)
+template <typename TIO, int PIXB>
+__device__ __forceinline__ void row_load16w(uint32_t (&v)[20], unsigned vl, unsigned vm, unsigned vr, i32x4 rs, int rb, int pix)
+{
+    static_assert(sizeof(TIO) == 2, "16-wide tiles take 16-bit activations");
+    int t, t2;
+    if constexpr (PIXB > 0 && PIXB * 15 <= 4095) {
+        (void)pix; (void)t2;
+        if constexpr (std::is_same<TIO, f16_t>::value)
+            asm volatile(UPW_ROW_IMM(CPT_LDH) : CPT_OUT20(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+        else
+            asm volatile(UPW_ROW_IMM(CPT_LD16) : CPT_OUT20(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+    } else {
+        if constexpr (std::is_same<TIO, f16_t>::value)
+            asm volatile(UPW_ROW_GEN(CPT_LDH) : CPT_OUT20(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+        else
+            asm volatile(UPW_ROW_GEN(CPT_LD16) : CPT_OUT20(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+    }
+}
+template <typename T16, int PIXB>
+__device__ __forceinline__ void row_store16w(const f32x2 (&a)[8], unsigned vo, i32x4 rs, int rb, int pix)
+{
+    uint32_t p[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if constexpr (std::is_same<T16, f16_t>::value) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p[j]) : "v"(a[j].x), "v"(a[j].y));
+        else asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p[j]) : "v"(a[j].x), "v"(a[j].y));
+    }
+    int t, t2;
+    if constexpr (PIXB > 0 && PIXB * 15 <= 4095) {
+        (void)pix; (void)t2;
+        asm volatile("s_add_i32 %[t], %[rb], 0\n\t"
+                     CPT_SI("buffer_store_short", 0, "t", 0) CPT_SI("buffer_store_short_d16_hi", 0, "t", 1) CPT_SI("buffer_store_short", 1, "t", 2)
+                     CPT_SI("buffer_store_short_d16_hi", 1, "t", 3) CPT_SI("buffer_store_short", 2, "t", 4) CPT_SI("buffer_store_short_d16_hi", 2, "t", 5)
+                     CPT_SI("buffer_store_short", 3, "t", 6) CPT_SI("buffer_store_short_d16_hi", 3, "t", 7) CPT_SI("buffer_store_short", 4, "t", 8)
+                     CPT_SI("buffer_store_short_d16_hi", 4, "t", 9) CPT_SI("buffer_store_short", 5, "t", 10) CPT_SI("buffer_store_short_d16_hi", 5, "t", 11)
+                     CPT_SI("buffer_store_short", 6, "t", 12) CPT_SI("buffer_store_short_d16_hi", 6, "t", 13) CPT_SI("buffer_store_short", 7, "t", 14)
+                     CPT_SI("buffer_store_short_d16_hi", 7, "t", 15)
+                     : [t] "=&s"(t)
+                     : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [p4] "v"(p[4]), [p5] "v"(p[5]), [p6] "v"(p[6]), [p7] "v"(p[7]),
+                       [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc", "memory");
+    } else {
+        asm volatile("s_add_i32 %[t2], %[rb], 0\n\t"
+                     CPT_SG("buffer_store_short", 0, "t2") CPT_SGN("buffer_store_short_d16_hi", 0) CPT_SGN("buffer_store_short", 1) CPT_SGN("buffer_store_short_d16_hi", 1)
+                     CPT_SGN("buffer_store_short", 2) CPT_SGN("buffer_store_short_d16_hi", 2) CPT_SGN("buffer_store_short", 3) CPT_SGN("buffer_store_short_d16_hi", 3)
+                     CPT_SGN("buffer_store_short", 4) CPT_SGN("buffer_store_short_d16_hi", 4) CPT_SGN("buffer_store_short", 5) CPT_SGN("buffer_store_short_d16_hi", 5)
+                     CPT_SGN("buffer_store_short", 6) CPT_SGN("buffer_store_short_d16_hi", 6) CPT_SGN("buffer_store_short", 7) CPT_SGN("buffer_store_short_d16_hi", 7)
+                     : [t2] "=&s"(t2)
+                     : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [p4] "v"(p[4]), [p5] "v"(p[5]), [p6] "v"(p[6]), [p7] "v"(p[7]),
+                       [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc", "memory");
+        (void)t;
+    }
+}
+// the tile-width-generic faces of the row statements
+template <typename TIO, int PIXB> __device__ __forceinline__ void xrow_load(uint32_t (&v)[18], unsigned vl, unsigned vm, unsigned vr, i32x4 rs, int rb, int pix) { row_load<TIO, PIXB>(v, vl, vm, vr, rs, rb, pix); }
+template <typename TIO, int PIXB> __device__ __forceinline__ void xrow_load(uint32_t (&v)[20], unsigned vl, unsigned vm, unsigned vr, i32x4 rs, int rb, int pix) { row_load16w<TIO, PIXB>(v, vl, vm, vr, rs, rb, pix); }
+template <int PENDING> __device__ __forceinline__ void xrow_pin(uint32_t (&v)[18]) { pin_row<PENDING>(v); }
+template <int PENDING> __device__ __forceinline__ void xrow_pin(uint32_t (&v)[20]) { pin_row20<PENDING>(v); }
+template <typename TIO, int PIXB> __device__ __forceinline__ void yrow_store(const f32x2 (&a)[7], unsigned vo, i32x4 rs, int rb, int pix) { RowSt<TIO, PIXB>::st(a, vo, rs, rb, pix); }
+template <typename TIO, int PIXB> __device__ __forceinline__ void yrow_store(const f32x2 (&a)[8], unsigned vo, i32x4 rs, int rb, int pix) { row_store16w<TIO, PIXB>(a, vo, rs, rb, pix); }
 
 // MODE 0 bilinear (exact 2x: weights 1/4, 3/4, clamped borders = ATen's align_corners=False arithmetic), 1 nearest.
 // PIXB = bytes per pixel of x and y when known at compile time (64 or 128 channels of a 16-bit type), 0 = run time.
-template <int MODE, int PIXB, typename TIO, typename TC>
+template <int MODE, int PIXB, typename TIO, typename TC, int TW = 14>
 __global__ __launch_bounds__(256, 2) void k_upadd_cpt(const TIO* __restrict__ x, const TC* __restrict__ coarse, TIO* __restrict__ y,
                                                       const float* __restrict__ w, const float* __restrict__ bias, int N, int C, int H, int W, int has_bias)
 {
-    constexpr int ESZ = (int)sizeof(TIO), CSZ = (int)sizeof(TC), NST = 14;
+    constexpr int ESZ = (int)sizeof(TIO), CSZ = (int)sizeof(TC), NP = TW / 2, NCOL = TW + 4, NCR = TW / 2 + 4, NHP = NCOL / 2;
+    static_assert(TW == 14 || (TW == 16 && sizeof(TIO) == 2), "tile width");
     // float16 converts every element into a second register: one row less in flight keeps the kernel inside 256 registers (a spilled
     // row register would be stored before its load has landed)
-    constexpr int AHEAD = std::is_same<TIO, f16_t>::value ? 1 : 2;
-    using S = Sched<MODE, NST, AHEAD>;
-    const int nb = (C + 63) / 64, TR = (H + 13) / 14, TCn = W / 14, Hc = H / 2, Wc = W / 2;
+    constexpr int AHEAD = (std::is_same<TIO, f16_t>::value || TW == 16) ? 1 : 2;
+    using S = Sched<MODE, TW, AHEAD>;
+    const int nb = (C + 63) / 64, TR = (H + 13) / 14, TCn = W / TW, Hc = H / 2, Wc = W / 2;
     const int pix = PIXB ? PIXB : C * ESZ, pixc = C * CSZ;
     const unsigned total = (unsigned)N * nb * TR * TCn;
     const int lane = (int)(threadIdx.x & 63);
@@ -129,10 +228,10 @@ __global__ __launch_bounds__(256, 2) void k_upadd_cpt(const TIO* __restrict__ x,
         ysrc.w = 0x00020000;
     }
     const unsigned cvo = (unsigned)(cc * CSZ);
-    const int cb0 = 7 * tc;
+    const int cb0 = NP * tc;
     // scalar column offsets of the clamped outer coarse columns, relative to column cb0 of the row
     const int l0 = __builtin_amdgcn_readfirstlane(ledge ? 0 : -2 * pixc), l1 = __builtin_amdgcn_readfirstlane(ledge ? 0 : -pixc);
-    const int r0 = __builtin_amdgcn_readfirstlane((redge ? 6 : 7) * pixc), r1 = __builtin_amdgcn_readfirstlane((redge ? 6 : 8) * pixc);
+    const int r0 = __builtin_amdgcn_readfirstlane((redge ? NP - 1 : NP) * pixc), r1 = __builtin_amdgcn_readfirstlane((redge ? NP - 1 : NP + 1) * pixc);
     auto load_coarse = [&](uint32_t (&dst)[NCR], int i) {        // tile-local coarse row i, clamped into the plane (ATen's border rule)
         int ar = 7 * tr + i;
         ar = ar < 0 ? 0 : (ar > Hc - 1 ? Hc - 1 : ar);
@@ -141,38 +240,38 @@ __global__ __launch_bounds__(256, 2) void k_upadd_cpt(const TIO* __restrict__ x,
     };
     const float lmask = ledge ? 0.f : 1.f, rmask = redge ? 0.f : 1.f;
     const f32x2 wq = MODE == 1 ? splat(0.f) : splat(0.25f), wt = MODE == 1 ? splat(1.f) : splat(0.75f);
-    // H row: a coarse row resized horizontally to the 18 columns -2 .. 15 (pairs outside the image zeroed)
-    auto build_H = [&](f32x2 (&Hs)[9], const uint32_t (&cr)[NCR]) {
+    // H row: a coarse row resized horizontally to the columns -2 .. TW + 1 (pairs outside the image zeroed)
+    auto build_H = [&](f32x2 (&Hs)[NHP], const uint32_t (&cr)[NCR]) {
         float cv[NCR];
 #pragma unroll
         for (int k = 0; k < NCR; ++k) cv[k] = raw_f32<TC>(cr[k]);
         f32x2 P[6], Pq[6];
 #pragma unroll
-        for (int m = 0; m < 6; ++m) { P[m] = f32x2{cv[2 * m], m < 5 ? cv[2 * m + 1] : 0.f}; Pq[m] = P[m] * wq; }
-        sfor<9>([&](auto jc) {
+        for (int m = 0; m < 6; ++m) { P[m] = f32x2{cv[2 * m], 2 * m + 1 < NCR ? cv[2 * m + 1 < NCR ? 2 * m + 1 : 0] : 0.f}; Pq[m] = P[m] * wq; }
+        sfor<NHP>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             const f32x2 e = f32x2{(j & 1) ? Pq[j >> 1].y : Pq[j >> 1].x, (j & 1) ? Pq[(j >> 1) + 1].y : Pq[(j >> 1) + 1].x};
             const float mid = ((j + 1) & 1) ? P[(j + 1) >> 1].y : P[(j + 1) >> 1].x;
             Hs[j] = pfma(splat(mid), wt, e);
         });
         Hs[0] = Hs[0] * splat(lmask);
-        Hs[8] = Hs[8] * splat(rmask);
+        Hs[NHP - 1] = Hs[NHP - 1] * splat(rmask);
     };
 
-    const unsigned voffM = (unsigned)((14 * tc) * pix + cc * ESZ);
+    const unsigned voffM = (unsigned)((TW * tc) * pix + cc * ESZ);
     const unsigned voffL = ledge ? OOB : voffM - 2u * (unsigned)pix;
-    const unsigned voffR = redge ? OOB : voffM + 14u * (unsigned)pix;
-    auto load_row = [&](uint32_t (&raw)[18], int r) {            // rows outside the plane: a valid row is loaded and not used
+    const unsigned voffR = redge ? OOB : voffM + (unsigned)TW * (unsigned)pix;
+    auto load_row = [&](uint32_t (&raw)[NCOL], int r) {          // rows outside the plane: a valid row is loaded and not used
         int ar = 14 * tr + r;
         ar = ar < 0 ? 0 : (ar > H - 1 ? H - 1 : ar);
         const int rb = __builtin_amdgcn_readfirstlane(ar * (W * pix));
-        row_load<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
+        xrow_load<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
     };
     auto row_valid = [&](int r) -> bool { const int ar = 14 * tr + r; return ar >= 0 && ar < H; };       // uniform
 
-    uint32_t raw[NR][18];
-    f32x2 Hh[2][9];
-    f32x2 acc[5][7];
+    uint32_t raw[NR][NCOL];
+    f32x2 Hh[2][NHP];
+    f32x2 acc[5][NP];
     uint32_t craw[NCR];
     {
         // prologue, in the order Sched replays: coarse rows -2, -1, 0, then x rows -2, -1, then (compiler-counted) the taps
@@ -195,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void k_upadd_cpt(const TIO* __restrict__ x,
     for (int u = 0; u < 5; ++u) { pin(tf.p[u][0]); pin(tf.p[u][1]); pin(tf.p[u][2]); }
     f32x2 bf = splat(tf.bias);
     pin(bf);                                                     // a real register pair: no half of it is ever borrowed from a row in flight
-    const unsigned yoff = cvalid ? (unsigned)((14 * tc) * pix + c * ESZ) : OOB;
+    const unsigned yoff = cvalid ? (unsigned)((TW * tc) * pix + c * ESZ) : OOB;
 
     sfor<NR>([&](auto rc) {
         constexpr int ri = decltype(rc)::value, t = ri - 2;
@@ -212,43 +311,43 @@ __global__ __launch_bounds__(256, 2) void k_upadd_cpt(const TIO* __restrict__ x,
             build_H(Hh[(ib + 2) & 1], craw);
             if constexpr (ib + 1 <= S::c_last) load_coarse(craw, ib + 1);
         }
-        pin_row<S::cap(S::pending(2, ri))>(raw[ri]);
+        xrow_pin<S::cap(S::pending(2, ri))>(raw[ri]);
         if (row_valid(t)) {
-            f32x2 row[9], odd[8];
+            f32x2 row[NHP], odd[NHP - 1];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
+            for (int k = 0; k < NHP; ++k) {
                 const f32x2 xv = f32x2{raw_f32<TIO>(raw[ri][2 * k]), raw_f32<TIO>(raw[ri][2 * k + 1])};
                 if (MODE == 1) row[k] = xv + Hh[(i0 + 2) & 1][k];
                 else row[k] = pfma(splat(lam), Hh[(i1 + 2) & 1][k], pfma(splat(1.f - lam), Hh[(i0 + 2) & 1][k], xv));
             }
             // the two columns left of the image and right of it are zero padding of the conv INPUT: x read 0 there and H was zeroed
 #pragma unroll
-            for (int j = 0; j < 8; ++j) odd[j] = shift1(row[j], row[j + 1]);
+            for (int j = 0; j < NHP - 1; ++j) odd[j] = shift1(row[j], row[j + 1]);
 #pragma unroll
             for (int u = 0; u < 5; ++u) {
                 const int o = t - u + 2;
                 if (o < 0 || o > 13) continue;
-                f32x2(&a)[7] = acc[o % 5];
+                f32x2(&a)[NP] = acc[o % 5];
 #pragma unroll
-                for (int j = 0; j < 7; ++j) a[j] = pfma(row[j], splat(tf.at(u, 0)), u == 0 ? bf : a[j]);
+                for (int j = 0; j < NP; ++j) a[j] = pfma(row[j], splat(tf.at(u, 0)), u == 0 ? bf : a[j]);
 #pragma unroll
-                for (int j = 0; j < 7; ++j) a[j] = pfma(odd[j], splat(tf.at(u, 1)), a[j]);
+                for (int j = 0; j < NP; ++j) a[j] = pfma(odd[j], splat(tf.at(u, 1)), a[j]);
 #pragma unroll
-                for (int j = 0; j < 7; ++j) a[j] = pfma(row[j + 1], splat(tf.at(u, 2)), a[j]);
+                for (int j = 0; j < NP; ++j) a[j] = pfma(row[j + 1], splat(tf.at(u, 2)), a[j]);
 #pragma unroll
-                for (int j = 0; j < 7; ++j) a[j] = pfma(odd[j + 1], splat(tf.at(u, 3)), a[j]);
+                for (int j = 0; j < NP; ++j) a[j] = pfma(odd[j + 1], splat(tf.at(u, 3)), a[j]);
 #pragma unroll
-                for (int j = 0; j < 7; ++j) a[j] = pfma(row[j + 2], splat(tf.at(u, 4)), a[j]);
+                for (int j = 0; j < NP; ++j) a[j] = pfma(row[j + 2], splat(tf.at(u, 4)), a[j]);
             }
         } else if constexpr (t + 2 >= 0 && t + 2 <= 13) {
 #pragma unroll
-            for (int j = 0; j < 7; ++j) acc[(t + 2) % 5][j] = bf;
+            for (int j = 0; j < NP; ++j) acc[(t + 2) % 5][j] = bf;
         }
         if constexpr (t - 2 >= 0 && t - 2 <= 13) {
             constexpr int o = t - 2;
             const int arow = 14 * tr + o;
             const int yrb = __builtin_amdgcn_readfirstlane((arow < H ? arow : 0) * (W * pix));
-            RowSt<TIO, PIXB>::st(acc[o % 5], arow < H ? yoff : OOB, ysrc, yrb, pix);     // rows past the plane: dropped, but issued (Sched counts them)
+            yrow_store<TIO, PIXB>(acc[o % 5], arow < H ? yoff : OOB, ysrc, yrb, pix);      // rows past the plane: dropped, but issued (Sched counts them)
         }
 #pragma unroll
         for (int o = 0; o < 14; ++o) if (o > t - 2 && o <= t + 2) pin(acc[o % 5]);
@@ -266,22 +365,22 @@ __global__ __launch_bounds__(256, 2) void k_upadd_cpt(const TIO* __restrict__ x,
 // output share a register pair and are added at the end), an output row of 7 pixels leaves as one statement.
 constexpr int NR1 = 17;           // input rows of a tile: -2 .. 14
 
-template <int AHEAD> struct SchedDown {
+template <int AHEAD, int TW> struct SchedDown {
     static constexpr int pending(int ri_target)
     {
         int seq = 0, xend[NR1 + AHEAD + 1] = {};
-        for (int r = 0; r < AHEAD; ++r) { seq += 18; xend[r] = seq; }
+        for (int r = 0; r < AHEAD; ++r) { seq += TW + 4; xend[r] = seq; }
         for (int ri = 0; ri < NR1; ++ri) {
-            if (ri + AHEAD < NR1) { seq += 18; xend[ri + AHEAD] = seq; }
+            if (ri + AHEAD < NR1) { seq += TW + 4; xend[ri + AHEAD] = seq; }
             if (ri == ri_target) return seq - xend[ri];
-            if (ri >= 4 && (ri & 1) == 0) seq += 7;               // output row (ri - 4) / 2 leaves at the end of the iteration
+            if (ri >= 4 && (ri & 1) == 0) seq += TW / 2;          // output row (ri - 4) / 2 leaves at the end of the iteration
         }
         return 0;
     }
     static constexpr int cap(int v) { return v > 63 ? 63 : v; }
 };
 
-// one output row: 7 pixels, pitch `pix` bytes; vo out of range -> dropped (but issued)
+// one output row: 7 (8: 16-wide tiles) pixels, pitch `pix` bytes; vo out of range -> dropped (but issued)
 #define DN_S(OP, d) OP " %[p" #d "], %[vo], %[rs], %[t] offen\n\t"
 #define DN_N "s_add_i32 %[t], %[t], %[pix]\n\t"
 template <typename TO> struct DownSt;
@@ -293,6 +392,16 @@ template <> struct DownSt<float> {
                      DN_S("buffer_store_dword", 3) DN_N DN_S("buffer_store_dword", 4) DN_N DN_S("buffer_store_dword", 5) DN_N DN_S("buffer_store_dword", 6)
                      : [t] "=&s"(t)
                      : [p0] "v"(v[0]), [p1] "v"(v[1]), [p2] "v"(v[2]), [p3] "v"(v[3]), [p4] "v"(v[4]), [p5] "v"(v[5]), [p6] "v"(v[6]),
+                       [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc", "memory");
+    }
+    static __device__ __forceinline__ void st(const float (&v)[8], unsigned vo, i32x4 rs, int rb, int pix)
+    {
+        int t;
+        asm volatile("s_add_i32 %[t], %[rb], 0\n\t" DN_S("buffer_store_dword", 0) DN_N DN_S("buffer_store_dword", 1) DN_N DN_S("buffer_store_dword", 2) DN_N
+                     DN_S("buffer_store_dword", 3) DN_N DN_S("buffer_store_dword", 4) DN_N DN_S("buffer_store_dword", 5) DN_N DN_S("buffer_store_dword", 6) DN_N
+                     DN_S("buffer_store_dword", 7)
+                     : [t] "=&s"(t)
+                     : [p0] "v"(v[0]), [p1] "v"(v[1]), [p2] "v"(v[2]), [p3] "v"(v[3]), [p4] "v"(v[4]), [p5] "v"(v[5]), [p6] "v"(v[6]), [p7] "v"(v[7]),
                        [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc", "memory");
     }
 };
@@ -308,17 +417,30 @@ template <typename T16> struct DownSt16 {
                      : [t] "=&s"(t)
                      : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc", "memory");
     }
+    static __device__ __forceinline__ void st(const float (&v)[8], unsigned vo, i32x4 rs, int rb, int pix)
+    {
+        uint32_t p[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = pk16<T16>(v[2 * j], v[2 * j + 1]);
+        int t;
+        asm volatile("s_add_i32 %[t], %[rb], 0\n\t" DN_S("buffer_store_short", 0) DN_N DN_S("buffer_store_short_d16_hi", 0) DN_N DN_S("buffer_store_short", 1) DN_N
+                     DN_S("buffer_store_short_d16_hi", 1) DN_N DN_S("buffer_store_short", 2) DN_N DN_S("buffer_store_short_d16_hi", 2) DN_N DN_S("buffer_store_short", 3) DN_N
+                     DN_S("buffer_store_short_d16_hi", 3)
+                     : [t] "=&s"(t)
+                     : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc", "memory");
+    }
 };
 template <> struct DownSt<bf16_t> : DownSt16<bf16_t> {};
 template <> struct DownSt<f16_t> : DownSt16<f16_t> {};
 
-template <int PIXB, typename TIO, typename TO>
+template <int PIXB, typename TIO, typename TO, int TW = 14>
 __global__ __launch_bounds__(256, 2) void k_down5_cpt(const TIO* __restrict__ x, TO* __restrict__ y, const float* __restrict__ w, const float* __restrict__ bias,
                                                       int N, int C, int H, int W, int has_bias)
 {
-    constexpr int ESZ = (int)sizeof(TIO), OSZ = (int)sizeof(TO), AHEAD = 3;
-    using S = SchedDown<AHEAD>;
-    const int nb = (C + 63) / 64, TR = (H + 13) / 14, TCn = W / 14, Ho = H / 2, Wo = W / 2;
+    constexpr int ESZ = (int)sizeof(TIO), OSZ = (int)sizeof(TO), AHEAD = 3, NPO = TW / 2, NCOL = TW + 4, NHP = NCOL / 2;
+    static_assert(TW == 14 || (TW == 16 && sizeof(TIO) == 2), "tile width");
+    using S = SchedDown<AHEAD, TW>;
+    const int nb = (C + 63) / 64, TR = (H + 13) / 14, TCn = W / TW, Ho = H / 2, Wo = W / 2;
     const int pix = PIXB ? PIXB : C * ESZ, pixo = C * OSZ;
     const unsigned total = (unsigned)N * nb * TR * TCn;
     const int lane = (int)(threadIdx.x & 63);
@@ -347,17 +469,17 @@ __global__ __launch_bounds__(256, 2) void k_down5_cpt(const TIO* __restrict__ x,
         ysrc.z = Ho * Wo * pixo;
         ysrc.w = 0x00020000;
     }
-    const unsigned voffM = (unsigned)((14 * tc) * pix + cc * ESZ);
+    const unsigned voffM = (unsigned)((TW * tc) * pix + cc * ESZ);
     const unsigned voffL = ledge ? OOB : voffM - 2u * (unsigned)pix;
-    const unsigned voffR = redge ? OOB : voffM + 14u * (unsigned)pix;
-    auto load_row = [&](uint32_t (&raw)[18], int r) {
+    const unsigned voffR = redge ? OOB : voffM + (unsigned)TW * (unsigned)pix;
+    auto load_row = [&](uint32_t (&raw)[NCOL], int r) {
         int ar = 14 * tr + r;
         ar = ar < 0 ? 0 : (ar > H - 1 ? H - 1 : ar);
         const int rb = __builtin_amdgcn_readfirstlane(ar * (W * pix));
-        row_load<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
+        xrow_load<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
     };
     auto row_valid = [&](int r) -> bool { const int ar = 14 * tr + r; return ar >= 0 && ar < H; };
-    uint32_t raw[NR1][18];
+    uint32_t raw[NR1][NCOL];
     sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], -2 + decltype(rc)::value); });
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 25 * C * 4, 0x00020000);
     Taps td;
@@ -366,36 +488,36 @@ __global__ __launch_bounds__(256, 2) void k_down5_cpt(const TIO* __restrict__ x,
     for (int u = 0; u < 5; ++u) { pin(td.p[u][0]); pin(td.p[u][1]); pin(td.p[u][2]); }       // landed here, on every path (see k_upadd_cpt)
     f32x2 b0 = f32x2{td.bias, 0.f};
     pin(b0);
-    const unsigned yoff = cvalid ? (unsigned)((7 * tc) * pixo + c * OSZ) : OOB;
-    f32x2 facc[3][7];
+    const unsigned yoff = cvalid ? (unsigned)((NPO * tc) * pixo + c * OSZ) : OOB;
+    f32x2 facc[3][NPO];
     sfor<NR1>([&](auto rc) {
         constexpr int ri = decltype(rc)::value, r = ri - 2;
         if constexpr (ri + AHEAD < NR1) load_row(raw[ri + AHEAD], r + AHEAD);
-        pin_row<S::cap(S::pending(ri))>(raw[ri]);
-        f32x2 xr[9];
+        xrow_pin<S::cap(S::pending(ri))>(raw[ri]);
+        f32x2 xr[NHP];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) xr[k] = f32x2{raw_f32<TIO>(raw[ri][2 * k]), raw_f32<TIO>(raw[ri][2 * k + 1])};
+        for (int k = 0; k < NHP; ++k) xr[k] = f32x2{raw_f32<TIO>(raw[ri][2 * k]), raw_f32<TIO>(raw[ri][2 * k + 1])};
         const bool rv = row_valid(r);
 #pragma unroll
         for (int o = 0; o < 7; ++o) {
             const int u = r - 2 * o + 2;
             if (u < 0 || u > 4) continue;
-            f32x2(&a)[7] = facc[o % 3];
+            f32x2(&a)[NPO] = facc[o % 3];
             if (rv) {
 #pragma unroll
-                for (int i = 0; i < 7; ++i) a[i] = pfma(xr[i], td.p[u][0], u == 0 ? b0 : a[i]);
+                for (int i = 0; i < NPO; ++i) a[i] = pfma(xr[i], td.p[u][0], u == 0 ? b0 : a[i]);
 #pragma unroll
-                for (int i = 0; i < 7; ++i) a[i] = pfma(xr[i + 1], td.p[u][1], a[i]);
+                for (int i = 0; i < NPO; ++i) a[i] = pfma(xr[i + 1], td.p[u][1], a[i]);
 #pragma unroll
-                for (int i = 0; i < 7; ++i) a[i].x = fmaf(xr[i + 2].x, td.p[u][2].x, a[i].x);
+                for (int i = 0; i < NPO; ++i) a[i].x = fmaf(xr[i + 2].x, td.p[u][2].x, a[i].x);
             } else if (u == 0) {
 #pragma unroll
-                for (int i = 0; i < 7; ++i) a[i] = b0;
+                for (int i = 0; i < NPO; ++i) a[i] = b0;
             }
             if (u == 4) {
-                float out[7];
+                float out[NPO];
 #pragma unroll
-                for (int i = 0; i < 7; ++i) out[i] = a[i].x + a[i].y;
+                for (int i = 0; i < NPO; ++i) out[i] = a[i].x + a[i].y;
                 const int orow = 7 * tr + o;
                 const int yrb = __builtin_amdgcn_readfirstlane((orow < Ho ? orow : 0) * (Wo * pixo));
                 DownSt<TO>::st(out, orow < Ho ? yoff : OOB, ysrc, yrb, pixo);
@@ -410,16 +532,26 @@ __global__ __launch_bounds__(256, 2) void k_down5_cpt(const TIO* __restrict__ x,
 template <typename TIO, typename TO>
 static hipError_t launch_down(const void* x, void* y, const float* w, const float* b, int N, int C, int H, int W, hipStream_t s)
 {
-    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / 14);
+    const int tw = tile_width(W, std::is_same<TIO, bf16_t>::value ? 1 : 0);
+    if (tw == 0) return hipErrorInvalidConfiguration;
+    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / tw);
     const dim3 grid((unsigned)((units + 3) / 4)), block(256);
     const int hb = b != nullptr;
     const int pixb = C * (int)sizeof(TIO);
-#define RCX_GO(PB) hipLaunchKernelGGL((k_down5_cpt<PB, TIO, TO>), grid, block, 0, s, (const TIO*)x, (TO*)y, w, b, N, C, H, W, hb)
-    if constexpr (sizeof(TIO) == 2) {
-        if (pixb == 128) { RCX_GO(128); return hipGetLastError(); }
-        if (pixb == 256) { RCX_GO(256); return hipGetLastError(); }
+#define RCX_GO(PB, TW) hipLaunchKernelGGL((k_down5_cpt<PB, TIO, TO, TW>), grid, block, 0, s, (const TIO*)x, (TO*)y, w, b, N, C, H, W, hb)
+    if constexpr (std::is_same<TIO, bf16_t>::value) {
+        if (tw == 16) {
+            if (pixb == 128) RCX_GO(128, 16);
+            else if (pixb == 256) RCX_GO(256, 16);
+            else RCX_GO(0, 16);
+            return hipGetLastError();
+        }
     }
-    RCX_GO(0);
+    if constexpr (sizeof(TIO) == 2) {
+        if (pixb == 128) { RCX_GO(128, 14); return hipGetLastError(); }
+        if (pixb == 256) { RCX_GO(256, 14); return hipGetLastError(); }
+    }
+    RCX_GO(0, 14);
 #undef RCX_GO
     return hipGetLastError();
 }
@@ -434,38 +566,49 @@ static inline bool enabled()
 template <int MODE, typename TIO, typename TC>
 static hipError_t launch(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int H, int W, hipStream_t s)
 {
-    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / 14);
+    const int tw = tile_width(W, std::is_same<TIO, bf16_t>::value ? 1 : 0);
+    if (tw == 0) return hipErrorInvalidConfiguration;
+    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / tw);
     const dim3 grid((unsigned)((units + 3) / 4)), block(256);
     const int hb = b != nullptr;
     const int pixb = C * (int)sizeof(TIO);
-#define RCX_GO(PB) hipLaunchKernelGGL((k_upadd_cpt<MODE, PB, TIO, TC>), grid, block, 0, s, (const TIO*)x, (const TC*)coarse, (TIO*)y, w, b, N, C, H, W, hb)
-    if constexpr (sizeof(TIO) == 2) {
-        if (pixb == 128) { RCX_GO(128); return hipGetLastError(); }
-        if (pixb == 256) { RCX_GO(256); return hipGetLastError(); }
+#define RCX_GO(PB, TW) hipLaunchKernelGGL((k_upadd_cpt<MODE, PB, TIO, TC, TW>), grid, block, 0, s, (const TIO*)x, (const TC*)coarse, (TIO*)y, w, b, N, C, H, W, hb)
+    if constexpr (std::is_same<TIO, bf16_t>::value) {
+        if (tw == 16) {
+            if (pixb == 128) RCX_GO(128, 16);
+            else if (pixb == 256) RCX_GO(256, 16);
+            else RCX_GO(0, 16);
+            return hipGetLastError();
+        }
     }
-    RCX_GO(0);
+    if constexpr (sizeof(TIO) == 2) {
+        if (pixb == 128) { RCX_GO(128, 14); return hipGetLastError(); }
+        if (pixb == 256) { RCX_GO(256, 14); return hipGetLastError(); }
+    }
+    RCX_GO(0, 14);
 #undef RCX_GO
     return hipGetLastError();
 }
 
 }  // namespace upcpt
 
-// y = conv5(x + resize2x(coarse)): exact 2x planes whose width is a multiple of 14, at least one full tile high; the 14 x 14 plane has
-// its own whole-plane kernel (rcx_cpl14.hip)
+// y = conv5(x + resize2x(coarse)): exact 2x planes whose width is a multiple of 14 (or of 16: 16-bit x), at least 28 x 28; the 14 x 14
+// plane has its own whole-plane kernel (rcx_cpl14.hip)
 bool upadd_cpt_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int x_dt, int c_dt, int out_dt)
 {
     if (!upcpt::enabled() || k != 5 || out_dt != x_dt || x_dt < 0 || x_dt > 2 || !(c_dt == x_dt || c_dt == 0)) return false;
-    if (N < 1 || C < 1 || Hc * 2 != H || Wc * 2 != W || W % 14 != 0 || H < 28 || W < 28) return false;
+    const int tw = upcpt::tile_width(W, x_dt);
+    if (N < 1 || C < 1 || Hc * 2 != H || Wc * 2 != W || tw == 0 || H < 28 || W < 28) return false;
     const long long img = (long long)H * W * C * 4;
-    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / 14);
+    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / tw);
     return img < (1ll << 31) && units < (1ll << 31);
 }
 
 int upadd_cpt_describe(int N, int C, int H, int W, int mode, int x_dt, char* buf, int len)
 {
-    const int pixb = x_dt != 0 && (C == 64 || C == 128) ? C * 2 : 0;
-    return snprintf(buf, len, "upadd_cpt(k_upadd_cpt<%d, %d>,cb=64,nt=256,tiles=%lld)", mode, pixb,
-                    (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / 14));
+    const int pixb = x_dt != 0 && (C == 64 || C == 128) ? C * 2 : 0, tw = upcpt::tile_width(W, x_dt);
+    return snprintf(buf, len, "upadd_cpt(k_upadd_cpt<%d, %d>,tw=%d,cb=64,nt=256,tiles=%lld)", mode, pixb, tw,
+                    (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / (tw ? tw : 14)));
 }
 
 hipError_t upadd_cpt(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int H, int W, int mode,
@@ -482,9 +625,10 @@ hipError_t upadd_cpt(const void* x, const void* coarse, void* y, const float* w,
 bool down5_cpt_applicable(int N, int C, int H, int W, int k, int stride, int in_dt, int out_dt)
 {
     if (!upcpt::enabled() || k != 5 || stride != 2 || in_dt < 0 || in_dt > 2 || !(out_dt == in_dt || out_dt == 0)) return false;
-    if (N < 1 || C < 1 || (H & 1) || W % 14 != 0 || H < 28 || W < 28) return false;
+    const int tw = upcpt::tile_width(W, in_dt);
+    if (N < 1 || C < 1 || (H & 1) || tw == 0 || H < 28 || W < 28) return false;
     const long long img = (long long)H * W * C * 4;
-    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / 14);
+    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / tw);
     return img < (1ll << 31) && units < (1ll << 31);
 }
 
