@@ -83,8 +83,25 @@ class Downsample(nn.Module):
         self.channel_mixer = channel_mlp(out_channels, out_channels * mlp_ratio, act_layer)
         object.__setattr__(self, "_hip", None)          # set by use_hip_downsample; never a registered child (state_dict keys stay)
 
+    def _hip_path(self):
+        """The HIP reroute if it still wraps THIS module's current children.  A child replaced after use_hip_downsample
+        (SyncBatchNorm.convert_sync_batchnorm, a fusion pass, `m.norm = ...`) must be followed: the old module's parameters
+        are in neither state_dict nor the optimizer any more.  Whole-model pickles from before the reroute existed have no attribute."""
+        hip = self.__dict__.get("_hip")
+        if hip is not None and (hip.token_mixer is not self.token_mixer or hip.norm is not self.norm):
+            hip = None
+            if isinstance(self.token_mixer, nn.Conv2d) and type(self.norm) is nn.BatchNorm2d:
+                from .dwconv import DownsampleDwConv
+                try:
+                    hip = DownsampleDwConv(self.token_mixer, self.norm)
+                except ValueError:                       # not the depthwise C -> 2C conv any more: the PyTorch operators
+                    hip = None
+            object.__setattr__(self, "_hip", hip)
+        return hip
+
     def forward(self, x):
-        x = self._hip(x) if self._hip is not None else self.norm(self.token_mixer(x))
+        hip = self._hip_path()
+        x = hip(x) if hip is not None else self.norm(self.token_mixer(x))
         return x + self.channel_mixer(x)
 
 

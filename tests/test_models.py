@@ -59,6 +59,27 @@ def test_hip_skeleton_has_reference_state_dict_keys():
         assert keys == set(sd)
 
 
+def test_downsample_reroute_follows_replaced_children():
+    """use_hip_downsample keeps direct references to token_mixer and norm; a child replaced afterwards (SyncBatchNorm conversion, a
+    fusion pass, `m.norm = ...`) must be the one that runs, and a module pickled before the reroute existed must still run."""
+    from recnext_amd.models import Downsample
+    m = Downsample(8, 2, torch.nn.GELU).eval()
+    net = torch.nn.Sequential(m)
+    assert models.use_hip_downsample(net) == 1 and m._hip is not None
+    x = torch.randn(2, 8, 8, 8)
+    m.norm = torch.nn.GroupNorm(4, 16)                          # not a BatchNorm2d: the reroute is dropped, the new norm runs (on the CPU here)
+    want = m.norm(m.token_mixer(x))
+    want = want + m.channel_mixer(want)
+    assert torch.allclose(m(x), want) and m._hip is None
+    m.norm = torch.nn.BatchNorm2d(16).eval()                    # a fresh BatchNorm2d: rerouted again, around the NEW module
+    models.use_hip_downsample(net)
+    old = m._hip
+    m.norm = torch.nn.BatchNorm2d(16).eval()
+    assert m._hip_path() is not old and m._hip_path().norm is m.norm and m._hip_path().token_mixer is m.token_mixer
+    del m.__dict__["_hip"]                                      # a whole-model pickle from before the attribute existed
+    assert m._hip_path() is None
+
+
 def test_token_mixer_shapes_and_algorithmic_bytes():
     assert models.token_mixer_shapes("recnext_m3") == [(64, 56, 56, 4, 3), (128, 28, 28, 3, 3), (256, 14, 14, 2, 13), (512, 7, 7, 1, 2)]
     # SURVEY 8d / BASELINE.md section 3 (MB per image)
