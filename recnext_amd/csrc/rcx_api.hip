@@ -592,9 +592,16 @@ int rcx_dwconv2d_mult2_fwd(const void* x, void* y, const float* w_kkc, const flo
     if (int rc = check_common(x, y, N, Cin, H, W, k, dtype)) return rc;
     if (!w_kkc) return fail(RCX_ERR_BAD_ARG, "null weight");
     if (stride != 1 && stride != 2) return fail(RCX_ERR_UNSUPPORTED, "stride %d not supported (1 or 2)", stride);
-    const char* f = rcx::opt::value(rcx::opt::FORCE_GENERIC);
+    // Downsample's conv: the register-resident lanes kernel on the planes it was built for (28 x 28 .. 64 x 64: 256 x 64 x 56 x 56 56.7 us
+    // = 0.34 of 8 TB/s against the tiled kernel's 64.3), the tiled channel-per-lane kernel (rcx_upcpt.hip, round 3) on the large lanes planes
+    // (32 x 64 x 128 x 128: 55 us against 164; 64 x 64 x 112 x 112: 61 against 246), on 14 x 14 (20.6 against 25.9) and on everything the
+    // lanes kernel has no plan for (float16; COCO stages 200 x 336: 17 us against the generic kernel's 62).  Never a function of N.
     hipError_t e;
-    if (!(f && *f && *f != '0') && rcx::down_lanes_applicable(N, Cin, H, W, k, stride, dtype))
+    const bool lanes_ok = !lanes_off() && rcx::down_lanes_applicable(N, Cin, H, W, k, stride, dtype);
+    const bool tiled_ok = !lanes_off() && rcx::down7m2_cpt_applicable(N, Cin, H, W, k, stride, dtype);
+    if (tiled_ok && (!lanes_ok || H > 64 || W > 64 || (H <= 14 && W <= 14) || upcpt_everywhere()))
+        e = rcx::down7m2_cpt(x, y, w_kkc, bias, N, Cin, H, W, dtype, (hipStream_t)stream);
+    else if (lanes_ok)
         e = rcx::down_lanes(x, y, w_kkc, bias, N, Cin, H, W, k, stride, dtype, (hipStream_t)stream);
     else
         e = rcx::generic_dwconv_mult2(x, y, w_kkc, bias, N, Cin, H, W, k, stride, dtype, (hipStream_t)stream);

@@ -69,6 +69,8 @@ bool upadd_cpt_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int
 int upadd_cpt_describe(int N, int C, int H, int W, int mode, int x_dt, char* buf, int len);
 hipError_t upadd_cpt(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int H, int W, int mode,
                      int x_dt, int c_dt, hipStream_t s);
+bool down7m2_cpt_applicable(int N, int Cin, int H, int W, int k, int stride, int dtype);
+hipError_t down7m2_cpt(const void* x, void* y, const float* w, const float* b, int N, int Cin, int H, int W, int dtype, hipStream_t s);
 bool down5_cpt_applicable(int N, int C, int H, int W, int k, int stride, int in_dt, int out_dt);
 hipError_t down5_cpt(const void* x, void* y, const float* w, const float* b, int N, int C, int H, int W, int in_dt, int out_dt, hipStream_t s);
 bool upadd_cpl14_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int x_dt, int c_dt, int out_dt);

@@ -556,6 +556,183 @@ static hipError_t launch_down(const void* x, void* y, const float* w, const floa
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+//   k_down7m2_cpt   y = conv 7x7, stride 2, channel multiplier 2 (x) + bias   -- Downsample.token_mixer (+ its folded BatchNorm),
+//                                                                                 model/recnext.py:165-166, on ANY even plane
+// A lane owns one OUTPUT channel o (input channel o / 2: the two lanes of a pair load the same element, a wave reads 64 contiguous
+// bytes per pixel and writes 128), a wave = 64 output channels of one 14 x 14 input tile = 7 x 7 outputs; input rows -3 .. 15 stream
+// through registers, taps paired ((w0,w1), (w2,w3), (w4,w5), (w6,0)), four output rows in flight.
+// Rows are addressed through PER-ROW buffer descriptors (base = the row, num_records = its bytes): a column left of the plane or right
+// of it is out of range and reads 0, a store past the row's end is dropped -- no edge flags, and the last tile column may be ragged, so
+// any even width works (the two kernels above carry image descriptors and edge flags; this is the form they should take next).
+#define DN7_ROW_IMM(OP)                                                                                                              \
+    "s_add_i32 %[t], %[rb], 0\n\t"                                                                                                  \
+    CPT_LI(OP, 0, "vl", "t", 0) CPT_LI(OP, 1, "vl", "t", 1) CPT_LI(OP, 2, "vl", "t", 2)                                              \
+    CPT_LI(OP, 3, "vm", "t", 0) CPT_LI(OP, 4, "vm", "t", 1) CPT_LI(OP, 5, "vm", "t", 2) CPT_LI(OP, 6, "vm", "t", 3)                  \
+    CPT_LI(OP, 7, "vm", "t", 4) CPT_LI(OP, 8, "vm", "t", 5) CPT_LI(OP, 9, "vm", "t", 6) CPT_LI(OP, 10, "vm", "t", 7)                 \
+    CPT_LI(OP, 11, "vm", "t", 8) CPT_LI(OP, 12, "vm", "t", 9) CPT_LI(OP, 13, "vm", "t", 10) CPT_LI(OP, 14, "vm", "t", 11)            \
+    CPT_LI(OP, 15, "vm", "t", 12) CPT_LI(OP, 16, "vm", "t", 13)                                                                      \
+    CPT_LI(OP, 17, "vr", "t", 0) CPT_LI(OP, 18, "vr", "t", 1) CPT_LI(OP, 19, "vr", "t", 2)
+#define DN7_N(OP, d, V) "s_add_i32 %[t2], %[t2], %[pix]\n\t" CPT_LG(OP, d, V, "t2")
+#define DN7_ROW_GEN(OP)                                                                                                              \
+    "s_add_i32 %[t2], %[rb], 0\n\t" CPT_LG(OP, 0, "vl", "t2") DN7_N(OP, 1, "vl") DN7_N(OP, 2, "vl")                                    \
+    "s_add_i32 %[t2], %[rb], 0\n\t" CPT_LG(OP, 17, "vr", "t2") DN7_N(OP, 18, "vr") DN7_N(OP, 19, "vr")                                 \
+    "s_add_i32 %[t2], %[rb], 0\n\t" CPT_LG(OP, 3, "vm", "t2") DN7_N(OP, 4, "vm") DN7_N(OP, 5, "vm") DN7_N(OP, 6, "vm") DN7_N(OP, 7, "vm")   \
+    DN7_N(OP, 8, "vm") DN7_N(OP, 9, "vm") DN7_N(OP, 10, "vm") DN7_N(OP, 11, "vm") DN7_N(OP, 12, "vm") DN7_N(OP, 13, "vm") DN7_N(OP, 14, "vm") \
+    DN7_N(OP, 15, "vm") DN7_N(OP, 16, "vm")
+// columns -3, -2, -1 (vl), 0 .. 13 (vm), 14, 15, 16 (vr)
+template <typename TIO, int PIXB>
+__device__ __forceinline__ void row_load7(uint32_t (&v)[20], unsigned vl, unsigned vm, unsigned vr, i32x4 rs, int rb, int pix)
+{
+    int t, t2;
+    if constexpr (PIXB > 0 && PIXB * 13 <= 4095) {
+        (void)pix; (void)t2;
+        if constexpr (std::is_same<TIO, f16_t>::value)
+            asm volatile(DN7_ROW_IMM(CPT_LDH) : CPT_OUT20(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+        else if constexpr (sizeof(TIO) == 2)
+            asm volatile(DN7_ROW_IMM(CPT_LD16) : CPT_OUT20(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+        else
+            asm volatile(DN7_ROW_IMM(CPT_LD32) : CPT_OUT20(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+    } else {
+        (void)t;
+        if constexpr (std::is_same<TIO, f16_t>::value)
+            asm volatile(DN7_ROW_GEN(CPT_LDH) : CPT_OUT20(v), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+        else if constexpr (sizeof(TIO) == 2)
+            asm volatile(DN7_ROW_GEN(CPT_LD16) : CPT_OUT20(v), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+        else
+            asm volatile(DN7_ROW_GEN(CPT_LD32) : CPT_OUT20(v), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+    }
+}
+
+constexpr int NR7 = 19;           // input rows of a tile: -3 .. 15
+template <int AHEAD> struct SchedDown7 {
+    static constexpr int pending(int ri_target)
+    {
+        int seq = 0, xend[NR7 + AHEAD + 1] = {};
+        for (int r = 0; r < AHEAD; ++r) { seq += 20; xend[r] = seq; }
+        for (int ri = 0; ri < NR7; ++ri) {
+            if (ri + AHEAD < NR7) { seq += 20; xend[ri + AHEAD] = seq; }
+            if (ri == ri_target) return seq - xend[ri];
+            if (ri >= 6 && (ri & 1) == 0) seq += 7;               // output row (ri - 6) / 2 leaves at the end of the iteration
+        }
+        return 0;
+    }
+    static constexpr int cap(int v) { return v > 63 ? 63 : v; }
+};
+
+template <int PIXB, typename TIO>
+__global__ __launch_bounds__(256, 2) void k_down7m2_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        int N, int Cin, int H, int W, int has_bias)
+{
+    constexpr int ESZ = (int)sizeof(TIO), AHEAD = 2;
+    using S = SchedDown7<AHEAD>;
+    const int Co = 2 * Cin, nb = (Co + 63) / 64, TR = (H + 13) / 14, TCn = (W + 13) / 14, Ho = H / 2, Wo = W / 2;
+    const int pix = PIXB ? PIXB : Cin * ESZ, pixo = Co * ESZ;
+    const unsigned total = (unsigned)N * nb * TR * TCn;
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (unit >= total) return;
+    const int tc = (int)(unit % (unsigned)TCn);
+    unsigned q = unit / (unsigned)TCn;
+    const int tr = (int)(q % (unsigned)TR);
+    q /= (unsigned)TR;
+    const int ob = (int)(q % (unsigned)nb), n = (int)(q / (unsigned)nb);
+    const int o = ob * 64 + lane;
+    const bool ovalid = o < Co;
+    const int oo = ovalid ? o : Co - 1;
+    const unsigned OOB = 0x80000000u;
+    const unsigned long long xbase = (unsigned long long)(reinterpret_cast<const char*>(x) + (size_t)n * H * W * pix);
+    const unsigned long long ybase = (unsigned long long)(reinterpret_cast<char*>(y) + (size_t)n * Ho * Wo * pixo);
+    // a row of x / of y as a buffer of its own: everything left, right of it (and, with zero records, an absent row) is out of range
+    auto row_desc = [&](unsigned long long base, int row, int rows, int rowbytes) {
+        const bool ok = row >= 0 && row < rows;
+        const unsigned long long a = base + (unsigned long long)(ok ? row : 0) * (unsigned long long)rowbytes;
+        // scalar arithmetic on uniform values only (n, tr, tc come out of one readfirstlane at the top): a v_readfirstlane_b32 HERE would
+        // write the descriptor's SGPRs from the vector pipe right in front of the loads that read them (5 wait states the compiler does not
+        // insert inside an asm statement; tools/check_asm_hazards.py)
+        i32x4 d;
+        d.x = (int)(unsigned)a;
+        d.y = (int)(unsigned)(a >> 32) & 0xffff;
+        d.z = ok ? rowbytes : 0;
+        d.w = 0x00020000;
+        return d;
+    };
+    const unsigned voffM = (unsigned)((14 * tc) * pix + (oo >> 1) * ESZ);
+    const unsigned voffL = voffM - 3u * (unsigned)pix;            // tile column 0: negative = out of range
+    const unsigned voffR = voffM + 14u * (unsigned)pix;
+    auto load_row = [&](uint32_t (&raw)[20], int r) { row_load7<TIO, PIXB>(raw, voffL, voffM, voffR, row_desc(xbase, 14 * tr + r, H, W * pix), 0, pix); };
+    uint32_t raw[NR7][20];
+    sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], -3 + decltype(rc)::value); });
+    // the 49 taps of this output channel as four register pairs per tap row, landed before the loop on every path (see k_upadd_cpt)
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 49 * Co * 4, 0x00020000);
+    f32x2 tp[7][4];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+#pragma unroll
+        for (int v = 0; v < 7; ++v) {
+            const float wv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wsrc, oo * 4, (u * 7 + v) * Co * 4, 0));
+            if (v & 1) tp[u][v >> 1].y = wv;
+            else tp[u][v >> 1].x = wv;
+        }
+        tp[u][3].y = 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 7; ++u) { pin(tp[u][0]); pin(tp[u][1]); pin(tp[u][2]); pin(tp[u][3]); }
+    f32x2 b0 = f32x2{has_bias ? bias[oo] : 0.f, 0.f};
+    pin(b0);
+    const unsigned yoff = ovalid ? (unsigned)((7 * tc) * pixo + o * ESZ) : OOB;
+    f32x2 facc[4][7];
+    sfor<NR7>([&](auto rc) {
+        constexpr int ri = decltype(rc)::value, r = ri - 3;
+        if constexpr (ri + AHEAD < NR7) load_row(raw[ri + AHEAD], r + AHEAD);
+        pin_row20<S::cap(S::pending(ri))>(raw[ri]);
+        f32x2 xr[10];                                             // (column 2k - 3, column 2k - 2)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) xr[k] = f32x2{raw_f32<TIO>(raw[ri][2 * k]), raw_f32<TIO>(raw[ri][2 * k + 1])};
+        // a row outside the plane was read through an empty descriptor: zeros, so it adds nothing and needs no branch
+#pragma unroll
+        for (int ot = 0; ot < 7; ++ot) {
+            const int u = r - 2 * ot + 3;
+            if (u < 0 || u > 6) continue;
+            f32x2(&a)[7] = facc[ot % 4];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) a[i] = pfma(xr[i], tp[u][0], u == 0 ? b0 : a[i]);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) a[i] = pfma(xr[i + 1], tp[u][1], a[i]);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) a[i] = pfma(xr[i + 2], tp[u][2], a[i]);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) a[i].x = fmaf(xr[i + 3].x, tp[u][3].x, a[i].x);
+            if (u == 6) {
+                float out[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) out[i] = a[i].x + a[i].y;
+                DownSt<TIO>::st(out, yoff, row_desc(ybase, 7 * tr + ot, Ho, Wo * pixo), 0, pixo);
+            }
+        }
+#pragma unroll
+        for (int ot = 0; ot < 7; ++ot) if (r - 2 * ot + 3 >= 0 && r - 2 * ot + 3 < 6) pin(facc[ot % 4]);
+        CPT_FENCE;
+    });
+}
+
+template <typename TIO>
+static hipError_t launch_down7(const void* x, void* y, const float* w, const float* b, int N, int Cin, int H, int W, hipStream_t s)
+{
+    const long long units = (long long)N * ((2 * Cin + 63) / 64) * ((H + 13) / 14) * ((W + 13) / 14);
+    const dim3 grid((unsigned)((units + 3) / 4)), block(256);
+    const int hb = b != nullptr;
+    const int pixb = Cin * (int)sizeof(TIO);
+#define RCX_GO(PB) hipLaunchKernelGGL((k_down7m2_cpt<PB, TIO>), grid, block, 0, s, (const TIO*)x, (TIO*)y, w, b, N, Cin, H, W, hb)
+    if constexpr (sizeof(TIO) == 2) {
+        if (pixb == 128) { RCX_GO(128); return hipGetLastError(); }
+        if (pixb == 256) { RCX_GO(256); return hipGetLastError(); }
+    }
+    RCX_GO(0);
+#undef RCX_GO
+    return hipGetLastError();
+}
+
 static inline bool enabled()
 {
     const char* v = rcx::opt::value(rcx::opt::UPADD_CPT);
@@ -637,6 +814,23 @@ hipError_t down5_cpt(const void* x, void* y, const float* w, const float* b, int
     if (in_dt == 1) return out_dt == 1 ? upcpt::launch_down<bf16_t, bf16_t>(x, y, w, b, N, C, H, W, s) : upcpt::launch_down<bf16_t, float>(x, y, w, b, N, C, H, W, s);
     if (in_dt == 2) return out_dt == 2 ? upcpt::launch_down<f16_t, f16_t>(x, y, w, b, N, C, H, W, s) : upcpt::launch_down<f16_t, float>(x, y, w, b, N, C, H, W, s);
     return upcpt::launch_down<float, float>(x, y, w, b, N, C, H, W, s);
+}
+
+// y = conv7 stride 2, channel multiplier 2 (Downsample.token_mixer): any even plane of at least 14 x 14
+bool down7m2_cpt_applicable(int N, int Cin, int H, int W, int k, int stride, int dtype)
+{
+    if (!upcpt::enabled() || k != 7 || stride != 2 || dtype < 0 || dtype > 2) return false;
+    if (N < 1 || Cin < 1 || (H & 1) || (W & 1) || H < 14 || W < 14) return false;
+    const long long img = (long long)H * W * Cin * 4;
+    const long long units = (long long)N * ((2 * Cin + 63) / 64) * ((H + 13) / 14) * ((W + 13) / 14);
+    return img < (1ll << 31) && units < (1ll << 31);
+}
+
+hipError_t down7m2_cpt(const void* x, void* y, const float* w, const float* b, int N, int Cin, int H, int W, int dtype, hipStream_t s)
+{
+    if (dtype == 1) return upcpt::launch_down7<bf16_t>(x, y, w, b, N, Cin, H, W, s);
+    if (dtype == 2) return upcpt::launch_down7<f16_t>(x, y, w, b, N, Cin, H, W, s);
+    return upcpt::launch_down7<float>(x, y, w, b, N, Cin, H, W, s);
 }
 
 }  // namespace rcx

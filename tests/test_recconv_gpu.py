@@ -496,6 +496,42 @@ def test_channel_multiplier_dwconv(shape, k, stride):
     assert np.allclose(ybf.float().cpu().numpy(), ref, atol=BF16_ATOL, rtol=BF16_RTOL)
 
 
+@pytest.mark.parametrize("bias", [False, True], ids=["nobias", "bias"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("shape", [(2, 64, 56, 56), (1, 128, 28, 28), (2, 32, 128, 128), (1, 64, 200, 336), (2, 24, 30, 44), (3, 40, 14, 14),
+                                   (1, 16, 18, 130), (1, 72, 100, 168), (2, 8, 64, 64)], ids=lambda v: "x".join(map(str, v)))
+def test_downsample_conv_tiled_channel_per_lane_kernel(shape, dt, bias):
+    """k_down7m2_cpt (rcx_upcpt.hip): Downsample's 7x7 stride-2 conv with channel multiplier 2 on ANY even plane (rows through per-row
+    buffer descriptors: ragged last tile column, ragged 64-output-channel blocks), against the NumPy oracle and the kernels it replaces."""
+    from oracle import recconv_np
+    n, c, h, w = shape
+    DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[dt]
+    rng = np.random.default_rng(zlib.crc32(repr(("down7", shape, dt, bias)).encode()))
+    rnd = (lambda a: a.astype(np.float16).astype(np.float32)) if dt == "f16" else bf16_round_np
+    x = rnd(rng.standard_normal(shape).astype(np.float32))
+    wt = (rng.standard_normal((2 * c, 1, 7, 7)) * 0.15).astype(np.float32)
+    b = rng.standard_normal(2 * c).astype(np.float32) if bias else None
+    ref = recconv_np.dwconv2d_mult(x.astype(np.float64), wt, b, stride=2)
+    t = lambda a: torch.from_numpy(a).to(dev())
+    wp, bp = ops.pack_dw_weight(t(wt)), (ops.pack_bias(t(b)) if bias else None)
+    run = lambda: ops.dwconv2d_mult2(t(x).to(DT), wp, bp, k=7, stride=2)
+    with rcx_env(RCX_UPADD_CPT="all"):
+        y = run()
+        assert torch.equal(run(), y)
+    assert y.dtype == DT and tuple(y.shape) == ref.shape
+    got = y.float().cpu().numpy()
+    if dt == "f32":
+        assert np.abs(got - ref).max() < F32_TIGHT
+    elif dt == "f16":
+        assert np.allclose(got, ref, atol=2e-3, rtol=2e-3)
+    else:
+        assert np.allclose(got, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
+        assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 1e-5)
+    with rcx_env(RCX_UPADD_CPT="0"):
+        other = run().float().cpu().numpy()
+    assert np.allclose(other, got, atol={"f32": 1e-4, "bf16": 1e-2, "f16": 2e-3}[dt], rtol=1e-2)
+
+
 def test_hip_downsample_module_folds_the_batchnorm():
     from recnext_amd.dwconv import DownsampleDwConv
     torch.manual_seed(1)
