@@ -1,24 +1,27 @@
-// Single steps of the recursion on planes of ANY even height and a width that is a multiple of 14 (or, 16-bit activations, of 16),
-// channel per lane (round 3):
+// Single steps of the recursion on ANY even plane, channel per lane (round 3):
 //
 //   k_upadd_cpt   y = conv5(x + resize2x(coarse))   -- the last line of RecConv2d.forward (model/recnext.py:31-34) and of
 //                                                      RecAttn2d.forward (model/recattn.py:67) as one launch
 //
 // It is pass 2 of k_recconv_cpt (rcx_cpt_kernel.h) made a kernel of its own: a wave = 64 channels of one 14 x 14 tile, a lane = one
 // channel; x streams one row at a time from global memory into registers through the same hand-issued row statements (18 columns with
-// the halo, out-of-image columns = out-of-range offsets that read 0), the conv is input-row stationary on v_pk_fma_f32 with five
-// accumulator rows in flight, a row of 14 outputs leaves as one statement.  What the fused kernel reads from its LDS planes -- the rows
-// of the coarse plane, 11 columns per tile -- comes from global memory here, one row every second input row, hand-issued like x (the
-// coarse plane is a quarter of x and stays in L2).  No LDS, no barrier, nothing shared between waves: any plane whose width is a
-// multiple of 14 (56, 28, 112; the 200 x 336, 100 x 168, 50 x 84 stages of a COCO input), any even height (rows past the plane are
-// loaded from a valid row and not used, their stores go out of range), any channel count (lanes past the last channel load channel
-// C - 1 and store out of range).
+// the halo), the conv is input-row stationary on v_pk_fma_f32 with five accumulator rows in flight, a row of 14 outputs leaves as one
+// statement.  What the fused kernel reads from its LDS planes -- the rows of the coarse plane, 11 columns per tile -- comes from global
+// memory here, one row every second input row, hand-issued like x (the coarse plane is a quarter of x and stays in L2).  No LDS, no
+// barrier, nothing shared between waves.
+//
+// Rows of x and y are addressed through PER-ROW buffer descriptors (row_desc below): a column left of the plane or right of it is out of
+// range and reads 0, a store past the row's end is dropped.  So there are no edge flags, the last tile column may be ragged, and ANY even
+// plane works (56, 28, 112, 128; the 200 x 336, 100 x 168, 50 x 84 stages of a COCO input; 200 x 334); the coarse columns are clamped
+// into the plane one by one (ATen's border rule), the resized coarse row is masked to zero outside the plane pair by pair.  Any even
+// height (rows past the plane are loaded from a valid row and not used, their stores go to an empty descriptor), any channel count
+// (lanes past the last channel load channel C - 1 and store out of range).
 //
 // Every wave issues the SAME sequence of memory instructions whatever its tile (skipped rows still load, stores of absent rows are
 // dropped by the hardware), so the s_waitcnt counts are exact compile-time numbers: `Sched` replays the issue order at compile time.
 //
-// TW = tile width: 14 (the 7 * 2^k planes, COCO stages) or 16 (the 16 * 2^k planes of 256 x 256 / 512 x 512 inputs; 16-bit activations
-// only: the 20-column row statements exist for the 2-byte loads).  Tiles are 14 rows high either way.
+// TW = tile width: 14, or 16 where 16 divides the width and 14 does not (the 16 * 2^k planes of 256 x 256 / 512 x 512 inputs: no ragged
+// column; bfloat16 only).  Tiles are 14 rows high either way.
 #include "rcx_cpt_kernel.h"
 #include "rcx_opts.h"
 
@@ -27,9 +30,10 @@ namespace upcpt {
 
 using namespace cpt;
 
-// tile width of a plane: 14 where it divides the width, else 16 (bfloat16 activations: float16's extra conversion registers do not fit
-// beside the 16-wide tile's accumulators, float32 has no 20-column row statement), else 0 = not ours
-static inline int tile_width(int W, int x_dt) { return W % 14 == 0 ? 14 : ((W % 16 == 0 && x_dt == 1) ? 16 : 0); }
+// tile width of a plane: 14; 16 where that divides the width and 14 does not (bfloat16 activations only: float16's extra conversion
+// registers do not fit beside the 16-wide tile's accumulators, float32 has no 20-column row statement).  Any other width: 14-wide tiles with
+// a ragged last column (rows are addressed through per-row descriptors: what lies past the row's end reads 0 and is not stored).
+static inline int tile_width(int W, int x_dt) { return (W % 14 != 0 && W % 16 == 0 && x_dt == 1) ? 16 : 14; }
 
 constexpr int NR = 18;            // input rows of a tile: -2 .. 15
 
@@ -63,34 +67,29 @@ template <int MODE, int TW, int AHEAD> struct Sched {
     static constexpr int cap(int v) { return v > 63 ? 63 : v; }
 };
 
-// one row of the coarse plane: columns -2 .. TW/2 + 1 of the tile (the outer two on each side clamped into the plane by the offsets)
+// one row of the coarse plane: columns -2 .. TW/2 + 1 of the tile, each at its own scalar byte offset (column index clamped into the plane
+// by the caller: ATen's border rule; a ragged last tile clamps in its middle)
 #define UPC_OUT11(v) "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10])
-#define UPC_L(OP, d) OP " %" #d ", %[vo], %[rs], %[t] offen\n\t"
-#define UPC_N "s_add_i32 %[t], %[t], %[pix]\n\t"
-#define UPC_ROW11(OP)                                                                                                                \
-    "s_add_i32 %[t], %[rb], %[l0]\n\t" UPC_L(OP, 0) "s_add_i32 %[t], %[rb], %[l1]\n\t" UPC_L(OP, 1)                                    \
-    "s_add_i32 %[t], %[rb], 0\n\t" UPC_L(OP, 2) UPC_N UPC_L(OP, 3) UPC_N UPC_L(OP, 4) UPC_N UPC_L(OP, 5) UPC_N UPC_L(OP, 6) UPC_N UPC_L(OP, 7) UPC_N UPC_L(OP, 8) \
-    "s_add_i32 %[t], %[rb], %[r0]\n\t" UPC_L(OP, 9) "s_add_i32 %[t], %[rb], %[r1]\n\t" UPC_L(OP, 10)
-#define UPC_ROW12(OP)                                                                                                                \
-    "s_add_i32 %[t], %[rb], %[l0]\n\t" UPC_L(OP, 0) "s_add_i32 %[t], %[rb], %[l1]\n\t" UPC_L(OP, 1)                                    \
-    "s_add_i32 %[t], %[rb], 0\n\t" UPC_L(OP, 2) UPC_N UPC_L(OP, 3) UPC_N UPC_L(OP, 4) UPC_N UPC_L(OP, 5) UPC_N UPC_L(OP, 6) UPC_N UPC_L(OP, 7) UPC_N UPC_L(OP, 8) UPC_N UPC_L(OP, 9) \
-    "s_add_i32 %[t], %[rb], %[r0]\n\t" UPC_L(OP, 10) "s_add_i32 %[t], %[rb], %[r1]\n\t" UPC_L(OP, 11)
-#define UPC_IN [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [l0] "s"(l0), [l1] "s"(l1), [r0] "s"(r0), [r1] "s"(r1), [pix] "s"(pix)
+#define UPC_C(OP, d) "s_add_i32 %[t], %[rb], %[c" #d "]\n\t" OP " %" #d ", %[vo], %[rs], %[t] offen\n\t"
+#define UPC_ROW11(OP) UPC_C(OP, 0) UPC_C(OP, 1) UPC_C(OP, 2) UPC_C(OP, 3) UPC_C(OP, 4) UPC_C(OP, 5) UPC_C(OP, 6) UPC_C(OP, 7) UPC_C(OP, 8) UPC_C(OP, 9) UPC_C(OP, 10)
+#define UPC_ROW12(OP) UPC_ROW11(OP) UPC_C(OP, 11)
+#define UPC_IN11 [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [c0] "s"(ck[0]), [c1] "s"(ck[1]), [c2] "s"(ck[2]), [c3] "s"(ck[3]), [c4] "s"(ck[4]), [c5] "s"(ck[5]), \
+                 [c6] "s"(ck[6]), [c7] "s"(ck[7]), [c8] "s"(ck[8]), [c9] "s"(ck[9]), [c10] "s"(ck[10])
 template <typename TC>
-__device__ __forceinline__ void coarse_row_load(uint32_t (&v)[11], unsigned vo, i32x4 rs, int rb, int l0, int l1, int r0, int r1, int pix)
+__device__ __forceinline__ void coarse_row_load(uint32_t (&v)[11], unsigned vo, i32x4 rs, int rb, const int (&ck)[11])
 {
     int t;
-    if constexpr (std::is_same<TC, f16_t>::value) asm volatile(UPC_ROW11(CPT_LDH) : UPC_OUT11(v), [t] "=&s"(t) : UPC_IN : "scc");
-    else if constexpr (sizeof(TC) == 2) asm volatile(UPC_ROW11(CPT_LD16) : UPC_OUT11(v), [t] "=&s"(t) : UPC_IN : "scc");
-    else asm volatile(UPC_ROW11(CPT_LD32) : UPC_OUT11(v), [t] "=&s"(t) : UPC_IN : "scc");
+    if constexpr (std::is_same<TC, f16_t>::value) asm volatile(UPC_ROW11(CPT_LDH) : UPC_OUT11(v), [t] "=&s"(t) : UPC_IN11 : "scc");
+    else if constexpr (sizeof(TC) == 2) asm volatile(UPC_ROW11(CPT_LD16) : UPC_OUT11(v), [t] "=&s"(t) : UPC_IN11 : "scc");
+    else asm volatile(UPC_ROW11(CPT_LD32) : UPC_OUT11(v), [t] "=&s"(t) : UPC_IN11 : "scc");
 }
 template <typename TC>
-__device__ __forceinline__ void coarse_row_load(uint32_t (&v)[12], unsigned vo, i32x4 rs, int rb, int l0, int l1, int r0, int r1, int pix)
+__device__ __forceinline__ void coarse_row_load(uint32_t (&v)[12], unsigned vo, i32x4 rs, int rb, const int (&ck)[12])
 {
     int t;
-    if constexpr (std::is_same<TC, f16_t>::value) asm volatile(UPC_ROW12(CPT_LDH) : UPC_OUT11(v), "=&v"(v[11]), [t] "=&s"(t) : UPC_IN : "scc");
-    else if constexpr (sizeof(TC) == 2) asm volatile(UPC_ROW12(CPT_LD16) : UPC_OUT11(v), "=&v"(v[11]), [t] "=&s"(t) : UPC_IN : "scc");
-    else asm volatile(UPC_ROW12(CPT_LD32) : UPC_OUT11(v), "=&v"(v[11]), [t] "=&s"(t) : UPC_IN : "scc");
+    if constexpr (std::is_same<TC, f16_t>::value) asm volatile(UPC_ROW12(CPT_LDH) : UPC_OUT11(v), "=&v"(v[11]), [t] "=&s"(t) : UPC_IN11, [c11] "s"(ck[11]) : "scc");
+    else if constexpr (sizeof(TC) == 2) asm volatile(UPC_ROW12(CPT_LD16) : UPC_OUT11(v), "=&v"(v[11]), [t] "=&s"(t) : UPC_IN11, [c11] "s"(ck[11]) : "scc");
+    else asm volatile(UPC_ROW12(CPT_LD32) : UPC_OUT11(v), "=&v"(v[11]), [t] "=&s"(t) : UPC_IN11, [c11] "s"(ck[11]) : "scc");
 }
 template <int PENDING> __device__ __forceinline__ void pin_coarse(uint32_t (&v)[11])
 {
@@ -178,6 +177,22 @@ template <int PENDING> __device__ __forceinline__ void xrow_pin(uint32_t (&v)[20
 template <typename TIO, int PIXB> __device__ __forceinline__ void yrow_store(const f32x2 (&a)[7], unsigned vo, i32x4 rs, int rb, int pix) { RowSt<TIO, PIXB>::st(a, vo, rs, rb, pix); }
 template <typename TIO, int PIXB> __device__ __forceinline__ void yrow_store(const f32x2 (&a)[8], unsigned vo, i32x4 rs, int rb, int pix) { row_store16w<TIO, PIXB>(a, vo, rs, rb, pix); }
 
+// A row of a plane as a buffer of its own (base = the row, num_records = its bytes): everything left and right of it -- and, with zero
+// records, an absent row -- is out of range: loads return 0, stores are dropped.  No edge flags, and the last tile column may be ragged.
+// Scalar arithmetic on uniform values only: a v_readfirstlane_b32 here would write the descriptor's SGPRs from the vector pipe right in
+// front of the loads that read them (5 wait states the compiler does not insert inside an asm statement; tools/check_asm_hazards.py).
+__device__ __forceinline__ i32x4 row_desc(unsigned long long base, int row, int rows, int rowbytes)
+{
+    const bool ok = row >= 0 && row < rows;
+    const unsigned long long a = base + (unsigned long long)(ok ? row : 0) * (unsigned long long)rowbytes;
+    i32x4 d;
+    d.x = (int)(unsigned)a;
+    d.y = (int)(unsigned)(a >> 32) & 0xffff;
+    d.z = ok ? rowbytes : 0;
+    d.w = 0x00020000;
+    return d;
+}
+
 // MODE 0 bilinear (exact 2x: weights 1/4, 3/4, clamped borders = ATen's align_corners=False arithmetic), 1 nearest.
 // PIXB = bytes per pixel of x and y when known at compile time (64 or 128 channels of a 16-bit type), 0 = run time.
 template <int MODE, int PIXB, typename TIO, typename TC, int TW = 14>
@@ -190,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void k_upadd_cpt(const TIO* __restrict__ x,
     // row register would be stored before its load has landed)
     constexpr int AHEAD = (std::is_same<TIO, f16_t>::value || TW == 16) ? 1 : 2;
     using S = Sched<MODE, TW, AHEAD>;
-    const int nb = (C + 63) / 64, TR = (H + 13) / 14, TCn = W / TW, Hc = H / 2, Wc = W / 2;
+    const int nb = (C + 63) / 64, TR = (H + 13) / 14, TCn = (W + TW - 1) / TW, Hc = H / 2, Wc = W / 2;
     const int pix = PIXB ? PIXB : C * ESZ, pixc = C * CSZ;
     const unsigned total = (unsigned)N * nb * TR * TCn;
     const int lane = (int)(threadIdx.x & 63);
@@ -205,40 +220,37 @@ __global__ __launch_bounds__(256, 2) void k_upadd_cpt(const TIO* __restrict__ x,
     const int c = cb * 64 + lane;
     const bool cvalid = c < C;
     const int cc = cvalid ? c : C - 1;
-    const bool ledge = tc == 0, redge = tc == TCn - 1;
     const unsigned OOB = 0x80000000u;
 
-    // the coarse rows -2, -1, 0 first (they are needed first), then the first rows of x, then the taps
-    i32x4 csrc, rsrc, ysrc;
+    // the coarse plane of this image as one buffer (its column and row indices are clamped, never out of range); x and y row by row
+    i32x4 csrc;
     {
         const unsigned long long a = (unsigned long long)(reinterpret_cast<const char*>(coarse) + (size_t)n * Hc * Wc * pixc);
-        csrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-        csrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+        csrc.x = (int)(unsigned)a;
+        csrc.y = (int)(unsigned)(a >> 32) & 0xffff;
         csrc.z = Hc * Wc * pixc;
         csrc.w = 0x00020000;
-        const unsigned long long ax = (unsigned long long)(reinterpret_cast<const char*>(x) + (size_t)n * H * W * pix);
-        rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ax);
-        rsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(ax >> 32) & 0xffff);
-        rsrc.z = H * W * pix;
-        rsrc.w = 0x00020000;
-        const unsigned long long ay = (unsigned long long)(reinterpret_cast<char*>(y) + (size_t)n * H * W * pix);
-        ysrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ay);
-        ysrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(ay >> 32) & 0xffff);
-        ysrc.z = H * W * pix;
-        ysrc.w = 0x00020000;
     }
+    const unsigned long long xbase = (unsigned long long)(reinterpret_cast<const char*>(x) + (size_t)n * H * W * pix);
+    const unsigned long long ybase = (unsigned long long)(reinterpret_cast<char*>(y) + (size_t)n * H * W * pix);
     const unsigned cvo = (unsigned)(cc * CSZ);
     const int cb0 = NP * tc;
-    // scalar column offsets of the clamped outer coarse columns, relative to column cb0 of the row
-    const int l0 = __builtin_amdgcn_readfirstlane(ledge ? 0 : -2 * pixc), l1 = __builtin_amdgcn_readfirstlane(ledge ? 0 : -pixc);
-    const int r0 = __builtin_amdgcn_readfirstlane((redge ? NP - 1 : NP) * pixc), r1 = __builtin_amdgcn_readfirstlane((redge ? NP - 1 : NP + 1) * pixc);
+    int ck[NCR];                                                 // byte offsets of the coarse columns -2 .. NP + 1 of the tile, clamped into the plane
+#pragma unroll
+    for (int k = 0; k < NCR; ++k) {
+        int col = cb0 - 2 + k;
+        col = col < 0 ? 0 : (col > Wc - 1 ? Wc - 1 : col);
+        ck[k] = col * pixc;
+    }
     auto load_coarse = [&](uint32_t (&dst)[NCR], int i) {        // tile-local coarse row i, clamped into the plane (ATen's border rule)
         int ar = 7 * tr + i;
         ar = ar < 0 ? 0 : (ar > Hc - 1 ? Hc - 1 : ar);
-        const int rb = __builtin_amdgcn_readfirstlane((ar * Wc + cb0) * pixc);
-        coarse_row_load<TC>(dst, cvo, csrc, rb, l0, l1, r0, r1, pixc);
+        coarse_row_load<TC>(dst, cvo, csrc, ar * Wc * pixc, ck);
     };
-    const float lmask = ledge ? 0.f : 1.f, rmask = redge ? 0.f : 1.f;
+    // the resized coarse row is zero outside the plane (the conv pads x + resize(coarse) with zeros): one mask per column pair
+    float hm[NHP];
+#pragma unroll
+    for (int j2 = 0; j2 < NHP; ++j2) { const int col = TW * tc - 2 + 2 * j2; hm[j2] = (col >= 0 && col < W) ? 1.f : 0.f; }
     const f32x2 wq = MODE == 1 ? splat(0.f) : splat(0.25f), wt = MODE == 1 ? splat(1.f) : splat(0.75f);
     // H row: a coarse row resized horizontally to the columns -2 .. TW + 1 (pairs outside the image zeroed)
     auto build_H = [&](f32x2 (&Hs)[NHP], const uint32_t (&cr)[NCR]) {
@@ -254,18 +266,17 @@ __global__ __launch_bounds__(256, 2) void k_upadd_cpt(const TIO* __restrict__ x,
             const float mid = ((j + 1) & 1) ? P[(j + 1) >> 1].y : P[(j + 1) >> 1].x;
             Hs[j] = pfma(splat(mid), wt, e);
         });
-        Hs[0] = Hs[0] * splat(lmask);
-        Hs[NHP - 1] = Hs[NHP - 1] * splat(rmask);
+#pragma unroll
+        for (int j2 = 0; j2 < NHP; ++j2) Hs[j2] = Hs[j2] * splat(hm[j2]);
     };
 
     const unsigned voffM = (unsigned)((TW * tc) * pix + cc * ESZ);
-    const unsigned voffL = ledge ? OOB : voffM - 2u * (unsigned)pix;
-    const unsigned voffR = redge ? OOB : voffM + (unsigned)TW * (unsigned)pix;
+    const unsigned voffL = voffM - 2u * (unsigned)pix;            // tile column 0: negative = out of range
+    const unsigned voffR = voffM + (unsigned)TW * (unsigned)pix;
     auto load_row = [&](uint32_t (&raw)[NCOL], int r) {          // rows outside the plane: a valid row is loaded and not used
         int ar = 14 * tr + r;
         ar = ar < 0 ? 0 : (ar > H - 1 ? H - 1 : ar);
-        const int rb = __builtin_amdgcn_readfirstlane(ar * (W * pix));
-        xrow_load<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
+        xrow_load<TIO, PIXB>(raw, voffL, voffM, voffR, row_desc(xbase, ar, H, W * pix), 0, pix);
     };
     auto row_valid = [&](int r) -> bool { const int ar = 14 * tr + r; return ar >= 0 && ar < H; };       // uniform
 
@@ -345,9 +356,7 @@ __global__ __launch_bounds__(256, 2) void k_upadd_cpt(const TIO* __restrict__ x,
         }
         if constexpr (t - 2 >= 0 && t - 2 <= 13) {
             constexpr int o = t - 2;
-            const int arow = 14 * tr + o;
-            const int yrb = __builtin_amdgcn_readfirstlane((arow < H ? arow : 0) * (W * pix));
-            yrow_store<TIO, PIXB>(acc[o % 5], arow < H ? yoff : OOB, ysrc, yrb, pix);      // rows past the plane: dropped, but issued (Sched counts them)
+            yrow_store<TIO, PIXB>(acc[o % 5], yoff, row_desc(ybase, 14 * tr + o, H, W * pix), 0, pix);   // rows past the plane, columns past the row: dropped, but issued (Sched counts them)
         }
 #pragma unroll
         for (int o = 0; o < 14; ++o) if (o > t - 2 && o <= t + 2) pin(acc[o % 5]);
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void k_down5_cpt(const TIO* __restrict__ x,
     constexpr int ESZ = (int)sizeof(TIO), OSZ = (int)sizeof(TO), AHEAD = 3, NPO = TW / 2, NCOL = TW + 4, NHP = NCOL / 2;
     static_assert(TW == 14 || (TW == 16 && sizeof(TIO) == 2), "tile width");
     using S = SchedDown<AHEAD, TW>;
-    const int nb = (C + 63) / 64, TR = (H + 13) / 14, TCn = W / TW, Ho = H / 2, Wo = W / 2;
+    const int nb = (C + 63) / 64, TR = (H + 13) / 14, TCn = (W + TW - 1) / TW, Ho = H / 2, Wo = W / 2;
     const int pix = PIXB ? PIXB : C * ESZ, pixo = C * OSZ;
     const unsigned total = (unsigned)N * nb * TR * TCn;
     const int lane = (int)(threadIdx.x & 63);
@@ -454,29 +463,16 @@ __global__ __launch_bounds__(256, 2) void k_down5_cpt(const TIO* __restrict__ x,
     const int c = cb * 64 + lane;
     const bool cvalid = c < C;
     const int cc = cvalid ? c : C - 1;
-    const bool ledge = tc == 0, redge = tc == TCn - 1;
     const unsigned OOB = 0x80000000u;
-    i32x4 rsrc, ysrc;
-    {
-        const unsigned long long ax = (unsigned long long)(reinterpret_cast<const char*>(x) + (size_t)n * H * W * pix);
-        rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ax);
-        rsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(ax >> 32) & 0xffff);
-        rsrc.z = H * W * pix;
-        rsrc.w = 0x00020000;
-        const unsigned long long ay = (unsigned long long)(reinterpret_cast<char*>(y) + (size_t)n * Ho * Wo * pixo);
-        ysrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ay);
-        ysrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(ay >> 32) & 0xffff);
-        ysrc.z = Ho * Wo * pixo;
-        ysrc.w = 0x00020000;
-    }
+    const unsigned long long xbase = (unsigned long long)(reinterpret_cast<const char*>(x) + (size_t)n * H * W * pix);
+    const unsigned long long ybase = (unsigned long long)(reinterpret_cast<char*>(y) + (size_t)n * Ho * Wo * pixo);
     const unsigned voffM = (unsigned)((TW * tc) * pix + cc * ESZ);
-    const unsigned voffL = ledge ? OOB : voffM - 2u * (unsigned)pix;
-    const unsigned voffR = redge ? OOB : voffM + (unsigned)TW * (unsigned)pix;
+    const unsigned voffL = voffM - 2u * (unsigned)pix;            // tile column 0: negative = out of range
+    const unsigned voffR = voffM + (unsigned)TW * (unsigned)pix;
     auto load_row = [&](uint32_t (&raw)[NCOL], int r) {
         int ar = 14 * tr + r;
         ar = ar < 0 ? 0 : (ar > H - 1 ? H - 1 : ar);
-        const int rb = __builtin_amdgcn_readfirstlane(ar * (W * pix));
-        xrow_load<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
+        xrow_load<TIO, PIXB>(raw, voffL, voffM, voffR, row_desc(xbase, ar, H, W * pix), 0, pix);
     };
     auto row_valid = [&](int r) -> bool { const int ar = 14 * tr + r; return ar >= 0 && ar < H; };
     uint32_t raw[NR1][NCOL];
@@ -518,9 +514,7 @@ __global__ __launch_bounds__(256, 2) void k_down5_cpt(const TIO* __restrict__ x,
                 float out[NPO];
 #pragma unroll
                 for (int i = 0; i < NPO; ++i) out[i] = a[i].x + a[i].y;
-                const int orow = 7 * tr + o;
-                const int yrb = __builtin_amdgcn_readfirstlane((orow < Ho ? orow : 0) * (Wo * pixo));
-                DownSt<TO>::st(out, orow < Ho ? yoff : OOB, ysrc, yrb, pixo);
+                DownSt<TO>::st(out, yoff, row_desc(ybase, 7 * tr + o, Ho, Wo * pixo), 0, pixo);
             }
         }
 #pragma unroll
@@ -533,8 +527,7 @@ template <typename TIO, typename TO>
 static hipError_t launch_down(const void* x, void* y, const float* w, const float* b, int N, int C, int H, int W, hipStream_t s)
 {
     const int tw = tile_width(W, std::is_same<TIO, bf16_t>::value ? 1 : 0);
-    if (tw == 0) return hipErrorInvalidConfiguration;
-    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / tw);
+    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * ((W + tw - 1) / tw);
     const dim3 grid((unsigned)((units + 3) / 4)), block(256);
     const int hb = b != nullptr;
     const int pixb = C * (int)sizeof(TIO);
@@ -643,20 +636,6 @@ __global__ __launch_bounds__(256, 2) void k_down7m2_cpt(const TIO* __restrict__ 
     const unsigned OOB = 0x80000000u;
     const unsigned long long xbase = (unsigned long long)(reinterpret_cast<const char*>(x) + (size_t)n * H * W * pix);
     const unsigned long long ybase = (unsigned long long)(reinterpret_cast<char*>(y) + (size_t)n * Ho * Wo * pixo);
-    // a row of x / of y as a buffer of its own: everything left, right of it (and, with zero records, an absent row) is out of range
-    auto row_desc = [&](unsigned long long base, int row, int rows, int rowbytes) {
-        const bool ok = row >= 0 && row < rows;
-        const unsigned long long a = base + (unsigned long long)(ok ? row : 0) * (unsigned long long)rowbytes;
-        // scalar arithmetic on uniform values only (n, tr, tc come out of one readfirstlane at the top): a v_readfirstlane_b32 HERE would
-        // write the descriptor's SGPRs from the vector pipe right in front of the loads that read them (5 wait states the compiler does not
-        // insert inside an asm statement; tools/check_asm_hazards.py)
-        i32x4 d;
-        d.x = (int)(unsigned)a;
-        d.y = (int)(unsigned)(a >> 32) & 0xffff;
-        d.z = ok ? rowbytes : 0;
-        d.w = 0x00020000;
-        return d;
-    };
     const unsigned voffM = (unsigned)((14 * tc) * pix + (oo >> 1) * ESZ);
     const unsigned voffL = voffM - 3u * (unsigned)pix;            // tile column 0: negative = out of range
     const unsigned voffR = voffM + 14u * (unsigned)pix;
@@ -744,8 +723,7 @@ template <int MODE, typename TIO, typename TC>
 static hipError_t launch(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int H, int W, hipStream_t s)
 {
     const int tw = tile_width(W, std::is_same<TIO, bf16_t>::value ? 1 : 0);
-    if (tw == 0) return hipErrorInvalidConfiguration;
-    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / tw);
+    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * ((W + tw - 1) / tw);
     const dim3 grid((unsigned)((units + 3) / 4)), block(256);
     const int hb = b != nullptr;
     const int pixb = C * (int)sizeof(TIO);
@@ -769,15 +747,15 @@ static hipError_t launch(const void* x, const void* coarse, void* y, const float
 
 }  // namespace upcpt
 
-// y = conv5(x + resize2x(coarse)): exact 2x planes whose width is a multiple of 14 (or of 16: 16-bit x), at least 28 x 28; the 14 x 14
-// plane has its own whole-plane kernel (rcx_cpl14.hip)
+// y = conv5(x + resize2x(coarse)): any plane that is exactly twice its coarse plane, at least 28 x 28; the 14 x 14 plane has its own
+// whole-plane kernel (rcx_cpl14.hip)
 bool upadd_cpt_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int x_dt, int c_dt, int out_dt)
 {
     if (!upcpt::enabled() || k != 5 || out_dt != x_dt || x_dt < 0 || x_dt > 2 || !(c_dt == x_dt || c_dt == 0)) return false;
     const int tw = upcpt::tile_width(W, x_dt);
-    if (N < 1 || C < 1 || Hc * 2 != H || Wc * 2 != W || tw == 0 || H < 28 || W < 28) return false;
+    if (N < 1 || C < 1 || Hc * 2 != H || Wc * 2 != W || H < 28 || W < 28) return false;
     const long long img = (long long)H * W * C * 4;
-    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / tw);
+    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * ((W + tw - 1) / tw);
     return img < (1ll << 31) && units < (1ll << 31);
 }
 
@@ -785,7 +763,7 @@ int upadd_cpt_describe(int N, int C, int H, int W, int mode, int x_dt, char* buf
 {
     const int pixb = x_dt != 0 && (C == 64 || C == 128) ? C * 2 : 0, tw = upcpt::tile_width(W, x_dt);
     return snprintf(buf, len, "upadd_cpt(k_upadd_cpt<%d, %d>,tw=%d,cb=64,nt=256,tiles=%lld)", mode, pixb, tw,
-                    (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / (tw ? tw : 14)));
+                    (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * ((W + tw - 1) / tw));
 }
 
 hipError_t upadd_cpt(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int H, int W, int mode,
@@ -798,14 +776,14 @@ hipError_t upadd_cpt(const void* x, const void* coarse, void* y, const float* w,
 #undef RCX_UP
 }
 
-// y = conv5 stride 2 (x): even planes whose width is a multiple of 14, at least one full tile
+// y = conv5 stride 2 (x): any even plane of at least 28 x 28
 bool down5_cpt_applicable(int N, int C, int H, int W, int k, int stride, int in_dt, int out_dt)
 {
     if (!upcpt::enabled() || k != 5 || stride != 2 || in_dt < 0 || in_dt > 2 || !(out_dt == in_dt || out_dt == 0)) return false;
     const int tw = upcpt::tile_width(W, in_dt);
-    if (N < 1 || C < 1 || (H & 1) || tw == 0 || H < 28 || W < 28) return false;
+    if (N < 1 || C < 1 || (H & 1) || (W & 1) || H < 28 || W < 28) return false;
     const long long img = (long long)H * W * C * 4;
-    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * (W / tw);
+    const long long units = (long long)N * ((C + 63) / 64) * ((H + 13) / 14) * ((W + tw - 1) / tw);
     return img < (1ll << 31) && units < (1ll << 31);
 }
 

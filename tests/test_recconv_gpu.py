@@ -709,8 +709,9 @@ UPCPT_CASES = [
     # non-square planes, a last tile row that is partly (30, 100) or by one row pair (200) outside the plane, one and three tile columns
     (3, 64, 56, 56), (2, 128, 28, 28), (2, 48, 56, 56), (2, 96, 28, 28), (1, 130, 28, 56), (2, 24, 30, 42), (1, 64, 100, 168), (1, 16, 200, 28),
     (1, 8, 50, 84), (5, 40, 28, 28),
-    # 16-wide tiles (bfloat16 only; the other types keep the kernels they had): the 16 * 2^k planes of 256 x 256 / 512 x 512 inputs
-    (2, 64, 128, 128), (2, 128, 64, 64), (1, 40, 32, 32), (1, 72, 44, 80),
+    # widths that are not multiples of 14: 16-wide tiles (bfloat16, the 16 * 2^k planes of 256 x 256 / 512 x 512 inputs, 80) and a ragged
+    # last tile column (every other type on those planes; 44, 100, 334 = a 1333-wide COCO image; 30 = two valid columns in the third tile)
+    (2, 64, 128, 128), (2, 128, 64, 64), (1, 40, 32, 32), (1, 72, 44, 80), (1, 64, 30, 44), (2, 24, 28, 100), (1, 16, 200, 334), (1, 8, 28, 30),
 ]
 
 
@@ -731,11 +732,12 @@ def test_upadd_tiled_channel_per_lane_kernel(mode, bias, case, dts):
     ref = c_oracle.dwconv2d(c_oracle.add_resized(x, cs, mode), wt, b, 1)
     t = lambda a: torch.from_numpy(a).to(dev())
     run = lambda: ops.upadd_dwconv(t(x).to(xdt), t(cs).to(cdt), ops.pack_dw_weight(t(wt)), ops.pack_bias(t(b)) if bias else None, k=5, mode=mode)
-    ours = w % 14 == 0 or xdt == torch.bfloat16            # 16-wide tiles exist for bfloat16 only
+    ours = True                                            # any even plane (per-row descriptors: ragged last tile column)
+    tw = 16 if (w % 14 and w % 16 == 0 and xdt == torch.bfloat16) else 14     # 16-wide tiles exist for bfloat16 only
     with rcx_env(RCX_UPADD_CPT="all"):                     # also where the lanes kernel would keep a ragged channel count
         plan = ops.upadd_dwconv_plan(n, c, h, w, h // 2, w // 2, 5, mode, xdt, cdt)
-        assert plan.startswith(f"upadd_cpt(k_upadd_cpt<{1 if mode == 'nearest' else 0}, ") == ours, plan
-        assert (f"tw={14 if w % 14 == 0 else 16}," in plan) == ours
+        assert plan.startswith(f"upadd_cpt(k_upadd_cpt<{1 if mode == 'nearest' else 0}, "), plan
+        assert f"tw={tw}," in plan
         y = run()
         assert torch.equal(run(), y)
     if c % 64 == 0 and ours and not (w % 14 and h < 64):    # the default rule: whole 64-channel waves take the tiled kernel (16-wide tiles: from 64 rows)
