@@ -149,6 +149,27 @@ StepKernel pick_upadd(int N, int C, int H, int W, int Hc, int Wc, int k, int x_d
     return lanes_ok ? STEP_LANES : STEP_GENERIC;
 }
 
+// Nested schedule for a plane no fused kernel takes (COCO stages, 112 x 112, ...): the split schedule made recursive,
+//   F_1 = conv5 stride 2 (x) (float32, workspace) ; C_1 = RecConv2d_{level-1}(F_1) by WHATEVER schedule that block has -- a fused kernel
+//   (lanes / LDS pyramid), or this schedule again -- ; y = conv5(x + resize(C_1)),
+// both outer steps on single-step kernels (rcx_upcpt.hip / the lanes step kernels).  200 x 336 / level 4: five launches (two down, the
+// LDS-pyramid kernel on 50 x 84 / level 2, two up) instead of the generic ladder's nine.  It only ever replaces the generic ladder.
+bool use_nested(int N, int C, int H, int W, int level, int k, int dtype)
+{
+    if (lanes_off() || level < 1 || k != 5 || (H & 1) || (W & 1)) return false;
+    const char* v = rcx::opt::value(rcx::opt::NESTED);
+    if (v && *v == '0') return false;
+    if (use_lanes(N, C, H, W, level, k, dtype) || use_split(N, C, H, W, level, k, dtype) || use_plane(N, C, H, W, level, k, dtype)) return false;
+    const StepKernel d = pick_dwconv(N, C, H, W, k, 2, dtype, RCX_DTYPE_F32);
+    const StepKernel u = pick_upadd(N, C, H, W, H / 2, W / 2, k, dtype, RCX_DTYPE_F32, dtype, true);
+    if (d == STEP_GENERIC || u == STEP_GENERIC) return false;
+    const int h2 = H / 2, w2 = W / 2;
+    return use_lanes(N, C, h2, w2, level - 1, k, RCX_DTYPE_F32) || use_split(N, C, h2, w2, level - 1, k, RCX_DTYPE_F32) ||
+           use_plane(N, C, h2, w2, level - 1, k, RCX_DTYPE_F32) || use_nested(N, C, h2, w2, level - 1, k, RCX_DTYPE_F32);
+}
+
+size_t nested_own_bytes(int N, int C, int H, int W) { return 2 * align256(sizeof(float) * (size_t)N * C * (H / 2) * (W / 2)); }
+
 hipError_t step_dwconv(const void* x, void* y, const float* w, const float* b, int N, int C, int H, int W, int k, int stride,
                        int in_dt, int out_dt, hipStream_t s)
 {
@@ -197,6 +218,14 @@ const char* rcx_recconv2d_fwd_plan(int N, int C, int H, int W, int level, int k,
         const bool dcpt = pick_dwconv(N, C, H, W, k, 2, dtype, RCX_DTYPE_F32) == STEP_CPT;
         const bool ucpt = pick_upadd(N, C, H, W, H / 2, W / 2, k, dtype, RCX_DTYPE_F32, dtype, true) == STEP_CPT;
         snprintf(desc, sizeof(desc), "split(%s + %s + %s)", dcpt ? "k_down5_cpt" : "k_down5_lanes", inner, ucpt ? "k_upadd_cpt" : "k_upadd_lanes");
+        return desc;
+    }
+    if (use_nested(N, C, H, W, level, k, dtype)) {
+        char inner[192];
+        snprintf(inner, sizeof(inner), "%s", rcx_recconv2d_fwd_plan(N, C, H / 2, W / 2, level - 1, k, mode, RCX_DTYPE_F32));   // (overwrites desc)
+        const bool dcpt = pick_dwconv(N, C, H, W, k, 2, dtype, RCX_DTYPE_F32) == STEP_CPT;
+        const bool ucpt = pick_upadd(N, C, H, W, H / 2, W / 2, k, dtype, RCX_DTYPE_F32, dtype, true) == STEP_CPT;
+        snprintf(desc, sizeof(desc), "nested(%s + %s + %s)", dcpt ? "k_down5_cpt" : "k_down5_lanes", inner, ucpt ? "k_upadd_cpt" : "k_upadd_lanes");
         return desc;
     }
     if (!use_plane(N, C, H, W, level, k, dtype)) return "generic";
@@ -255,6 +284,8 @@ size_t rcx_recconv2d_fwd_workspace_bytes(int N, int C, int H, int W, int level, 
     if (use_lanes(N, C, H, W, level, k, dtype)) return 0;          // registers only
     if (use_split(N, C, H, W, level, k, dtype)) return split_bytes(N, C, H, W);
     if (use_plane(N, C, H, W, level, k, dtype)) return 0;          // the fused schedule keeps every intermediate in LDS
+    if (use_nested(N, C, H, W, level, k, dtype))                    // F_1, C_1, then whatever the inner block needs
+        return nested_own_bytes(N, C, H, W) + rcx_recconv2d_fwd_workspace_bytes(N, C, H / 2, W / 2, level - 1, k, RCX_DTYPE_F32);
     return make_ladder(N, C, H, W, level, k).total;
 }
 
@@ -290,6 +321,24 @@ int rcx_recconv2d_fwd(const void* x, void* y, const float* wpack, const float* b
     if (use_plane(N, C, H, W, level, k, dtype)) {
         hipError_t pe = rcx::plane_recconv(x, y, wpack, bpack, N, C, H, W, level, k, mode, dtype, (hipStream_t)stream);
         return pe == hipSuccess ? 0 : hip_fail(pe, "plane schedule");
+    }
+    if (use_nested(N, C, H, W, level, k, dtype)) {
+        const size_t own = nested_own_bytes(N, C, H, W);
+        const size_t need = own + rcx_recconv2d_fwd_workspace_bytes(N, C, H / 2, W / 2, level - 1, k, RCX_DTYPE_F32);
+        if (!workspace || workspace_bytes < need)
+            return fail(RCX_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+        hipStream_t s = (hipStream_t)stream;
+        float* f1 = (float*)workspace;
+        float* c1 = (float*)((char*)workspace + own / 2);
+        const size_t wsz = (size_t)k * k * C;
+        hipError_t e = step_dwconv(x, f1, wpack, bpack, N, C, H, W, k, 2, dtype, RCX_DTYPE_F32, s);
+        if (e != hipSuccess) return hip_fail(e, "nested schedule: down");
+        // the inner block owns the first level + 1 packs (down, convs[0 .. level - 1]) exactly as the whole block owns level + 2
+        if (int rc = rcx_recconv2d_fwd(f1, c1, wpack, bpack, (char*)workspace + own, need - own, N, C, H / 2, W / 2, level - 1, k, mode, RCX_DTYPE_F32, stream))
+            return rc;
+        e = step_upadd(x, c1, y, wpack + (size_t)(1 + level) * wsz, bpack ? bpack + (size_t)(1 + level) * C : nullptr,
+                       N, C, H, W, H / 2, W / 2, k, mode, dtype, RCX_DTYPE_F32, dtype, s);
+        return e == hipSuccess ? 0 : hip_fail(e, "nested schedule: final conv");
     }
     const Ladder L = make_ladder(N, C, H, W, level, k);
     if (L.total > 0 && (!workspace || workspace_bytes < L.total))

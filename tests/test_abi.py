@@ -78,6 +78,12 @@ def test_abi_version_and_argument_errors_without_gpu():
     with rcx_env(RCX_CPL="0"):
         assert lib.rcx_recconv2d_fwd_plan(2, 40, 7, 7, 1, 5, 0, 1).startswith(b"lanes(k_recconv_lanes<7, 1, 8, 0,")   # C % 64 != 0
     assert lib.rcx_recconv2d_fwd_plan(1, 8, 7, 7, 1, 3, 0, 0) == b"generic"
+    # planes no fused kernel takes: the nested schedule (single-step kernels around whatever schedule the half-size block has), round 3
+    p = lib.rcx_recconv2d_fwd_plan(2, 64, 200, 336, 4, 5, 0, 1)
+    assert p.startswith(b"nested(k_down5_cpt + nested(k_down5_cpt + plane(") and p.endswith(b" + k_upadd_cpt) + k_upadd_cpt)"), p
+    assert lib.rcx_recconv2d_fwd_workspace_bytes(2, 64, 200, 336, 4, 5, 1) >= 2 * 4 * 2 * 64 * (100 * 168 + 50 * 84)
+    with rcx_env(RCX_NESTED="0"):
+        assert lib.rcx_recconv2d_fwd_plan(2, 64, 200, 336, 4, 5, 0, 1) == b"generic"
     assert lib.rcx_recconv2d_fwd(one, one, one, None, None, 0, 1, 8, 7, 7, 0, 5, 0, 0, None) == -1      # alias
     assert lib.rcx_dwconv2d_fwd(one, two, one, None, 1, 8, 7, 7, 5, 3, 0, 0, None) == -2                # stride 3
 
