@@ -172,10 +172,13 @@ def kernel_name(plan, elem_bytes):
         return f"rcx::lanes::{kern}, {t}>"
     if plan.startswith("cpt(k_recconv_cpt"):
         kern = plan[len("cpt("):plan.index(">")]
-        return f"rcx::cpt::{kern}, {t}, false, false>"                 # template arguments after the type: training, matrix cores
+        # template arguments after the type: training, matrix cores, levels (4 / 3 = the full ladder of a 56 / 28 plane; one less: "levels-1")
+        t_ = int(kern[len("k_recconv_cpt<"):].split(",")[0])
+        lv = (4 if t_ == 4 else 3) - (1 if ">,levels-1," in plan else 0)
+        return f"rcx::cpt::{kern}, {t}, false, false, {lv}>"
     if plan.startswith("cpt_mx(k_recconv_cpt"):
         kern = plan[len("cpt_mx("):plan.index(">")].rsplit(", ", 2)[0]        # "... <4, 2, mode, pixb, bf16, MX" -> up to the pitch
-        return f"rcx::cpt::{kern}, {'_Float16' if ', f16,' in plan else 'unsigned short'}, false, true>"
+        return f"rcx::cpt::{kern}, {'_Float16' if ', f16,' in plan else 'unsigned short'}, false, true, 4>"
     if plan.startswith("cpl14_mx(k_recconv_mx14"):
         mode = plan[len("cpl14_mx(k_recconv_mx14<"):].split(",")[0]
         return f"rcx::mx14::k_recconv_mx14<{mode}, {'_Float16' if ', f16>' in plan else 'unsigned short'}>"

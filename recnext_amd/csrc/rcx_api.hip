@@ -490,7 +490,7 @@ int rcx_recconv2d_fwd_train(const void* x, void* y, const float* wpack, const fl
         const bool fused_ok = !(tf && *tf == '0') && !lanes_off() && !(rcx::opt::value(rcx::opt::FORCE_SPLIT));
         const int md = mode == RCX_MODE_NEAREST ? 1 : 0;
         if (fused_ok && rcx::cpt_train_applicable(N, C, H, W, level, k, md, dtype)) {
-            hipError_t fe = rcx::cpt_recconv(x, y, wpack, bpack, N, C, H, md, dtype, s, (float*)saved, L.f_off, L.c_off);
+            hipError_t fe = rcx::cpt_recconv(x, y, wpack, bpack, N, C, H, level, md, dtype, s, (float*)saved, L.f_off, L.c_off);
             return fe == hipSuccess ? 0 : hip_fail(fe, "train fwd: fused tiled block");
         }
         if (fused_ok && rcx::cpl14_applicable(N, C, H, W, level, k, dtype)) {

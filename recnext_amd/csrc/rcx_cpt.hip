@@ -6,6 +6,7 @@
 namespace rcx {
 namespace cpt {
 hipError_t launch_t2(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s, const SavedPyr& sv);
+hipError_t launch_lv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int H, int mode, int dtype, hipStream_t s);   // rcx_cpt3.hip
 }  // namespace cpt
 
 // RCX_CPT=0 gives both blocks back to the banded lanes kernels.  The 28x28 block with a channel count that is not a multiple of 64
@@ -28,21 +29,28 @@ bool cpt_applicable(int N, int C, int H, int W, int level, int k, int dtype)
     if (!cpt::enabled() || k != 5 || C < 1 || !(dtype == 0 || dtype == 1 || dtype == 2)) return false;
     if (H == 56 && W == 56 && level == 4) return true;
     if (H == 28 && W == 28 && level == 3) return C % 64 == 0 || cpt28_ragged(N, C);
+    // one level less (round 3): stages 1 and 2 of a 448 x 448 input, inner blocks of the nested schedule; RCX_CPT=full: not these
+    const char* v = rcx::opt::value(rcx::opt::CPT);
+    if (v && *v == 'f') return false;
+    if (H == 56 && W == 56 && level == 3) return true;
+    if (H == 28 && W == 28 && level == 2) return C % 64 == 0;
     return false;
 }
 
 // the training forward has the bilinear, whole-block instantiations only
 bool cpt_train_applicable(int N, int C, int H, int W, int level, int k, int mode, int dtype)
 {
-    return mode == 0 && cpt_applicable(N, C, H, W, level, k, dtype) && !(H == 28 && C % 64 != 0);
+    return mode == 0 && cpt_applicable(N, C, H, W, level, k, dtype) && !(H == 28 && C % 64 != 0) && level == (H == 56 ? 4 : 3);
 }
 
-int cpt_describe(int N, int C, int H, int mode, int dtype, char* buf, int len)
+int cpt_describe(int N, int C, int H, int level, int mode, int dtype, char* buf, int len)
 {
     const int T = H / 14, halves = T == 4 ? (cpt::cb16(N, C) ? 4 : 2) : (C % 64 != 0 ? 2 : 1), pixf = 64 / halves;
-    const int pixb = C == (T == 4 ? 64 : 128) ? C * (dtype == 0 ? 4 : 2) : 0;
+    const bool full = level == (T == 4 ? 4 : 3);
+    const int pixb = full && C == (T == 4 ? 64 : 128) ? C * (dtype == 0 ? 4 : 2) : 0;
     const int total = N * ((C + pixf - 1) / pixf);
-    return snprintf(buf, len, "cpt(k_recconv_cpt<%d, %d, %d, %d>,cb=%d,nt=%d,units=%d,lds=%d)", T, halves, mode, pixb, pixf, T * T / halves * 64, total,
+    return snprintf(buf, len, full ? "cpt(k_recconv_cpt<%d, %d, %d, %d>,cb=%d,nt=%d,units=%d,lds=%d)" : "cpt(k_recconv_cpt<%d, %d, %d, %d>,levels-1,cb=%d,nt=%d,units=%d,lds=%d)",
+                    T, halves, mode, pixb, pixf, T * T / halves * 64, total,
                     T == 4 ? (halves == 4 ? cpt::Geo<4, 4, 0, float>::LDS_BYTES : cpt::Geo<4, 2, 0, float>::LDS_BYTES)
                            : (halves == 2 ? cpt::Geo<2, 2, 0, float>::LDS_BYTES : cpt::Geo<2, 1, 0, float>::LDS_BYTES));
 }
@@ -68,9 +76,10 @@ hipError_t cpt_mx_recconv(const void* x, void* y, const float* wpack, const floa
     return cpt::launch_mx(x, y, wpack, bpack, mxpack, N, C, mode, dtype, s);
 }
 
-hipError_t cpt_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int H, int mode, int dtype, hipStream_t s,
+hipError_t cpt_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int H, int level, int mode, int dtype, hipStream_t s,
                        float* saved, const size_t* f_off, const size_t* c_off)
 {
+    if (level != (H == 56 ? 4 : 3)) return saved ? hipErrorInvalidConfiguration : cpt::launch_lv(x, y, wpack, bpack, N, C, H, mode, dtype, s);
     cpt::SavedPyr sv{};
     sv.base = saved;
     if (saved)

@@ -568,10 +568,13 @@ constexpr Rel rel2(int mode, int par, int c)
     return Rel{(c & 1) ? (c - 1) / 2 : c / 2, (c & 1) ? 0.75f : 0.25f};
 }
 
-template <int T_, int HALVES, int MODE, typename TIO, bool MX_ = false>
+// NL_ = levels of the block: the full ladder down to 4 x 4 (56 x 56 / level 4, 28 x 28 / level 3: RecNeXt at 224 x 224) or one level less
+// (56 x 56 / level 3, 28 x 28 / level 2: the same stages of a 448 x 448 input, and the inner blocks of the nested schedule)
+template <int T_, int HALVES, int MODE, typename TIO, bool MX_ = false, int NL_ = (T_ == 4 ? 4 : 3)>
 struct Geo {
     static constexpr int T = T_;
-    static constexpr int NL = T == 4 ? 4 : 3;
+    static constexpr int NL = NL_;
+    static_assert(NL == (T == 4 ? 4 : 3) || NL == (T == 4 ? 3 : 2), "levels");
     static constexpr int NW = T * T / HALVES;
     static constexpr int NT = NW * 64;
     static constexpr int CB = 64 / HALVES;                 // channels of a workgroup's block
@@ -606,13 +609,14 @@ struct Geo {
 // workgroup = four waves = 16 channels of an image with 69 KB of LDS -- TWO workgroups per CU, which run different units and so are
 // in different phases: one's barrier-bound small-plane phases and load waits fill with the other's passes (a 32-channel workgroup
 // alone on its CU serialises ~105 k cycles of phases that each leave most of the CU idle).  Used where cb16() says so.
-template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool TRAIN = false, bool MX = false>
+template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool TRAIN = false, bool MX = false, int LV = (T == 4 ? 4 : 3)>
 __global__ __launch_bounds__(T * T / HALVES * 64, (T == 4 && HALVES == 2) ? 1 : 2)          // 256 registers either way: 8 waves per CU
 void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack,
                    int N, int C, int has_bias, SavedPyr sv, const void* __restrict__ mxpack)
 {
-    using G = Geo<T, HALVES, MODE, TIO, MX>;
+    using G = Geo<T, HALVES, MODE, TIO, MX, LV>;
     static_assert(!MX || (T == 4 && HALVES == 2 && !TRAIN && sizeof(TIO) == 2), "matrix-core variant: 56x56, inference, 16-bit activations");
+    static_assert(LV == (T == 4 ? 4 : 3) || (!TRAIN && !MX), "the shorter ladder: inference, vector pipe");
     constexpr int NL = G::NL, PIXF = G::PIXF, NWORK = G::NWORK, P0 = G::P0, P1 = G::P1, P2 = G::P2, P3 = G::P3, P4 = G::P4;
     constexpr int NCOL = MX ? 20 : 18;                             // columns of a level-0 input row held by a lane
     constexpr int ESZ = (int)sizeof(TIO);
@@ -1405,15 +1409,15 @@ static inline bool enabled()
     return !(v && *v == '0') && !(l && *l == '0');
 }
 
-template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool TRAIN = false, bool MX = false>
+template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool TRAIN = false, bool MX = false, int LV = (T == 4 ? 4 : 3)>
 static hipError_t launch(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv, const void* mxpack = nullptr)
 {
-    using G = Geo<T, HALVES, MODE, TIO, MX>;
-    if constexpr (!TRAIN && MODE == 0 && !MX && HALVES != 4 && !(T == 2 && HALVES == 2)) {      // training forward: bilinear only (what RecConv2d trains with), whole-block variants
+    using G = Geo<T, HALVES, MODE, TIO, MX, LV>;
+    if constexpr (!TRAIN && MODE == 0 && !MX && HALVES != 4 && !(T == 2 && HALVES == 2) && LV == (T == 4 ? 4 : 3)) {      // training forward: bilinear only (what RecConv2d trains with), whole-block variants, full ladder
         if (sv.base) return launch<T, HALVES, MODE, PIXB, TIO, true>(x, y, wpack, bpack, N, C, s, sv);
     }
     if (!TRAIN && sv.base) return hipErrorInvalidConfiguration;
-    auto kfn = k_recconv_cpt<T, HALVES, MODE, PIXB, TIO, TRAIN, MX>;
+    auto kfn = k_recconv_cpt<T, HALVES, MODE, PIXB, TIO, TRAIN, MX, LV>;
     RCX_SET_LDS_ONCE(kfn, G::LDS_BYTES);                       // once per instantiation and device
     static std::atomic<int> cus_cache{0};
     int cus = cus_cache.load(std::memory_order_relaxed);
@@ -1437,10 +1441,13 @@ static hipError_t launch(const void* x, void* y, const float* wpack, const float
 }
 
 // the channel counts of RecNeXt-M3 / M4 get the compile-time pixel pitch (immediate column offsets), the rest the run-time one
-template <int T, int HALVES, int MODE, typename TIO>
+template <int T, int HALVES, int MODE, typename TIO, int LV = (T == 4 ? 4 : 3)>
 static hipError_t launch_c(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv)
 {
     constexpr int CM3 = T == 4 ? 64 : 128;
+    if constexpr (LV != (T == 4 ? 4 : 3)) {                    // the shorter ladder (other resolutions, inner blocks): the run-time pitch only
+        return launch<T, HALVES, MODE, 0, TIO, false, false, LV>(x, y, wpack, bpack, N, C, s, sv);
+    } else {
     if (C == CM3) return launch<T, HALVES, MODE, CM3 * (int)sizeof(TIO), TIO>(x, y, wpack, bpack, N, C, s, sv);
     if constexpr (T == 2 && HALVES == 1) {
         // channel counts that are not multiples of 64 (RecNeXt-M1: 96, M5: 160, M0: 80): 32-channel workgroups of two waves, a wave = the two
@@ -1448,6 +1455,7 @@ static hipError_t launch_c(const void* x, void* y, const float* wpack, const flo
         if (C % 64 != 0 && !sv.base) return launch<2, 2, MODE, 0, TIO>(x, y, wpack, bpack, N, C, s, sv);
     }
     return launch<T, HALVES, MODE, 0, TIO>(x, y, wpack, bpack, N, C, s, sv);
+    }
 }
 
 // matrix-core variant (56x56 / level 4, bf16 or float16 activations; rcx_cpt.hip decides when it applies)
@@ -1479,12 +1487,12 @@ static inline bool cb16(int N, int C)
     return C % 32 != 0 || (long long)N * ((C + 31) / 32) < 256;
 }
 
-template <int T, int HALVES>
+template <int T, int HALVES, int LV = (T == 4 ? 4 : 3)>
 static hipError_t launch_md(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s, const SavedPyr& sv)
 {
-    if (dtype == 1) return mode == 1 ? launch_c<T, HALVES, 1, bf16_t>(x, y, wpack, bpack, N, C, s, sv) : launch_c<T, HALVES, 0, bf16_t>(x, y, wpack, bpack, N, C, s, sv);
-    if (dtype == 2) return mode == 1 ? launch_c<T, HALVES, 1, f16_t>(x, y, wpack, bpack, N, C, s, sv) : launch_c<T, HALVES, 0, f16_t>(x, y, wpack, bpack, N, C, s, sv);
-    return mode == 1 ? launch_c<T, HALVES, 1, float>(x, y, wpack, bpack, N, C, s, sv) : launch_c<T, HALVES, 0, float>(x, y, wpack, bpack, N, C, s, sv);
+    if (dtype == 1) return mode == 1 ? launch_c<T, HALVES, 1, bf16_t, LV>(x, y, wpack, bpack, N, C, s, sv) : launch_c<T, HALVES, 0, bf16_t, LV>(x, y, wpack, bpack, N, C, s, sv);
+    if (dtype == 2) return mode == 1 ? launch_c<T, HALVES, 1, f16_t, LV>(x, y, wpack, bpack, N, C, s, sv) : launch_c<T, HALVES, 0, f16_t, LV>(x, y, wpack, bpack, N, C, s, sv);
+    return mode == 1 ? launch_c<T, HALVES, 1, float, LV>(x, y, wpack, bpack, N, C, s, sv) : launch_c<T, HALVES, 0, float, LV>(x, y, wpack, bpack, N, C, s, sv);
 }
 
 }  // namespace cpt

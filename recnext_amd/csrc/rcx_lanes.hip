@@ -69,7 +69,7 @@ bool lanes_applicable(int N, int C, int H, int W, int level, int k, int dtype)
 
 int lanes_describe(int N, int C, int H, int W, int level, int k, int mode, int dtype, char* buf, int len)
 {
-    if (cpt_applicable(N, C, H, W, level, k, dtype)) return cpt_describe(N, C, H, mode, dtype, buf, len);
+    if (cpt_applicable(N, C, H, W, level, k, dtype)) return cpt_describe(N, C, H, level, mode, dtype, buf, len);
     if (cpl14_applicable(N, C, H, W, level, k, dtype)) return cpl14_describe(N, C, mode, dtype, buf, len);
     if (cpl7b_applicable(N, C, H, W, level, k, dtype)) return cpl7b_describe(N, C, mode, buf, len);
     const lanes::LanesPlan p = lanes::plan(N, C, H, W, level, k, dtype);
@@ -84,7 +84,7 @@ int lanes_describe(int N, int C, int H, int W, int level, int k, int mode, int d
 hipError_t lanes_recconv(const void* x, void* y, const float* wpack, const float* bpack,
                          int N, int C, int H, int W, int level, int k, int mode, int dtype, hipStream_t s)
 {
-    if (cpt_applicable(N, C, H, W, level, k, dtype)) return cpt_recconv(x, y, wpack, bpack, N, C, H, mode, dtype, s);
+    if (cpt_applicable(N, C, H, W, level, k, dtype)) return cpt_recconv(x, y, wpack, bpack, N, C, H, level, mode, dtype, s);
     if (cpl14_applicable(N, C, H, W, level, k, dtype)) return cpl14_recconv(x, y, wpack, bpack, N, C, mode, dtype, s);
     if (cpl7b_applicable(N, C, H, W, level, k, dtype)) return cpl7b_recconv(x, y, wpack, bpack, N, C, mode, dtype, s);
     const lanes::LanesPlan p = lanes::plan(N, C, H, W, level, k, dtype);

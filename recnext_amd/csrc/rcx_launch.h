@@ -104,9 +104,9 @@ hipError_t wgrad2m_cpl(const void* a, int a_dt, const float* g, float* partial, 
 
 // channel-per-lane, tiled kernel of the 56x56 / level 4 and 28x28 / level 3 blocks (rcx_cpt.hip): any channel count
 bool cpt_applicable(int N, int C, int H, int W, int level, int k, int dtype);
-int cpt_describe(int N, int C, int H, int mode, int dtype, char* buf, int len);
+int cpt_describe(int N, int C, int H, int level, int mode, int dtype, char* buf, int len);
 bool cpt_train_applicable(int N, int C, int H, int W, int level, int k, int mode, int dtype);
-hipError_t cpt_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int H, int mode, int dtype, hipStream_t s,
+hipError_t cpt_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int H, int level, int mode, int dtype, hipStream_t s,
                        float* saved = nullptr, const size_t* f_off = nullptr, const size_t* c_off = nullptr);
 // the same block with its two level-0 passes on the matrix cores (16-bit activations, taps rounded to their type: rcx_recconv2d_fwd_mx)
 bool cpt_mx_applicable(int N, int C, int H, int W, int level, int k, int dtype);

@@ -55,6 +55,12 @@ def test_abi_version_and_argument_errors_without_gpu():
     with rcx_env(RCX_CPT_CB="16"):
         assert lib.rcx_recconv2d_fwd_plan(256, 64, 56, 56, 4, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<4, 4, 0, 128>,cb=16")
     assert lib.rcx_recconv2d_fwd_plan(256, 128, 28, 28, 3, 5, 1, 0).startswith(b"cpt(k_recconv_cpt<2, 1, 1, 512>")
+    # one level less: stages 1 and 2 of a 448 x 448 input (run-time pitch; no training instantiation)
+    assert lib.rcx_recconv2d_fwd_plan(64, 128, 56, 56, 3, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<4, 2, 0, 0>,levels-1,cb=32")
+    assert lib.rcx_recconv2d_fwd_plan(64, 256, 28, 28, 2, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<2, 1, 0, 0>,levels-1,cb=64")
+    assert lib.rcx_recconv2d_fwd_plan(64, 96, 28, 28, 2, 5, 0, 1).startswith(b"plane(")
+    with rcx_env(RCX_CPT="full"):
+        assert lib.rcx_recconv2d_fwd_plan(64, 128, 56, 56, 3, 5, 0, 1).startswith(b"plane(")
     assert lib.rcx_recconv2d_fwd_plan(256, 48, 56, 56, 4, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<4, 4, 0, 0>,cb=16")    # run-time pixel pitch; ragged 32-blocks: 16
     with rcx_env(RCX_CPT_CB="32"):
         assert lib.rcx_recconv2d_fwd_plan(256, 48, 56, 56, 4, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<4, 2, 0, 0>,cb=32")

@@ -208,7 +208,10 @@ def test_56_block_with_16_and_32_channel_workgroups_is_the_same_function(mode, d
 @pytest.mark.parametrize("bias", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 64, 56, 4), (1, 48, 56, 4), (2, 80, 56, 4), (1, 8, 56, 4), (2, 128, 28, 3), (1, 96, 28, 3), (3, 160, 28, 3),
-                                   (2, 40, 28, 3), (3, 96, 28, 3), (1, 72, 28, 3)], ids=lambda v: "x".join(map(str, v)))
+                                   (2, 40, 28, 3), (3, 96, 28, 3), (1, 72, 28, 3),
+                                   # one level less (the same stages of a 448 x 448 input, inner blocks of the nested schedule; round 3)
+                                   (2, 64, 56, 3), (1, 48, 56, 3), (3, 128, 56, 3), (2, 128, 28, 2), (1, 64, 28, 2), (3, 256, 28, 2)],
+                         ids=lambda v: "x".join(map(str, v)))
 def test_tiled_channel_per_lane_kernel_against_oracle_and_lanes_kernel(mode, bias, dtype, shape, monkeypatch):
     """The 56x56 / level 4 and 28x28 / level 3 blocks on rcx_cpt.hip (a lane owns one channel of one 14x14 tile, the planes of
     level >= 1 in LDS) against the oracle: whole channel blocks (64, 128), ragged last blocks (48, 80, 8, 96, 160, 40), both
@@ -226,6 +229,7 @@ def test_tiled_channel_per_lane_kernel_against_oracle_and_lanes_kernel(mode, bia
     plan = ops.recconv2d_plan(n, c, hw, hw, level, k, mode, dtype)
     assert plan.startswith("cpt(k_recconv_cpt<")
     assert plan.startswith("cpt(k_recconv_cpt<2, 2,") == (hw == 28 and c % 64 != 0)
+    assert ("levels-1" in plan) == (level != (4 if hw == 56 else 3))
     got = _run_hip(x, wd, wc, bd, bc, level, k, mode, dtype)
     if dtype == torch.float32:
         assert np.abs(got - ref).max() < F32_TIGHT

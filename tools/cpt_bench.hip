@@ -52,7 +52,7 @@ int main(int argc, char** argv)
             }
         CK(hipMalloc(&mxp, hm.size() * 2)); CK(hipMemcpy(mxp, hm.data(), hm.size() * 2, hipMemcpyHostToDevice));
     }
-    auto run = [&](hipStream_t st_) { return mx ? rcx::cpt_mx_recconv(x, y, w, nullptr, mxp, N, C, 0, dt, st_) : rcx::cpt_recconv(x, y, w, nullptr, N, C, H, 0, dt, st_); };
+    auto run = [&](hipStream_t st_) { return mx ? rcx::cpt_mx_recconv(x, y, w, nullptr, mxp, N, C, 0, dt, st_) : rcx::cpt_recconv(x, y, w, nullptr, N, C, H, level, 0, dt, st_); };
     hipStream_t s; CK(hipStreamCreate(&s));
     for (int i = 0; i < 3; ++i) CK(run(s));
     CK(hipStreamSynchronize(s));
