@@ -185,9 +185,9 @@ def kernel_name(plan, elem_bytes):
     if plan.startswith("cpl(k_recconv_cpl"):
         kern = plan[len("cpl("):plan.index(">")]
         ns = "cpl14"                                                          # rcx_cpl14.hip
-        if kern.startswith("k_recconv_cpl14<"):                              # last template argument: x through LDS (A/B variant)
+        if kern.startswith("k_recconv_cpl14<"):                              # template arguments after the type: x through LDS (A/B variant), levels
             xl = kern.endswith(", XL")
-            return f"rcx::{ns}::{kern[:-4] if xl else kern}, {t}, {'true' if xl else 'false'}>"
+            return f"rcx::{ns}::{kern[:-4] if xl else kern}, {t}, {'true' if xl else 'false'}, {1 if '>,levels-1,' in plan else 2}>"
         return f"rcx::{ns}::{kern}, {t}>"
     return "rcx::k_conv_generic<...> (one launch per ladder step)"
 

@@ -113,7 +113,8 @@ __device__ __forceinline__ void load_taps_asm(float (&w)[25], i32x4 wsrc, unsign
 #undef RCX_TL
 #undef RCX_TSTEP
 
-template <int MODE, int CT, typename TIO, bool XL = false>
+// LV = levels of the block: 2 (14 -> 7 -> 4: RecNeXt's stage 2 at 224 x 224) or 1 (14 -> 7: stage 3 of a 448 x 448 input; inference only)
+template <int MODE, int CT, typename TIO, bool XL = false, int LV = 2>
 __global__ __launch_bounds__(64)
 void k_recconv_cpl14(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack,
                      int N, int C_rt, int has_bias, SavedPyr sv)
@@ -263,7 +264,14 @@ void k_recconv_cpl14(const TIO* __restrict__ x, TIO* __restrict__ y, const float
     // ---- the level-1 block on the 7x7 plane: C1 = conv_1(F1 + resize(conv_0(down(F1))))          (:27-33)
     f32x2 C1[W1][P1];
     Taps t2;
-    {
+    if constexpr (LV == 1) {                                // one level: C1 = conv_0(F1), the final conv is pack 2
+        Taps t0;
+        load_taps<CT>(t0, wpack, bpack, 1, C, vow, has_bias);
+        RCX_FENCE;
+        load_taps<CT>(t2, wpack, bpack, 2, C, vow, has_bias);
+        RCX_FENCE;
+        conv5_plane<W1>(F1, C1, t0);
+    } else {
         Taps t0;                                            // tap sets are fetched one stage ahead of their use and no earlier
         load_taps<CT>(t0, wpack, bpack, 1, C, vow, has_bias);
         f32x2 F2[W2][P2];
@@ -582,6 +590,16 @@ static hipError_t launch7(const void* x, void* y, const float* wpack, const floa
     return hipGetLastError();
 }
 
+// 14 x 14 / level 1 (stage 3 of a 448 x 448 input): the same kernel without its 4 x 4 level
+template <int MODE, typename TIO>
+static hipError_t launch_short(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s)
+{
+    const SavedPyr sv{};
+    const unsigned grid = (unsigned)(N * ((C + 63) / 64));
+    hipLaunchKernelGGL((k_recconv_cpl14<MODE, 0, TIO, false, 1>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
+    return hipGetLastError();
+}
+
 template <int MODE, typename TIO>
 static hipError_t launch7_c(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv)
 {
@@ -590,6 +608,25 @@ static hipError_t launch7_c(const void* x, void* y, const float* wpack, const fl
 }
 
 }  // namespace cpl14
+
+// 14 x 14 / level 1: inference only (no saved pyramid, no fused backward behind it: cpl14_applicable stays the level-2 block)
+bool cpl14_short_applicable(int N, int C, int H, int W, int level, int k, int dtype)
+{
+    (void)N;
+    return cpl14::enabled() && H == 14 && W == 14 && level == 1 && k == 5 && C >= 1 && (dtype == 0 || dtype == 1 || dtype == 2);
+}
+
+int cpl14_short_describe(int N, int C, int mode, char* buf, int len)
+{
+    return snprintf(buf, len, "cpl(k_recconv_cpl14<%d, 0>,levels-1,cb=64,nt=64,blocks=%d,lds=0)", mode, N * ((C + 63) / 64));
+}
+
+hipError_t cpl14_short_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s)
+{
+    if (dtype == 1) return mode == 1 ? cpl14::launch_short<1, bf16_t>(x, y, wpack, bpack, N, C, s) : cpl14::launch_short<0, bf16_t>(x, y, wpack, bpack, N, C, s);
+    if (dtype == 2) return mode == 1 ? cpl14::launch_short<1, f16_t>(x, y, wpack, bpack, N, C, s) : cpl14::launch_short<0, f16_t>(x, y, wpack, bpack, N, C, s);
+    return mode == 1 ? cpl14::launch_short<1, float>(x, y, wpack, bpack, N, C, s) : cpl14::launch_short<0, float>(x, y, wpack, bpack, N, C, s);
+}
 
 // the 7x7 / level 1 block on the pieces of this file (round 1's first version, rcx_cpl.hip, left the tree in round 3: profiles/r01*, r02a_*)
 bool cpl7b_applicable(int N, int C, int H, int W, int level, int k, int dtype)

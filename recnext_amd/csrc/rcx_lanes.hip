@@ -64,13 +64,14 @@ hipError_t set_stamp_buffer(void* p)
 
 bool lanes_applicable(int N, int C, int H, int W, int level, int k, int dtype)
 {
-    return cpt_applicable(N, C, H, W, level, k, dtype) || cpl14_applicable(N, C, H, W, level, k, dtype) || cpl7b_applicable(N, C, H, W, level, k, dtype) || lanes::plan(N, C, H, W, level, k, dtype).ok;
+    return cpt_applicable(N, C, H, W, level, k, dtype) || cpl14_applicable(N, C, H, W, level, k, dtype) || cpl14_short_applicable(N, C, H, W, level, k, dtype) || cpl7b_applicable(N, C, H, W, level, k, dtype) || lanes::plan(N, C, H, W, level, k, dtype).ok;
 }
 
 int lanes_describe(int N, int C, int H, int W, int level, int k, int mode, int dtype, char* buf, int len)
 {
     if (cpt_applicable(N, C, H, W, level, k, dtype)) return cpt_describe(N, C, H, level, mode, dtype, buf, len);
     if (cpl14_applicable(N, C, H, W, level, k, dtype)) return cpl14_describe(N, C, mode, dtype, buf, len);
+    if (cpl14_short_applicable(N, C, H, W, level, k, dtype)) return cpl14_short_describe(N, C, mode, buf, len);
     if (cpl7b_applicable(N, C, H, W, level, k, dtype)) return cpl7b_describe(N, C, mode, buf, len);
     const lanes::LanesPlan p = lanes::plan(N, C, H, W, level, k, dtype);
     if (!p.ok) return 0;
@@ -86,6 +87,7 @@ hipError_t lanes_recconv(const void* x, void* y, const float* wpack, const float
 {
     if (cpt_applicable(N, C, H, W, level, k, dtype)) return cpt_recconv(x, y, wpack, bpack, N, C, H, level, mode, dtype, s);
     if (cpl14_applicable(N, C, H, W, level, k, dtype)) return cpl14_recconv(x, y, wpack, bpack, N, C, mode, dtype, s);
+    if (cpl14_short_applicable(N, C, H, W, level, k, dtype)) return cpl14_short_recconv(x, y, wpack, bpack, N, C, mode, dtype, s);
     if (cpl7b_applicable(N, C, H, W, level, k, dtype)) return cpl7b_recconv(x, y, wpack, bpack, N, C, mode, dtype, s);
     const lanes::LanesPlan p = lanes::plan(N, C, H, W, level, k, dtype);
     if (!p.ok) return hipErrorInvalidConfiguration;

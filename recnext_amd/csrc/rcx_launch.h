@@ -58,6 +58,9 @@ hipError_t lanes16_recconv(const void* x, void* y, const float* wpack, const flo
 
 // channel-per-lane kernel of the 14x14 / level 2 block (rcx_cpl14.hip): any channel count
 bool cpl14_applicable(int N, int C, int H, int W, int level, int k, int dtype);
+bool cpl14_short_applicable(int N, int C, int H, int W, int level, int k, int dtype);       // 14 x 14 / level 1, inference
+int cpl14_short_describe(int N, int C, int mode, char* buf, int len);
+hipError_t cpl14_short_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s);
 int cpl14_describe(int N, int C, int mode, int dtype, char* buf, int len);
 // saved != nullptr (training forward): the launch also writes the float32 pyramid F_l at saved + f_off[l], C_l at saved + c_off[l] (bytes, l >= 1)
 hipError_t cpl14_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s,

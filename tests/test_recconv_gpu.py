@@ -154,19 +154,22 @@ def test_channel_per_lane_kernel_against_oracle_and_lanes_kernel(mode, bias, dty
 @pytest.mark.parametrize("mode", ["bilinear", "nearest"])
 @pytest.mark.parametrize("bias", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("level", [2, 1], ids=["L2", "L1"])
 @pytest.mark.parametrize("nc", [(3, 256), (2, 192), (2, 40), (1, 100), (5, 8), (2, 320)], ids=lambda v: f"{v[0]}x{v[1]}")
-def test_channel_per_lane_14x14_kernel_against_oracle_and_lanes_kernel(mode, bias, dtype, nc, monkeypatch):
+def test_channel_per_lane_14x14_kernel_against_oracle_and_lanes_kernel(mode, bias, dtype, nc, level, monkeypatch):
     """The 14x14 / level 2 block (13 of RecNeXt-M3's 21 blocks): rcx_cpl14.hip, one lane per (image, channel) plane, against the
     oracle; channel counts with the compile-time-C instantiation (256), whole waves (192, 320) and ragged last waves (40, 100, 8).
-    Where the lanes kernel applies too the two must agree to float32 round-off (different summation orders)."""
+    Where the lanes kernel applies too the two must agree to float32 round-off (different summation orders).  Level 1 (round 3): the
+    same kernel without its 4 x 4 level -- stage 3 of a 448 x 448 input."""
     n, c = nc
-    level, k = 2, 5
+    k = 5
     rng = np.random.default_rng(zlib.crc32(repr((mode, bias, str(dtype), nc)).encode()))
     x, wd, wc, bd, bc = _rand_case(rng, n, c, 14, 14, level, k, bias)
     if dtype == torch.bfloat16:
         x = bf16_round_np(x)
     ref = c_oracle.recconv2d(x, wd, wc, bd, bc, level, mode)
-    assert ops.recconv2d_plan(n, c, 14, 14, level, k, mode, dtype).startswith("cpl(k_recconv_cpl14<")
+    plan = ops.recconv2d_plan(n, c, 14, 14, level, k, mode, dtype)
+    assert plan.startswith("cpl(k_recconv_cpl14<") and ("levels-1" in plan) == (level == 1)
     got = _run_hip(x, wd, wc, bd, bc, level, k, mode, dtype)
     if dtype == torch.float32:
         assert np.abs(got - ref).max() < F32_TIGHT
