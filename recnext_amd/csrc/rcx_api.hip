@@ -83,6 +83,7 @@ bool use_split(int N, int C, int H, int W, int level, int k, int dtype)
     const char* f = rcx::opt::value(rcx::opt::FORCE_GENERIC);
     if (f && *f && *f != '0') return false;
     if (level < 1 || k != 5 || H != W || (H & 1)) return false;
+    if (H < 64 && !rcx::opt::value(rcx::opt::FORCE_SPLIT)) return false;   // small planes: the fused LDS-pyramid kernel (or the nested schedule) decides
     const char* force = rcx::opt::value(rcx::opt::FORCE_SPLIT);                  // A/B knob: three launches even where one fused kernel exists
     if (rcx::lanes_applicable(N, C, H, W, level, k, dtype) && !(force && *force == '1')) return false;
     return rcx::down5_lanes_applicable(N, C, H, W, k, 2, dtype, RCX_DTYPE_F32) &&
