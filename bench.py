@@ -185,9 +185,10 @@ def kernel_name(plan, elem_bytes):
     if plan.startswith("cpl(k_recconv_cpl"):
         kern = plan[len("cpl("):plan.index(">")]
         ns = "cpl14"                                                          # rcx_cpl14.hip
-        if kern.startswith("k_recconv_cpl14<"):                              # template arguments after the type: x through LDS (A/B variant), levels
-            xl = kern.endswith(", XL")
-            return f"rcx::{ns}::{kern[:-4] if xl else kern}, {t}, {'true' if xl else 'false'}, {1 if '>,levels-1,' in plan else 2}>"
+        if kern.startswith("k_recconv_cpl14<"):                              # template arguments after the type: x through LDS (A/B variant), levels, reload form
+            xl, rl = kern.endswith(", XL"), kern.endswith(", RL")
+            return (f"rcx::{ns}::{kern[:-4] if xl or rl else kern}, {t}, {'true' if xl else 'false'}, {1 if '>,levels-1,' in plan else 2}, "
+                    f"{'true' if rl else 'false'}>")
         return f"rcx::{ns}::{kern}, {t}>"
     return "rcx::k_conv_generic<...> (one launch per ladder step)"
 

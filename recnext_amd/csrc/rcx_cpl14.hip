@@ -114,8 +114,12 @@ __device__ __forceinline__ void load_taps_asm(float (&w)[25], i32x4 wsrc, unsign
 #undef RCX_TSTEP
 
 // LV = levels of the block: 2 (14 -> 7 -> 4: RecNeXt's stage 2 at 224 x 224) or 1 (14 -> 7: stage 3 of a 448 x 448 input; inference only)
-template <int MODE, int CT, typename TIO, bool XL = false, int LV = 2>
-__global__ __launch_bounds__(64)
+// RL = "reload" (round 3): x is not kept in the accumulator registers between the passes but read a second time (from L2) in pass 2, so a
+// wave fits 256 registers and TWO waves share a SIMD.  Same arithmetic on the same values: bit-identical to the stash form.  It pays
+// where the launch has more waves than the chip has SIMDs (N * ceil(C / 64) > 1 024: RecNeXt-M5's 256 x 320, any batch above 256 of M3):
+// the stash form then runs a second round on a fraction of the chip.
+template <int MODE, int CT, typename TIO, bool XL = false, int LV = 2, bool RL = false>
+__global__ __launch_bounds__(64, RL ? 2 : 1)
 void k_recconv_cpl14(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack,
                      int N, int C_rt, int has_bias, SavedPyr sv)
 {
@@ -220,10 +224,12 @@ void k_recconv_cpl14(const TIO* __restrict__ x, TIO* __restrict__ y, const float
             pin_row<14 * (W - 1 - r < AHEAD ? W - 1 - r : AHEAD)>(raw[r]);
 #pragma unroll
             for (int j = 0; j < P; ++j) xr[j] = f32x2{PixLd<TIO>::cvt(raw[r][2 * j]), PixLd<TIO>::cvt(raw[r][2 * j + 1])};
+            if constexpr (!RL) {
 #pragma unroll
-            for (int j = 0; j < P; ++j) {
-                S[r][2 * j] = stash(xr[j].x);
-                S[r][2 * j + 1] = stash(xr[j].y);
+                for (int j = 0; j < P; ++j) {
+                    S[r][2 * j] = stash(xr[j].x);
+                    S[r][2 * j + 1] = stash(xr[j].y);
+                }
             }
         }
 #pragma unroll
@@ -260,6 +266,15 @@ void k_recconv_cpl14(const TIO* __restrict__ x, TIO* __restrict__ y, const float
     });
     RCX_FENCE;
 
+    // RL: the first rows of x again, requested before the level-1 block so that they arrive behind it (ordered loads the compiler counts itself)
+    constexpr int AHEAD2 = 2;
+    uint32_t raw2[W][W];
+    auto load_row2 = [&](int r) {
+        ra.row(xb, r, [&](auto qc, gcptr base, unsigned voff, auto immc) {
+            raw2[r][decltype(qc)::value] = SafeLd<TIO>::ld(base + decltype(immc)::value + voff);
+        });
+    };
+    if constexpr (RL) lanes::sfor<AHEAD2>([&](auto rc) { load_row2(decltype(rc)::value); });
     if (sv.base) save_plane<W1>(sv.base, sv.f_off[0], n, C, c, F1);                               // training forward: F_1
     // ---- the level-1 block on the 7x7 plane: C1 = conv_1(F1 + resize(conv_0(down(F1))))          (:27-33)
     f32x2 C1[W1][P1];
@@ -329,6 +344,11 @@ void k_recconv_cpl14(const TIO* __restrict__ x, TIO* __restrict__ y, const float
             else pin_lds_row<0>(xl[t & 1]);
 #pragma unroll
             for (int j = 0; j < P; ++j) row[j] = f32x2{PixLd<TIO>::cvt(xl[t & 1][2 * j]), PixLd<TIO>::cvt(xl[t & 1][2 * j + 1])};
+        } else if constexpr (RL) {
+            if (t + AHEAD2 < W) load_row2(t + AHEAD2);
+            pin_raw(raw2[t]);
+#pragma unroll
+            for (int j = 0; j < P; ++j) row[j] = f32x2{SafeLd<TIO>::cvt(raw2[t][2 * j]), SafeLd<TIO>::cvt(raw2[t][2 * j + 1])};
         } else {
 #pragma unroll
             for (int j = 0; j < P; ++j) row[j] = f32x2{unstash(S[t][2 * j]), unstash(S[t][2 * j + 1])};
@@ -538,10 +558,29 @@ static inline bool enabled()
     return !(v && *v == '0') && !(l && *l == '0');
 }
 
+// more waves than SIMDs (4 x 256 CUs): the reload form, two waves per SIMD, takes them in one round.  RCX_CPL14_RL=0 / 1 pins either form.
+static inline bool use_reload(unsigned waves)
+{
+    const char* v = rcx::opt::value(rcx::opt::CPL14_RL);
+    if (v && *v == '0') return false;
+    if (v && *v == '1') return true;
+    return waves > 1024u;
+}
+
+template <int CT, typename TIO> constexpr bool reload_built() { return CT > 0 && sizeof(TIO) == 2; }
+
 template <int MODE, int CT, typename TIO>
 static hipError_t launch(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv)
 {
     const unsigned grid = (unsigned)(N * ((C + 63) / 64));
+    // (the run-time-pitch instantiations spend 14 registers on column offsets, the float32 ones convert nothing in place: neither fits 256
+    // registers without scratch, and they keep the stash form)
+    if constexpr (reload_built<CT, TIO>()) {
+        if (!sv.base && use_reload(grid)) {
+            hipLaunchKernelGGL((k_recconv_cpl14<MODE, CT, TIO, false, 2, true>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((k_recconv_cpl14<MODE, CT, TIO>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
     return hipGetLastError();
 }
@@ -579,6 +618,7 @@ static hipError_t launch_c(const void* x, void* y, const float* wpack, const flo
     }
 #endif
     if (C == 256) return launch<MODE, 256, TIO>(x, y, wpack, bpack, N, C, s, sv);          // RecNeXt-M3/M4 stage 2: immediates instead of scalar adds
+    if (C == 320) return launch<MODE, 320, TIO>(x, y, wpack, bpack, N, C, s, sv);          // RecNeXt-M5 stage 2 (BASELINE config 3): the reload form needs them to fit 256 registers
     return launch<MODE, 0, TIO>(x, y, wpack, bpack, N, C, s, sv);
 }
 
@@ -681,7 +721,9 @@ bool cpl14_applicable(int N, int C, int H, int W, int level, int k, int dtype)
 int cpl14_describe(int N, int C, int mode, int dtype, char* buf, int len)
 {
     const bool xl = cpl14::use_xl(C, dtype == 0 ? 4 : 2);
-    return snprintf(buf, len, "cpl(k_recconv_cpl14<%d, %d%s>,cb=64,nt=64,blocks=%d,lds=%d)", mode, C == 256 ? 256 : 0, xl ? ", XL" : "", N * ((C + 63) / 64), xl ? 25 * 1024 : 0);
+    const int ct = C == 256 || C == 320 ? C : 0;
+    const bool rl = !xl && ct > 0 && dtype != 0 && cpl14::use_reload((unsigned)(N * ((C + 63) / 64)));       // inference launches (the training forward keeps the stash form)
+    return snprintf(buf, len, "cpl(k_recconv_cpl14<%d, %d%s>,cb=64,nt=64,blocks=%d,lds=%d)", mode, ct, xl ? ", XL" : (rl ? ", RL" : ""), N * ((C + 63) / 64), xl ? 25 * 1024 : 0);
 }
 
 hipError_t cpl14_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s,

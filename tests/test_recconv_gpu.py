@@ -187,6 +187,29 @@ def test_channel_per_lane_14x14_kernel_against_oracle_and_lanes_kernel(mode, bia
 
 
 @pytest.mark.parametrize("mode", ["bilinear", "nearest"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("nc", [(3, 256), (5, 320), (260, 320)], ids=lambda v: "x".join(map(str, v)))
+def test_14_block_reload_form_is_the_same_function(mode, dtype, nc):
+    """Round 3: the 14x14 / level 2 kernel also exists in a form that reads x a second time in pass 2 instead of keeping it in the
+    accumulator registers (256 registers, two waves per SIMD: chosen when the launch has more waves than the chip has SIMDs, i.e. by a
+    rule on N).  Same arithmetic on the same values: bit-identical to the stash form, so a batch shard still gives the batch's rows."""
+    n, c = nc
+    torch.manual_seed(n + c)
+    mod = recnext_amd.RecConv2d(c, kernel_size=5, level=2, mode=mode, bias=True).to(dev()).eval()
+    x = torch.randn(n, c, 14, 14, device=dev()).to(dtype).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        with rcx_env(RCX_CPL14_RL="1"):
+            assert ", RL>" in ops.recconv2d_plan(n, c, 14, 14, 2, 5, mode, dtype)
+            y_rl = mod(x)
+        with rcx_env(RCX_CPL14_RL="0"):
+            assert ", RL>" not in ops.recconv2d_plan(n, c, 14, 14, 2, 5, mode, dtype)
+            y_st = mod(x)
+        assert (", RL>" in ops.recconv2d_plan(n, c, 14, 14, 2, 5, mode, dtype)) == (n * ((c + 63) // 64) > 1024)     # the default rule
+        y = mod(x)
+    assert torch.equal(y_rl, y_st) and torch.equal(y, y_st)
+
+
+@pytest.mark.parametrize("mode", ["bilinear", "nearest"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("shape", [(3, 64), (2, 80), (5, 8), (2, 48)], ids=lambda v: "x".join(map(str, v)))
 def test_56_block_with_16_and_32_channel_workgroups_is_the_same_function(mode, dtype, shape):

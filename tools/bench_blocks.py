@@ -29,6 +29,8 @@ SHAPES = {
     # RecNeXt-M3 at 448 x 448 (twice the training resolution): 112 x 112 / level 4 is the split schedule (conv5 stride 2 -> the fused 56 x 56 block ->
     # conv5(x + resize)); its two outer steps are the tiled channel-per-lane kernels of rcx_upcpt.hip since round 3
     "m3_448": [(64, 64, 112, 112, 4), (64, 128, 56, 56, 3), (64, 256, 28, 28, 2), (64, 512, 14, 14, 1)],
+    # the 14x14 / level 2 block with more waves than the chip has SIMDs (reload form, RCX_CPL14_RL=0 / 1 pins either form)
+    "cpl14_waves": [(256, 256, 14, 14, 2), (256, 320, 14, 14, 2), (320, 256, 14, 14, 2), (512, 256, 14, 14, 2), (512, 320, 14, 14, 2)],
     "m3_512": [(32, 64, 128, 128, 4), (32, 128, 64, 64, 3), (32, 256, 32, 32, 2), (32, 512, 16, 16, 1)],
     # RecNeXt-M3 backbone on a COCO batch (detection/configs/_base_/datasets/coco_instance.py:9-12: 800 x 1344 padded, 2 images per GPU)
     "m3_coco": [(2, 64, 200, 336, 4), (2, 128, 100, 168, 3), (2, 256, 50, 84, 2), (2, 512, 25, 42, 1)],
