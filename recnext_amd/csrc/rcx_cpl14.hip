@@ -619,6 +619,7 @@ static hipError_t launch_c(const void* x, void* y, const float* wpack, const flo
 #endif
     if (C == 256) return launch<MODE, 256, TIO>(x, y, wpack, bpack, N, C, s, sv);          // RecNeXt-M3/M4 stage 2: immediates instead of scalar adds
     if (C == 320) return launch<MODE, 320, TIO>(x, y, wpack, bpack, N, C, s, sv);          // RecNeXt-M5 stage 2 (BASELINE config 3): the reload form needs them to fit 256 registers
+    if (C == 192) return launch<MODE, 192, TIO>(x, y, wpack, bpack, N, C, s, sv);          // RecNeXt-M1 stage 2 (BASELINE config 2)
     return launch<MODE, 0, TIO>(x, y, wpack, bpack, N, C, s, sv);
 }
 
@@ -721,7 +722,7 @@ bool cpl14_applicable(int N, int C, int H, int W, int level, int k, int dtype)
 int cpl14_describe(int N, int C, int mode, int dtype, char* buf, int len)
 {
     const bool xl = cpl14::use_xl(C, dtype == 0 ? 4 : 2);
-    const int ct = C == 256 || C == 320 ? C : 0;
+    const int ct = C == 256 || C == 320 || C == 192 ? C : 0;
     const bool rl = !xl && ct > 0 && dtype != 0 && cpl14::use_reload((unsigned)(N * ((C + 63) / 64)));       // inference launches (the training forward keeps the stash form)
     return snprintf(buf, len, "cpl(k_recconv_cpl14<%d, %d%s>,cb=64,nt=64,blocks=%d,lds=%d)", mode, ct, xl ? ", XL" : (rl ? ", RL" : ""), N * ((C + 63) / 64), xl ? 25 * 1024 : 0);
 }

@@ -74,7 +74,9 @@ def test_abi_version_and_argument_errors_without_gpu():
     with rcx_env(RCX_CPT="0"):
         assert lib.rcx_recconv2d_fwd_plan(256, 64, 56, 56, 4, 5, 0, 1).startswith(b"lanes(k_recconv_lanes_banded<56, 4, 16, 0,")
     assert lib.rcx_recconv2d_fwd_plan(256, 256, 14, 14, 2, 5, 1, 0).startswith(b"cpl(k_recconv_cpl14<1, 256>")       # channel per lane
-    assert lib.rcx_recconv2d_fwd_plan(256, 192, 14, 14, 2, 5, 0, 1).startswith(b"cpl(k_recconv_cpl14<0, 0>")          # any channel count
+    assert lib.rcx_recconv2d_fwd_plan(256, 192, 14, 14, 2, 5, 0, 1).startswith(b"cpl(k_recconv_cpl14<0, 192>")        # RecNeXt-M1 (M5: 320): compile-time pitch too
+    assert lib.rcx_recconv2d_fwd_plan(256, 320, 14, 14, 2, 5, 0, 1).startswith(b"cpl(k_recconv_cpl14<0, 320, RL>")    # more waves than SIMDs: the reload form
+    assert lib.rcx_recconv2d_fwd_plan(256, 128, 14, 14, 2, 5, 0, 1).startswith(b"cpl(k_recconv_cpl14<0, 0>")          # any channel count
     with rcx_env(RCX_CPL14="0"):
         assert lib.rcx_recconv2d_fwd_plan(256, 256, 14, 14, 2, 5, 1, 0).startswith(b"lanes(k_recconv_lanes<14, 2, 8, 1,")
     assert lib.rcx_recconv2d_fwd_plan(32, 64, 32, 32, 2, 5, 0, 1).startswith(b"lanes(k_recconv_lanes_banded<32, 2, 16, 0,")
