@@ -182,6 +182,15 @@ int rcx_dwconv2d_mult2_bwd(const void* x, const float* gy, const float* w_kkc, v
  */
 int rcx_linear_attention_fwd(const void* qpre, const void* kpre, const void* v, const void* pe, void* out,
                              int B, int n, int C, int heads, int dtype, void* stream);
+/*
+ * The same with `pe` computed where it is used (round 3): pe = depthwise 3x3 conv (pad 1) of v + bias -- LinearAttention's `pe`
+ * ConvNorm (model/recattn.py:14, :27 / :50) with its BatchNorm folded -- from the (3, 3, C) float32 pack of rcx_pack_dw_weight and the
+ * (C) bias pack (or NULL); v is the H x W plane in NHWC.  One launch and one tensor less than rcx_dwconv2d_fwd + rcx_linear_attention_fwd.
+ * RCX_ERR_UNSUPPORTED unless C/heads is a multiple of 4 (every head of the A-series is 32 wide) and the call runs on the vector-pipe kernel
+ * (fewer than 512 tokens for 32-wide heads and 16-bit I/O: on the matrix-core kernel the fused form measured slower and is not offered).
+ */
+int rcx_linear_attention_pe_fwd(const void* qpre, const void* kpre, const void* v, const float* w_pe_kkc, const float* b_pe, void* out,
+                                int B, int H, int W, int C, int heads, int dtype, void* stream);
 
 /*
  * Backward of rcx_linear_attention_fwd (the gradients engine.py:48-64 needs through RecAttn2d, model/recattn.py:16-28 / :39-51):

@@ -746,6 +746,21 @@ int rcx_linear_attention_fwd(const void* qpre, const void* kpre, const void* v, 
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_linear_attention_fwd");
 }
 
+int rcx_linear_attention_pe_fwd(const void* qpre, const void* kpre, const void* v, const float* w_pe_kkc, const float* b_pe, void* out,
+                                int B, int H, int W, int C, int heads, int dtype, void* stream)
+{
+    if (!qpre || !kpre || !v || !w_pe_kkc || !out) return fail(RCX_ERR_BAD_ARG, "rcx_linear_attention_pe_fwd: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive extent B=%d H=%d W=%d C=%d heads=%d", B, H, W, C, heads);
+    if (!known_dtype(dtype)) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
+    if (C % heads) return fail(RCX_ERR_BAD_ARG, "C=%d is not a multiple of heads=%d", C, heads);
+    const int D = C / heads;
+    if (D > 64 || !rcx::linattn_core_fuses_pe(H * W, C, heads, dtype))
+        return fail(RCX_ERR_UNSUPPORTED, "head dimension %d, %d tokens: the fused form exists on the vector-pipe kernel of head dimensions that are multiples of "
+                                         "four, at most 64 (use rcx_dwconv2d_fwd + rcx_linear_attention_fwd)", D, H * W);
+    hipError_t e = rcx::linattn_core(qpre, kpre, v, nullptr, out, B, H * W, C, heads, dtype, (hipStream_t)stream, w_pe_kkc, b_pe, W);
+    return e == hipSuccess ? 0 : hip_fail(e, "rcx_linear_attention_pe_fwd");
+}
+
 int rcx_linear_attention_bwd(const void* qpre, const void* kpre, const void* v, const void* gout, void* gq, void* gk, void* gv,
                              int B, int n, int C, int heads, int dtype, void* stream)
 {

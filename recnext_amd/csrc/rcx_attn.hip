@@ -40,6 +40,38 @@ template <int G> __device__ __forceinline__ void la_stv(bf16_t* p, const float (
 template <int G> __device__ __forceinline__ void la_ldv(const f16_t* p, float (&o)[G]) { load_vec<G>(p, o); }
 template <int G> __device__ __forceinline__ void la_stv(f16_t* p, const float (&o)[G]) { store_vec<G>(p, o); }
 
+// `pe` computed where it is used (round 3): pe = depthwise 3x3 conv (pad 1) of v + bias (model/recattn.py:27 / :50; LinearAttention.pe with
+// its BatchNorm folded), the taps as a float32 (3, 3, C) pack.  w == nullptr: pe is read from memory as before.  Wp = plane width (tokens
+// are the plane's pixels row by row), n = Hp * Wp.  float32 accumulation, nothing rounded in between.
+struct PeConv {
+    const float* w;
+    const float* b;
+    int Wp;
+};
+// G consecutive channels from absolute channel c of token `tok`; vimg = v + image offset (channel 0)
+template <typename T, int G>
+__device__ __forceinline__ void pe_conv3(const T* __restrict__ vimg, const PeConv& pc, int tok, int n, int C, int c, float (&pp)[G])
+{
+    const int y = tok / pc.Wp, x = tok - y * pc.Wp, Hp = n / pc.Wp;
+#pragma unroll
+    for (int j = 0; j < G; ++j) pp[j] = pc.b ? pc.b[c + j] : 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= Hp) continue;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= pc.Wp) continue;
+            float vv[G], ww[G];
+            la_ldv<G>(vimg + (size_t)(yy * pc.Wp + xx) * C + c, vv);
+            la_ldv<G>(pc.w + (size_t)((dy + 1) * 3 + dx + 1) * C + c, ww);
+#pragma unroll
+            for (int j = 0; j < G; ++j) pp[j] = fmaf(ww[j], vv[j], pp[j]);
+        }
+    }
+}
+
 template <typename T, int G>
 __global__ void __launch_bounds__(LA_NT)
 k_linattn_core(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* __restrict__ v, const T* __restrict__ pe,
@@ -166,7 +198,7 @@ k_linattn_core(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* 
 template <typename T, int DM>
 __global__ void __launch_bounds__(LA_NT)
 k_linattn_core4(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* __restrict__ v, const T* __restrict__ pe,
-                T* __restrict__ out, int n, int C, int heads)
+                T* __restrict__ out, int n, int C, int heads, PeConv pc)
 {
     __shared__ __attribute__((aligned(16))) float a_s[LA_TT][DM + 4];      // + 4: rows stay 16-byte aligned, odd multiple of 16 B
     __shared__ __attribute__((aligned(16))) float v_s[LA_TT][DM];
@@ -289,7 +321,8 @@ k_linattn_core4(const T* __restrict__ qpre, const T* __restrict__ kpre, const T*
                     const float inv = 1.f / den_s[t];
                     const size_t gi = base + (size_t)(t0 + t) * C + e2;
                     float pp[4], r[4];
-                    la_ldv<4>(pe + gi, pp);
+                    if (pc.w) pe_conv3<T, 4>(v + (size_t)b * n * C, pc, t0 + t, n, C, h * D + e2, pp);
+                    else la_ldv<4>(pe + gi, pp);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) r[j] = fmaf(o[w][j], inv, pp[j]);
                     la_stv<4>(out + gi, r);
@@ -334,7 +367,7 @@ constexpr int LM_NW = RCX_LM_NW;    // waves per (image, head): the tokens are d
 template <typename T>
 __global__ void __launch_bounds__(LM_NW * 64)
 k_linattn_mfma(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* __restrict__ v, const T* __restrict__ pe,
-               T* __restrict__ out, int n, int C, int heads)
+               T* __restrict__ out, int n, int C, int heads, PeConv pc)
 {
     typedef typename Mf<T>::frag frag;
     __shared__ float kvp_s[LM_NW][16][64];                    // partial kv tiles in accumulator layout
@@ -405,7 +438,11 @@ k_linattn_mfma(const T* __restrict__ qpre, const T* __restrict__ kpre, const T* 
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int tok = g0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            pv[i] = la_ld(pe + base + (size_t)(tok < n ? tok : n - 1) * C + r);
+            if (pc.w) {
+                float p1[1];
+                pe_conv3<T, 1>(v + (size_t)b * n * C, pc, tok < n ? tok : n - 1, n, C, hd * 32 + r, p1);
+                pv[i] = p1[0];
+            } else pv[i] = la_ld(pe + base + (size_t)(tok < n ? tok : n - 1) * C + r);
         }
 #pragma unroll
         for (int sj = 0; sj < 4; ++sj) {
@@ -878,18 +915,38 @@ hipError_t linattn_core_bwd(const void* qpre, const void* kpre, const void* v, c
     return hipGetLastError();
 }
 
+// pew != nullptr: pe is computed inside the kernel from v (pe is ignored); only the kernels of head dimensions that are multiples of four
+// have that form (every head of the A-series is 32 wide)
+// ... and only the vector-pipe kernel gains from it: on the matrix-core kernel (head dimension 32, 16-bit I/O, >= 512 tokens) a lane owns ONE
+// channel of 16 tokens, its nine taps are scalar loads, and the unit of RecNeXt-A3's stage 0 went from 239 to 394 us; the shorter
+// sequences (vector-pipe kernel, four channels per thread) went 80.4 -> 74.2 us (49 tokens x 256 channels), 118 -> 116.5, 99 -> 97.5.
+static bool linattn_uses_mfma(int n, int C, int heads, int dtype)
+{
+    const char* m = rcx::opt::value(rcx::opt::ATTN_MFMA);
+    return C / heads == 32 && dtype != 0 && n >= 512 && !(m && *m == '0');
+}
+
+bool linattn_core_fuses_pe(int n, int C, int heads, int dtype)
+{
+    const char* old = rcx::opt::value(rcx::opt::ATTN_SCALAR);
+    return ((C / heads) % 4) == 0 && !(old && *old == '1') && !linattn_uses_mfma(n, C, heads, dtype);
+}
+
 hipError_t linattn_core(const void* qpre, const void* kpre, const void* v, const void* pe, void* out,
-                        int B, int n, int C, int heads, int dtype, hipStream_t s)
+                        int B, int n, int C, int heads, int dtype, hipStream_t s, const float* pew, const float* peb, int Wp)
 {
     const dim3 grid((unsigned)(B * heads)), block(LA_NT);
     const bool wide = ((C / heads) % 4) == 0;
+    const PeConv pc{pew, peb, Wp > 0 ? Wp : 1};
+    if (pew && !linattn_core_fuses_pe(n, C, heads, dtype)) return hipErrorInvalidConfiguration;
     {
         const char* m = rcx::opt::value(rcx::opt::ATTN_MFMA);                     // A/B knob: 0 = the vector-pipe kernels for every head dimension
         // Measured (batch 256, bf16): 784 tokens 88 -> 61 us with 4 waves per head; 196 / 49 / 16 tokens no faster than the vector-pipe kernel
         // (36 / 23 / 31 against 36 / 20 / 20 us: too few tokens per head to amortise the partial-sum exchange) -- so only the long sequences
-        if (C / heads == 32 && dtype != 0 && n >= 512 && !(m && *m == '0')) {
-            if (dtype == 1) hipLaunchKernelGGL((k_linattn_mfma<bf16_t>), grid, dim3(LM_NW * 64), 0, s, (const bf16_t*)qpre, (const bf16_t*)kpre, (const bf16_t*)v, (const bf16_t*)pe, (bf16_t*)out, n, C, heads);
-            else hipLaunchKernelGGL((k_linattn_mfma<f16_t>), grid, dim3(LM_NW * 64), 0, s, (const f16_t*)qpre, (const f16_t*)kpre, (const f16_t*)v, (const f16_t*)pe, (f16_t*)out, n, C, heads);
+        (void)m;
+        if (linattn_uses_mfma(n, C, heads, dtype)) {
+            if (dtype == 1) hipLaunchKernelGGL((k_linattn_mfma<bf16_t>), grid, dim3(LM_NW * 64), 0, s, (const bf16_t*)qpre, (const bf16_t*)kpre, (const bf16_t*)v, (const bf16_t*)pe, (bf16_t*)out, n, C, heads, pc);
+            else hipLaunchKernelGGL((k_linattn_mfma<f16_t>), grid, dim3(LM_NW * 64), 0, s, (const f16_t*)qpre, (const f16_t*)kpre, (const f16_t*)v, (const f16_t*)pe, (f16_t*)out, n, C, heads, pc);
             return hipGetLastError();
         }
     }
@@ -898,7 +955,7 @@ hipError_t linattn_core(const void* qpre, const void* kpre, const void* v, const
     const char* old = rcx::opt::value(rcx::opt::ATTN_SCALAR);                 // A/B knob: the untiled kernel for every head dimension
     const bool tiled = wide && !(old && *old == '1');
     if (tiled) {
-#define RCX_LA4(T, DM) hipLaunchKernelGGL((k_linattn_core4<T, DM>), grid, block, 0, s, (const T*)qpre, (const T*)kpre, (const T*)v, (const T*)pe, (T*)out, n, C, heads)
+#define RCX_LA4(T, DM) hipLaunchKernelGGL((k_linattn_core4<T, DM>), grid, block, 0, s, (const T*)qpre, (const T*)kpre, (const T*)v, (const T*)pe, (T*)out, n, C, heads, pc)
         const bool small = C / heads <= 32;
         if (dtype == 1) { if (small) RCX_LA4(bf16_t, 32); else RCX_LA4(bf16_t, 64); }
         else if (dtype == 2) { if (small) RCX_LA4(f16_t, 32); else RCX_LA4(f16_t, 64); }

@@ -136,7 +136,8 @@ hipError_t down5_lanes(const void* x, void* y, const float* w, const float* b, i
 
 // rcx_attn.hip -- linear-attention core of RecAttn2d (after the qk projection)
 hipError_t linattn_core(const void* qpre, const void* kpre, const void* v, const void* pe, void* out,
-                        int B, int n, int C, int heads, int dtype, hipStream_t s);
+                        int B, int n, int C, int heads, int dtype, hipStream_t s, const float* pew = nullptr, const float* peb = nullptr, int Wp = 0);
+bool linattn_core_fuses_pe(int n, int C, int heads, int dtype);
 
 hipError_t linattn_core_bwd(const void* qpre, const void* kpre, const void* v, const void* gout, void* gq, void* gk, void* gv,
                             int B, int n, int C, int heads, int dtype, hipStream_t s);

@@ -305,6 +305,39 @@ def linear_attention_core(qpre, kpre, v, pe, heads):
     return out
 
 
+FUSE_PE = __import__("os").environ.get("RCX_ATTN_FUSE_PE", "1") != "0"      # A/B switch, read at import
+
+
+def linear_attention_core_fuses_pe(c, heads):
+    """Whether linear_attention_core_pe has a kernel for this head size (a multiple of four, at most 64)."""
+    d = c // heads
+    return c % heads == 0 and d % 4 == 0 and d <= 64 and FUSE_PE
+
+
+def linear_attention_core_pe(qpre, kpre, v, w_pe_kkc, b_pe, heads):
+    """linear_attention_core with pe = dwconv3x3(v) + bias computed inside the kernel (rcx_linear_attention_pe_fwd): w_pe_kkc / b_pe are
+    the float32 packs of pack_dw_weight / pack_bias of LinearAttention.pe (BatchNorm folded).  None if the library has no such kernel for
+    this configuration (the long sequences that run on the matrix cores: measured slower there)."""
+    v = _nhwc(v, "v")
+    b, c, h, w = v.shape
+    n = h * w
+    for t, name in ((qpre, "qpre"), (kpre, "kpre")):
+        _require_gpu(t, name)
+        if tuple(t.shape) != (b, n, c) or not t.is_contiguous() or t.dtype != v.dtype:
+            raise ValueError(f"{name} must be a contiguous ({b}, {n}, {c}) tensor of {v.dtype}, got {tuple(t.shape)} {t.dtype}")
+    if w_pe_kkc.dtype != torch.float32 or w_pe_kkc.numel() != 9 * c:
+        raise ValueError("w_pe_kkc must be the float32 (3, 3, C) pack of pack_dw_weight")
+    out = _empty_nhwc(b, c, h, w, v.dtype, v.device)
+    with torch.cuda.device(v.device):
+        rc = _lib.load().rcx_linear_attention_pe_fwd(qpre.data_ptr(), kpre.data_ptr(), v.data_ptr(), w_pe_kkc.data_ptr(),
+                                                     b_pe.data_ptr() if b_pe is not None else None, out.data_ptr(),
+                                                     b, h, w, c, heads, _dt(v), _stream(v.device))
+    if rc == -2:                         # RCX_ERR_UNSUPPORTED (RCX_ATTN_SCALAR=1 pins the kernel without this form): the caller runs the two steps
+        return None
+    _lib.check(rc, "rcx_linear_attention_pe_fwd")
+    return out
+
+
 def linear_attention_core_backward(qpre, kpre, v, gout, heads):
     """Gradients of linear_attention_core with respect to qpre, kpre (B, n, C) and v (N x C x h x w); dL/dpe = gout."""
     v = _nhwc(v, "v")

@@ -166,6 +166,10 @@ class RecAttn2d(nn.Module):
         dt = d.dtype
         qpre = F.linear(tok[:, :c // 2], wq.to(dt), bq.to(dt)).view(b, h * w, c)    # grouped 1x1 conv = two GEMMs, :21 / :44
         kpre = F.linear(tok[:, c // 2:], wk.to(dt), bk.to(dt)).view(b, h * w, c)
-        pe = ops.dwconv2d(d, wpe, bpe, k=3, stride=1)                               # ConvNorm(dw 3x3), :27 / :50
-        a = ops.linear_attention_core(qpre, kpre, d, pe, la.num_heads)              # :22-27 / :45-50
+        a = None
+        if ops.linear_attention_core_fuses_pe(c, la.num_heads):                      # pe = ConvNorm(dw 3x3)(d) inside the core kernel (round 3)
+            a = ops.linear_attention_core_pe(qpre, kpre, d, wpe, bpe, la.num_heads)  # :22-27 / :45-50
+        if a is None:
+            pe = ops.dwconv2d(d, wpe, bpe, k=3, stride=1)                           # ConvNorm(dw 3x3), :27 / :50
+            a = ops.linear_attention_core(qpre, kpre, d, pe, la.num_heads)          # :22-27 / :45-50
         return ops.upadd_dwconv(x, a, wc, bc, k=k, mode=self.mode)                  # conv(x + resize(.)), :67

@@ -615,6 +615,22 @@ def test_linear_attention_core(case, dtype):
         o = (qf.transpose(-2, -1) @ kv * z).transpose(-2, -1).reshape(b, c, h, w) + pe       # :25-28
         ref_bf16 = o.float().cpu().numpy()
         _assert_bf16_no_worse_than_reference(got, ref.astype(np.float32), ref_bf16, "x".join(map(str, case)))
+    # round 3: pe = dwconv3x3(d) + bias computed inside the core kernel (rcx_linear_attention_pe_fwd) -- one launch and one rounding less
+    if ops.linear_attention_core_fuses_pe(c, heads):
+        fused = ops.linear_attention_core_pe(qpre, kpre, dd, ops.pack_dw_weight(t(w_pe)), ops.pack_bias(t(b_pe)), heads)
+        on_mfma = c // heads == 32 and dtype != torch.float32 and h * w >= 512            # matrix-core kernel: the fused form is not offered there
+        assert (fused is None) == on_mfma
+    if ops.linear_attention_core_fuses_pe(c, heads) and fused is not None:
+        assert torch.equal(fused, ops.linear_attention_core_pe(qpre, kpre, dd, ops.pack_dw_weight(t(w_pe)), ops.pack_bias(t(b_pe)), heads))
+        gf = fused.float().cpu().numpy()
+        if dtype == torch.float32:
+            assert np.abs(gf - ref).max() < 2e-4 and np.abs(gf - got).max() < 1e-4
+        else:
+            _assert_bf16_no_worse_than_reference(gf, ref.astype(np.float32), ref_bf16, "fused pe " + "x".join(map(str, case)))
+        nob = ops.linear_attention_core_pe(qpre, kpre, dd, ops.pack_dw_weight(t(w_pe)), None, heads)           # no bias pack
+        pe0 = ops.dwconv2d(dd, ops.pack_dw_weight(t(w_pe)), None, k=3, stride=1)
+        want0 = ops.linear_attention_core(qpre, kpre, dd, pe0, heads)
+        assert torch.allclose(nob.float(), want0.float(), atol=2e-2 if dtype != torch.float32 else 1e-4, rtol=1e-2)
 
 
 @pytest.mark.parametrize("name", recattn_cases())
