@@ -42,8 +42,34 @@ def _empty_nhwc(n, c, h, w, dtype, device):
     return torch.empty((n, h, w, c), dtype=dtype, device=device).permute(0, 3, 1, 2)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(device):
+    """The current stream of `device` as a hipStream_t (an integer): the raw getter where this PyTorch has it (0.3 us against 2 us)."""
+    if _raw_stream is not None:
+        idx = device.index
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on(device):
+    """Device guard for a launch: nothing when `device` is already the current device (the usual case; saves ~2 us a call)."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)
 
 
 def down_size(h, k):
@@ -58,7 +84,7 @@ def pack_dw_weight(w, out=None):
     w = w.detach().contiguous()
     if out is None:
         out = torch.empty(k * k * c, dtype=torch.float32, device=w.device)
-    with torch.cuda.device(w.device):
+    with _on(w.device):
         _lib.check(_lib.load().rcx_pack_dw_weight(w.data_ptr(), out.data_ptr(), c, k, _dt(w), _stream(w.device)),
                    "rcx_pack_dw_weight")
     return out
@@ -69,7 +95,7 @@ def pack_bias(b, out=None):
     b = b.detach().contiguous()
     if out is None:
         out = torch.empty(b.numel(), dtype=torch.float32, device=b.device)
-    with torch.cuda.device(b.device):
+    with _on(b.device):
         _lib.check(_lib.load().rcx_pack_bias(b.data_ptr(), out.data_ptr(), b.numel(), _dt(b), _stream(b.device)),
                    "rcx_pack_bias")
     return out
@@ -107,7 +133,7 @@ def pack_recconv_params(w_down, w_convs, b_down=None, b_convs=None, with_flipped
     ws = [w.detach().contiguous() for w in ws]
     bs = [b.detach().contiguous() for b in bs] if bs else None
     wflip = torch.empty_like(wpack) if with_flipped else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = _lib.load().rcx_pack_recconv_params(_ptr_array(ws), _ptr_array(bs) if bs else None, wpack.data_ptr(),
                                                  wflip.data_ptr() if wflip is not None else None,
                                                  bpack.data_ptr() if bpack is not None else None,
@@ -119,7 +145,7 @@ def pack_recconv_params(w_down, w_convs, b_down=None, b_convs=None, with_flipped
 def unpack_recconv_grads(gwpack, count, c, k):
     """gwpack (count, k*k*C) f32 -> (count, C, 1, k, k) f32, each [i] contiguous in the parameter's layout; one launch."""
     out = torch.empty((count, c, 1, k, k), dtype=torch.float32, device=gwpack.device)
-    with torch.cuda.device(gwpack.device):
+    with _on(gwpack.device):
         rc = _lib.load().rcx_unpack_recconv_grads(gwpack.data_ptr(), _ptr_array([out[i] for i in range(count)]), count, c, k,
                                                   _stream(gwpack.device))
     _lib.check(rc, "rcx_unpack_recconv_grads")
@@ -143,7 +169,7 @@ def pack_recconv_mx(wpack, level, c, k, dtype):
     if not nbytes:
         return None
     mx = torch.empty(nbytes, dtype=torch.uint8, device=wpack.device)
-    with torch.cuda.device(wpack.device):
+    with _on(wpack.device):
         rc = lib.rcx_pack_recconv_mx(wpack.data_ptr(), mx.data_ptr(), c, level, k, _DT[dtype], _stream(wpack.device))
     _lib.check(rc, "rcx_pack_recconv_mx")
     return mx
@@ -167,7 +193,7 @@ def recconv2d_forward(x, wpack, bpack, level, k, mode="bilinear", mxpack=None):
     y = _empty_nhwc(n, c, h, w, x.dtype, x.device)
     nbytes = lib.rcx_recconv2d_fwd_workspace_bytes(n, c, h, w, level, k, dt)    # 0 on the fused schedules: nothing to allocate
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         if mxpack is not None and dt != _lib.DTYPE_F32:
             rc = lib.rcx_recconv2d_fwd_mx(x.data_ptr(), y.data_ptr(), wpack.data_ptr(),
                                           bpack.data_ptr() if bpack is not None else None, mxpack.data_ptr(),
@@ -190,7 +216,7 @@ def dwconv2d(x, w_kkc, bias=None, k=5, stride=1, out_dtype=None):
     p = k // 2
     ho, wo = (h + 2 * p - k) // stride + 1, (w + 2 * p - k) // stride + 1
     y = _empty_nhwc(n, c, ho, wo, out_dtype, x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = _lib.load().rcx_dwconv2d_fwd(x.data_ptr(), y.data_ptr(), w_kkc.data_ptr(),
                                           bias.data_ptr() if bias is not None else None,
                                           n, c, h, w, k, stride, _dt(x), _DT[out_dtype], _stream(x.device))
@@ -219,7 +245,7 @@ def upadd_dwconv(x, coarse, w_kkc, bias=None, k=5, mode="nearest", out_dtype=Non
         hc, wc = coarse.shape[2:]
         cdt = _dt(coarse)
     y = _empty_nhwc(n, c, h, w, out_dtype, x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = _lib.load().rcx_upadd_dwconv_fwd(x.data_ptr(), coarse.data_ptr() if coarse is not None else None, y.data_ptr(),
                                               w_kkc.data_ptr(), bias.data_ptr() if bias is not None else None,
                                               n, c, h, w, hc, wc, k, _lib.MODES[mode], _dt(x), cdt, _DT[out_dtype],
@@ -235,7 +261,7 @@ def dwconv2d_mult2(x, w_kkc, bias=None, k=7, stride=2):
     p = k // 2
     ho, wo = (h + 2 * p - k) // stride + 1, (w + 2 * p - k) // stride + 1
     y = _empty_nhwc(n, 2 * c, ho, wo, x.dtype, x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = _lib.load().rcx_dwconv2d_mult2_fwd(x.data_ptr(), y.data_ptr(), w_kkc.data_ptr(),
                                                 bias.data_ptr() if bias is not None else None,
                                                 n, c, h, w, k, stride, _dt(x), _stream(x.device))
@@ -255,7 +281,7 @@ def dwconv2d_backward(x, gy, w_kkc, k, stride, need_input_grad=True, need_bias=F
     gb = torch.empty(c, dtype=torch.float32, device=x.device) if need_bias else None
     nbytes = lib.rcx_dwconv2d_bwd_workspace_bytes(c, k)
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.rcx_dwconv2d_bwd(x.data_ptr(), gy.data_ptr(), w_kkc.data_ptr(), wflip.data_ptr(),
                                   gx.data_ptr() if gx is not None else None, gw.data_ptr(), gb.data_ptr() if gb is not None else None,
                                   ws.data_ptr(), nbytes, n, c, h, w, k, stride, _dt(x), _stream(x.device))
@@ -274,7 +300,7 @@ def dwconv2d_mult2_backward(x, gy, w_kkc, k, need_input_grad=True, need_bias=Fal
     gb = torch.empty(2 * c, dtype=torch.float32, device=x.device) if need_bias else None
     nbytes = lib.rcx_dwconv2d_bwd_workspace_bytes(2 * c, k)
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.rcx_dwconv2d_mult2_bwd(x.data_ptr(), gy.data_ptr(), w_kkc.data_ptr(), gx.data_ptr() if gx is not None else None,
                                         gw.data_ptr(), gb.data_ptr() if gb is not None else None, ws.data_ptr(), nbytes,
                                         n, c, h, w, k, _dt(x), _stream(x.device))
@@ -298,7 +324,7 @@ def linear_attention_core(qpre, kpre, v, pe, heads):
     if pe.shape != v.shape or pe.dtype != v.dtype:
         raise ValueError("pe must match v")
     out = _empty_nhwc(b, c, h, w, v.dtype, v.device)
-    with torch.cuda.device(v.device):
+    with _on(v.device):
         rc = _lib.load().rcx_linear_attention_fwd(qpre.data_ptr(), kpre.data_ptr(), v.data_ptr(), pe.data_ptr(), out.data_ptr(),
                                                   b, n, c, heads, _dt(v), _stream(v.device))
     _lib.check(rc, "rcx_linear_attention_fwd")
@@ -328,7 +354,7 @@ def linear_attention_core_pe(qpre, kpre, v, w_pe_kkc, b_pe, heads):
     if w_pe_kkc.dtype != torch.float32 or w_pe_kkc.numel() != 9 * c:
         raise ValueError("w_pe_kkc must be the float32 (3, 3, C) pack of pack_dw_weight")
     out = _empty_nhwc(b, c, h, w, v.dtype, v.device)
-    with torch.cuda.device(v.device):
+    with _on(v.device):
         rc = _lib.load().rcx_linear_attention_pe_fwd(qpre.data_ptr(), kpre.data_ptr(), v.data_ptr(), w_pe_kkc.data_ptr(),
                                                      b_pe.data_ptr() if b_pe is not None else None, out.data_ptr(),
                                                      b, h, w, c, heads, _dt(v), _stream(v.device))
@@ -349,7 +375,7 @@ def linear_attention_core_backward(qpre, kpre, v, gout, heads):
     gq = torch.empty_like(qpre)
     gk = torch.empty_like(kpre)
     gv = _empty_nhwc(b, c, h, w, v.dtype, v.device)
-    with torch.cuda.device(v.device):
+    with _on(v.device):
         rc = _lib.load().rcx_linear_attention_bwd(qpre.data_ptr(), kpre.data_ptr(), v.data_ptr(), gout.data_ptr(),
                                                   gq.data_ptr(), gk.data_ptr(), gv.data_ptr(), b, n, c, heads, _dt(v), _stream(v.device))
     _lib.check(rc, "rcx_linear_attention_bwd")
@@ -382,7 +408,7 @@ def recconv2d_forward_train(x, wpack, bpack, level, k, mode="bilinear"):
     y = _empty_nhwc(n, c, h, w, x.dtype, x.device)
     nbytes = lib.rcx_recconv2d_train_saved_bytes(n, c, h, w, level, k)
     saved = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.rcx_recconv2d_fwd_train(x.data_ptr(), y.data_ptr(), wpack.data_ptr(),
                                          bpack.data_ptr() if bpack is not None else None, saved.data_ptr(), nbytes,
                                          n, c, h, w, level, k, _lib.MODES[mode], dt, _stream(x.device))
@@ -404,7 +430,7 @@ def recconv2d_backward(x, gy, wpack, saved, level, k, mode="bilinear", need_bias
     gb = torch.empty((level + 2, c), dtype=torch.float32, device=x.device) if need_bias else None
     nbytes = lib.rcx_recconv2d_bwd_workspace_bytes(n, c, h, w, level, k)
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.rcx_recconv2d_bwd(x.data_ptr(), gy.data_ptr(), wpack.data_ptr(), wflip.data_ptr(), saved.data_ptr(),
                                    gx.data_ptr(), gw.data_ptr(), gb.data_ptr() if gb is not None else None,
                                    ws.data_ptr(), nbytes, n, c, h, w, level, k, _lib.MODES[mode], _dt(x), _stream(x.device))
