@@ -122,14 +122,21 @@ class RecAttn2d(nn.Module):
         self._pack = None
 
     def _tensors(self):
+        # read out of the registries: this runs on every forward, and nn.Module.__getattr__ costs ~0.3 us a look-up (40 of them here)
+        mods = self._modules
+        down = mods["down"]._modules
+        la = down["1"]._modules
         out = []
-        for m in (self.down[0], self.conv, self.down[1].qk, self.down[1].pe):
-            out += [m.weight, m.bias] if isinstance(m, nn.Conv2d) else \
-                [m.conv.weight, m.norm.weight, m.norm.bias, m.norm.running_mean, m.norm.running_var]
+        for m in (down["0"], mods["conv"], la["qk"], la["pe"]):
+            if isinstance(m, nn.Conv2d):
+                out += [m._parameters["weight"], m._parameters["bias"]]
+            else:
+                cv, bn = m._modules["conv"], m._modules["norm"]
+                out += [cv._parameters["weight"], bn._parameters["weight"], bn._parameters["bias"], bn._buffers["running_mean"], bn._buffers["running_var"]]
         return [t for t in out if t is not None]
 
     def packed_params(self):
-        key = tuple((t.data_ptr(), t._version, t.dtype, str(t.device)) for t in self._tensors())
+        key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in self._tensors())
         if key != self._pack_key:
             with torch.no_grad():
                 wd, bd = _folded(self.down[0])
