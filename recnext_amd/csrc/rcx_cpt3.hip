@@ -9,6 +9,8 @@ hipError_t launch_lv(const void* x, void* y, const float* wpack, const float* bp
 {
     const SavedPyr sv{};
     if (H == 56) return cb16(N, C) ? launch_md<4, 4, 3>(x, y, wpack, bpack, N, C, mode, dtype, s, sv) : launch_md<4, 2, 3>(x, y, wpack, bpack, N, C, mode, dtype, s, sv);
+    // channel counts that are not multiples of 64: 32-channel workgroups (the alternative here is the LDS-pyramid kernel, not the banded one)
+    if (C % 64 != 0) return launch_md<2, 2, 2>(x, y, wpack, bpack, N, C, mode, dtype, s, sv);
     return launch_md<2, 1, 2>(x, y, wpack, bpack, N, C, mode, dtype, s, sv);
 }
 

@@ -58,7 +58,7 @@ def test_abi_version_and_argument_errors_without_gpu():
     # one level less: stages 1 and 2 of a 448 x 448 input (run-time pitch; no training instantiation)
     assert lib.rcx_recconv2d_fwd_plan(64, 128, 56, 56, 3, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<4, 2, 0, 0>,levels-1,cb=32")
     assert lib.rcx_recconv2d_fwd_plan(64, 256, 28, 28, 2, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<2, 1, 0, 0>,levels-1,cb=64")
-    assert lib.rcx_recconv2d_fwd_plan(64, 96, 28, 28, 2, 5, 0, 1).startswith(b"plane(")
+    assert lib.rcx_recconv2d_fwd_plan(64, 96, 28, 28, 2, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<2, 2, 0, 0>,levels-1,cb=32")
     with rcx_env(RCX_CPT="full"):
         assert lib.rcx_recconv2d_fwd_plan(64, 128, 56, 56, 3, 5, 0, 1).startswith(b"plane(")
     assert lib.rcx_recconv2d_fwd_plan(256, 48, 56, 56, 4, 5, 0, 1).startswith(b"cpt(k_recconv_cpt<4, 4, 0, 0>,cb=16")    # run-time pixel pitch; ragged 32-blocks: 16

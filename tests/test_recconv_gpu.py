@@ -236,7 +236,7 @@ def test_56_block_with_16_and_32_channel_workgroups_is_the_same_function(mode, d
 @pytest.mark.parametrize("shape", [(2, 64, 56, 4), (1, 48, 56, 4), (2, 80, 56, 4), (1, 8, 56, 4), (2, 128, 28, 3), (1, 96, 28, 3), (3, 160, 28, 3),
                                    (2, 40, 28, 3), (3, 96, 28, 3), (1, 72, 28, 3),
                                    # one level less (the same stages of a 448 x 448 input, inner blocks of the nested schedule; round 3)
-                                   (2, 64, 56, 3), (1, 48, 56, 3), (3, 128, 56, 3), (2, 128, 28, 2), (1, 64, 28, 2), (3, 256, 28, 2)],
+                                   (2, 64, 56, 3), (1, 48, 56, 3), (3, 128, 56, 3), (2, 128, 28, 2), (1, 64, 28, 2), (3, 256, 28, 2), (2, 96, 28, 2), (3, 40, 28, 2)],
                          ids=lambda v: "x".join(map(str, v)))
 def test_tiled_channel_per_lane_kernel_against_oracle_and_lanes_kernel(mode, bias, dtype, shape, monkeypatch):
     """The 56x56 / level 4 and 28x28 / level 3 blocks on rcx_cpt.hip (a lane owns one channel of one 14x14 tile, the planes of
