@@ -631,7 +631,11 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     constexpr int CHB = G::CB;                                     // channels per block
     const int nb = (C + CHB - 1) / CHB;
     const unsigned total = (unsigned)N * (unsigned)nb, GD = gridDim.x;
+#ifdef RCX_CPT_NOXCD
+    const bool xcd = false;
+#else
     const bool xcd = (total & 7u) == 0 && (GD & 7u) == 0;
+#endif
     const int tid = (int)threadIdx.x;
   for (unsigned it = 0;; ++it) {
     unsigned unit;
