@@ -91,6 +91,7 @@ void k_recconv_mx14(const TIO* __restrict__ x, TIO* __restrict__ y, const void* 
         ysrc.x = (int)(unsigned)b; ysrc.y = (int)(unsigned)(b >> 32) & 0xffff; ysrc.z = (int)bytes; ysrc.w = 0x00020000;
     }
     const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc((void*)mxpack, 0, 4 * 5 * cpt::MXP_SLOTS * 4 * C * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bsrc_ = __builtin_amdgcn_make_buffer_rsrc((void*)bpack, 0, has_bias ? 4 * C * 4 : 0, 0x00020000);   // zero records without a bias
 
     // ---- x -> LDS image of this wave: [pixel 0 .. 197][channel 0 .. 15][image 0 .. 3] of 16-bit values (128 bytes per pixel; pixels 196, 197
     // are only ever read into registers nobody uses)
@@ -126,7 +127,7 @@ void k_recconv_mx14(const TIO* __restrict__ x, TIO* __restrict__ y, const void* 
     // lane 4 q + p of a 16-lane group g supplies row q (pixel) and 8-byte chunk p (channel 4 g + p, four images) of the transposed block
     const unsigned char* const trp = wl + ((lane >> 2) & 3) * 128 + (4 * (lane >> 4) + (lane & 3)) * 8;
     MxTaps<TIO, 2> ad;
-    cpt::load_mxtaps(ad, msrc, bpack, 0, C, ccM, has_bias, lane & 3);
+    cpt::load_mxtaps(ad, msrc, bsrc_, 0, C, ccM, lane & 3);
     f32x4 F1[W1][2];                                              // columns 0 .. 7 of each row (column 7 is not a pixel)
     {
         f32x4 facc[3][2];
@@ -188,7 +189,7 @@ void k_recconv_mx14(const TIO* __restrict__ x, TIO* __restrict__ y, const void* 
         f32x4 C2[W2];
         {
             MxTaps<TIO, 1> a0;
-            cpt::load_mxtaps(a0, msrc, bpack, 1, C, ccM, has_bias, lane & 3);
+            cpt::load_mxtaps(a0, msrc, bsrc_, 1, C, ccM, lane & 3);
             const f32x4 b4 = f32x4{a0.bias, a0.bias, a0.bias, a0.bias};
             u32x2 K[W2][3];
 #pragma unroll
@@ -233,7 +234,7 @@ void k_recconv_mx14(const TIO* __restrict__ x, TIO* __restrict__ y, const void* 
         // C1 = conv_1(T1) on 7x7: two output blocks, K blocks m, m + 1
         {
             MxTaps<TIO, 1> a1;
-            cpt::load_mxtaps(a1, msrc, bpack, 2, C, ccM, has_bias, lane & 3);
+            cpt::load_mxtaps(a1, msrc, bsrc_, 2, C, ccM, lane & 3);
             const f32x4 b4 = f32x4{a1.bias, a1.bias, a1.bias, a1.bias};
             u32x2 K[W1][3];
 #pragma unroll
@@ -258,7 +259,7 @@ void k_recconv_mx14(const TIO* __restrict__ x, TIO* __restrict__ y, const void* 
     // ---- y = conv_2(x + resize(C1)): input-row stationary, five accumulator rows in flight                         (:34)
     {
         MxTaps<TIO, 1> a2;
-        cpt::load_mxtaps(a2, msrc, bpack, 3, C, ccM, has_bias, lane & 3);
+        cpt::load_mxtaps(a2, msrc, bsrc_, 3, C, ccM, lane & 3);
         const f32x4 b4 = f32x4{a2.bias, a2.bias, a2.bias, a2.bias};
         float H1[W1][W];                                          // C1 rows resized horizontally, each computed just before its first use
         f32x4 acc[5][4];

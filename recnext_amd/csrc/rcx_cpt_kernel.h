@@ -377,6 +377,61 @@ typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+// ---- staged x rows (STG, round 4).  What bounds the passes is the NUMBER of vector-memory wave-instructions: a load costs the CU ~7.3 cycles
+// (8.7 at 8 waves per CU) whatever its width up to 4 bytes per lane, 15.8 at 16 bytes (tools/ubench/vmem_rate.hip, profiles/r04_vmem_rate.txt);
+// eighteen 2-byte loads per row and lane are 157 cycles of the CU's one texture-address path, three 16-byte LDS-DMA pieces are ~48, and the
+// row no longer waits in registers.  A row = the wave's 2 x 18 x 64-byte image (Geo::SLOTB) in LDS order = piece order: piece j, lane i =
+// 16-byte chunk 64 j + i; the source address is per lane (an out-of-range offset writes zeros: the padding left and right of the image;
+// probed: tools/ubench/ldsdma_probe.hip).  M0 = the LDS byte address of the piece; it is written and restored inside the statement (the
+// compiler owns M0), one wait state between an SALU write of M0 and the instruction that reads it, SCC declared.
+__device__ __forceinline__ void stage_row(unsigned v0, unsigned v1, unsigned v2, i32x4 rs, int rb, int ldsaddr)
+{
+    int t, keep;
+    unsigned long long ex;
+    asm volatile("s_add_i32 %[t], %[rb], 0\n\t"
+                 "s_mov_b32 %[keep], m0\n\t"
+                 "s_add_i32 m0, %[la], 0\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %[v0], %[rs], %[t] offen lds\n\t"
+                 "s_add_i32 m0, %[la], 1024\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %[v1], %[rs], %[t] offen lds\n\t"
+                 "s_add_i32 m0, %[la], 2048\n\t"
+                 "s_mov_b64 %[ex], exec\n\ts_mov_b64 exec, 0xffff\n\t"
+                 "buffer_load_dwordx4 %[v2], %[rs], %[t] offen lds\n\t"
+                 "s_mov_b64 exec, %[ex]\n\t"
+                 "s_mov_b32 m0, %[keep]"
+                 : [t] "=&s"(t), [keep] "=&s"(keep), [ex] "=&s"(ex)
+                 : [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [rs] "s"(rs), [rb] "s"(rb), [la] "s"(ldsaddr)
+                 : "scc", "memory");
+}
+// The row back as 18 float32-position (bf16) / zero-extended (float16) elements of this lane's channel, exactly what row_load leaves: wait
+// until at most PENDING younger memory operations are outstanding, five transposing reads (four pixels of the lane's channel each: lane
+// 16 g + 4 q + p supplies the address of pixel 4 m + q, 8-byte chunk p of the group's 16 channels; lane 16 g + i receives channel i), their
+// wait, and one shift or mask per element.  Loads and waits in ONE statement: no register is in flight outside it.
+template <typename TIO, int PENDING, int OFF>
+__device__ __forceinline__ void fetch_row(uint32_t (&raw)[18], unsigned addr)
+{
+    u32x2 d0, d1, d2, d3, d4;
+    asm volatile("s_waitcnt vmcnt(%[n])\n\t"
+                 "ds_read_b64_tr_b16 %[d0], %[a] offset:%[o]\n\t"
+                 "ds_read_b64_tr_b16 %[d1], %[a] offset:%[o]+256\n\t"
+                 "ds_read_b64_tr_b16 %[d2], %[a] offset:%[o]+512\n\t"
+                 "ds_read_b64_tr_b16 %[d3], %[a] offset:%[o]+768\n\t"
+                 "ds_read_b64_tr_b16 %[d4], %[a] offset:%[o]+1024\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4)
+                 : [a] "v"(addr), [n] "n"(PENDING), [o] "n"(OFF) : "memory");
+    const u32x2 d[5] = {d0, d1, d2, d3, d4};
+#pragma unroll
+    for (int m = 0; m < 5; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (4 * m + e >= 18) continue;
+            const uint32_t v = (e >> 1) ? d[m].y : d[m].x;
+            if constexpr (std::is_same<TIO, f16_t>::value) raw[4 * m + e] = (e & 1) ? (v >> 16) : (v & 0xffffu);
+            else raw[4 * m + e] = (e & 1) ? (v & 0xffff0000u) : (v << 16);
+        }
+}
+
 __device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
 template <int A> __device__ __forceinline__ void pin(f32x4 (&v)[A]) {
 #pragma unroll
@@ -421,7 +476,7 @@ template <typename TIO, int STRIDE> struct MxTaps {
     float bias;
 };
 template <typename TIO, int STRIDE>
-__device__ __forceinline__ void load_mxtaps(MxTaps<TIO, STRIDE>& t, __amdgpu_buffer_rsrc_t msrc, const float* __restrict__ bpack, int conv, int C, int c, int has_bias, int i)
+__device__ __forceinline__ void load_mxtaps(MxTaps<TIO, STRIDE>& t, __amdgpu_buffer_rsrc_t msrc, __amdgpu_buffer_rsrc_t bsrc, int conv, int C, int c, int i)
 {
     const int voff = (i * C + c) * 8;
 #pragma unroll
@@ -431,7 +486,7 @@ __device__ __forceinline__ void load_mxtaps(MxTaps<TIO, STRIDE>& t, __amdgpu_buf
             const int soff = ((conv * 5 + u) * MXP_SLOTS + kb) * 4 * C * 8;
             t.a[u][kb] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(msrc, voff, soff, 0));
         }
-    t.bias = has_bias ? bpack[(size_t)conv * C + c] : 0.f;
+    t.bias = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bsrc, c * 4, conv * C * 4, 0));    // bsrc has zero records when there is no bias: the load returns 0
 }
 
 // the 25 taps of one conv for this lane's channel as three register pairs per tap row: (w0,w1) (w2,w3) (w4,0)
@@ -442,8 +497,9 @@ struct Taps {
 };
 
 // wsrc = the weight pack as a raw buffer: one scalar add and one load per tap, no 64-bit vector address arithmetic
-__device__ __forceinline__ void load_taps(Taps& t, __amdgpu_buffer_rsrc_t wsrc, const float* __restrict__ bpack, int conv, int C, int c, int has_bias)
+__device__ __forceinline__ void load_taps(Taps& t, __amdgpu_buffer_rsrc_t wsrc, __amdgpu_buffer_rsrc_t bsrc, int conv, int C, int c)
 {
+    asm volatile("" : "+s"(C));                               // the 25 scalar offsets are recomputed here, not hoisted out of the unit loop and spilled
     const int vow = c * 4, base = conv * 25 * C * 4;
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
@@ -455,7 +511,7 @@ __device__ __forceinline__ void load_taps(Taps& t, __amdgpu_buffer_rsrc_t wsrc, 
         }
         t.p[u][2].y = 0.f;
     }
-    t.bias = has_bias ? bpack[(size_t)conv * C + c] : 0.f;
+    t.bias = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bsrc, c * 4, conv * C * 4, 0));    // bsrc has zero records when there is no bias: the load returns 0
 }
 
 // training forward (rcx_recconv2d_fwd_train): base != nullptr -> the launch also leaves the float32 pyramid the backward reads, F_l at
@@ -570,7 +626,7 @@ constexpr Rel rel2(int mode, int par, int c)
 
 // NL_ = levels of the block: the full ladder down to 4 x 4 (56 x 56 / level 4, 28 x 28 / level 3: RecNeXt at 224 x 224) or one level less
 // (56 x 56 / level 3, 28 x 28 / level 2: the same stages of a 448 x 448 input, and the inner blocks of the nested schedule)
-template <int T_, int HALVES, int MODE, typename TIO, bool MX_ = false, int NL_ = (T_ == 4 ? 4 : 3)>
+template <int T_, int HALVES, int MODE, typename TIO, bool MX_ = false, int NL_ = (T_ == 4 ? 4 : 3), int STG_ = 0>
 struct Geo {
     static constexpr int T = T_;
     static constexpr int NL = NL_;
@@ -595,8 +651,17 @@ struct Geo {
     static constexpr int XBAND = 68 * CB * 2 + 32;
     static constexpr int XSTAGE = 4 * XBAND;
     static constexpr int XOFF = O2 * PIXF * 4;              // byte offset of the staging area
-    static constexpr int LDS_BYTES = MX_ ? 160 * 1024 : NPIX * PIXF * 4;
+    // STG (round 4): the two streaming passes fetch their x rows by LDS-DMA into per-wave slots behind the level-1 plane -- over the planes of
+    // the levels below, dead during both passes -- and read them back with the transposing read.  A slot = one row of the wave's window:
+    // two sub-images [18 pixels: tile columns -2 .. 15][64 bytes = 32 channels] (the wave's two tiles at T = 4, the two channel halves of its
+    // tile at T = 2): 2304 bytes = 144 16-byte pieces = three DMA instructions (the third on 16 lanes).  STG_ = slots per wave (rows in flight + 1).
+    static constexpr int NSLOT = STG_;
+    static constexpr int SLOTB = 2 * 18 * 64;
+    static constexpr int STGOFF = O2 * PIXF * 4;            // byte offset of the slots
+    static constexpr int STGEND = STGOFF + NW * NSLOT * SLOTB + 256;      // + what the last transposing read of the last slot reaches past its image
+    static constexpr int LDS_BYTES = MX_ ? 160 * 1024 : (STG_ && STGEND > NPIX * PIXF * 4 ? STGEND : NPIX * PIXF * 4);
     static_assert(!MX_ || XOFF + 2 * XSTAGE <= 160 * 1024, "staging area does not fit");
+    static_assert(!STG_ || (!MX_ && sizeof(TIO) == 2 && ((T == 4 && HALVES == 2) || (T == 2 && HALVES == 1)) && LDS_BYTES <= 160 * 1024), "staged rows: 16-bit activations, 64-byte sub-images");
 };
 
 // T = 2, HALVES = 2 (round 3): a wave = 32 channels x the two tiles of one tile row, a workgroup = two waves = 32 channels of an image with
@@ -609,12 +674,12 @@ struct Geo {
 // workgroup = four waves = 16 channels of an image with 69 KB of LDS -- TWO workgroups per CU, which run different units and so are
 // in different phases: one's barrier-bound small-plane phases and load waits fill with the other's passes (a 32-channel workgroup
 // alone on its CU serialises ~105 k cycles of phases that each leave most of the CU idle).  Used where cb16() says so.
-template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool TRAIN = false, bool MX = false, int LV = (T == 4 ? 4 : 3)>
+template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool TRAIN = false, bool MX = false, int LV = (T == 4 ? 4 : 3), int STG = 0>
 __global__ __launch_bounds__(T * T / HALVES * 64, (T == 4 && HALVES == 2) ? 1 : 2)          // 256 registers either way: 8 waves per CU
 void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack,
                    int N, int C, int has_bias, SavedPyr sv, const void* __restrict__ mxpack)
 {
-    using G = Geo<T, HALVES, MODE, TIO, MX, LV>;
+    using G = Geo<T, HALVES, MODE, TIO, MX, LV, STG>;
     static_assert(!MX || (T == 4 && HALVES == 2 && !TRAIN && sizeof(TIO) == 2), "matrix-core variant: 56x56, inference, 16-bit activations");
     static_assert(LV == (T == 4 ? 4 : 3) || (!TRAIN && !MX), "the shorter ladder: inference, vector pipe");
     constexpr int NL = G::NL, PIXF = G::PIXF, NWORK = G::NWORK, P0 = G::P0, P1 = G::P1, P2 = G::P2, P3 = G::P3, P4 = G::P4;
@@ -637,6 +702,12 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     const bool xcd = (total & 7u) == 0 && (GD & 7u) == 0;
 #endif
     const int tid = (int)threadIdx.x;
+    // the wave index stays in a scalar register; the lane index is recomputed per unit from the execution mask (v_mbcnt: no input register), so
+    // the workitem id is dead after the LDS clearing and nothing per-lane is kept live -- or spilled -- across the units
+    const int w_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- zero the whole LDS image once (zero row, guards; and every later read is of finite data)
+    for (int i = tid; i < G::LDS_BYTES / 16; i += G::NT) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (STG > 0) __syncthreads();                       // a row fetched by LDS-DMA before the first unit's barrier must not meet another wave's clearing stores
   for (unsigned it = 0;; ++it) {
     unsigned unit;
     if (xcd) {
@@ -649,9 +720,10 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     }
     const int n = (int)(unit / (unsigned)nb), cb = (int)(unit - (unsigned)n * (unsigned)nb);
 
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int lane_ = tid & 63;
-    if constexpr (MX || HALVES == 4 || (T == 2 && HALVES == 2)) asm volatile("" : "+v"(lane_));   // per unit: what derives from the lane index is recomputed, not kept live across units
+    int w = w_all;
+    asm volatile("" : "+s"(w));                                   // per unit: what derives from the wave index is recomputed, not hoisted out of the unit loop and spilled
+    int lane_ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane_));                               // per unit: what derives from the lane index is recomputed, not kept live (or spilled) across units
     const int lane = lane_;
     constexpr int WPR = T / HALVES;                              // waves per tile row (a wave holds HALVES tiles of one tile row)
     const int h = HALVES == 4 ? (lane >> 4) : (HALVES == 2 ? (lane >> 5) : 0);
@@ -685,9 +757,6 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     float* const L3 = L + G::O3 * PIXF;
     float* const L4 = L + G::O4 * PIXF;
 
-    // ---- zero the whole LDS image once (zero row, guards; and every later read is of finite data)
-    if (it == 0)
-        for (int i = tid; i < G::LDS_BYTES / 16; i += G::NT) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // x image as a raw buffer: base, num_records = bytes of the image (offsets past it read 0)
     const char* ximg = reinterpret_cast<const char*>(x) + (size_t)n * P0 * P0 * pix;
@@ -718,6 +787,31 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         else row_load<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
     };
     auto row_valid = [&](int r) -> bool { const int ar = 14 * tr + r; return ar >= 0 && ar < P0; };   // uniform
+    // STG: this lane's three source offsets (piece j, lane i = chunk 64 j + i of the row image: sub-image s = chunk / 72, pixel (chunk % 72) / 4 =
+    // tile column - 2, 16-byte quarter chunk % 4 of the sub-image's 32 channels; s = the wave's tile (T = 4) or the channel half (T = 2)), the
+    // LDS byte address of the wave's first slot, and this lane's address for the transposing reads
+    unsigned dv[3] = {0u, 0u, 0u};
+    int stg_lds = 0;
+    unsigned stg_tra = 0;
+    if constexpr (STG > 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int item = 64 * j + lane, sI = item >= 72 ? 1 : 0, rem = item - 72 * sI, px = rem >> 2, q4 = rem & 3;
+            const int col = 14 * (T == 4 ? tcb + WPR * sI : tc) + px - 2;
+            const int c0 = cb * CHB + (T == 4 ? 0 : 32 * sI) + 8 * q4;                       // first of the chunk's eight channels
+            dv[j] = (col >= 0 && col < P0 && c0 < C && item < 144) ? (unsigned)(col * pix + c0 * ESZ) : OOB;
+        }
+        const int lbase = G::STGOFF + w * (G::NSLOT * G::SLOTB);
+        stg_lds = __builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)(reinterpret_cast<char*>(lds) + lbase));
+        const int g = lane >> 4;
+        stg_tra = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(reinterpret_cast<char*>(lds) + lbase + (g >> 1) * (18 * 64) + ((lane >> 2) & 3) * 64 + (g & 1) * 32 + (lane & 3) * 8);
+    }
+    auto stg_request = [&](auto sc, int r) {                      // request row r (tile-local) into slot sc
+        int ar = 14 * tr + r;
+        ar = ar < 0 ? 0 : (ar > P0 - 1 ? P0 - 1 : ar);
+        const int rb = __builtin_amdgcn_readfirstlane(ar * (P0 * pix));
+        stage_row(dv[0], dv[1], dv[2], rsrc, rb, stg_lds + decltype(sc)::value * G::SLOTB);
+    };
     // MX, both passes: the band-synchronous staging of x rows (see pass 1).  Loader role of this wave: band w >> 1, two 1 KB pieces per step
     char* const xst = reinterpret_cast<char*>(lds) + G::XOFF;
     const int bandL = w >> 1;
@@ -737,7 +831,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         *reinterpret_cast<u32x4*>(st + wrB) = b;
     };
     auto zero_pads = [&]() {                                  // columns -4 .. -1 of both stages (the ladder has written over this area)
-        for (int i = tid; i < 2 * 4 * 4 * 4; i += G::NT) {   // stage, band, pad pixel, 16-byte quarter
+        for (int i = w * 64 + lane; i < 2 * 4 * 4 * 4; i += G::NT) {   // stage, band, pad pixel, 16-byte quarter
             const int q = i & 3, pp = (i >> 2) & 3, bnd = (i >> 4) & 3, sg = i >> 6;
             *reinterpret_cast<u32x4*>(xst + sg * G::XSTAGE + bnd * G::XBAND + pp * (G::CB * 2) + q * 16) = u32x4{0u, 0u, 0u, 0u};
         }
@@ -746,14 +840,18 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     // pass 1's first rows are requested before the taps, the LDS clearing's tail and the barrier: their HBM latency runs behind those
     constexpr int AHEAD1 = RCX_CPT_PF > 0 ? 2 : RCX_CPT_AHEAD1, R01 = -2, NR1 = 17;
     uint32_t raw1[NR1][NCOL];
-    if constexpr (RCX_CPT_PF == 0 && !(MX && MX_STAGE1)) sfor<AHEAD1>([&](auto rc) { load_row(raw1[decltype(rc)::value], R01 + decltype(rc)::value); });
+    constexpr int SAH = STG > 0 ? STG - 1 : 0;                 // staged rows in flight in front of the row being used
+    if constexpr (STG > 0) sfor<SAH>([&](auto rc) { stg_request(IC<decltype(rc)::value % (STG > 0 ? STG : 1)>{}, R01 + decltype(rc)::value); });
+    else if constexpr (RCX_CPT_PF == 0 && !(MX && MX_STAGE1)) sfor<AHEAD1>([&](auto rc) { load_row(raw1[decltype(rc)::value], R01 + decltype(rc)::value); });
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, (NL + 2) * 25 * C * 4, 0x00020000);
+    // no bias: a buffer of zero records, every load returns 0 (no per-lane flag for an exec-masked load kept live -- or spilled -- across the units)
+    const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc((void*)bpack, 0, has_bias ? (NL + 2) * C * 4 : 0, 0x00020000);
     Taps td;
     MxTaps<TIO, 2> ad;                                       // MX: the down conv as Toeplitz blocks (pass 1); td is loaded after the pass
     const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc((void*)(MX ? mxpack : (const void*)wpack), 0, (NL + 2) * 5 * MXP_SLOTS * 4 * C * 8, 0x00020000);
     const int cM = cb * CHB + chM, ccM = cM < C ? cM : C - 1;       // map M: the channel whose taps and results this lane holds
-    if constexpr (MX) load_mxtaps(ad, msrc, bpack, 0, C, ccM, has_bias, lane & 3);
-    else load_taps(td, wsrc, bpack, 0, C, cc, has_bias);
+    if constexpr (MX) load_mxtaps(ad, msrc, bsrc, 0, C, ccM, lane & 3);
+    else load_taps(td, wsrc, bsrc, 0, C, cc);
     __syncthreads();
     CPT_STAMP(1);
 
@@ -803,7 +901,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             for (int o = 0; o < 7; ++o) if (r - 2 * o + 2 >= 0 && r - 2 * o + 2 < 4) pin(facc[o % 3]);
             CPT_FENCE;
         });
-        load_taps(td, wsrc, bpack, 0, C, cc, has_bias);      // the ladder below runs on the vector pipe in float32
+        load_taps(td, wsrc, bsrc, 0, C, cc);      // the ladder below runs on the vector pipe in float32
     } else if constexpr (MX) {
         // Matrix cores, band-synchronous streaming.  The four lanes of a matrix block are the four BANDS of the plane (tile rows
         // j = 0 .. 3: rows 14 j + r), a wave = (tile column tcw = w >> 1) x 16 channels (w & 1), and all eight waves walk r = -2 .. 14
@@ -865,7 +963,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             }
             if constexpr (!ABL_NOBAR) __syncthreads();           // the other stage is complete; this one may be refilled
         });
-        load_taps(td, wsrc, bpack, 0, C, cc, has_bias);      // the ladder below runs on the vector pipe in float32
+        load_taps(td, wsrc, bsrc, 0, C, cc);      // the ladder below runs on the vector pipe in float32
     } else {
         constexpr int AHEAD = AHEAD1, R0 = R01, NR = NR1;
         const f32x2 b0 = f32x2{td.bias, 0.f};
@@ -902,10 +1000,16 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                 }
             }
         };
-        sfor<AHEAD + PF>([&](auto rc) { prefetch_row(R0 + decltype(rc)::value); });
-        if constexpr (PF > 0) sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], R0 + decltype(rc)::value); });
+        if constexpr (STG == 0) sfor<AHEAD + PF>([&](auto rc) { prefetch_row(R0 + decltype(rc)::value); });
+        if constexpr (PF > 0 && STG == 0) sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], R0 + decltype(rc)::value); });
         sfor<NR>([&](auto rc) {
             constexpr int ri = decltype(rc)::value, r = R0 + ri;
+            if constexpr (STG > 0) {
+                constexpr int SN = STG > 0 ? STG : 1;
+                if constexpr (ri + SAH < NR) stg_request(IC<(ri + SAH) % SN>{}, r + SAH);          // its slot held row ri - 1: read and waited for in the last iteration
+                constexpr int NYS = 3 * (NR - 1 - ri < SAH ? NR - 1 - ri : SAH);
+                fetch_row<TIO, NYS, (ri % SN) * G::SLOTB>(raw[ri], stg_tra);
+            } else {
             if constexpr (ri + AHEAD + PF < NR) prefetch_row(r + AHEAD + PF);
             if constexpr (ri + AHEAD < NR) load_row(raw[ri + AHEAD], r + AHEAD);
             // younger memory operations: what the iterations since row ri was requested have issued (wide loads first, then a row)
@@ -915,6 +1019,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                 return k > 63 ? 63 : k;
             }();
             pin_row<NY>(raw[ri]);
+            }
             f32x2 xr[9];
 #pragma unroll
             for (int k = 0; k < 9; ++k) xr[k] = f32x2{raw_f32<TIO>(raw[ri][2 * k]), raw_f32<TIO>(raw[ri][2 * k + 1])};
@@ -1011,7 +1116,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         constexpr int l = NL - decltype(lc)::value;
         constexpr int P = PL[l];
         Taps tc_;
-        load_taps(tc_, wsrc, bpack, 1 + (NL - l), C, cc, has_bias);
+        load_taps(tc_, wsrc, bsrc, 1 + (NL - l), C, cc);
         if constexpr (l < NL) {
             constexpr int PC = PL[l + 1];
             for_pieces(IC<P>{}, [&](auto, auto col0c, auto noutc, int row, bool act) {
@@ -1048,7 +1153,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     CPT_STAMP(5);
     // ================= level 1, per tile: T1 = F1 + resize(C2) (exact 2x), C1 = conv(T1) =================
     Taps t1;
-    load_taps(t1, wsrc, bpack, NL, C, cc, has_bias);         // conv of level 1 = pack 1 + (NL - 1)
+    load_taps(t1, wsrc, bsrc, NL, C, cc);         // conv of level 1 = pack 1 + (NL - 1)
     {
         // columns: run of 7 starting at absolute column 7*tc (parity uniform), source columns b .. b+4 of C2, clamped
         const int d0 = 7 * tc;
@@ -1198,8 +1303,8 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     }
     Taps tf;
     MxTaps<TIO, 1> af;                                       // MX: the final conv as Toeplitz blocks
-    if constexpr (MX) { load_mxtaps(af, msrc, bpack, 1 + NL, C, ccM, has_bias, lane & 3); tf.bias = af.bias; }
-    else load_taps(tf, wsrc, bpack, 1 + NL, C, cc, has_bias);
+    if constexpr (MX) { load_mxtaps(af, msrc, bsrc, 1 + NL, C, ccM, lane & 3); tf.bias = af.bias; }
+    else load_taps(tf, wsrc, bsrc, 1 + NL, C, cc);
     __syncthreads();
     CPT_STAMP(7);
 
@@ -1280,7 +1385,8 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             sfor<AH + 1>([&](auto sc) { fetch(sc); });
             stage(IC<0>{});
             __syncthreads();
-        } else sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], R0 + decltype(rc)::value); });
+        } else if constexpr (STG > 0) sfor<SAH>([&](auto rc) { stg_request(IC<decltype(rc)::value % (STG > 0 ? STG : 1)>{}, R0 + decltype(rc)::value); });
+        else sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], R0 + decltype(rc)::value); });
         build_H(H[0], -2);
         build_H(H[1], -1);
         sfor<NR>([&](auto rc) {
@@ -1292,6 +1398,8 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                 }
                 if constexpr (ABL_NOTR) { for (int k = 0; k < 20; ++k) raw[ri][k] = (uint32_t)(lane + k + ri) << 16; }
                 else lds_row20<TIO>(raw[ri], rdL + (ri & 1) * G::XSTAGE);
+            } else if constexpr (STG > 0) {
+                if constexpr (ri + SAH < NR) stg_request(IC<(ri + SAH) % (STG > 0 ? STG : 1)>{}, t + SAH);
             } else if constexpr (ri + AHEAD < NR) load_row(raw[ri + AHEAD], t + AHEAD);
             // vertical source rows (tile origin is even): t even -> (t/2 - 1, t/2) weight 0.75; t odd -> ((t-1)/2, (t+1)/2) weight 0.25
             constexpr int te = (t + 2) & 1;                  // parity of t (t + 2 >= 0)
@@ -1306,7 +1414,14 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             constexpr int NLD = NR - 1 - ri < AHEAD ? NR - 1 - ri : AHEAD;
             constexpr int NST = [] { int k = 0; for (int j = 1; j <= AHEAD; ++j) k += (ri - j >= 4 && ri - j <= 17) ? 1 : 0; return k; }();
             if constexpr (MX && !MX_STAGE2) pin_row20<(NCOL * NLD + 14 * NST > 63 ? 63 : NCOL * NLD + 14 * NST)>(raw[ri]);
-            if constexpr (!MX) pin_row<(18 * NLD + 14 * NST > 63 ? 63 : 18 * NLD + 14 * NST)>(raw[ri]);
+            if constexpr (!MX && STG > 0) {
+                // younger: the pieces of the rows requested since (3 each) and the output rows stored at the end of the iterations in between
+                constexpr int SLD = NR - 1 - ri < SAH ? NR - 1 - ri : SAH;
+                constexpr int SST = [] { int k = 0; for (int j = 1; j <= SAH; ++j) k += (ri - j >= 4 && ri - j <= 17) ? 1 : 0; return k; }();
+                constexpr int SNY = 3 * SLD + (sizeof(TIO) == 2 ? 14 : 14) * SST;
+                fetch_row<TIO, (SNY > 63 ? 63 : SNY), (ri % (STG > 0 ? STG : 1)) * G::SLOTB>(raw[ri], stg_tra);
+            }
+            if constexpr (!MX && STG == 0) pin_row<(18 * NLD + 14 * NST > 63 ? 63 : 18 * NLD + 14 * NST)>(raw[ri]);
             if constexpr (MX) {
               if (row_valid(t)) {
                 // T0 row = x + resize(C1), columns -2 .. 17 (16, 17: x alone -- they only meet zero Toeplitz entries), rounded once to the
@@ -1413,15 +1528,37 @@ static inline bool enabled()
     return !(v && *v == '0') && !(l && *l == '0');
 }
 
-template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool TRAIN = false, bool MX = false, int LV = (T == 4 ? 4 : 3)>
+// x rows by LDS-DMA + transposing reads (STG) where the kernel has the form and the data allow it: 16-bit activations, whole 16-byte chunks of
+// eight channels (C % 8 == 0: every RecNeXt width) at 16-byte-aligned addresses, inference.  Parity-green (the 820 bf16 / float16 / golden cases of
+// tests/test_recconv_gpu.py) and NOT faster inside a model -- 56x56 x 64: 123.3 us either way (a loop over one input: 112.2 against 113.8), 28x28 x 128:
+// 55.6 against 53.6 (loop: 49.2 against 53.7), profiles/r04_staged_rows.txt: with two waves per SIMD these kernels are bound by their vector-ALU
+// issue, not by the 976 -> 451 vector-memory instructions per wave this removes.  So the instantiations exist in the diagnostic build only
+// (make diag, RCX_AB_VARIANTS; RCX_CPT_STG=0 there: element loads).
+template <int T, int HALVES, typename TIO, bool TRAIN, bool MX> constexpr int stg_slots()
+{
+#ifndef RCX_AB_VARIANTS
+    return 0;
+#endif
+    if (MX || TRAIN || sizeof(TIO) != 2) return 0;
+    if (T == 4 && HALVES == 2) return 3;
+    if (T == 2 && HALVES == 1) return 2;
+    return 0;
+}
+static inline bool stg_enabled() { return !rcx::opt::is_zero(rcx::opt::CPT_STG); }
+
+template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool TRAIN = false, bool MX = false, int LV = (T == 4 ? 4 : 3), int STG = 0>
 static hipError_t launch(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv, const void* mxpack = nullptr)
 {
-    using G = Geo<T, HALVES, MODE, TIO, MX, LV>;
+    using G = Geo<T, HALVES, MODE, TIO, MX, LV, STG>;
+    if constexpr (STG == 0 && stg_slots<T, HALVES, TIO, TRAIN, MX>() > 0) {
+        if (!sv.base && C % 8 == 0 && ((size_t)x & 15) == 0 && stg_enabled())
+            return launch<T, HALVES, MODE, PIXB, TIO, TRAIN, MX, LV, stg_slots<T, HALVES, TIO, TRAIN, MX>()>(x, y, wpack, bpack, N, C, s, sv, mxpack);
+    }
     if constexpr (!TRAIN && MODE == 0 && !MX && HALVES != 4 && !(T == 2 && HALVES == 2) && LV == (T == 4 ? 4 : 3)) {      // training forward: bilinear only (what RecConv2d trains with), whole-block variants, full ladder
         if (sv.base) return launch<T, HALVES, MODE, PIXB, TIO, true>(x, y, wpack, bpack, N, C, s, sv);
     }
     if (!TRAIN && sv.base) return hipErrorInvalidConfiguration;
-    auto kfn = k_recconv_cpt<T, HALVES, MODE, PIXB, TIO, TRAIN, MX, LV>;
+    auto kfn = k_recconv_cpt<T, HALVES, MODE, PIXB, TIO, TRAIN, MX, LV, STG>;
     RCX_SET_LDS_ONCE(kfn, G::LDS_BYTES);                       // once per instantiation and device
     static std::atomic<int> cus_cache{0};
     int cus = cus_cache.load(std::memory_order_relaxed);

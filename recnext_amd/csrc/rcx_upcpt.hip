@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void k_upadd_cpt(const TIO* __restrict__ x,
     }
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 25 * C * 4, 0x00020000);
     Taps tf;
-    load_taps(tf, wsrc, bias, 0, C, cc, has_bias);
+    load_taps(tf, wsrc, __builtin_amdgcn_make_buffer_rsrc((void*)bias, 0, has_bias ? C * 4 : 0, 0x00020000), 0, C, cc);      // zero records without a bias: the load returns 0
     // the taps land HERE, on every path: left to the compiler, their loads sink to the first use inside the conditional row bodies, and
     // its own count of outstanding loads (which knows nothing of the hand-issued ones) then drains the row prefetch in every iteration
 #pragma unroll
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void k_down5_cpt(const TIO* __restrict__ x,
     sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], -2 + decltype(rc)::value); });
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 25 * C * 4, 0x00020000);
     Taps td;
-    load_taps(td, wsrc, bias, 0, C, cc, has_bias);
+    load_taps(td, wsrc, __builtin_amdgcn_make_buffer_rsrc((void*)bias, 0, has_bias ? C * 4 : 0, 0x00020000), 0, C, cc);      // zero records without a bias: the load returns 0
 #pragma unroll
     for (int u = 0; u < 5; ++u) { pin(td.p[u][0]); pin(td.p[u][1]); pin(td.p[u][2]); }       // landed here, on every path (see k_upadd_cpt)
     f32x2 b0 = f32x2{td.bias, 0.f};

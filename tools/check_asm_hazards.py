@@ -51,6 +51,18 @@ for i, l in enumerate(lines):
             if s & used and a <= 5:
                 bad += 1
                 print(f"line {i + 1}: {t}   <- SGPR {sorted(s & used)} written by VALU {a} instruction(s) earlier")
+    if op.startswith("s_") and not op.startswith(("s_cmp", "s_waitcnt", "s_nop", "s_cbranch", "s_branch", "s_barrier", "s_setprio", "s_sleep", "s_endpgm")):
+        # a scalar-ALU write replaces the VALU-written value: what a later vector-memory instruction reads is the SALU result (no wait states needed)
+        d = args.split(",")[0].strip()
+        wr = set()
+        mm = re.match(r"s(\d+)$", d)
+        if mm:
+            wr.add(int(mm.group(1)))
+        mm = re.match(r"s\[(\d+):(\d+)\]$", d)
+        if mm:
+            wr.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
+        if wr:
+            recent = [(sg - wr, a) for (sg, a) in recent if sg - wr]
     if op.startswith("v_readlane") or op.startswith("v_readfirstlane"):
         d = args.split(",")[0].strip()
         mm = re.match(r"s(\d+)$", d)
