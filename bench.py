@@ -172,16 +172,11 @@ def kernel_name(plan, elem_bytes):
         return f"rcx::lanes::{kern}, {t}>"
     if plan.startswith("cpt(k_recconv_cpt"):
         kern = plan[len("cpt("):plan.index(">")]
-        # template arguments after the type: training, matrix cores, levels (4 / 3 = the full ladder of a 56 / 28 plane; one less: "levels-1")
+        # template arguments after the type: training, matrix cores (diagnostic build), levels (4 / 3 = the full ladder of a 56 / 28 plane; one
+        # less: "levels-1"), staged rows (diagnostic build)
         t_ = int(kern[len("k_recconv_cpt<"):].split(",")[0])
         lv = (4 if t_ == 4 else 3) - (1 if ">,levels-1," in plan else 0)
-        return f"rcx::cpt::{kern}, {t}, false, false, {lv}>"
-    if plan.startswith("cpt_mx(k_recconv_cpt"):
-        kern = plan[len("cpt_mx("):plan.index(">")].rsplit(", ", 2)[0]        # "... <4, 2, mode, pixb, bf16, MX" -> up to the pitch
-        return f"rcx::cpt::{kern}, {'_Float16' if ', f16,' in plan else 'unsigned short'}, false, true, 4>"
-    if plan.startswith("cpl14_mx(k_recconv_mx14"):
-        mode = plan[len("cpl14_mx(k_recconv_mx14<"):].split(",")[0]
-        return f"rcx::mx14::k_recconv_mx14<{mode}, {'_Float16' if ', f16>' in plan else 'unsigned short'}>"
+        return f"rcx::cpt::{kern}, {t}, false, false, {lv}, 0>"
     if plan.startswith("cpl(k_recconv_cpl"):
         kern = plan[len("cpl("):plan.index(">")]
         ns = "cpl14"                                                          # rcx_cpl14.hip
@@ -258,19 +253,34 @@ def cpu_baseline(model_name, resolution, seconds, torch):
                       f"{share:.1f} s per thread count in {counts}, best = {best} threads; config 1 (M0, batch 1) timed beside it"}
 
 
-def load_traffic(kernel):
-    """(HBM bytes per launch of `kernel`, source file) from the committed PMC profiles (profiles/*traffic*.json; the newest
-    round that lists the kernel), or (None, None).  Not measured in this run: PMC collection needs rocprofv3 around the process."""
+def load_traffic(kernel, fingerprint=None, profiles_dir=None):
+    """(HBM bytes per launch of `kernel`, source file, note) from the committed PMC profiles (profiles/*traffic*.json).  Not measured in this
+    run -- PMC collection needs rocprofv3 around the process -- so a profile counts only if it was taken on THESE kernel sources: it records
+    the sha256 of recnext_amd/csrc (recnext_amd/build.py::source_fingerprint) and a file without that field, or with another value, is stale:
+    (None, None, reason).  The newest matching round that lists the kernel wins."""
     import glob
-    best = (None, None)
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+    import importlib.util
+    if fingerprint is None:
+        spec = importlib.util.spec_from_file_location("_rcx_build", os.path.join(ROOT, "recnext_amd", "build.py"))   # torch-free
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        fingerprint = mod.source_fingerprint()
+    best, stale = (None, None), 0
+    for p in sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "*traffic*.json"))):
         try:
-            for rec in json.load(open(p)).get("kernels", []):
-                if rec.get("kernel") == kernel and rec.get("hbm_bytes_per_launch") is not None:
-                    best = (rec["hbm_bytes_per_launch"], os.path.relpath(p, ROOT))
+            doc = json.load(open(p))
         except (OSError, ValueError):
-            pass
-    return best
+            continue
+        if doc.get("library_sources_sha256") != fingerprint:
+            stale += 1
+            continue
+        for rec in doc.get("kernels", []):
+            if rec.get("kernel") == kernel and rec.get("hbm_bytes_per_launch") is not None:
+                best = (rec["hbm_bytes_per_launch"], os.path.relpath(p, ROOT))
+    if best[0] is None:
+        return None, None, (f"no PMC profile of this kernel taken on the current kernel sources (sha256 {fingerprint[:12]}...; {stale} profile file(s) "
+                            f"are from other sources): re-run tools/collect_profiles.sh")
+    return best[0], best[1], None
 
 
 def maybe_spawn_ranks(argv):
@@ -321,7 +331,6 @@ def main():
     from recnext_amd.speed import tune_gemms
     gemm_tuned = tune_gemms(net, x)                       # before the warm-up steps, outside the timed region
     copy_gbs = measure_copy_ceiling(torch, device) if rank == 0 else None
-    mx_on = False
     plan_of = None
     with torch.no_grad():
         # warm-up: the first step builds the packs and sets the kernels' attributes; the others are bracketed mixer by mixer
@@ -331,9 +340,7 @@ def main():
             net(x)
         timers.enabled = False
         torch.cuda.synchronize(device)
-        from recnext_amd import recconv as _rc
-        mx_on = _rc.MATRIX_CORES_DEFAULT and dtype != torch.float32         # RCX_MX=1: the matrix-core schedules where they exist
-        plan_of = lambda n, c, h, w, level, k: (ops.recconv2d_plan_mx if mx_on else ops.recconv2d_plan)(n, c, h, w, level, k, "bilinear", dtype)
+        plan_of = lambda n, c, h, w, level, k: ops.recconv2d_plan(n, c, h, w, level, k, "bilinear", dtype)
         survey_steps = max(args.warmup - skip, 0)
         survey = timers.summarize(elem, plan_of) if survey_steps else None
         if survey:                                            # timed region: only the launches of the kernel with the most time in a step
@@ -359,7 +366,7 @@ def main():
         dom = timed_kernels[0]                                # the kernel instantiation with the most time in the step, bracketed in the timed region
         per_shape, per_kernel = survey if survey else (timed_shapes, timed_kernels)
         table_steps = survey_steps if survey else args.steps
-        traffic, traffic_source = load_traffic(dom["kernel"])
+        traffic, traffic_source, traffic_note = load_traffic(dom["kernel"])
         dom_shape = next(rr for rr in timed_shapes if kernel_name(rr["plan"], elem) == dom["kernel"])
         if dom_shape["level"] is None:                        # RecAttn2d (A family): a unit of several launches, no single-kernel flop count
             dom_flops = dom_tfs = None
@@ -382,7 +389,7 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world} (batch-sharded replicas, no collective in the timed region)"},
             "roofline": {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "traffic_note": traffic_note,
                          # the measured copy ceiling of this device beside the nominal peak, and the vector-ALU ceiling
                          "peak_measured": copy_gbs, "frac_of_measured": dom["achieved_GBs"] / copy_gbs if copy_gbs else None,
                          "valu": None if dom_flops is None else

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RCX_ABI_VERSION 3
+#define RCX_ABI_VERSION 4
 
 enum { RCX_DTYPE_F32 = 0, RCX_DTYPE_BF16 = 1, RCX_DTYPE_F16 = 2 };   /* F16: the reference's autocast dtype (engine.py:48) */
 enum { RCX_MODE_BILINEAR = 0, RCX_MODE_NEAREST = 1 };   /* F.interpolate(mode=...), model/recnext.py:33 */
@@ -46,6 +46,14 @@ const char* rcx_last_error(void);
 /* The RCX_* environment switches (A/B measurement knobs) are read once, at the first call that consults one; this
  * re-reads them.  For tests and A/B tools that flip a switch inside one process; not to be called while another thread is in the library. */
 void rcx_reload_options(void);
+
+/* Start-up self-test of one hardware behaviour the 16-bit load paths rely on and the ISA does not promise: a D16 "hi" load
+ * (global_load_short_d16_hi, buffer_load_short_d16_hi, ds_read_u16_d16_hi) ZEROES the other half of its destination register on gfx950, so a
+ * bf16 element lands in float32 position with no conversion (rcx_cpt_kernel.h row loads, rcx_cpl14_pieces.h, rcx_lanes.h).  One 64-lane launch:
+ * reads the 64 16-bit values at `src`, ORs a failure mask into *flag (caller-zeroed uint32: bit 0 global, 1 buffer, 2 LDS form); asynchronous on
+ * `stream` -- the caller reads *flag after synchronising.  The Python binding runs it once per device before its first 16-bit launch and raises
+ * if the flag is not 0.  Replaces nothing in the reference. */
+int rcx_selftest_d16(const void* src, void* flag, void* stream);
 
 /* Description of the kernel schedule rcx_recconv2d_fwd would use for this problem, e.g. "generic" or
  * "plane(cb=16,band8,nt=512,lds=157760)"; thread-local storage, valid until the next call on this thread. */
@@ -79,25 +87,6 @@ size_t rcx_recconv2d_fwd_workspace_bytes(int N, int C, int H, int W, int level, 
 int rcx_recconv2d_fwd(const void* x, void* y, const float* wpack, const float* bpack,
                       void* workspace, size_t workspace_bytes,
                       int N, int C, int H, int W, int level, int k, int mode, int dtype, void* stream);
-
-/*
- * The same forward for 16-bit activations whose taps may be rounded to the activations' type -- which is every case the reference
- * itself can run in 16 bits: model.bfloat16() / .half() (the parameters already have that type, the rounding is exact) and
- * torch.autocast (engine.py:48: the conv casts its weight).  It allows the schedules that run the 5 x 5 convs as banded 4 x 4 x 4
- * products on the matrix cores: operands in the activations' type, float32 accumulation, and the input of the final conv,
- * x + resize(C_1), rounded once (the reference's 16-bit run rounds after the resize, after the add and after every conv).  Where no
- * such schedule exists for the shape this is rcx_recconv2d_fwd.  Results: within north_star's 1e-2 of the float32 forward, not within
- * half an ulp of it as rcx_recconv2d_fwd's are.
- *   mxpack : rcx_recconv2d_mxpack_bytes(C, level, k) bytes written by rcx_pack_recconv_mx from wpack (same life cycle as wpack: rebuilt
- *            when a parameter changes); NULL selects rcx_recconv2d_fwd.  k = 5 only (0 bytes otherwise).
- *   rcx_recconv2d_fwd_plan_mx : the schedule this call would use (cf. rcx_recconv2d_fwd_plan).
- */
-size_t rcx_recconv2d_mxpack_bytes(int C, int level, int k);
-int rcx_pack_recconv_mx(const float* wpack, void* mxpack, int C, int level, int k, int dtype, void* stream);
-const char* rcx_recconv2d_fwd_plan_mx(int N, int C, int H, int W, int level, int k, int mode, int dtype);
-int rcx_recconv2d_fwd_mx(const void* x, void* y, const float* wpack, const float* bpack, const void* mxpack,
-                         void* workspace, size_t workspace_bytes,
-                         int N, int C, int H, int W, int level, int k, int mode, int dtype, void* stream);
 
 /*
  * Training (engine.py:48-64): a forward that keeps the fp32 pyramid F_1..F_L, C_1..C_L in `saved`, and the backward pass.

@@ -14,12 +14,14 @@ DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 MODE_BILINEAR, MODE_NEAREST = 0, 1
 MODES = {"bilinear": MODE_BILINEAR, "nearest": MODE_NEAREST}
 MAX_LEVEL = 8
-ABI_VERSION = 3
+ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE = -1, -2, -3     # include/recnext_amd.h (rcx_status); positive = hipError_t
+ABI_VERSION = 4
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 
 # name -> (restype, argtypes); every symbol include/recnext_amd.h declares
 SIGNATURES = {
+    "rcx_selftest_d16": (_i, [_vp, _vp, _vp]),
     "rcx_abi_version": (_i, []),
     "rcx_last_error": (ctypes.c_char_p, []),
     "rcx_reload_options": (None, []),
@@ -30,10 +32,6 @@ SIGNATURES = {
     "rcx_unpack_recconv_grads": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "rcx_recconv2d_fwd_workspace_bytes": (_sz, [_i] * 7),
     "rcx_recconv2d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 8 + [_vp]),
-    "rcx_recconv2d_mxpack_bytes": (_sz, [_i] * 3),
-    "rcx_pack_recconv_mx": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "rcx_recconv2d_fwd_plan_mx": (ctypes.c_char_p, [_i] * 8),
-    "rcx_recconv2d_fwd_mx": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 8 + [_vp]),
     "rcx_recconv2d_train_saved_bytes": (_sz, [_i] * 6),
     "rcx_recconv2d_bwd_workspace_bytes": (_sz, [_i] * 6),
     "rcx_recconv2d_fwd_train": (_i, [_vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 8 + [_vp]),

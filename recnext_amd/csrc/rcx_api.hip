@@ -206,6 +206,13 @@ int rcx_abi_version(void) { return RCX_ABI_VERSION; }
 
 void rcx_reload_options(void) { rcx::opt::reload(); }
 
+int rcx_selftest_d16(const void* src, void* flag, void* stream)
+{
+    if (!src || !flag) return fail(RCX_ERR_BAD_ARG, "rcx_selftest_d16: null pointer");
+    hipError_t e = rcx::selftest_d16(src, flag, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "rcx_selftest_d16");
+}
+
 const char* rcx_last_error(void) { return g_err; }
 
 const char* rcx_recconv2d_fwd_plan(int N, int C, int H, int W, int level, int k, int mode, int dtype)
@@ -377,55 +384,7 @@ int rcx_recconv2d_fwd(const void* x, void* y, const float* wpack, const float* b
 
 // ---- matrix-core schedules: 16-bit activations whose taps may be rounded to the same type ----
 namespace {
-bool use_mx(int N, int C, int H, int W, int level, int k, int dtype)
-{
-    if (lanes_off() || rcx::opt::value(rcx::opt::FORCE_SPLIT)) return false;
-    return rcx::cpt_mx_applicable(N, C, H, W, level, k, dtype) || rcx::cpl14mx_applicable(N, C, H, W, level, k, dtype);
-}
 }  // namespace
-
-size_t rcx_recconv2d_mxpack_bytes(int C, int level, int k)
-{
-    if (C <= 0 || level < 0 || level > RCX_MAX_LEVEL || k != 5) return 0;
-    return rcx::mxpack_bytes(level + 2, C);
-}
-
-int rcx_pack_recconv_mx(const float* wpack, void* mxpack, int C, int level, int k, int dtype, void* stream)
-{
-    if (!wpack || !mxpack || C <= 0 || level < 0 || level > RCX_MAX_LEVEL) return fail(RCX_ERR_BAD_ARG, "rcx_pack_recconv_mx: bad argument");
-    if (k != 5) return fail(RCX_ERR_UNSUPPORTED, "rcx_pack_recconv_mx: the matrix pack exists for kernel_size 5 only, got %d", k);
-    if (dtype != RCX_DTYPE_BF16 && dtype != RCX_DTYPE_F16) return fail(RCX_ERR_BAD_ARG, "rcx_pack_recconv_mx: dtype must be bf16 or f16, got %d", dtype);
-    hipError_t e = rcx::pack_mx(wpack, mxpack, level + 2, C, dtype, (hipStream_t)stream);
-    return e == hipSuccess ? 0 : hip_fail(e, "rcx_pack_recconv_mx");
-}
-
-const char* rcx_recconv2d_fwd_plan_mx(int N, int C, int H, int W, int level, int k, int mode, int dtype)
-{
-    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0) return "invalid";
-    static thread_local char desc[256];
-    if (use_mx(N, C, H, W, level, k, dtype)) {
-        const int md = mode == RCX_MODE_NEAREST ? 1 : 0;
-        if ((H == 14 ? rcx::cpl14mx_describe(N, C, md, dtype, desc, (int)sizeof(desc)) : rcx::cpt_mx_describe(N, C, md, dtype, desc, (int)sizeof(desc))) > 0) return desc;
-    }
-    return rcx_recconv2d_fwd_plan(N, C, H, W, level, k, mode, dtype);
-}
-
-int rcx_recconv2d_fwd_mx(const void* x, void* y, const float* wpack, const float* bpack, const void* mxpack,
-                         void* workspace, size_t workspace_bytes,
-                         int N, int C, int H, int W, int level, int k, int mode, int dtype, void* stream)
-{
-    if (mxpack && level >= 0 && level <= RCX_MAX_LEVEL && use_mx(N, C, H, W, level, k, dtype)) {
-        if (int rc = check_common(x, y, N, C, H, W, k, dtype)) return rc;
-        if (!wpack) return fail(RCX_ERR_BAD_ARG, "null weight pack");
-        if (x == y) return fail(RCX_ERR_BAD_ARG, "y must not alias x");
-        if (mode != RCX_MODE_BILINEAR && mode != RCX_MODE_NEAREST) return fail(RCX_ERR_BAD_ARG, "unknown mode %d", mode);
-        const int md = mode == RCX_MODE_NEAREST ? 1 : 0;
-        hipError_t e = H == 14 ? rcx::cpl14mx_recconv(x, y, mxpack, bpack, N, C, md, dtype, (hipStream_t)stream)
-                               : rcx::cpt_mx_recconv(x, y, wpack, bpack, mxpack, N, C, md, dtype, (hipStream_t)stream);
-        return e == hipSuccess ? 0 : hip_fail(e, "matrix-core schedule");
-    }
-    return rcx_recconv2d_fwd(x, y, wpack, bpack, workspace, workspace_bytes, N, C, H, W, level, k, mode, dtype, stream);
-}
 
 // ---- training: forward that keeps the fp32 pyramid, and the backward pass (rcx_bwd.hip) ----
 namespace {

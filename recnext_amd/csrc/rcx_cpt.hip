@@ -16,7 +16,9 @@ hipError_t launch_lv(const void* x, void* y, const float* wpack, const float* bp
 // unit's own ~37 us of phases is the floor (128 x 96: 37.8 / 28.9, 64 x 160: 37.3 / 27.8) and with more the second round runs on a fraction
 // of the chip (256 x 160: 63.0 / 67.3 alone, 75.6 / 68.7 inside RecNeXt-M5; 512 x 96: 84.0 / 79.3).  A rule on the unit count would pick a
 // different summation order for a batch and for its shards (the two kernels agree to float32 round-off, not bit for bit), and "a batch
-// shard gives the same rows"  is kept exact: the choice never depends on N.
+// shard gives the same rows"  is kept exact: the choice between kernels that are NOT bit-identical never depends on N.  (cb16() below
+// and the reload form of rcx_cpl14.hip do look at N -- they choose between variants that are bit-identical by construction and by test:
+// test_56_block_with_16_and_32_channel_workgroups_is_the_same_function, test_14_block_reload_form_is_the_same_function.)
 static bool cpt28_ragged(int N, int C)
 {
     (void)N; (void)C;
@@ -53,27 +55,6 @@ int cpt_describe(int N, int C, int H, int level, int mode, int dtype, char* buf,
                     T, halves, mode, pixb, pixf, T * T / halves * 64, total,
                     T == 4 ? (halves == 4 ? cpt::Geo<4, 4, 0, float>::LDS_BYTES : cpt::Geo<4, 2, 0, float>::LDS_BYTES)
                            : (halves == 2 ? cpt::Geo<2, 2, 0, float>::LDS_BYTES : cpt::Geo<2, 1, 0, float>::LDS_BYTES));
-}
-
-// Matrix-core variant (rcx_cpt_kernel.h, MX): the 56x56 / level 4 block with bf16 or float16 activations.  RCX_CPT_MX=0: off (A/B).
-bool cpt_mx_applicable(int N, int C, int H, int W, int level, int k, int dtype)
-{
-    (void)N;
-    const char* v = rcx::opt::value(rcx::opt::CPT_MX);
-    if (v && *v == '0') return false;
-    return cpt::enabled() && k == 5 && C >= 1 && (dtype == 1 || dtype == 2) && H == 56 && W == 56 && level == 4;
-}
-
-int cpt_mx_describe(int N, int C, int mode, int dtype, char* buf, int len)
-{
-    using G = cpt::Geo<4, 2, 0, bf16_t, true>;
-    return snprintf(buf, len, "cpt_mx(k_recconv_cpt<4, 2, %d, %d, %s, MX>,cb=%d,nt=%d,units=%d,lds=%d)", mode, C == 64 ? 128 : 0, dtype == 2 ? "f16" : "bf16",
-                    G::CB, G::NT, N * ((C + G::CB - 1) / G::CB), G::LDS_BYTES);
-}
-
-hipError_t cpt_mx_recconv(const void* x, void* y, const float* wpack, const float* bpack, const void* mxpack, int N, int C, int mode, int dtype, hipStream_t s)
-{
-    return cpt::launch_mx(x, y, wpack, bpack, mxpack, N, C, mode, dtype, s);
 }
 
 hipError_t cpt_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int H, int level, int mode, int dtype, hipStream_t s,

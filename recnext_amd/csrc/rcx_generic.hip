@@ -321,42 +321,6 @@ hipError_t pack_params(const PackPtrs& P, float* wpack, float* wflip, float* bpa
     return hipGetLastError();
 }
 
-// The matrix pack (round 3): the 5 x 5 taps of every conv of a block as the A operands of the 4 x 4 x 4 matrix products
-// (rcx_cpt_kernel.h, "matrix-core variant"): banded Toeplitz blocks, row i of a block = four 16-bit values
-//   conv 0 (the shared stride-2 conv): slot kb = 0..2, entry k:  w[u][4 kb + k - 2 i]
-//   convs 1.. (stride 1)             : slot kb = 0..1, entry k:  w[u][4 kb + k - i]     (slot 2 is zero)
-// or 0 where that tap index is outside 0 .. 4; laid out [conv][tap row u][slot][i][channel] x 8 bytes.  Source: the float32 pack, so a
-// folded output affine (RecConv2d.fold_output_affine) is already in the taps; they are rounded to the activations' type here.
-template <typename T16>
-__global__ void k_pack_mx(const float* __restrict__ wpack, uint2* __restrict__ dst, int C, int count)
-{
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = count * 5 * 3 * 4 * C;
-    if (idx >= total) return;
-    const int c = idx % C, i = (idx / C) % 4, kb = (idx / (4 * C)) % 3, u = (idx / (12 * C)) % 5, j = idx / (60 * C);
-    const int stride = j == 0 ? 2 : 1;
-    uint16_t e[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int v = 4 * kb + k - stride * i;
-        const bool on = v >= 0 && v <= 4 && (stride == 2 || kb < 2);
-        const float w = on ? wpack[((size_t)(j * 25 + u * 5 + v)) * C + c] : 0.f;
-        if constexpr (std::is_same<T16, f16_t>::value) e[k] = __builtin_bit_cast(uint16_t, (f16_t)w);
-        else e[k] = f32_to_bf16(w);
-    }
-    dst[idx] = make_uint2((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16));
-}
-
-size_t mxpack_bytes(int count, int C) { return (size_t)count * 5 * 3 * 4 * C * 8; }
-
-hipError_t pack_mx(const float* wpack, void* mxpack, int count, int C, int dt, hipStream_t s)
-{
-    const int n = count * 5 * 3 * 4 * C;
-    if (dt == 2) hipLaunchKernelGGL(k_pack_mx<f16_t>, dim3((n + 255) / 256), dim3(256), 0, s, wpack, (uint2*)mxpack, C, count);
-    else if (dt == 1) hipLaunchKernelGGL(k_pack_mx<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, s, wpack, (uint2*)mxpack, C, count);
-    else return hipErrorInvalidValue;
-    return hipGetLastError();
-}
 
 // the packed weight gradients (count, k*k, C) back into the parameters' layout, each (C, 1, k, k) float32 contiguous: one launch
 __global__ void k_unpack_grads(const float* __restrict__ gwpack, PackPtrs P, int C, int kk)
@@ -381,6 +345,42 @@ hipError_t pack_bias(const void* b, float* dst, int C, int dt, hipStream_t s)
     if (dt == 0) hipLaunchKernelGGL(k_pack_dw_weight<float>, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)b, dst, C, 1);
     else if (dt == 2) hipLaunchKernelGGL(k_pack_dw_weight<f16_t>, dim3((C + 255) / 256), dim3(256), 0, s, (const f16_t*)b, dst, C, 1);
     else hipLaunchKernelGGL(k_pack_dw_weight<bf16_t>, dim3((C + 255) / 256), dim3(256), 0, s, (const bf16_t*)b, dst, C, 1);
+    return hipGetLastError();
+}
+
+// ---- start-up self-test (rcx_selftest_d16): the D16 "hi" loads must zero the other half of their destination on this device.  Registers
+// preset to patterns; every lane compares what the three load forms leave with (element << 16) and ORs its verdict into *flag.
+__global__ void k_selftest_d16(const uint16_t* __restrict__ src, unsigned* __restrict__ flag)
+{
+    __shared__ uint16_t sm[64];
+    const int lane = threadIdx.x;
+    sm[lane] = src[lane];
+    __syncthreads();
+    uint32_t a = 0xAAAAAAAAu, b = 0xBBBBBBBBu, c = 0xCCCCCCCCu;
+    const uint16_t* p = src + lane;
+    const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) uint16_t*)(sm + lane);
+    typedef int i32x4_ __attribute__((ext_vector_type(4)));
+    i32x4_ rs;
+    const unsigned long long base = (unsigned long long)src;
+    rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
+    rs.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32) & 0xffff);
+    rs.z = 128;
+    rs.w = 0x00020000;
+    const unsigned voff = (unsigned)lane * 2u;
+    asm volatile("s_nop 4\n\t"
+                 "global_load_short_d16_hi %0, %3, off\n\t"
+                 "buffer_load_short_d16_hi %1, %4, %5, 0 offen\n\t"
+                 "ds_read_u16_d16_hi %2, %6\n\t"
+                 "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(a), "+v"(b), "+v"(c) : "v"(p), "v"(voff), "s"(rs), "v"(la) : "memory");
+    const uint32_t want = (uint32_t)sm[lane] << 16;
+    const unsigned bad = (a != want ? 1u : 0u) | (b != want ? 2u : 0u) | (c != want ? 4u : 0u);
+    if (bad) atomicOr(flag, bad);
+}
+
+hipError_t selftest_d16(const void* src, void* flag, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_selftest_d16, dim3(1), dim3(64), 0, s, (const uint16_t*)src, (unsigned*)flag);
     return hipGetLastError();
 }
 

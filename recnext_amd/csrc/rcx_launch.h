@@ -31,13 +31,11 @@ hipError_t generic_upadd_dwconv(const void* x, const void* coarse, void* y, cons
 hipError_t generic_dwconv_mult2(const void* x, void* y, const float* w, const float* b,
                                 int N, int Cin, int H, int W, int k, int stride, int dt, hipStream_t s);
 hipError_t pack_dw_weight(const void* w, float* dst, int C, int k, int dt, hipStream_t s);
+hipError_t selftest_d16(const void* src, void* flag, hipStream_t s);      // the D16-hi zero-fill the 16-bit load paths rely on
 hipError_t pack_bias(const void* b, float* dst, int C, int dt, hipStream_t s);
 struct PackPtrs { const void* w[10]; const void* b[10]; };         // RCX_MAX_LEVEL + 2 convs
 hipError_t pack_params(const PackPtrs& P, float* wpack, float* wflip, float* bpack, int count, int C, int k, int dt, hipStream_t s);
 hipError_t unpack_grads(const float* gwpack, const PackPtrs& P, int count, int C, int k, hipStream_t s);
-// the taps as Toeplitz blocks for the matrix-core schedules (k = 5; dt = the activations' 16-bit type)
-size_t mxpack_bytes(int count, int C);
-hipError_t pack_mx(const float* wpack, void* mxpack, int count, int C, int dt, hipStream_t s);
 
 // rcx_plane.hip -- fused single-launch schedule (k=5, C%8==0, pyramid fits in LDS)
 bool plane_applicable(int N, int C, int H, int W, int level, int k, int dtype);
@@ -67,7 +65,8 @@ hipError_t cpl14_recconv(const void* x, void* y, const float* wpack, const float
                          float* saved = nullptr, const size_t* f_off = nullptr, const size_t* c_off = nullptr);
 
 // one step, channel per lane: y = conv5(x + resize(coarse)) + bias on the 14x14 plane (RecAttn2d's fused kernel; rcx_cpl14.hip)
-// rcx_upcpt.hip -- conv5(x + resize2x(coarse)) on any plane whose width is a multiple of 14: channel per lane, tiled, no LDS (round 3)
+// rcx_upcpt.hip -- conv5(x + resize2x(coarse)) on any even plane of at least 28 x 28 (per-row descriptors; ragged last tiles): channel per
+// lane, tiled, no LDS (round 3)
 bool upadd_cpt_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int x_dt, int c_dt, int out_dt);
 int upadd_cpt_describe(int N, int C, int H, int W, int mode, int x_dt, char* buf, int len);
 hipError_t upadd_cpt(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int H, int W, int mode,
@@ -111,16 +110,6 @@ int cpt_describe(int N, int C, int H, int level, int mode, int dtype, char* buf,
 bool cpt_train_applicable(int N, int C, int H, int W, int level, int k, int mode, int dtype);
 hipError_t cpt_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int H, int level, int mode, int dtype, hipStream_t s,
                        float* saved = nullptr, const size_t* f_off = nullptr, const size_t* c_off = nullptr);
-// the same block with its two level-0 passes on the matrix cores (16-bit activations, taps rounded to their type: rcx_recconv2d_fwd_mx)
-bool cpt_mx_applicable(int N, int C, int H, int W, int level, int k, int dtype);
-int cpt_mx_describe(int N, int C, int mode, int dtype, char* buf, int len);
-hipError_t cpt_mx_recconv(const void* x, void* y, const float* wpack, const float* bpack, const void* mxpack, int N, int C, int mode, int dtype, hipStream_t s);
-
-// matrix-core kernel of the 14x14 / level 2 block (rcx_cpl14mx.hip): 16-bit activations, any channel count
-bool cpl14mx_applicable(int N, int C, int H, int W, int level, int k, int dtype);
-int cpl14mx_describe(int N, int C, int mode, int dtype, char* buf, int len);
-hipError_t cpl14mx_recconv(const void* x, void* y, const void* mxpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s);
-
 // rcx_down.hip -- register-resident depthwise 7x7 stride-2 conv with channel multiplier 2 (Downsample) on the 7*2^k planes
 bool down_lanes_applicable(int N, int Cin, int H, int W, int k, int stride, int dtype);
 hipError_t down_lanes(const void* x, void* y, const float* w, const float* b, int N, int Cin, int H, int W, int k, int stride, int dtype, hipStream_t s);

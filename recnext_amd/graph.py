@@ -11,6 +11,14 @@ kernel attributes are fixed by the warm-up calls before the capture.
     y = run(x)            # captures on the first call with this shape / dtype, replays afterwards
 
 The output is the graph's own buffer: it is overwritten by the next call with the same shape (clone it to keep it).
+
+Weights.  A captured graph holds raw addresses: of the parameters (the GEMMs, the norms) and of the DERIVED packs the token mixers build from
+them during the warm-up (RecConv2d._pack, RecAttn2d._pack, DownsampleDwConv._pack), which are rebuilt -- reallocated -- when a parameter's
+version changes.  So every call checks a fingerprint of the module's parameters and buffers (address and in-place version counter of each:
+load_state_dict, optimizer steps, fold_output_affine and in-place edits all bump a version) and drops every graph when it has changed; the
+next call captures again on the new weights.  Each graph also keeps references to the packs it was captured with, so their memory cannot be
+handed to another tensor while the graph lives.  What the fingerprint cannot see is a parameter OBJECT replaced after construction
+(``module.to(...)``, ``m.weight = nn.Parameter(...)``): call ``reset()`` after such a change (it re-reads the tensor list).
 """
 import torch
 
@@ -20,6 +28,16 @@ class GraphedInference:
         self.module = module
         self.warmup = warmup
         self._graphs = {}
+        self.reset()
+
+    def reset(self):
+        """Forget every captured graph and re-read which tensors make up the module's weights."""
+        self._graphs.clear()
+        self._tensors = [t for t in list(self.module.parameters()) + list(self.module.buffers()) if t is not None]
+        self._fingerprint = self._weights_fingerprint()
+
+    def _weights_fingerprint(self):
+        return tuple((t.data_ptr(), t._version) for t in self._tensors)
 
     def _capture(self, x):
         static_x = x.clone(memory_format=torch.preserve_format)
@@ -32,18 +50,24 @@ class GraphedInference:
         graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(graph):
             static_y = self.module(static_x)
-        return graph, static_x, static_y
+        # the derived packs whose addresses the graph has baked in: kept alive with it
+        packs = [getattr(m, a) for m in self.module.modules() for a in ("_pack",) if getattr(m, a, None) is not None]
+        return graph, static_x, static_y, packs
 
     def __call__(self, x):
         if not x.is_cuda:
             raise RuntimeError("GraphedInference replays a HIP graph: the input must be on the GPU")
         if self.module.training:
             raise RuntimeError("GraphedInference is for inference: call module.eval() first")
+        fp = self._weights_fingerprint()
+        if fp != self._fingerprint:                              # the weights changed under the graphs: their packs and results are stale
+            self._graphs.clear()
+            self._fingerprint = fp
         key = (tuple(x.shape), x.dtype, x.device, x.is_contiguous(memory_format=torch.channels_last))
         entry = self._graphs.get(key)
         if entry is None:
             entry = self._graphs[key] = self._capture(x)
-        graph, static_x, static_y = entry
+        graph, static_x, static_y, _ = entry
         static_x.copy_(x)
         graph.replay()
         return static_y

@@ -10,11 +10,37 @@ from . import _lib
 _DT = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}
 
 
+_D16_CHECKED = set()            # device indices whose D16-hi zero-fill has been verified (rcx_selftest_d16)
+
+
+def selftest_d16(device):
+    """Run the library's start-up probe on `device` (once per process and device; raises RcxError if the hardware does not zero the other half
+    of a D16 "hi" load's destination, which the bf16 load paths rely on -- include/recnext_amd.h).  Returns the failure mask (0 = fine)."""
+    dev = torch.device(device)
+    src = (torch.arange(64, device=dev, dtype=torch.int32) * 517 + 0x1234).to(torch.int16)        # 64 distinct 16-bit patterns
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().rcx_selftest_d16(src.data_ptr(), flag.data_ptr(), _stream(dev))
+    _lib.check(rc, "rcx_selftest_d16")
+    mask = int(flag.item())
+    if mask:
+        raise _lib.RcxError(f"D16 self-test failed on {dev} (mask {mask:#x}: bit 0 global_load_short_d16_hi, 1 buffer_load_short_d16_hi, 2 "
+                            "ds_read_u16_d16_hi): this device does not zero the other half of a D16-hi load; the 16-bit kernels would return garbage")
+    return mask
+
+
 def _dt(t):
     try:
-        return _DT[t.dtype]
+        code = _DT[t.dtype]
     except KeyError:
         raise TypeError(f"recnext_amd kernels take float32, bfloat16 or float16 tensors, got {t.dtype}") from None
+    if code != _lib.DTYPE_F32 and t.is_cuda:
+        idx = t.device.index
+        if idx not in _D16_CHECKED:                      # once per device, before its first 16-bit launch; never while a graph is being captured
+            if not torch.cuda.is_current_stream_capturing():
+                selftest_d16(t.device)
+                _D16_CHECKED.add(idx)
+    return code
 
 
 def _require_gpu(t, name):
@@ -161,27 +187,8 @@ def recconv2d_plan(n, c, h, w, level, k, mode, dtype):
     return _lib.load().rcx_recconv2d_fwd_plan(n, c, h, w, level, k, _lib.MODES[mode], _DT[dtype]).decode()
 
 
-def pack_recconv_mx(wpack, level, c, k, dtype):
-    """The taps of a block as the matrix-core schedules want them (rcx_pack_recconv_mx): banded Toeplitz blocks in `dtype` (bfloat16 or
-    float16), built from the float32 pack.  None where no such pack exists (k != 5)."""
-    lib = _lib.load()
-    nbytes = lib.rcx_recconv2d_mxpack_bytes(c, level, k)
-    if not nbytes:
-        return None
-    mx = torch.empty(nbytes, dtype=torch.uint8, device=wpack.device)
-    with _on(wpack.device):
-        rc = lib.rcx_pack_recconv_mx(wpack.data_ptr(), mx.data_ptr(), c, level, k, _DT[dtype], _stream(wpack.device))
-    _lib.check(rc, "rcx_pack_recconv_mx")
-    return mx
-
-
-def recconv2d_plan_mx(n, c, h, w, level, k, mode, dtype):
-    return _lib.load().rcx_recconv2d_fwd_plan_mx(n, c, h, w, level, k, _lib.MODES[mode], _DT[dtype]).decode()
-
-
-def recconv2d_forward(x, wpack, bpack, level, k, mode="bilinear", mxpack=None):
-    """RecConv2d.forward (model/recnext.py:24-34) on the HIP kernels. Returns a channels_last tensor like x.
-    mxpack (pack_recconv_mx, in x's 16-bit dtype): the taps may be rounded to x's dtype -- rcx_recconv2d_fwd_mx."""
+def recconv2d_forward(x, wpack, bpack, level, k, mode="bilinear"):
+    """RecConv2d.forward (model/recnext.py:24-34) on the HIP kernels. Returns a channels_last tensor like x."""
     x = _nhwc(x)
     n, c, h, w = x.shape
     if mode not in _lib.MODES:
@@ -194,16 +201,10 @@ def recconv2d_forward(x, wpack, bpack, level, k, mode="bilinear", mxpack=None):
     nbytes = lib.rcx_recconv2d_fwd_workspace_bytes(n, c, h, w, level, k, dt)    # 0 on the fused schedules: nothing to allocate
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     with _on(x.device):
-        if mxpack is not None and dt != _lib.DTYPE_F32:
-            rc = lib.rcx_recconv2d_fwd_mx(x.data_ptr(), y.data_ptr(), wpack.data_ptr(),
-                                          bpack.data_ptr() if bpack is not None else None, mxpack.data_ptr(),
-                                          ws.data_ptr() if ws is not None else None, nbytes, n, c, h, w, level, k, _lib.MODES[mode], dt,
-                                          _stream(x.device))
-        else:
-            rc = lib.rcx_recconv2d_fwd(x.data_ptr(), y.data_ptr(), wpack.data_ptr(),
-                                       bpack.data_ptr() if bpack is not None else None,
-                                       ws.data_ptr() if ws is not None else None, nbytes, n, c, h, w, level, k, _lib.MODES[mode], dt,
-                                       _stream(x.device))
+        rc = lib.rcx_recconv2d_fwd(x.data_ptr(), y.data_ptr(), wpack.data_ptr(),
+                                   bpack.data_ptr() if bpack is not None else None,
+                                   ws.data_ptr() if ws is not None else None, nbytes, n, c, h, w, level, k, _lib.MODES[mode], dt,
+                                   _stream(x.device))
     _lib.check(rc, "rcx_recconv2d_fwd")
     return y
 
@@ -358,7 +359,7 @@ def linear_attention_core_pe(qpre, kpre, v, w_pe_kkc, b_pe, heads):
         rc = _lib.load().rcx_linear_attention_pe_fwd(qpre.data_ptr(), kpre.data_ptr(), v.data_ptr(), w_pe_kkc.data_ptr(),
                                                      b_pe.data_ptr() if b_pe is not None else None, out.data_ptr(),
                                                      b, h, w, c, heads, _dt(v), _stream(v.device))
-    if rc == -2:                         # RCX_ERR_UNSUPPORTED (RCX_ATTN_SCALAR=1 pins the kernel without this form): the caller runs the two steps
+    if rc == _lib.ERR_UNSUPPORTED:       # (RCX_ATTN_SCALAR=1 pins the kernel without this form): the caller runs the two steps
         return None
     _lib.check(rc, "rcx_linear_attention_pe_fwd")
     return out

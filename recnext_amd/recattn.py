@@ -8,8 +8,10 @@ weights here whether or not ``replace_batchnorm`` has already replaced the pair 
 ``nn.Conv2d`` (model/recattn.py:89-111).  The HIP kernels cover the two depthwise convs and the fused
 nearest-resize + add + conv, the `pe` depthwise 3x3 and the linear-attention core (q/k activation,
 k v^T, normaliser, + pe: ``rcx_linear_attention_fwd``); only the grouped 1x1
-`qk` projection -- two plain GEMMs -- goes through the GEMM library.  ``LinearAttention.forward`` keeps the
-reference's operator chain for CPU tensors (tests, oracle).  Parameter names and shapes equal the reference's.
+`qk` projection -- two plain GEMMs -- goes through the GEMM library.  There is no PyTorch-operator path: CPU tensors and head sizes the
+core does not take raise (the reference's formulation lives in oracle/torch_eager.py).  In eval mode everything between the stride-2 conv
+and the final conv -- the quarter-size tensors d, q, k, pe, the attention output -- stays float32 whatever x's type, so a bf16 / float16 run
+rounds once, at the store of y (north_star's flat 1e-2 against the float32 reference).  Parameter names and shapes equal the reference's.
 """
 import torch
 import torch.nn as nn
@@ -36,39 +38,23 @@ class LinearAttention(nn.Module):
         self.pe = ConvNorm(dim, dim, kernel_size=3, padding=1, groups=dim)
 
     def forward(self, x):
+        """The training-step form (RecAttn2d.forward's autograd branch calls it; the inference form is fused into RecAttn2d.forward): the
+        projection as two GEMMs + the module's BatchNorm, then everything after it -- activation, k v^T, normaliser, + pe -- in one HIP
+        kernel with a HIP backward (rcx_linear_attention_fwd / _bwd).  Like RecConv2d there is no PyTorch-operator path: a CPU tensor or a
+        head size the HIP core does not take raises (the reference's own formulation lives in oracle/torch_eager.py, for the tests)."""
         b, c, h, w = x.shape
         n = h * w
-        s = n ** -0.5
-        # the HIP core's own rule for the head size (rcx_linear_attention_fwd): any D <= 32, or a multiple of 4 up to 64
-        hd_ok = self.head_dim <= 32 or (self.head_dim <= 64 and self.head_dim % 4 == 0)
-        if x.is_cuda and c % 4 == 0 and hd_ok and x.dtype in ops._DT:
-            # GPU (training step): the projection as two GEMMs + the module's BatchNorm, then everything after it -- activation,
-            # k v^T, normaliser, + pe -- in one HIP kernel with a HIP backward (rcx_linear_attention_fwd / _bwd).  Under autocast the
-            # GEMMs answer in the autocast type while x stays float32: the core takes one type, x's
-            qkpre = self._qk_gpu(x).to(x.dtype)                 # (b, 2c, h, w), channels_last storage
-            tok = qkpre.permute(0, 2, 3, 1).reshape(b, n, 2 * c)
-            qpre, kpre = tok[..., :c].contiguous(), tok[..., c:].contiguous()
-            pe = _conv_norm_train(self.pe, x, 1).to(x.dtype)
-            return ops.LinearAttentionCoreFn.apply(qpre, kpre, x.contiguous(memory_format=torch.channels_last), pe, self.num_heads)
-        # What is left runs the reference's formulation (model/recattn.py:16-28 / :39-51) on PyTorch operators: CPU tensors (the
-        # parameter-count and golden tests of the model skeleton run there) and head sizes the HIP core does not take.  It is the
-        # reference's own code path, not a fallback OF the HIP path: RecConv2d, whose whole body is the product, raises instead.
-        if x.is_cuda:
-            qk = F.elu(self._qk_gpu(x)) + 1.0
-        else:
-            qk = F.elu(self.qk(x)) + 1.0
-        q, k = qk.reshape(b, 2, self.num_heads, self.head_dim, n).unbind(dim=1)
-        v = x.reshape(b, self.num_heads, self.head_dim, n)
-        q_t, v_t = q.transpose(-1, -2), v.transpose(-1, -2)
-        if self.variant == 1:
-            kv = (k * s) @ (v_t * s)
-            out = q_t @ kv / (q_t @ k.mean(dim=-1, keepdim=True) + 1e-6)
-        else:
-            a = q_t @ k
-            a = a / (a.mean(dim=-1, keepdim=True) + 1e-6)
-            out = (a * s) @ (v_t * s)
-        pe = _conv_norm_train(self.pe, x, 1) if (x.is_cuda and c % 4 == 0) else self.pe(x)
-        return out.transpose(-1, -2).reshape(b, c, h, w) + pe
+        if not x.is_cuda:
+            raise RuntimeError("recnext_amd.LinearAttention runs on the GPU only (HIP kernels); the CPU formulation is oracle/torch_eager.py")
+        if c % 4 or not head_dim_supported(self.head_dim) or x.dtype not in ops._DT:
+            raise NotImplementedError(f"LinearAttention: the HIP core takes head sizes up to 32, or multiples of 4 up to 64, and channel counts that "
+                                      f"are multiples of 4; got dim {c}, {self.num_heads} heads, {x.dtype}")
+        # Under autocast the GEMMs answer in the autocast type while x stays float32: the core takes one type, x's
+        qkpre = self._qk_gpu(x).to(x.dtype)                 # (b, 2c, h, w), channels_last storage
+        tok = qkpre.permute(0, 2, 3, 1).reshape(b, n, 2 * c)
+        qpre, kpre = tok[..., :c].contiguous(), tok[..., c:].contiguous()
+        pe = _conv_norm_train(self.pe, x, 1).to(x.dtype)
+        return ops.LinearAttentionCoreFn.apply(qpre, kpre, x.contiguous(memory_format=torch.channels_last), pe, self.num_heads)
 
     def _qk_gpu(self, x):
         """The grouped 1x1 `qk` conv as two GEMMs on the token-major view (same function; the GEMM library's forward and
@@ -83,6 +69,11 @@ class LinearAttention(nn.Module):
         y = torch.cat((F.linear(tok[:, :c // 2], wq, bq), F.linear(tok[:, c // 2:], wk, bk)), dim=1)
         y = y.view(b, h, w, 2 * c).permute(0, 3, 1, 2)
         return y if isinstance(m, nn.Conv2d) else m.norm(y)
+
+
+def head_dim_supported(d):
+    """The HIP core's own rule for the head size (rcx_linear_attention_fwd): any size up to 32, or a multiple of 4 up to 64."""
+    return d <= 32 or (d <= 64 and d % 4 == 0)
 
 
 def _conv_norm_train(m, x, stride):
@@ -123,16 +114,24 @@ class RecAttn2d(nn.Module):
 
     def _tensors(self):
         # read out of the registries: this runs on every forward, and nn.Module.__getattr__ costs ~0.3 us a look-up (40 of them here)
-        mods = self._modules
-        down = mods["down"]._modules
-        la = down["1"]._modules
-        out = []
-        for m in (down["0"], mods["conv"], la["qk"], la["pe"]):
-            if isinstance(m, nn.Conv2d):
-                out += [m._parameters["weight"], m._parameters["bias"]]
-            else:
-                cv, bn = m._modules["conv"], m._modules["norm"]
-                out += [cv._parameters["weight"], bn._parameters["weight"], bn._parameters["bias"], bn._buffers["running_mean"], bn._buffers["running_var"]]
+        try:
+            mods = self._modules
+            down = mods["down"]._modules
+            la = down["1"]._modules
+            out = []
+            for m in (down["0"], mods["conv"], la["qk"], la["pe"]):
+                if isinstance(m, nn.Conv2d):
+                    out += [m._parameters["weight"], m._parameters["bias"]]
+                else:
+                    cv, bn = m._modules["conv"], m._modules["norm"]
+                    out += [cv._parameters["weight"], bn._parameters["weight"], bn._parameters["bias"], bn._buffers["running_mean"], bn._buffers["running_var"]]
+        except KeyError:             # a parametrized weight (torch.nn.utils.parametrize, weight_norm) or a wrapped ConvNorm: the attribute path
+            out = []
+            for m in (self.down[0], self.conv, self.down[1].qk, self.down[1].pe):
+                if isinstance(m, nn.Conv2d):
+                    out += [m.weight, m.bias]
+                else:
+                    out += [m.conv.weight, m.norm.weight, m.norm.bias, m.norm.running_mean, m.norm.running_var]
         return [t for t in out if t is not None]
 
     def packed_params(self):
@@ -145,12 +144,11 @@ class RecAttn2d(nn.Module):
                 wqk, bqk = _folded(la.qk)                       # (2C, C/2, 1, 1): rows [0,C) = q from channels [0,C/2), rows [C,2C) = k
                 wpe, bpe = _folded(la.pe)
                 c = wqk.shape[0] // 2
-                dt = self.conv.conv.weight.dtype if not isinstance(self.conv, nn.Conv2d) else self.conv.weight.dtype     # the GEMM operands' type
                 zeros = lambda b_, n_: torch.zeros(n_, device=wd.device) if b_ is None else b_.float()
                 self._pack = (ops.pack_dw_weight(wd.float()), None if bd is None else ops.pack_bias(bd.float()),
                               ops.pack_dw_weight(wc.float()), None if bc is None else ops.pack_bias(bc.float()),
-                              wqk[:c, :, 0, 0].contiguous().to(dt), zeros(bqk, 2 * c)[:c].to(dt).contiguous(),
-                              wqk[c:, :, 0, 0].contiguous().to(dt), zeros(bqk, 2 * c)[c:].to(dt).contiguous(),
+                              wqk[:c, :, 0, 0].float().contiguous(), zeros(bqk, 2 * c)[:c].contiguous(),        # float32 GEMM operands: the coarse chain is float32
+                              wqk[c:, :, 0, 0].float().contiguous(), zeros(bqk, 2 * c)[c:].contiguous(),
                               ops.pack_dw_weight(wpe.float()), None if bpe is None else ops.pack_bias(bpe.float()))
             self._pack_key = key
         return self._pack
@@ -167,12 +165,14 @@ class RecAttn2d(nn.Module):
         wd, bd, wc, bc, wq, bq, wk, bk, wpe, bpe = self.packed_params()
         k = self.kernel_size
         la = self.down[1]
-        d = ops.dwconv2d(x, wd, bd, k=k, stride=2)                                  # ConvNorm(dw k5 s2), :61
+        if x.shape[1] % la.num_heads or not head_dim_supported(x.shape[1] // la.num_heads):
+            raise NotImplementedError(f"RecAttn2d: the HIP attention core takes head sizes up to 32, or multiples of 4 up to 64; got dim {x.shape[1]}, {la.num_heads} heads")
+        # the coarse chain in float32 (quarter-size tensors: ~1/4 of x's bytes per tensor even at twice the element size)
+        d = ops.dwconv2d(x, wd, bd, k=k, stride=2, out_dtype=torch.float32)        # ConvNorm(dw k5 s2), :61
         b, c, h, w = d.shape
         tok = d.permute(0, 2, 3, 1).reshape(b * h * w, c)                           # NHWC storage viewed token-major, no copy
-        dt = d.dtype
-        qpre = F.linear(tok[:, :c // 2], wq.to(dt), bq.to(dt)).view(b, h * w, c)    # grouped 1x1 conv = two GEMMs, :21 / :44
-        kpre = F.linear(tok[:, c // 2:], wk.to(dt), bk.to(dt)).view(b, h * w, c)
+        qpre = F.linear(tok[:, :c // 2], wq, bq).view(b, h * w, c)                  # grouped 1x1 conv = two GEMMs, :21 / :44
+        kpre = F.linear(tok[:, c // 2:], wk, bk).view(b, h * w, c)
         a = None
         if ops.linear_attention_core_fuses_pe(c, la.num_heads):                      # pe = ConvNorm(dw 3x3)(d) inside the core kernel (round 3)
             a = ops.linear_attention_core_pe(qpre, kpre, d, wpe, bpe, la.num_heads)  # :22-27 / :45-50

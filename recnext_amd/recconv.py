@@ -11,19 +11,11 @@ Forward and backward accept float32, bfloat16 or float16 CUDA tensors (logical N
 storage is consumed zero-copy, anything else is converted once) and returns a channels_last tensor
 of the same shape and dtype.  All arithmetic is float32 inside the kernels.  There is no CPU path.
 """
-import os
 
 import torch
 import torch.nn as nn
 
 from . import ops
-
-
-# The matrix-core schedules (rcx_recconv2d_fwd_mx: 56x56 / level 4 and 14x14 / level 2 blocks with 16-bit activations and taps) are
-# parity-green at north_star's 1e-2 but, as measured in round 3 (DESIGN.md, profiles/r03_mfma4x4x4.txt), only 0 - 4 % faster than the
-# float32 vector kernels, whose results are within half an ulp of the float32 forward: they are opt-in.  RCX_MX=1 turns them on for
-# every module; ``module.matrix_cores = True`` for one.
-MATRIX_CORES_DEFAULT = os.environ.get("RCX_MX", "0") not in ("", "0")
 
 
 class RecConv2d(nn.Module):
@@ -46,10 +38,6 @@ class RecConv2d(nn.Module):
         self._pack_key = None
         self._pack = None
         self._wflip = None                                  # the pack with every k x k flipped (the backward's taps)
-        self._mx_key = None
-        self._mx = None                                     # the taps as Toeplitz blocks in a 16-bit type (matrix-core schedules)
-        # None: follow MATRIX_CORES_DEFAULT (environment RCX_MX at import time); True / False: this module's own choice
-        self.matrix_cores = None
         # Optional per-channel affine applied to the block's OUTPUT (y*scale + shift), folded into
         # convs[level] when the packs are built: used to absorb the eval-mode BatchNorm that follows the
         # token mixer in MetaNeXtBlock (model/recnext.py:153,158) -- SURVEY.md section 8f row 2.
@@ -132,27 +120,7 @@ class RecConv2d(nn.Module):
                 _warn_eval_with_grad()
             return _RecConv2dFn.apply(x, self, *plist)
         wpack, bpack = self.packed_params()
-        return ops.recconv2d_forward(x, wpack, bpack, self.level, self.kernel_size, self.mode, mxpack=self.packed_mx(x.dtype))
-
-    def packed_mx(self, dtype):
-        """The taps as the matrix-core schedules want them, or None where the float32 vector kernels must run.
-
-        They apply when the taps may be rounded to the activations' 16-bit type, i.e. in exactly the situations in which the
-        reference can run the block in 16 bits at all (nn.Conv2d refuses mixed dtypes): the parameters have the activations' type
-        (``model.bfloat16()`` / ``.half()`` -- the rounding is then exact) or autocast is on (the conv casts its weight,
-        engine.py:48).  float32 parameters with 16-bit activations outside autocast -- which only this module accepts -- keep
-        the exact float32 taps on the vector pipe.  Call after packed_params() (same cache key)."""
-        mc = getattr(self, "matrix_cores", None)
-        if not (mc if mc is not None else MATRIX_CORES_DEFAULT):
-            return None
-        if dtype not in (torch.bfloat16, torch.float16) or self.kernel_size != 5:
-            return None
-        if self.down.weight.dtype != dtype and not torch.is_autocast_enabled():
-            return None
-        if getattr(self, "_mx_key", None) != (self._pack_key, dtype):           # getattr: modules pickled before round 3
-            self._mx = ops.pack_recconv_mx(self._pack[0], self.level, self.in_channels, self.kernel_size, dtype)
-            self._mx_key = (self._pack_key, dtype)
-        return self._mx
+        return ops.recconv2d_forward(x, wpack, bpack, self.level, self.kernel_size, self.mode)
 
     def extra_repr(self):
         return (f"{self.in_channels}, kernel_size={self.kernel_size}, level={self.level}, mode={self.mode!r}, "

@@ -22,6 +22,32 @@ def test_graph_replay_equals_eager(name):
     assert len(run._graphs) == 2
 
 
+def test_graph_follows_a_weight_change():
+    """a graph bakes in the addresses of the parameters and of the packs derived from them; after load_state_dict / an in-place edit
+    the replay must use the new weights (the graphs are dropped and captured again), not a mix of old packs and new GEMM weights."""
+    from recnext_amd.graph import GraphedInference
+    from recnext_amd.speed import build_inference_model, synthetic_batch
+    dev = torch.device("cuda:0")
+    net = build_inference_model("recnext_m0", dev, torch.bfloat16, seed=0)
+    other = build_inference_model("recnext_m0", dev, torch.bfloat16, seed=1)
+    run = GraphedInference(net)
+    x = synthetic_batch(2, 224, dev, torch.bfloat16, seed=0)
+    with torch.no_grad():
+        assert torch.equal(run(x), net(x))
+        before = net(x).clone()
+        net.load_state_dict(other.state_dict())                      # in place: every parameter's version moves
+        want = net(x).clone()
+        assert not torch.equal(want, before)
+        assert torch.equal(run(x), want)
+        for m in net.modules():                                      # one in-place edit of one token mixer's taps
+            if type(m).__name__ == "RecConv2d":
+                m.convs[0].weight.mul_(1.5)
+                break
+        want2 = net(x).clone()
+        assert torch.equal(run(x), want2) and not torch.equal(want2, want)
+    assert len(run._graphs) == 1
+
+
 def test_graph_refuses_training_mode_and_cpu_tensors():
     from recnext_amd.graph import GraphedInference
     from recnext_amd.speed import build_inference_model

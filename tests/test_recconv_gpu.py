@@ -472,6 +472,17 @@ def test_repeated_launches_are_bit_identical(case):
     assert different == 0
 
 
+def test_d16_selftest_passes_and_guards_the_first_16_bit_launch():
+    """the bf16 load paths rely on a D16 "hi" load zeroing the other half of its destination register (measured on gfx950, not an
+    ISA promise).  rcx_selftest_d16 probes the three load forms; the binding runs it once per device before the first 16-bit launch."""
+    assert ops.selftest_d16(dev()) == 0
+    ops._D16_CHECKED.discard(dev().index)
+    x = torch.randn(1, 8, 14, 14, device=dev()).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = ops.pack_dw_weight(torch.randn(8, 1, 5, 5, device=dev()))
+    ops.dwconv2d(x, w, None, k=5, stride=1)
+    assert dev().index in ops._D16_CHECKED
+
+
 def test_errors_surface_as_exceptions():
     mod = recnext_amd.RecConv2d(8, level=1).to(dev())
     with pytest.raises(TypeError):
@@ -603,18 +614,12 @@ def test_linear_attention_core(case, dtype):
     if dtype == torch.float32:
         assert np.abs(got - ref).max() < 2e-4
     else:
-        # the qk GEMM output and pe are rounded to bf16 on the way in, exactly as the reference's bf16 run rounds them; the yardstick is
-        # that chain (q/k activation, the two products, normaliser, + pe in bf16 PyTorch operators on the same rounded inputs)
-        import torch.nn.functional as F
-        s_ = (h * w) ** -0.5
-        qf = (F.elu(qpre) + 1.0).view(b, h * w, heads, c // heads).permute(0, 2, 3, 1)      # (b, heads, d, n), model/recattn.py:17-19
-        kf = (F.elu(kpre) + 1.0).view(b, h * w, heads, c // heads).permute(0, 2, 3, 1)
-        vf = dd.permute(0, 2, 3, 1).reshape(b, h * w, heads, c // heads).permute(0, 2, 3, 1)
-        kv = (kf * s_) @ (vf.transpose(-2, -1) * s_)                                         # :23
-        z = 1.0 / (qf.transpose(-2, -1) @ kf.mean(dim=-1, keepdim=True) + 1e-6)              # :24
-        o = (qf.transpose(-2, -1) @ kv * z).transpose(-2, -1).reshape(b, c, h, w) + pe       # :25-28
-        ref_bf16 = o.float().cpu().numpy()
-        _assert_bf16_no_worse_than_reference(got, ref.astype(np.float32), ref_bf16, "x".join(map(str, case)))
+        # the 16-bit core (the training step's kernel under a 16-bit dtype; eval keeps the coarse chain in float32): its inputs are the
+        # rounded qpre / kpre / d / pe, so the yardstick is the float32 core -- checked against the NumPy restatement in the f32 case -- on
+        # those very inputs, and the bar is north_star's flat one: a single rounding, at the store
+        ref_core = ops.linear_attention_core(qpre.float(), kpre.float(), dd.float(), pe.float(), heads).cpu().numpy()
+        print(f"{'x'.join(map(str, case))}: bf16 core max|err| {np.abs(got - ref_core).max():.3e} (against the unrounded chain: {np.abs(got - ref).max():.3e})")
+        assert np.allclose(got, ref_core, atol=BF16_ATOL, rtol=BF16_RTOL)
     # round 3: pe = dwconv3x3(d) + bias computed inside the core kernel (rcx_linear_attention_pe_fwd) -- one launch and one rounding less
     if ops.linear_attention_core_fuses_pe(c, heads):
         fused = ops.linear_attention_core_pe(qpre, kpre, dd, ops.pack_dw_weight(t(w_pe)), ops.pack_bias(t(b_pe)), heads)
@@ -626,7 +631,9 @@ def test_linear_attention_core(case, dtype):
         if dtype == torch.float32:
             assert np.abs(gf - ref).max() < 2e-4 and np.abs(gf - got).max() < 1e-4
         else:
-            _assert_bf16_no_worse_than_reference(gf, ref.astype(np.float32), ref_bf16, "fused pe " + "x".join(map(str, case)))
+            pe32 = ops.dwconv2d(dd.float(), ops.pack_dw_weight(t(w_pe)), ops.pack_bias(t(b_pe)), k=3, stride=1)
+            ref_fused = ops.linear_attention_core(qpre.float(), kpre.float(), dd.float(), pe32, heads).cpu().numpy()
+            assert np.allclose(gf, ref_fused, atol=BF16_ATOL, rtol=BF16_RTOL)
         nob = ops.linear_attention_core_pe(qpre, kpre, dd, ops.pack_dw_weight(t(w_pe)), None, heads)           # no bias pack
         pe0 = ops.dwconv2d(dd, ops.pack_dw_weight(t(w_pe)), None, k=3, stride=1)
         want0 = ops.linear_attention_core(qpre, kpre, dd, pe0, heads)
@@ -649,24 +656,25 @@ def test_recattn2d_module_matches_reference_golden(name):
     with torch.no_grad():
         y = mod(x)
     assert float((y.cpu() - torch.from_numpy(d["y"])).abs().max()) < 2e-4
-    # bf16 (north_star: 1e-2): against the float32 reference on the bf16-rounded input, with the reference's OWN bf16 run of the same
-    # input (fixture y_bf16, tests/golden/make_golden.py) as the yardstick where that run itself is outside 1e-2
+    # bf16 (north_star: a flat 1e-2): bf16 activations through the module with the fixture's own float32 parameters -- the packs are float32 whatever
+    # the parameters' type -- against the float32 reference on the bf16-rounded input (the fixture's y_bf16in_f32 keeps the weights unrounded; a module
+    # whose parameters were rounded by .bfloat16() is held to the same bar against a reference with THOSE weights in test_recattn2d_full_size_properties).
+    # The reference's OWN bf16 run of the same input (fixture y_bf16) is printed beside it as information only: it is outside 1e-2 on some elements
     xr = torch.from_numpy(bf16_round_np(d["x"])).to(dev()).bfloat16().contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
-        yb = mod.bfloat16()(xr).float().cpu().numpy()
-    want, ref_bf16 = d["y_bf16in_f32"], d["y_bf16"]
-    _assert_bf16_no_worse_than_reference(yb, want, ref_bf16, name)
+        yb = mod(xr)
+    assert yb.dtype == torch.bfloat16
+    _assert_bf16_flat(yb.float().cpu().numpy(), d["y_bf16in_f32"], d["y_bf16"], name)
 
 
-def _assert_bf16_no_worse_than_reference(got, want, ref_bf16, label):
-    """err_hip <= max(1e-2 (1 + |ref|), 1.25 err_reference_bf16): element-wise north_star tolerance, relaxed only as far as the
-    reference's own bf16 run of the same inputs is from the float32 result (max and mean)."""
+def _assert_bf16_flat(got, want, ref_bf16, label):
+    """north_star's bar, element-wise and unrelaxed: |got - want| <= 1e-2 + 1e-2 |want|.  The reference's own bf16 run of the same inputs is
+    printed for comparison (it rounds after every operator and misses the bar on some elements); it does not enter the assertion."""
     err, err_ref = np.abs(got - want), np.abs(ref_bf16 - want)
     tol = BF16_ATOL + BF16_RTOL * np.abs(want)
     print(f"{label}: bf16 max|err| hip {err.max():.3e} (reference's own bf16 run {err_ref.max():.3e}), mean hip {err.mean():.3e} "
           f"(reference {err_ref.mean():.3e}), worst err/tol hip {(err / tol).max():.2f} (reference {(err_ref / tol).max():.2f})")
-    assert (err <= np.maximum(tol, 1.25 * err_ref.max())).all(), (float(err.max()), float(err_ref.max()))
-    assert err.mean() <= max(1e-3 * (1.0 + float(np.abs(want).mean())), 1.25 * float(err_ref.mean()))
+    assert np.allclose(got, want, atol=BF16_ATOL, rtol=BF16_RTOL), (float(err.max()), float((err / tol).max()))
 
 
 # ---- BASELINE config 4: the four token mixers of RecNeXt-A3 at 224x224, batch 256 (model/recattn.py:403, :163-171) ----
@@ -703,21 +711,25 @@ def test_recattn2d_full_size_properties(case, dtype):
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     assert (ys.float() - y[lo:lo + 5].float()).abs().max() <= tol * float(y.float().abs().max()), "batch shard differs from full batch"
     idx = [0, n // 2, n - 1]
+    import copy
+    # the oracle carries the weights the module actually has: mod.to(bf16) rounded every parameter and BatchNorm buffer (the user's choice, as under
+    # model.bfloat16() in the reference); the float32 reference with THOSE values is what one rounding at the store is measured against
+    ref_w = ref if dtype == torch.float32 else copy.deepcopy(ref).to(dtype).float()
     with torch.no_grad():
-        want = ref(x[idx].float().cpu().contiguous())
-        replace_batchnorm(ref)
-        want_fused = ref(x[idx].float().cpu().contiguous())
+        want = ref_w(x[idx].float().cpu().contiguous())
+        fused = copy.deepcopy(ref_w)
+        replace_batchnorm(fused)
+        want_fused = fused(x[idx].float().cpu().contiguous())
     assert float((want - want_fused).abs().max()) < 1e-4
     got = y[idx].float().cpu()
     scale = float(want.abs().max())
     if dtype == torch.float32:
         assert float((got - want).abs().max()) < 1e-3 * max(1.0, scale)
-    else:       # bf16: the qk GEMM, pe and the attention output are rounded to bf16 between the kernels (as in the reference, which
-        # rounds after EVERY operator): the yardstick is the reference chain's own bf16 run of the same three images
-        import copy
+    else:       # bf16: the coarse chain stays float32 between the kernels (round 4), one rounding at the store of y: north_star's flat bar; the
+        # reference chain's own bf16 run of the same three images is printed beside it
         with torch.no_grad():
             ref_bf16 = copy.deepcopy(ref).bfloat16()(x[idx].cpu().contiguous()).float()
-        _assert_bf16_no_worse_than_reference(got.numpy(), want.numpy(), ref_bf16.numpy(), case[0])
+        _assert_bf16_flat(got.numpy(), want.numpy(), ref_bf16.numpy(), case[0])
 
 
 # ---- register-resident single-step kernels (rcx_upadd.hip) on the 7*2^k planes ----

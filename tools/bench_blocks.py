@@ -80,10 +80,9 @@ def main():
     ap.add_argument("--mode", default="bilinear")
     ap.add_argument("--json", default=None)
     ap.add_argument("--taps", default="io", choices=["io", "fp32"],
-                    help="io: the module's parameters have the activations' dtype (model.bfloat16(): the matrix-core schedules apply); "
+                    help="io: the module's parameters have the activations' dtype (model.bfloat16()); "
                          "fp32: float32 parameters with 16-bit activations (exact taps, vector kernels)")
     ap.add_argument("--fresh", action="store_true", help="x rewritten (and 256 MB of other traffic) before every launch, each launch bracketed alone")
-    ap.add_argument("--mx", action="store_true", help="with --taps io: allow the matrix-core schedules (RecConv2d.matrix_cores)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     rows = []
@@ -97,7 +96,6 @@ def main():
                 mx = args.taps == "io" and dtype != torch.float32
                 if mx:
                     mod = mod.to(dtype)
-                    mod.matrix_cores = args.mx
                 x = torch.randn(n, c, h, w, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
                 with torch.no_grad():
                     for _ in range(3):
@@ -107,7 +105,7 @@ def main():
                     alg = 2 * n * c * h * w * eb + (level + 2) * c * 25 * eb
                     row = {"set": sname, "shape": [n, c, h, w], "level": level, "dtype": dname, "timing": "fresh" if args.fresh else "loop",
                            "taps": "io" if mx else "fp32",
-                           "plan": (ops.recconv2d_plan_mx if mx and args.mx else ops.recconv2d_plan)(n, c, h, w, level, 5, args.mode, dtype),
+                           "plan": ops.recconv2d_plan(n, c, h, w, level, 5, args.mode, dtype),
                            "ms": med, "ms_min": mn, "alg_GBs": alg / med / 1e6, "frac_8TBs": alg / med / 1e6 / 8000}
                     if args.eager:
                         from oracle.torch_eager import EagerRecConv2d

@@ -39,7 +39,6 @@ with torch.no_grad():
         ("module call mod(x)", lambda: mod(x)),
         ("  mod.forward(x) (no nn.Module.__call__ hooks)", lambda: mod.forward(x)),
         ("    packed_params()", lambda: mod.packed_params()),
-        ("    packed_mx()", lambda: mod.packed_mx(x.dtype)),
         ("    ops.recconv2d_forward", lambda: ops.recconv2d_forward(x, wpack, bpack, 1, 5, "bilinear")),
         ("      _nhwc(x)", lambda: ops._nhwc(x)),
         ("      _empty_nhwc", lambda: ops._empty_nhwc(n, c, h, w, x.dtype, x.device)),

@@ -51,7 +51,13 @@ for k, d in sorted(pmc.items()):
         rec["correction"] = ("2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes (gfx950: FETCH_SIZE tallies 128-B requests at 64 B; checked on the "
                              "whole-plane kernels, which read x exactly once: 1.02-1.05 x their algorithmic bytes)")
     kernels.append(rec)
-json.dump({"tag": tag, "command": "python3 bench.py --steps 20 --warmup 10 --no-cpu-baseline", "kernels": kernels},
+import importlib.util
+_spec = importlib.util.spec_from_file_location("_rcx_build", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "recnext_amd", "build.py"))
+_build = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_build)
+json.dump({"tag": tag, "command": "python3 bench.py --steps 20 --warmup 10 --no-cpu-baseline",
+           "library_sources_sha256": _build.source_fingerprint(),      # bench.py quotes these bytes only while the kernel sources are the ones measured
+           "kernels": kernels},
           open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
 
 for log in ("kt_bench.log",):
