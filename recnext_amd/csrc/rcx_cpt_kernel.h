@@ -68,6 +68,14 @@ using lanes::VT;
 #ifndef RCX_CPT_AHEAD2
 #define RCX_CPT_AHEAD2 2
 #endif
+#ifndef RCX_CPT_STAGGER
+#define RCX_CPT_STAGGER 0                  /* A/B (tools/cpt_one.hip): the second half of a workgroup's waves -- the SIMD partners of the first half -- sleep
+                                              64 x this many cycles behind the barrier in front of each streaming pass, so that partners do not burst their
+                                              loads and their FMAs in lockstep (MI355X_MICROARCH.md, two waves per SIMD, item 9) */
+#endif
+#ifndef RCX_CPT_PRIO
+#define RCX_CPT_PRIO 0                     /* A/B: s_setprio 1 for the second half of the waves (the arbitration losers by age; ibid. item 4) */
+#endif
 #ifndef RCX_CPT_PF
 #define RCX_CPT_PF 0                       /* wide-load L2 prefetch ahead of pass 1: measured slower, see pass 1 */
 #endif
@@ -854,6 +862,8 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     else load_taps(td, wsrc, bsrc, 0, C, cc);
     __syncthreads();
     CPT_STAMP(1);
+    if constexpr (RCX_CPT_PRIO > 0) { if (w >= G::NW / 2) __builtin_amdgcn_s_setprio(RCX_CPT_PRIO); }
+    if constexpr (RCX_CPT_STAGGER > 0) { if (w >= G::NW / 2) __builtin_amdgcn_s_sleep(RCX_CPT_STAGGER); }
 
     // ================= pass 1: F1 tile = down(x), rows -2 .. 14 of the tile, input-row stationary (tap pairs) =================
     float f1[7][7];                                          // this lane's F1 tile stays in registers until T1 is formed
@@ -1307,6 +1317,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     else load_taps(tf, wsrc, bsrc, 1 + NL, C, cc);
     __syncthreads();
     CPT_STAMP(7);
+    if constexpr (RCX_CPT_STAGGER > 0) { if (w >= G::NW / 2) __builtin_amdgcn_s_sleep(RCX_CPT_STAGGER); }
 
     // ================= pass 2: y tile = conv(x + resize(C1)), input rows -2 .. 15, five accumulator rows in flight =================
     {

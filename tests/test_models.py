@@ -135,6 +135,37 @@ def test_full_model_hip_vs_eager_gpu(name, batch):
     assert (bb - a).abs().max() <= 1.5 * (ab - a).abs().max() + 0.02 * scale
 
 
+@pytest.mark.gpu
+def test_full_model_at_512_hip_vs_eager_gpu():
+    """BASELINE config 5: RecNeXt-M3 on a 512 x 512 input (the detection backbone's resolution, detection/recnext.py:11-36; token-mixer planes
+    128 / 64 / 32 / 16: the split schedule and the 16 * 2^k kernels), HIP token mixers against the ATen restatement with the same weights."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    ref = models.create_model("recnext_m3", token_mixer=eager_token_mixer("m")).eval()
+    for m in ref.modules():
+        if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    net = models.create_model("recnext_m3").eval()
+    net.load_state_dict(ref.state_dict(), strict=True)
+    models.replace_batchnorm(ref)
+    models.replace_batchnorm(net)
+    ref, net = ref.to(dev), net.to(dev).to(memory_format=torch.channels_last)
+    x = torch.randn(2, 3, 512, 512, device=dev)
+    with torch.no_grad():
+        a, b = ref(x), net(x.contiguous(memory_format=torch.channels_last))
+        assert (a - b).abs().max() < 1e-3 * max(1.0, float(a.abs().max()))
+        ab = ref.bfloat16()(x.bfloat16()).float()
+        bb = net.bfloat16()(x.bfloat16().contiguous(memory_format=torch.channels_last)).float()
+    scale = float(a.abs().max())
+    assert (bb - a).abs().max() < 0.1 * scale + 0.05
+    assert (bb - a).abs().max() <= 1.5 * (ab - a).abs().max() + 0.02 * scale
+    # the plans of the four stage shapes at this resolution (what the forward above ran)
+    from recnext_amd import ops
+    plans = [ops.recconv2d_plan(2, c, hw, hw, lv, 5, "bilinear", torch.bfloat16) for c, hw, lv in ((64, 128, 4), (128, 64, 3), (256, 32, 2), (512, 16, 1))]
+    assert plans[0].startswith("split(") and all(p.startswith("lanes(") for p in plans[1:]), plans
+
+
 def test_fold_token_mixer_norms_counts_and_is_noop_for_other_mixers():
     net = models.create_model("recnext_m3").eval()
     models.replace_batchnorm(net)

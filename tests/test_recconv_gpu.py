@@ -419,6 +419,11 @@ FULL = [
     ("M1 cfg2 stage0", 256, 48, 56, 56, 4),
     ("M1 cfg2 stage2", 256, 192, 14, 14, 2),
     ("M1 cfg2 stage3", 256, 384, 7, 7, 1),
+    # BASELINE config 5 at its real (N, C): RecNeXt-M3 on a 512 x 512 detection input, batch 32 (detection/recnext.py:11-36; ladder 128 -> 64 -> 32 -> 16 -> 8)
+    ("M3@512 cfg5 stage0", 32, 64, 128, 128, 4),
+    ("M3@512 cfg5 stage1", 32, 128, 64, 64, 3),
+    ("M3@512 cfg5 stage2", 32, 256, 32, 32, 2),
+    ("M3@512 cfg5 stage3", 32, 512, 16, 16, 1),
 ]
 
 
