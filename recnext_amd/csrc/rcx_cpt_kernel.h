@@ -783,9 +783,15 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     const bool cvalidG = MX ? cG < C : cvalid;
     const int ccG = cvalidG ? cG : C - 1;
     const bool ledgeG = tcG == 0, redgeG = tcG == T - 1;
-    const unsigned voffM = (unsigned)((14 * tcG) * pix + ccG * ESZ);
-    const unsigned voffL = ledgeG ? OOB : voffM - 2u * (unsigned)pix;      // columns -2, -1 of the tile
-    const unsigned voffR = redgeG ? OOB : voffM + 14u * (unsigned)pix;     // columns 14, 15 (MX: 14 .. 17)
+    // this lane's three row-load offsets.  They are set here for pass 1 and AGAIN, from an opaque copy of the lane index, in front of pass 2:
+    // recomputed, not kept live (or spilled: the training-forward instantiation did) across the chain of small-plane phases in between
+    unsigned voffM, voffL, voffR;
+    auto set_voffs = [&](int tcg, int ccg) {
+        voffM = (unsigned)((14 * tcg) * pix + ccg * ESZ);
+        voffL = tcg == 0 ? OOB : voffM - 2u * (unsigned)pix;               // columns -2, -1 of the tile
+        voffR = tcg == T - 1 ? OOB : voffM + 14u * (unsigned)pix;          // columns 14, 15 (MX: 14 .. 17)
+    };
+    set_voffs(tcG, ccG);
     // row r (tile-local, -2 .. 15), all 18 (MX: 20) columns; rows outside the image are redirected to a valid row (loaded, not used)
     auto load_row = [&](uint32_t (&raw)[NCOL], int r) {
         int ar = 14 * tr + r;
@@ -1321,7 +1327,14 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
 
     // ================= pass 2: y tile = conv(x + resize(C1)), input rows -2 .. 15, five accumulator rows in flight =================
     {
-        constexpr int AHEAD = RCX_CPT_AHEAD2, R0 = -2, NR = 18;
+        constexpr int AHEAD = std::is_same<TIO, f16_t>::value && RCX_CPT_AHEAD2 > 1 ? 1 : RCX_CPT_AHEAD2, R0 = -2, NR = 18;   // float16: one row less in flight (its
+                                                                                  // per-element conversions otherwise spill eight registers at 256)
+        if constexpr (!MX) {                                  // see set_voffs
+            int l2 = lane;
+            asm volatile("" : "+v"(l2));
+            const int h2 = HALVES == 4 ? (l2 >> 4) : (HALVES == 2 ? (l2 >> 5) : 0), c2 = cb * CHB + (l2 & (G::CB - 1));
+            set_voffs(tcb + WPR * h2, c2 < C ? c2 : C - 1);
+        }
         // C1 columns -2 .. 8 of the tile: the two on each side may lie outside the plane (clamped: ATen's border rule)
         // (this pass reads C1 and x and writes y in the global-memory lane map: tcG, ledgeG ... = map A in the matrix-core variant)
         const int cb0 = 7 * tcG;
@@ -1345,7 +1358,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             ysrc.z = P0 * P0 * pix;
             ysrc.w = 0x00020000;
         }
-        const unsigned yoff = cvalidG ? (unsigned)((14 * tcG) * pix + cG * ESZ) : OOB;
+        const unsigned yoff = cvalidG ? voffM : OOB;          // a valid lane's own column 0 = where its row loads start
         // H[i]: C1 row i (tile-local, -2 .. 8; clamped into the plane) resized horizontally to the 18 columns -2 .. 15
         auto build_H = [&](f32x2 (&Hs)[9], int i) {
             int ar = 7 * tr + i;
