@@ -172,11 +172,11 @@ def kernel_name(plan, elem_bytes):
         return f"rcx::lanes::{kern}, {t}>"
     if plan.startswith("cpt(k_recconv_cpt"):
         kern = plan[len("cpt("):plan.index(">")]
-        # template arguments after the type: training, matrix cores (diagnostic build), levels (4 / 3 = the full ladder of a 56 / 28 plane; one
-        # less: "levels-1"), staged rows (diagnostic build)
+        # template arguments after the type: training, levels (4 / 3 = the full ladder of a 56 / 28 plane; one less: "levels-1"), staged rows
+        # (diagnostic build)
         t_ = int(kern[len("k_recconv_cpt<"):].split(",")[0])
         lv = (4 if t_ == 4 else 3) - (1 if ">,levels-1," in plan else 0)
-        return f"rcx::cpt::{kern}, {t}, false, false, {lv}, 0>"
+        return f"rcx::cpt::{kern}, {t}, false, {lv}, 0>"
     if plan.startswith("cpl(k_recconv_cpl"):
         kern = plan[len("cpl("):plan.index(">")]
         ns = "cpl14"                                                          # rcx_cpl14.hip

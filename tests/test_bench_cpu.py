@@ -33,7 +33,7 @@ def test_source_fingerprint_is_stable_and_follows_the_kernel_sources(tmp_path, m
 
 def test_traffic_is_quoted_only_for_the_sources_it_was_measured_on(tmp_path):
     bench = _load("_rcx_bench_t", "bench.py")
-    kern = "rcx::cpt::k_recconv_cpt<4, 2, 0, 128, unsigned short, false, false, 4, 0>"
+    kern = "rcx::cpt::k_recconv_cpt<4, 2, 0, 128, unsigned short, false, 4, 0>"
     rec = {"kernel": kern, "hbm_bytes_per_launch": 3.0e8}
     json.dump({"tag": "old", "kernels": [rec]}, open(tmp_path / "r01_traffic.json", "w"))                                   # no fingerprint: stale
     json.dump({"tag": "other", "library_sources_sha256": "0" * 64, "kernels": [rec]}, open(tmp_path / "r02_traffic.json", "w"))

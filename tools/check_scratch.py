@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Build gate (recnext_amd/csrc/Makefile): list every kernel of the given hipcc -S listings with its register and scratch figures and fail
 when a kernel the DEFAULT dispatch reaches has a private segment (registers spilled to memory).  Default dispatch = the inference
-instantiations for bf16 / float32 activations of the fused kernels (k_recconv_cpt without TRAIN / MX, k_recconv_cpl14, k_recconv_cpl7b) and the
-tiled step kernels (k_upadd_cpt, k_down5_cpt, k_down7m2_cpt); the training-forward, float16 and matrix-core instantiations are reported only.
+instantiations for bf16 / float32 activations of the fused kernels (k_recconv_cpt without TRAIN, k_recconv_cpl14, k_recconv_cpl7b) and the
+tiled step kernels (k_upadd_cpt, k_down5_cpt, k_down7m2_cpt); the training-forward and float16 instantiations are reported only.
 usage: check_scratch.py file.s [file.s ...]"""
 import re
 import subprocess
@@ -46,11 +46,11 @@ for (path, r), name in zip(rows, names):
     short = re.sub(r"^void rcx::", "", name)
     short = re.sub(r"\(.*$", "", short)
     fp16 = "_Float16" in short or "DF16_" in short
-    # template arguments of k_recconv_cpt: <T, HALVES, MODE, PIXB, TIO, TRAIN, MX, LV, STG>
-    m = re.match(r"cpt::k_recconv_cpt<(\d+), (\d+), (\d+), (\d+), ([^,]+), (true|false), (true|false)", short)
+    # template arguments of k_recconv_cpt: <T, HALVES, MODE, PIXB, TIO, TRAIN, LV, STG>
+    m = re.match(r"cpt::k_recconv_cpt<(\d+), (\d+), (\d+), (\d+), ([^,]+), (true|false), ", short)
     gated = False
     if m:
-        gated = m.group(6) == "false" and m.group(7) == "false" and not fp16
+        gated = m.group(6) == "false" and not fp16
     elif re.match(r"(cpl14::k_recconv_cpl14|cpl14::k_recconv_cpl7b|cpl14::k_upadd_cpl14|upcpt::k_upadd_cpt|upcpt::k_down5_cpt|upcpt::k_down7m2_cpt)<", short):
         gated = not fp16
     flag = ""

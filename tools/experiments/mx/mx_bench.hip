@@ -1,7 +1,7 @@
 // Timing / phase-stamp harness for the matrix-core variant alone (development tool): one instantiation, so it builds in under a minute;
 // -DRCX_ABL=<bits> switches parts of the passes off (rcx_cpt_kernel.h) to see what a step's time is made of -- results are then wrong.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -DRCX_STAMPS [-DRCX_ABL=n] [-DRCX_MX_AHEAD=n] tools/mx_bench.hip -o tools/mx_bench
-#include "../recnext_amd/csrc/rcx_cpt_kernel.h"
+#include "rcx_cpt_kernel_mx.h"   /* the frozen header with the matrix-core passes (this directory) */
 #include <algorithm>
 #include <cstdio>
 #include <cstring>

@@ -23,7 +23,7 @@
 // no barrier, 4 096 one-wave workgroups) was built and measured in round 3 and is not kept: a wave alone took 6.6 us instead of 14 (as
 // designed), the full problem 36.6 us -- 27 KB of LDS per wave leave 1.5 waves per SIMD, and every level is an LDS write -> read ->
 // matrix -> convert -> write chain that nothing hides (profiles/r03_mx14b_band_split.txt).
-#include "rcx_cpt_kernel.h"
+#include "rcx_cpt_kernel_mx.h"
 #include "rcx_opts.h"
 
 namespace rcx {

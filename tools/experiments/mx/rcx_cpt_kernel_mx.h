@@ -1,3 +1,5 @@
+// FROZEN COPY (round 4) of recnext_amd/csrc/rcx_cpt_kernel.h as it stood with the matrix-core (MX) passes still in it: the product header no longer
+// carries them.  Kept for tools/experiments/mx/ (mx_bench.hip, rcx_cpl14mx.hip) and for the record of profiles/r03_mfma4x4x4.txt.
 // Channel-per-lane, TILED RecConv2d for the two large blocks of RecNeXt at 224x224 (model/recnext.py:24-34):
 //   56x56 / level 4 (stage 0) and 28x28 / level 3 (stage 1).
 //
@@ -41,6 +43,27 @@ using lanes::vtab;
 using lanes::VT;
 
 #define CPT_FENCE __builtin_amdgcn_sched_barrier(0)
+#ifndef RCX_ABL
+#define RCX_ABL 0                          /* tools/mx_bench.hip: timing-only ablations of the matrix-core passes (results are wrong) */
+#endif
+#define ABL_NOPERM (RCX_ABL & 1)           /* no ds_bpermute */
+#define ABL_NOMFMA (RCX_ABL & 2)           /* one matrix instruction per K block instead of all */
+#define ABL_NOBAR (RCX_ABL & 4)            /* no per-step barrier */
+#define ABL_NOTR (RCX_ABL & 8)             /* no transposing / row reads from the stage */
+#define ABL_NOSTAGE (RCX_ABL & 16)         /* no global loads and LDS writes of the staging */
+#define ABL_NOSTORE (RCX_ABL & 32)         /* no y stores */
+#ifndef RCX_MX_STAGE
+#define RCX_MX_STAGE 0                     /* matrix-core variant, how x reaches the lanes: bit 0 / bit 1 = pass 1 / pass 2 through the band-synchronous LDS
+                                              staging (wide loads, transposing reads); 0 = element loads in lane map A.  Measured: profiles/r03_mx_*.txt */
+#endif
+#define MX_STAGE1 (RCX_MX_STAGE & 1)
+#define MX_STAGE2 (RCX_MX_STAGE & 2)
+#ifndef RCX_MX_AHEAD1
+#define RCX_MX_AHEAD1 5                    /* matrix-core variant: steps (rows of the four bands) in flight in registers, pass 1 / pass 2 */
+#endif
+#ifndef RCX_MX_AHEAD2
+#define RCX_MX_AHEAD2 2
+#endif
 #ifndef RCX_CPT_AHEAD1
 #define RCX_CPT_AHEAD1 3                   /* rows of x in flight in front of the row being used, pass 1 / pass 2 (tools/cpt_one.hip sweeps them) */
 #endif
@@ -276,8 +299,54 @@ __device__ __forceinline__ void pin_row(uint32_t (&v)[18])
                  "+v"(v[17]) : "n"(PENDING));
 }
 
-// twenty-register rows (the 16-wide tiles and the 7 x 7 stride-2 conv of rcx_upcpt.hip): the outputs and the first-touch wait
+// ================= matrix-core variant (MX; 16-bit activations, round 3) =================
+// The two level-0 passes as 4 x 4 x 4 products on the matrix cores (v_mfma_f32_4x4x4_16b_bf16 / _f16: 16 independent blocks per
+// instruction, a block = four consecutive lanes).  Block = channel.  D[i][j] = sum_k A[i][k] B[k][j] with
+//   B[k][j]  the DATA: lane (channel, j) holds four horizontally adjacent pixels k of ITS tile j (two registers of two 16-bit values),
+//   A[i][k]  the TAPS as a banded Toeplitz block: lane (channel, i) holds row i, A[i][k] = w[tap row][column(k) - column(i) + 2] or 0,
+//   D[i][j]  four adjacent outputs i of tile j in the four result registers of lane (channel, j)
+// (maps measured with exact integer data, tools/ubench/mfma444.hip).  So a lane still owns its tile and its channel, and the four
+// lanes of a block are the four tiles of one tile row.  Three lane maps of the same wave (16 channels x those four tiles):
+//   M  lane = 4 * channel + tile column   what the matrix instruction wants
+//   A  lane = 16 * tile column + channel  what memory wants: 16 consecutive lanes = 32 contiguous bytes of one pixel (with map M every
+//      lane of a quad is in another tile, 1792 bytes apart, and a 2-byte load instruction touches 64 sectors instead of 4: the first
+//      build's passes took twice the vector kernel's time); x is loaded, x + resize(C1) formed and y stored in this map
+//   O  the vector kernel's own map (32 channels x 2 tiles) for everything between the passes, which is unchanged
+// Packed operand registers go A -> M (and packed results M -> A) through ds_bpermute_b32 (the LDS crossbar, no LDS memory, not a DPP
+// instruction): 10 per input row and 7 per output row against 40 matrix instructions.  One input row of 20 columns (-2 .. 17) = five
+// K blocks; an output block of four columns takes two of them per tap row (stride 1: 20 of 32 Toeplitz entries are taps) or three
+// (stride 2: 20 of 48).  Accumulation is float32; the operands are the activations' own 16-bit type, so the taps are rounded to
+// it (exact when the module's parameters already have that type, which is the only case the reference itself can run:
+// model/recnext.py:21-22 under .bfloat16() / autocast), and pass 2's conv input x + resize(C1) is rounded once (the reference's
+// bf16 run rounds after the resize, after the add and after the conv).  0 * inf = NaN: a non-finite pixel reaches every output
+// of the blocks that read its K block (up to five columns away instead of two).
 #define CPT_OUT20(v) CPT_OUT18(v), "=&v"(v[18]), "=&v"(v[19])
+#define CPT_ROW_IMM20(OP) CPT_ROW_IMM(OP) CPT_LI(OP, 18, "vr", "t", 2) CPT_LI(OP, 19, "vr", "t", 3)
+#define CPT_ROW_GEN20(OP)                                                                                                            \
+    CPT_ROW_GEN(OP) "s_add_i32 %[t2], %[t], %[pix]\n\ts_add_i32 %[t2], %[t2], %[pix]\n\t" CPT_LG(OP, 18, "vr", "t2")                 \
+    "s_add_i32 %[t2], %[t2], %[pix]\n\t" CPT_LG(OP, 19, "vr", "t2")
+#define CPT_OUT20_ALL(v) CPT_OUT20(v)
+
+// columns -2, -1 (vl), 0 .. 13 (vm), 14 .. 17 (vr)
+template <typename TIO, int PIXB>
+__device__ __forceinline__ void row_load20(uint32_t (&v)[20], unsigned vl, unsigned vm, unsigned vr, i32x4 rs, int rb, int pix)
+{
+    static_assert(sizeof(TIO) == 2, "the matrix-core passes take 16-bit activations");
+    int t, t2;
+    if constexpr (PIXB > 0 && PIXB * 13 <= 4095) {
+        (void)pix; (void)t2;
+        if constexpr (std::is_same<TIO, f16_t>::value)
+            asm volatile(CPT_ROW_IMM20(CPT_LDH) : CPT_OUT20(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+        else
+            asm volatile(CPT_ROW_IMM20(CPT_LD16) : CPT_OUT20(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+    } else {
+        if constexpr (std::is_same<TIO, f16_t>::value)
+            asm volatile(CPT_ROW_GEN20(CPT_LDH) : CPT_OUT20(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+        else
+            asm volatile(CPT_ROW_GEN20(CPT_LD16) : CPT_OUT20(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+    }
+}
+
 template <int PENDING>
 __device__ __forceinline__ void pin_row20(uint32_t (&v)[20])
 {
@@ -286,15 +355,36 @@ __device__ __forceinline__ void pin_row20(uint32_t (&v)[20])
                  "+v"(v[17]), "+v"(v[18]), "+v"(v[19]) : "n"(PENDING));
 }
 
-// two float32 -> one register of two TIO, low half = the first (RNE, NaN stays NaN): v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 through the compiler
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-template <typename TIO> __device__ __forceinline__ uint32_t pk16(float lo, float hi)
+// two 16-byte loads per lane in one statement (same rules as row_load) and their counted wait
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wide_load2(u32x4& a, u32x4& b, unsigned va, unsigned vb, i32x4 rs, int rb)
 {
-    if constexpr (std::is_same<TIO, f16_t>::value) return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2_t));
-    else return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2_t));
+    int t;
+    asm volatile("s_add_i32 %[t], %[rb], 0\n\tbuffer_load_dwordx4 %[a], %[va], %[rs], %[t] offen\n\tbuffer_load_dwordx4 %[b], %[vb], %[rs], %[t] offen"
+                 : [a] "=&v"(a), [b] "=&v"(b), [t] "=&s"(t) : [va] "v"(va), [vb] "v"(vb), [rs] "s"(rs), [rb] "s"(rb) : "scc");
+}
+template <int PENDING> __device__ __forceinline__ void pin_wide2(u32x4& a, u32x4& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(PENDING)); }
+
+// twenty horizontally adjacent pixels of this lane's channel from an LDS image [pixel][channel] of 16-bit values (64 bytes per pixel):
+// loads and their wait in ONE statement, so no register is ever in flight outside it.  bf16 arrives in float32 position
+// (ds_read_u16_d16_hi), float16 zero-extended -- exactly what row_load20 leaves.
+#define CPT_DS20(OP)                                                                                                                  \
+    OP " %0, %20\n\t" OP " %1, %20 offset:64\n\t" OP " %2, %20 offset:128\n\t" OP " %3, %20 offset:192\n\t" OP " %4, %20 offset:256\n\t"     \
+    OP " %5, %20 offset:320\n\t" OP " %6, %20 offset:384\n\t" OP " %7, %20 offset:448\n\t" OP " %8, %20 offset:512\n\t"                     \
+    OP " %9, %20 offset:576\n\t" OP " %10, %20 offset:640\n\t" OP " %11, %20 offset:704\n\t" OP " %12, %20 offset:768\n\t"                  \
+    OP " %13, %20 offset:832\n\t" OP " %14, %20 offset:896\n\t" OP " %15, %20 offset:960\n\t" OP " %16, %20 offset:1024\n\t"                \
+    OP " %17, %20 offset:1088\n\t" OP " %18, %20 offset:1152\n\t" OP " %19, %20 offset:1216\n\ts_waitcnt lgkmcnt(0)"
+template <typename TIO>
+__device__ __forceinline__ void lds_row20(uint32_t (&v)[20], unsigned addr)
+{
+    static_assert(sizeof(TIO) == 2, "16-bit activations");
+    if constexpr (std::is_same<TIO, f16_t>::value) asm volatile(CPT_DS20("ds_read_u16") : CPT_OUT20(v) : "v"(addr) : "memory");
+    else asm volatile(CPT_DS20("ds_read_u16_d16_hi") : CPT_OUT20(v) : "v"(addr) : "memory");
 }
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // ---- staged x rows (STG, round 4).  What bounds the passes is the NUMBER of vector-memory wave-instructions: a load costs the CU ~7.3 cycles
@@ -350,6 +440,63 @@ __device__ __forceinline__ void fetch_row(uint32_t (&raw)[18], unsigned addr)
             if constexpr (std::is_same<TIO, f16_t>::value) raw[4 * m + e] = (e & 1) ? (v >> 16) : (v & 0xffffu);
             else raw[4 * m + e] = (e & 1) ? (v & 0xffff0000u) : (v << 16);
         }
+}
+
+__device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
+template <int A> __device__ __forceinline__ void pin(f32x4 (&v)[A]) {
+#pragma unroll
+    for (int i = 0; i < A; ++i) pin(v[i]);
+}
+
+// D = A B + C, sixteen 4 x 4 x 4 blocks (8 passes of the matrix pipe; 7.4 cycles back to back on independent accumulators)
+template <typename TIO> __device__ __forceinline__ f32x4 mx444(u32x2 a, u32x2 b, f32x4 c)
+{
+    if constexpr (std::is_same<TIO, f16_t>::value) return __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+// two float32 -> one register of two TIO, low half = the first (RNE, NaN stays NaN): v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32.
+// NOT inline asm: the matrix instructions write their results passes after they issue and nothing interlocks a vector instruction
+// that touches those registers meanwhile -- the compiler pads such neighbours itself, but it does not look inside an asm statement
+// (first build: a conversion in asm reused two registers of an accumulator whose last product was still in flight and lost its result
+// to the late write; tile rows 11 / 12, columns 0 and 1).  No asm VALU instruction may touch a register the matrix pipe reads or writes.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <typename TIO> __device__ __forceinline__ uint32_t pk16(float lo, float hi)
+{
+    if constexpr (std::is_same<TIO, f16_t>::value) return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2_t));
+    else return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2_t));
+}
+// two loaded elements as they stand in their registers (bf16: upper half, the D16-hi load; float16: lower half, zero-extended) -> one
+// register, low half = the first: one v_perm_b32 (bytes 0-3 of the selector address the second source, 4-7 the first)
+template <typename TIO> __device__ __forceinline__ uint32_t pack_raw(uint32_t lo, uint32_t hi)
+{
+    if constexpr (std::is_same<TIO, f16_t>::value) return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+    else return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
+
+// The taps of one conv as the A operands of this lane: row i = lane & 3 of every Toeplitz block, NKB blocks per tap row.
+// stride 1 (NKB = 2): output column 4m + i, K block kb = input columns 4(m + kb) - 2 + k  ->  tap v = 4 kb + k - i
+// stride 2 (NKB = 3): output column 4m + i, K block kb = input columns 8m + 4 kb - 2 + k   ->  tap v = 4 kb + k - 2 i   (0 outside 0 .. 4)
+// They come ready-made from the matrix pack (rcx_pack_recconv_mx, k_pack_mx in rcx_generic.hip: built once per parameter version like the float32
+// pack): [conv][tap row][K block slot 0..2][i][channel] of four 16-bit values = one 8-byte load per operand, no selects in here.
+constexpr int MXP_SLOTS = 3;                                // K block slots per tap row in the matrix pack (stride-1 convs use two)
+template <typename TIO, int STRIDE> struct MxTaps {
+    static constexpr int NKB = STRIDE == 1 ? 2 : 3;
+    u32x2 a[5][NKB];
+    float bias;
+};
+template <typename TIO, int STRIDE>
+__device__ __forceinline__ void load_mxtaps(MxTaps<TIO, STRIDE>& t, __amdgpu_buffer_rsrc_t msrc, __amdgpu_buffer_rsrc_t bsrc, int conv, int C, int c, int i)
+{
+    const int voff = (i * C + c) * 8;
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+#pragma unroll
+        for (int kb = 0; kb < MxTaps<TIO, STRIDE>::NKB; ++kb) {
+            const int soff = ((conv * 5 + u) * MXP_SLOTS + kb) * 4 * C * 8;
+            t.a[u][kb] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(msrc, voff, soff, 0));
+        }
+    t.bias = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bsrc, c * 4, conv * C * 4, 0));    // bsrc has zero records when there is no bias: the load returns 0
 }
 
 // the 25 taps of one conv for this lane's channel as three register pairs per tap row: (w0,w1) (w2,w3) (w4,0)
@@ -489,7 +636,7 @@ constexpr Rel rel2(int mode, int par, int c)
 
 // NL_ = levels of the block: the full ladder down to 4 x 4 (56 x 56 / level 4, 28 x 28 / level 3: RecNeXt at 224 x 224) or one level less
 // (56 x 56 / level 3, 28 x 28 / level 2: the same stages of a 448 x 448 input, and the inner blocks of the nested schedule)
-template <int T_, int HALVES, int MODE, typename TIO, int NL_ = (T_ == 4 ? 4 : 3), int STG_ = 0>
+template <int T_, int HALVES, int MODE, typename TIO, bool MX_ = false, int NL_ = (T_ == 4 ? 4 : 3), int STG_ = 0>
 struct Geo {
     static constexpr int T = T_;
     static constexpr int NL = NL_;
@@ -507,6 +654,13 @@ struct Geo {
     static constexpr int O3 = O2 + P2 * P2;
     static constexpr int O4 = O3 + P3 * P3;
     static constexpr int NPIX = O4 + (NL >= 4 ? P4 * P4 : 0);
+    // MX: the streaming passes stage rows of x behind the level-1 plane -- over the planes of the levels below, which are dead during
+    // both passes -- and use the CU's whole LDS.  One staged row of a band: 68 pixels (columns -4 .. 63; -4 .. -1 stay zero and 56 .. 63
+    // are written as zeros: the conv's padding) x 32 channels x 2 bytes, + 32 bytes so that the two bands a transposing read's
+    // 32-lane half touches fall on different banks.
+    static constexpr int XBAND = 68 * CB * 2 + 32;
+    static constexpr int XSTAGE = 4 * XBAND;
+    static constexpr int XOFF = O2 * PIXF * 4;              // byte offset of the staging area
     // STG (round 4): the two streaming passes fetch their x rows by LDS-DMA into per-wave slots behind the level-1 plane -- over the planes of
     // the levels below, dead during both passes -- and read them back with the transposing read.  A slot = one row of the wave's window:
     // two sub-images [18 pixels: tile columns -2 .. 15][64 bytes = 32 channels] (the wave's two tiles at T = 4, the two channel halves of its
@@ -515,27 +669,31 @@ struct Geo {
     static constexpr int SLOTB = 2 * 18 * 64;
     static constexpr int STGOFF = O2 * PIXF * 4;            // byte offset of the slots
     static constexpr int STGEND = STGOFF + NW * NSLOT * SLOTB + 256;      // + what the last transposing read of the last slot reaches past its image
-    static constexpr int LDS_BYTES = STG_ && STGEND > NPIX * PIXF * 4 ? STGEND : NPIX * PIXF * 4;
-    static_assert(!STG_ || (sizeof(TIO) == 2 && ((T == 4 && HALVES == 2) || (T == 2 && HALVES == 1)) && LDS_BYTES <= 160 * 1024), "staged rows: 16-bit activations, 64-byte sub-images");
+    static constexpr int LDS_BYTES = MX_ ? 160 * 1024 : (STG_ && STGEND > NPIX * PIXF * 4 ? STGEND : NPIX * PIXF * 4);
+    static_assert(!MX_ || XOFF + 2 * XSTAGE <= 160 * 1024, "staging area does not fit");
+    static_assert(!STG_ || (!MX_ && sizeof(TIO) == 2 && ((T == 4 && HALVES == 2) || (T == 2 && HALVES == 1)) && LDS_BYTES <= 160 * 1024), "staged rows: 16-bit activations, 64-byte sub-images");
 };
 
 // T = 2, HALVES = 2 (round 3): a wave = 32 channels x the two tiles of one tile row, a workgroup = two waves = 32 channels of an image with
 // 35.7 KB of LDS, four per CU -- for the channel counts that are not multiples of 64 (RecNeXt-M1: 96, M5: 160); it replaces round 2's
 // image-pair variant (two half-waves = two images; slower than the banded kernel, profiles/r02c_cpt_img2_variant.txt).
 // TRAIN: the training-forward instantiation (saves the pyramid); the inference instantiations carry none of that code.
+// MX: the matrix-core instantiation (16-bit activations whose taps may be rounded to the same type; 56x56 / level 4): passes 1 and 2 as
+// 4 x 4 x 4 products, a wave = 16 channels x the four tiles of one tile row; everything between the passes is the code below unchanged.
 // HALVES = 4 (T = 4; round 3): a wave = 16 channels x the four tiles of one tile row (the quarters of the wave are the tile columns), a
 // workgroup = four waves = 16 channels of an image with 69 KB of LDS -- TWO workgroups per CU, which run different units and so are
 // in different phases: one's barrier-bound small-plane phases and load waits fill with the other's passes (a 32-channel workgroup
 // alone on its CU serialises ~105 k cycles of phases that each leave most of the CU idle).  Used where cb16() says so.
-template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool TRAIN = false, int LV = (T == 4 ? 4 : 3), int STG = 0>
+template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool TRAIN = false, bool MX = false, int LV = (T == 4 ? 4 : 3), int STG = 0>
 __global__ __launch_bounds__(T * T / HALVES * 64, (T == 4 && HALVES == 2) ? 1 : 2)          // 256 registers either way: 8 waves per CU
 void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack,
-                   int N, int C, int has_bias, SavedPyr sv)
+                   int N, int C, int has_bias, SavedPyr sv, const void* __restrict__ mxpack)
 {
-    using G = Geo<T, HALVES, MODE, TIO, LV, STG>;
-    static_assert(LV == (T == 4 ? 4 : 3) || !TRAIN, "the shorter ladder: inference");
+    using G = Geo<T, HALVES, MODE, TIO, MX, LV, STG>;
+    static_assert(!MX || (T == 4 && HALVES == 2 && !TRAIN && sizeof(TIO) == 2), "matrix-core variant: 56x56, inference, 16-bit activations");
+    static_assert(LV == (T == 4 ? 4 : 3) || (!TRAIN && !MX), "the shorter ladder: inference, vector pipe");
     constexpr int NL = G::NL, PIXF = G::PIXF, NWORK = G::NWORK, P0 = G::P0, P1 = G::P1, P2 = G::P2, P3 = G::P3, P4 = G::P4;
-    constexpr int NCOL = 18;                                       // columns of a level-0 input row held by a lane
+    constexpr int NCOL = MX ? 20 : 18;                             // columns of a level-0 input row held by a lane
     constexpr int ESZ = (int)sizeof(TIO);
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -543,8 +701,8 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     // channel block) -- no relaunch gap between the rounds, LDS zeroed once.  XCD-aware order: workgroups are dealt round-robin
     // over the 8 XCDs; each XCD gets a contiguous run of units, so the channel blocks of one image (the two halves of its
     // 128-byte lines) pass through the same L2 at about the same time.
-    static_assert(HALVES != 4 || (T == 4 && !TRAIN), "quarter-wave tiles: the 56x56 inference kernel");
-    static_assert(!(T == 2 && HALVES == 2) || !TRAIN, "two tiles per wave at 28x28: inference");
+    static_assert(HALVES != 4 || (T == 4 && !TRAIN && !MX), "quarter-wave tiles: the 56x56 inference kernel");
+    static_assert(!(T == 2 && HALVES == 2) || (!TRAIN && !MX), "two tiles per wave at 28x28: inference");
     constexpr int CHB = G::CB;                                     // channels per block
     const int nb = (C + CHB - 1) / CHB;
     const unsigned total = (unsigned)N * (unsigned)nb, GD = gridDim.x;
@@ -583,6 +741,11 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     const int tr = w / WPR;
     const int tcb = w % WPR;
     const int tc = tcb + WPR * h;                                        // per lane (HALVES >= 2) / uniform
+    // MX: the passes' two lane maps of this wave's 16 channels (w & 1) x the four tiles of tile row tr (see "matrix-core variant")
+    const int chA = (w & 1) * 16 + (lane & 15), tcA = lane >> 4;         // A: memory
+    const int chM = (w & 1) * 16 + (lane >> 2), tcM = lane & 3;          // M: matrix operands and results
+    const int permAM = 4 * (16 * (lane & 3) + (lane >> 2));              // ds_bpermute address: lane (M) reads its value from lane (A)
+    const int permMA = 4 * (4 * (lane & 15) + (lane >> 4));              // ... and lane (A) from lane (M)
     const int q = tr * T + tc;                                          // this tile-lane's worker id
     const bool ledge = tc == 0, redge = tc == T - 1;
     const int c = cb * CHB + ch;
@@ -616,10 +779,10 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         rsrc.w = 0x00020000;
     }
     const unsigned OOB = 0x80000000u;
-    // the lane's tile column, channel and edge flags for global memory
-    const int tcG = tc;
-    const int cG = c;
-    const bool cvalidG = cvalid;
+    // the lane's tile column, channel and edge flags for global memory: map A in the matrix-core variant
+    const int tcG = MX ? tcA : tc;
+    const int cG = MX ? cb * CHB + chA : c;
+    const bool cvalidG = MX ? cG < C : cvalid;
     const int ccG = cvalidG ? cG : C - 1;
     const bool ledgeG = tcG == 0, redgeG = tcG == T - 1;
     // this lane's three row-load offsets.  They are set here for pass 1 and AGAIN, from an opaque copy of the lane index, in front of pass 2:
@@ -628,15 +791,16 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     auto set_voffs = [&](int tcg, int ccg) {
         voffM = (unsigned)((14 * tcg) * pix + ccg * ESZ);
         voffL = tcg == 0 ? OOB : voffM - 2u * (unsigned)pix;               // columns -2, -1 of the tile
-        voffR = tcg == T - 1 ? OOB : voffM + 14u * (unsigned)pix;          // columns 14, 15
+        voffR = tcg == T - 1 ? OOB : voffM + 14u * (unsigned)pix;          // columns 14, 15 (MX: 14 .. 17)
     };
     set_voffs(tcG, ccG);
-    // row r (tile-local, -2 .. 15), all 18 columns; rows outside the image are redirected to a valid row (loaded, not used)
+    // row r (tile-local, -2 .. 15), all 18 (MX: 20) columns; rows outside the image are redirected to a valid row (loaded, not used)
     auto load_row = [&](uint32_t (&raw)[NCOL], int r) {
         int ar = 14 * tr + r;
         ar = ar < 0 ? 0 : (ar > P0 - 1 ? P0 - 1 : ar);
         const int rb = __builtin_amdgcn_readfirstlane(ar * (P0 * pix));     // uniform by construction; the asm below needs it in an SGPR
-        row_load<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
+        if constexpr (MX) row_load20<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
+        else row_load<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
     };
     auto row_valid = [&](int r) -> bool { const int ar = 14 * tr + r; return ar >= 0 && ar < P0; };   // uniform
     // STG: this lane's three source offsets (piece j, lane i = chunk 64 j + i of the row image: sub-image s = chunk / 72, pixel (chunk % 72) / 4 =
@@ -664,17 +828,46 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         const int rb = __builtin_amdgcn_readfirstlane(ar * (P0 * pix));
         stage_row(dv[0], dv[1], dv[2], rsrc, rb, stg_lds + decltype(sc)::value * G::SLOTB);
     };
+    // MX, both passes: the band-synchronous staging of x rows (see pass 1).  Loader role of this wave: band w >> 1, two 1 KB pieces per step
+    char* const xst = reinterpret_cast<char*>(lds) + G::XOFF;
+    const int bandL = w >> 1;
+    const int colL = 32 * (w & 1) + (lane >> 2);              // piece 0: 16 columns from colL (4 lanes of 16 bytes per pixel), piece 1: from colL + 16
+    const unsigned qoffL = (unsigned)((cb * CHB) * ESZ + (lane & 3) * 16);
+    const unsigned vla = (unsigned)(colL * pix) + qoffL, vlb = colL + 16 < P0 ? (unsigned)((colL + 16) * pix) + qoffL : OOB;
+    const int wrA = bandL * G::XBAND + (colL + 4) * (G::CB * 2) + (lane & 3) * 16, wrB = wrA + 16 * (G::CB * 2);
+    auto sfetch = [&](u32x4& a, u32x4& b, int sI) {          // step sI: rows 14 j + sI - 2; rows outside the image read zeros
+        const int ar = 14 * bandL + sI - 2;                   // uniform
+        const bool ok = ar >= 0 && ar < P0;
+        const int rb = __builtin_amdgcn_readfirstlane((ok ? ar : 0) * (P0 * pix));
+        wide_load2(a, b, ok ? vla : OOB, ok ? vlb : OOB, rsrc, rb);
+    };
+    auto sstore = [&](const u32x4& a, const u32x4& b, int sI) {
+        char* st = xst + (sI & 1) * G::XSTAGE;
+        *reinterpret_cast<u32x4*>(st + wrA) = a;
+        *reinterpret_cast<u32x4*>(st + wrB) = b;
+    };
+    auto zero_pads = [&]() {                                  // columns -4 .. -1 of both stages (the ladder has written over this area)
+        for (int i = w * 64 + lane; i < 2 * 4 * 4 * 4; i += G::NT) {   // stage, band, pad pixel, 16-byte quarter
+            const int q = i & 3, pp = (i >> 2) & 3, bnd = (i >> 4) & 3, sg = i >> 6;
+            *reinterpret_cast<u32x4*>(xst + sg * G::XSTAGE + bnd * G::XBAND + pp * (G::CB * 2) + q * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+
     // pass 1's first rows are requested before the taps, the LDS clearing's tail and the barrier: their HBM latency runs behind those
     constexpr int AHEAD1 = RCX_CPT_PF > 0 ? 2 : RCX_CPT_AHEAD1, R01 = -2, NR1 = 17;
     uint32_t raw1[NR1][NCOL];
     constexpr int SAH = STG > 0 ? STG - 1 : 0;                 // staged rows in flight in front of the row being used
     if constexpr (STG > 0) sfor<SAH>([&](auto rc) { stg_request(IC<decltype(rc)::value % (STG > 0 ? STG : 1)>{}, R01 + decltype(rc)::value); });
-    else if constexpr (RCX_CPT_PF == 0) sfor<AHEAD1>([&](auto rc) { load_row(raw1[decltype(rc)::value], R01 + decltype(rc)::value); });
+    else if constexpr (RCX_CPT_PF == 0 && !(MX && MX_STAGE1)) sfor<AHEAD1>([&](auto rc) { load_row(raw1[decltype(rc)::value], R01 + decltype(rc)::value); });
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, (NL + 2) * 25 * C * 4, 0x00020000);
     // no bias: a buffer of zero records, every load returns 0 (no per-lane flag for an exec-masked load kept live -- or spilled -- across the units)
     const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc((void*)bpack, 0, has_bias ? (NL + 2) * C * 4 : 0, 0x00020000);
     Taps td;
-    load_taps(td, wsrc, bsrc, 0, C, cc);
+    MxTaps<TIO, 2> ad;                                       // MX: the down conv as Toeplitz blocks (pass 1); td is loaded after the pass
+    const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc((void*)(MX ? mxpack : (const void*)wpack), 0, (NL + 2) * 5 * MXP_SLOTS * 4 * C * 8, 0x00020000);
+    const int cM = cb * CHB + chM, ccM = cM < C ? cM : C - 1;       // map M: the channel whose taps and results this lane holds
+    if constexpr (MX) load_mxtaps(ad, msrc, bsrc, 0, C, ccM, lane & 3);
+    else load_taps(td, wsrc, bsrc, 0, C, cc);
     __syncthreads();
     CPT_STAMP(1);
     if constexpr (RCX_CPT_PRIO > 0) { if (w >= G::NW / 2) __builtin_amdgcn_s_setprio(RCX_CPT_PRIO); }
@@ -682,7 +875,114 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
 
     // ================= pass 1: F1 tile = down(x), rows -2 .. 14 of the tile, input-row stationary (tap pairs) =================
     float f1[7][7];                                          // this lane's F1 tile stays in registers until T1 is formed
-    {
+    if constexpr (MX && !MX_STAGE1) {
+        // Matrix cores, element loads in lane map A (wave = tile row tr x 16 channels, the four lanes of a matrix block = the four tile
+        // columns): an input row is five K blocks of four columns (two v_perm_b32 each, then ds_bpermute_b32 into map M); output block m
+        // (F1 columns 4m .. 4m+3, column 7 is not an output) takes the K blocks 2m, 2m+1, 2m+2 of every input row one of its tap rows reaches
+        constexpr int AHEAD = AHEAD1, R0 = R01, NR = NR1;
+        uint32_t (&raw)[NR][NCOL] = raw1;
+        f32x4 facc[3][2];
+        const f32x4 b4 = f32x4{ad.bias, ad.bias, ad.bias, ad.bias};
+        sfor<NR>([&](auto rc) {
+            constexpr int ri = decltype(rc)::value, r = R0 + ri;
+            if constexpr (ri + AHEAD < NR) load_row(raw[ri + AHEAD], r + AHEAD);
+            constexpr int NY = [] { int k = 0; for (int j = 1; j <= AHEAD; ++j) k += (ri + j < NR ? NCOL : 0); return k > 63 ? 63 : k; }();
+            pin_row20<NY>(raw[ri]);
+            u32x2 B[5];                                          // packed in map A, handed to map M
+#pragma unroll
+            for (int kb = 0; kb < 5; ++kb)
+                B[kb] = u32x2{(uint32_t)__builtin_amdgcn_ds_bpermute(permAM, (int)pack_raw<TIO>(raw[ri][4 * kb], raw[ri][4 * kb + 1])),
+                              (uint32_t)__builtin_amdgcn_ds_bpermute(permAM, (int)pack_raw<TIO>(raw[ri][4 * kb + 2], raw[ri][4 * kb + 3]))};
+            const bool rv = row_valid(r);
+#pragma unroll
+            for (int o = 0; o < 7; ++o) {
+                const int u = r - 2 * o + 2;
+                if (u < 0 || u > 4) continue;
+                f32x4(&a)[2] = facc[o % 3];
+                if (rv) {
+                    // u == 0, first K block: the first product of output row o carries the initial value (the bias) as its addend
+#pragma unroll
+                    for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) a[m] = mx444<TIO>(ad.a[u][kb], B[2 * m + kb], (u == 0 && kb == 0) ? b4 : a[m]);
+                } else if (u == 0) {
+                    a[0] = b4;
+                    a[1] = b4;
+                }
+                if (u == 4) {                                    // F1 row o of tile (tr, tcM), channel chM -> LDS (T1 is formed from there)
+                    float* dst = lds + chM + (G::O1 + (7 * tr + o) * P1 + 7 * tcM) * PIXF;
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) dst[i * PIXF] = i < 4 ? a[0][i] : a[1][i - 4];
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 7; ++o) if (r - 2 * o + 2 >= 0 && r - 2 * o + 2 < 4) pin(facc[o % 3]);
+            CPT_FENCE;
+        });
+        load_taps(td, wsrc, bsrc, 0, C, cc);      // the ladder below runs on the vector pipe in float32
+    } else if constexpr (MX) {
+        // Matrix cores, band-synchronous streaming.  The four lanes of a matrix block are the four BANDS of the plane (tile rows
+        // j = 0 .. 3: rows 14 j + r), a wave = (tile column tcw = w >> 1) x 16 channels (w & 1), and all eight waves walk r = -2 .. 14
+        // together.  Per step every wave fetches two 1 KB pieces of the four rows 14 j + r (16 bytes per lane: whole 64-byte
+        // half-lines, each pixel once -- the element loads of the first build touched 32 bytes per cache-line access and made this
+        // pass L1-tag bound at twice the vector kernel's time), AH steps ahead into registers, and drops them into a two-stage LDS
+        // image [band][pixel][channel]; a K block of four columns x 16 channels x 4 bands then is ONE ds_read_b64_tr_b16 (the
+        // transposing read hands lane 16 j + c the four pixels of channel c of band j) and two ds_bpermute_b32 into the matrix
+        // instruction's lane order 4 c + j.  Rows and columns outside the image are zeros in the image (out-of-range loads / pad pixels).
+        constexpr int AH = RCX_MX_AHEAD1, NR = NR1;          // steps in flight in registers, steps
+        u32x4 xa[AH + 1], xb[AH + 1];
+        auto fetch = [&](auto sc) { sfetch(xa[decltype(sc)::value % (AH + 1)], xb[decltype(sc)::value % (AH + 1)], decltype(sc)::value); };
+        auto stage = [&](auto sc) {                              // registers -> LDS stage s & 1 (younger loads in flight: the rows behind it)
+            constexpr int sI = decltype(sc)::value;
+            constexpr int NY = 2 * ((NR - 1 - sI) < AH ? (NR - 1 - sI) : AH);
+            pin_wide2<NY>(xa[sI % (AH + 1)], xb[sI % (AH + 1)]);
+            sstore(xa[sI % (AH + 1)], xb[sI % (AH + 1)], sI);
+        };
+        zero_pads();
+        sfor<AH + 1>([&](auto sc) { fetch(sc); });
+        stage(IC<0>{});
+        __syncthreads();
+        // reader role: K block kb of band j = pixels 14 tcw - 2 + 4 kb .. + 3 (image index + 4), channels 16 (w & 1) .. + 15; lane 4 q + p of a
+        // 16-lane group supplies row q, 8-byte chunk p
+        const int tcw = w >> 1;
+        const int rdA = (lane >> 4) * G::XBAND + (14 * tcw + 2 + ((lane >> 2) & 3)) * (G::CB * 2) + (w & 1) * 32 + (lane & 3) * 8;
+        f32x4 facc[3][2];
+        const f32x4 b4 = f32x4{ad.bias, ad.bias, ad.bias, ad.bias};
+        sfor<NR>([&](auto rc) {
+            constexpr int ri = decltype(rc)::value, r = R01 + ri;
+            if constexpr (!ABL_NOSTAGE) {
+            if constexpr (ri + 1 + AH < NR) fetch(IC<ri + 1 + AH>{});
+            if constexpr (ri + 1 < NR) stage(IC<ri + 1>{});      // next step's rows into the other stage
+            }
+            const char* st = xst + (ri & 1) * G::XSTAGE + rdA;
+            u32x2 B[5];
+#pragma unroll
+            for (int kb = 0; kb < 5; ++kb) {
+                u32x2 v = u32x2{(uint32_t)(lane + kb), (uint32_t)(ri + kb)};
+                if constexpr (!ABL_NOTR) v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + kb * 4 * (G::CB * 2))));
+                if constexpr (ABL_NOPERM) B[kb] = v;
+                else B[kb] = u32x2{(uint32_t)__builtin_amdgcn_ds_bpermute(permAM, (int)v.x), (uint32_t)__builtin_amdgcn_ds_bpermute(permAM, (int)v.y)};
+            }
+#pragma unroll
+            for (int o = 0; o < 7; ++o) {
+                const int u = r - 2 * o + 2;
+                if (u < 0 || u > 4) continue;
+                f32x4(&a)[2] = facc[o % 3];
+                // u == 0, first K block: the first product of output row o carries the initial value (the bias) as its addend
+#pragma unroll
+                for (int kb = 0; kb < (ABL_NOMFMA ? 1 : 3); ++kb)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) a[m] = mx444<TIO>(ad.a[u][kb], B[2 * m + kb], (u == 0 && kb == 0) ? b4 : a[m]);
+                if (u == 4) {                                    // F1 row o of tile (band tcM, tile column tcw), channel chM -> LDS
+                    float* dst = lds + chM + (G::O1 + (7 * tcM + o) * P1 + 7 * tcw) * PIXF;
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) dst[i * PIXF] = i < 4 ? a[0][i] : a[1][i - 4];
+                }
+            }
+            if constexpr (!ABL_NOBAR) __syncthreads();           // the other stage is complete; this one may be refilled
+        });
+        load_taps(td, wsrc, bsrc, 0, C, cc);      // the ladder below runs on the vector pipe in float32
+    } else {
         constexpr int AHEAD = AHEAD1, R0 = R01, NR = NR1;
         const f32x2 b0 = f32x2{td.bias, 0.f};
         uint32_t (&raw)[NR][18] = raw1;
@@ -883,6 +1183,13 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             cx = cx < 0 ? 0 : (cx > P2 - 1 ? P2 - 1 : cx);
             cofs[k] = cx * PIXF;
         }
+        if constexpr (MX) {                                   // pass 1 left F1 in LDS (its lane map is not this one)
+            const float* src = L1 + ((7 * tr) * P1 + 7 * tc) * PIXF;
+#pragma unroll
+            for (int r = 0; r < 7; ++r)
+#pragma unroll
+                for (int cI = 0; cI < 7; ++cI) f1[r][cI] = src[(r * P1 + cI) * PIXF];
+        }
         // HALVES = 4: the four tile columns of a wave have both parities -- the same sums with per-lane weights and selected neighbours
         auto form_lane = [&]() {
             const bool par = (d0 & 1) != 0;
@@ -1013,7 +1320,9 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         }
     }
     Taps tf;
-    load_taps(tf, wsrc, bsrc, 1 + NL, C, cc);
+    MxTaps<TIO, 1> af;                                       // MX: the final conv as Toeplitz blocks
+    if constexpr (MX) { load_mxtaps(af, msrc, bsrc, 1 + NL, C, ccM, lane & 3); tf.bias = af.bias; }
+    else load_taps(tf, wsrc, bsrc, 1 + NL, C, cc);
     __syncthreads();
     CPT_STAMP(7);
     if constexpr (RCX_CPT_STAGGER > 0) { if (w >= G::NW / 2) __builtin_amdgcn_s_sleep(RCX_CPT_STAGGER); }
@@ -1022,24 +1331,27 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     {
         constexpr int AHEAD = std::is_same<TIO, f16_t>::value && RCX_CPT_AHEAD2 > 1 ? 1 : RCX_CPT_AHEAD2, R0 = -2, NR = 18;   // float16: one row less in flight (its
                                                                                   // per-element conversions otherwise spill eight registers at 256)
-        {                                                     // see set_voffs
+        if constexpr (!MX) {                                  // see set_voffs
             int l2 = lane;
             asm volatile("" : "+v"(l2));
             const int h2 = HALVES == 4 ? (l2 >> 4) : (HALVES == 2 ? (l2 >> 5) : 0), c2 = cb * CHB + (l2 & (G::CB - 1));
             set_voffs(tcb + WPR * h2, c2 < C ? c2 : C - 1);
         }
         // C1 columns -2 .. 8 of the tile: the two on each side may lie outside the plane (clamped: ATen's border rule)
+        // (this pass reads C1 and x and writes y in the global-memory lane map: tcG, ledgeG ... = map A in the matrix-core variant)
         const int cb0 = 7 * tcG;
         const int cL0 = (ledgeG ? 0 : cb0 - 2) * PIXF, cL1 = (ledgeG ? 0 : cb0 - 1) * PIXF;
         const int cR0 = (redgeG ? P1 - 1 : cb0 + 7) * PIXF, cR1 = (redgeG ? P1 - 1 : cb0 + 8) * PIXF;
         const float lmaskG = ledgeG ? 0.f : 1.f, rmaskG = redgeG ? 0.f : 1.f;
-        const float* const L1G = L + G::O1 * PIXF;
+        const float* const L1G = (MX ? lds + chA : L) + G::O1 * PIXF;
         // horizontal weights; the pairs that lie outside the image (columns -2, -1 at the left edge, 14, 15 at the right) are zeroed here
         const f32x2 wq = MODE == 1 ? splat(0.f) : splat(0.25f), wt = MODE == 1 ? splat(1.f) : splat(0.75f);
         uint32_t raw[NR][NCOL];
         f32x2 H[2][9];
-        f32x2 acc[5][7];
+        f32x2 acc[MX ? 1 : 5][7];
+        f32x4 accm[MX ? 5 : 1][4];                            // MX: five output rows in flight, four blocks of four columns (14, 15 are not outputs)
         const f32x2 bf = splat(tf.bias);
+        const f32x4 bf4 = f32x4{tf.bias, tf.bias, tf.bias, tf.bias};
         i32x4 ysrc;                                           // y image as a raw buffer; lanes past the last channel store out of range (dropped)
         {
             const unsigned long long a = (unsigned long long)(reinterpret_cast<char*>(y) + (size_t)n * P0 * P0 * pix);
@@ -1075,13 +1387,44 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             Hs[0] = Hs[0] * splat(lmaskG);
             Hs[8] = Hs[8] * splat(rmaskG);
         };
-        if constexpr (STG > 0) sfor<SAH>([&](auto rc) { stg_request(IC<decltype(rc)::value % (STG > 0 ? STG : 1)>{}, R0 + decltype(rc)::value); });
+        // MX: x comes through the band-synchronous staging of pass 1 (this wave's band is its tile row tr; step = row t + 2 of every band);
+        // a lane then reads the 20 pixels of its tile and channel from the staged row (LDS, no cache-line tags, no halo re-reads)
+        constexpr int AH = RCX_MX_AHEAD2;
+        u32x4 xa[MX ? AH + 1 : 1], xb[MX ? AH + 1 : 1];
+        auto fetch = [&](auto sc) { sfetch(xa[decltype(sc)::value % (AH + 1)], xb[decltype(sc)::value % (AH + 1)], decltype(sc)::value); };
+        auto stage = [&](auto sc) {
+            constexpr int sI = decltype(sc)::value;
+            // younger memory operations: the loads of the steps behind it and the output rows stored since step sI was requested
+            // (in iteration sI - 1 - AH, or before the loop): iterations i = 4 .. 17 end with 14 stores
+            constexpr int NY = [] {
+                int k = 0;
+                for (int j = sI + 1; j <= sI + AH && j < NR; ++j) k += 2;
+                for (int i = (sI - 1 - AH < 0 ? 0 : sI - 1 - AH); i <= sI - 2; ++i) if (i >= 4 && i <= 17) k += 14;
+                return k > 63 ? 63 : k;
+            }();
+            pin_wide2<NY>(xa[sI % (AH + 1)], xb[sI % (AH + 1)]);
+            sstore(xa[sI % (AH + 1)], xb[sI % (AH + 1)], sI);
+        };
+        const unsigned rdL = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(xst + tr * G::XBAND + (14 * tcA + 2) * (G::CB * 2) + chA * 2);
+        if constexpr (MX && MX_STAGE2) {
+            zero_pads();
+            sfor<AH + 1>([&](auto sc) { fetch(sc); });
+            stage(IC<0>{});
+            __syncthreads();
+        } else if constexpr (STG > 0) sfor<SAH>([&](auto rc) { stg_request(IC<decltype(rc)::value % (STG > 0 ? STG : 1)>{}, R0 + decltype(rc)::value); });
         else sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], R0 + decltype(rc)::value); });
         build_H(H[0], -2);
         build_H(H[1], -1);
         sfor<NR>([&](auto rc) {
             constexpr int ri = decltype(rc)::value, t = R0 + ri;
-            if constexpr (STG > 0) {
+            if constexpr (MX && MX_STAGE2) {
+                if constexpr (!ABL_NOSTAGE) {
+                if constexpr (ri + 1 + AH < NR) fetch(IC<ri + 1 + AH>{});
+                if constexpr (ri + 1 < NR) stage(IC<ri + 1>{});
+                }
+                if constexpr (ABL_NOTR) { for (int k = 0; k < 20; ++k) raw[ri][k] = (uint32_t)(lane + k + ri) << 16; }
+                else lds_row20<TIO>(raw[ri], rdL + (ri & 1) * G::XSTAGE);
+            } else if constexpr (STG > 0) {
                 if constexpr (ri + SAH < NR) stg_request(IC<(ri + SAH) % (STG > 0 ? STG : 1)>{}, t + SAH);
             } else if constexpr (ri + AHEAD < NR) load_row(raw[ri + AHEAD], t + AHEAD);
             // vertical source rows (tile origin is even): t even -> (t/2 - 1, t/2) weight 0.75; t odd -> ((t-1)/2, (t+1)/2) weight 0.25
@@ -1096,14 +1439,63 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             // end of the iterations in between (14 stores each; iteration i stores a row for 4 <= i <= 17); the counter holds 63
             constexpr int NLD = NR - 1 - ri < AHEAD ? NR - 1 - ri : AHEAD;
             constexpr int NST = [] { int k = 0; for (int j = 1; j <= AHEAD; ++j) k += (ri - j >= 4 && ri - j <= 17) ? 1 : 0; return k; }();
-            if constexpr (STG > 0) {
+            if constexpr (MX && !MX_STAGE2) pin_row20<(NCOL * NLD + 14 * NST > 63 ? 63 : NCOL * NLD + 14 * NST)>(raw[ri]);
+            if constexpr (!MX && STG > 0) {
                 // younger: the pieces of the rows requested since (3 each) and the output rows stored at the end of the iterations in between
                 constexpr int SLD = NR - 1 - ri < SAH ? NR - 1 - ri : SAH;
                 constexpr int SST = [] { int k = 0; for (int j = 1; j <= SAH; ++j) k += (ri - j >= 4 && ri - j <= 17) ? 1 : 0; return k; }();
                 constexpr int SNY = 3 * SLD + (sizeof(TIO) == 2 ? 14 : 14) * SST;
                 fetch_row<TIO, (SNY > 63 ? 63 : SNY), (ri % (STG > 0 ? STG : 1)) * G::SLOTB>(raw[ri], stg_tra);
             }
-            if constexpr (STG == 0) pin_row<(18 * NLD + 14 * NST > 63 ? 63 : 18 * NLD + 14 * NST)>(raw[ri]);
+            if constexpr (!MX && STG == 0) pin_row<(18 * NLD + 14 * NST > 63 ? 63 : 18 * NLD + 14 * NST)>(raw[ri]);
+            if constexpr (MX) {
+              if (row_valid(t)) {
+                // T0 row = x + resize(C1), columns -2 .. 17 (16, 17: x alone -- they only meet zero Toeplitz entries), rounded once to the
+                // activations' type as five K blocks; output block m takes the K blocks m and m + 1 of each of its five input rows
+                f32x2 row[10];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const f32x2 xv = f32x2{raw_f32<TIO>(raw[ri][2 * k]), raw_f32<TIO>(raw[ri][2 * k + 1])};
+                    if (MODE == 1) row[k] = xv + H[(i0 + 2) & 1][k];
+                    else row[k] = pfma(splat(lam), H[(i1 + 2) & 1][k], pfma(splat(1.f - lam), H[(i0 + 2) & 1][k], xv));
+                }
+                row[9] = f32x2{raw_f32<TIO>(raw[ri][18]), raw_f32<TIO>(raw[ri][19])};
+                u32x2 B[5];                                      // rounded and packed in map A, handed to map M
+#pragma unroll
+                for (int kb = 0; kb < 5; ++kb)
+                    if constexpr (ABL_NOPERM) B[kb] = u32x2{pk16<TIO>(row[2 * kb].x, row[2 * kb].y), pk16<TIO>(row[2 * kb + 1].x, row[2 * kb + 1].y)};
+                    else
+                    B[kb] = u32x2{(uint32_t)__builtin_amdgcn_ds_bpermute(permAM, (int)pk16<TIO>(row[2 * kb].x, row[2 * kb].y)),
+                                  (uint32_t)__builtin_amdgcn_ds_bpermute(permAM, (int)pk16<TIO>(row[2 * kb + 1].x, row[2 * kb + 1].y))};
+                CPT_FENCE;
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const int o = t - u + 2;
+                    if (o < 0 || o > 13) continue;
+                    f32x4(&a)[4] = accm[o % 5];
+#pragma unroll
+                    for (int kb = 0; kb < (ABL_NOMFMA ? 1 : 2); ++kb)
+#pragma unroll
+                        for (int m = 0; m < (ABL_NOMFMA ? 1 : 4); ++m) a[m] = mx444<TIO>(af.a[u][kb], B[m + kb], (u == 0 && kb == 0) ? bf4 : a[m]);     // u == 0: output row t + 2 enters the window
+                }
+              } else if constexpr (t + 2 >= 0 && t + 2 <= 13) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) accm[(t + 2) % 5][m] = bf4;
+              }
+              if constexpr (t - 2 >= 0 && t - 2 <= 13) {
+                constexpr int o = t - 2;
+                uint32_t p7[7];                               // converted by compiler-visible instructions (pk16): they read matrix results
+#pragma unroll
+                for (int j = 0; j < 7; ++j)                   // ... in map M, stored from map A
+                    p7[j] = ABL_NOPERM ? pk16<TIO>(accm[o % 5][j >> 1][2 * (j & 1)], accm[o % 5][j >> 1][2 * (j & 1) + 1])
+                                       : (uint32_t)__builtin_amdgcn_ds_bpermute(permMA, (int)pk16<TIO>(accm[o % 5][j >> 1][2 * (j & 1)], accm[o % 5][j >> 1][2 * (j & 1) + 1]));
+                const int yrb = __builtin_amdgcn_readfirstlane((14 * tr + o) * (P0 * pix));
+                if constexpr (ABL_NOSTORE) { if (p7[0] == 0x12345678u && p7[3] == 77u) RowSt<TIO, PIXB>::st_packed(p7, yoff, ysrc, yrb, pix); }
+                else RowSt<TIO, PIXB>::st_packed(p7, yoff, ysrc, yrb, pix);
+              }
+#pragma unroll
+              for (int o = 0; o < 14; ++o) if (o > t - 2 && o <= t + 2) pin(accm[o % 5]);
+            } else {
             if (row_valid(t)) {
                 f32x2 row[9], odd[8];
 #pragma unroll
@@ -1142,9 +1534,11 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             }
 #pragma unroll
             for (int o = 0; o < 14; ++o) if (o > t - 2 && o <= t + 2) pin(acc[o % 5]);
+            }
             pin(H[0]);
             pin(H[1]);
             CPT_FENCE;
+            if constexpr (MX && MX_STAGE2 && !ABL_NOBAR) __syncthreads();    // the other stage is complete; this one may be refilled
         });
     }
     CPT_STAMP(8);
@@ -1166,31 +1560,31 @@ static inline bool enabled()
 // 55.6 against 53.6 (loop: 49.2 against 53.7), profiles/r04_staged_rows.txt: with two waves per SIMD these kernels are bound by their vector-ALU
 // issue, not by the 976 -> 451 vector-memory instructions per wave this removes.  So the instantiations exist in the diagnostic build only
 // (make diag, RCX_AB_VARIANTS; RCX_CPT_STG=0 there: element loads).
-template <int T, int HALVES, typename TIO, bool TRAIN> constexpr int stg_slots()
+template <int T, int HALVES, typename TIO, bool TRAIN, bool MX> constexpr int stg_slots()
 {
 #ifndef RCX_AB_VARIANTS
     return 0;
 #endif
-    if (TRAIN || sizeof(TIO) != 2) return 0;
+    if (MX || TRAIN || sizeof(TIO) != 2) return 0;
     if (T == 4 && HALVES == 2) return 3;
     if (T == 2 && HALVES == 1) return 2;
     return 0;
 }
 static inline bool stg_enabled() { return !rcx::opt::is_zero(rcx::opt::CPT_STG); }
 
-template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool TRAIN = false, int LV = (T == 4 ? 4 : 3), int STG = 0>
-static hipError_t launch(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv)
+template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool TRAIN = false, bool MX = false, int LV = (T == 4 ? 4 : 3), int STG = 0>
+static hipError_t launch(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv, const void* mxpack = nullptr)
 {
-    using G = Geo<T, HALVES, MODE, TIO, LV, STG>;
-    if constexpr (STG == 0 && stg_slots<T, HALVES, TIO, TRAIN>() > 0) {
+    using G = Geo<T, HALVES, MODE, TIO, MX, LV, STG>;
+    if constexpr (STG == 0 && stg_slots<T, HALVES, TIO, TRAIN, MX>() > 0) {
         if (!sv.base && C % 8 == 0 && ((size_t)x & 15) == 0 && stg_enabled())
-            return launch<T, HALVES, MODE, PIXB, TIO, TRAIN, LV, stg_slots<T, HALVES, TIO, TRAIN>()>(x, y, wpack, bpack, N, C, s, sv);
+            return launch<T, HALVES, MODE, PIXB, TIO, TRAIN, MX, LV, stg_slots<T, HALVES, TIO, TRAIN, MX>()>(x, y, wpack, bpack, N, C, s, sv, mxpack);
     }
-    if constexpr (!TRAIN && MODE == 0 && HALVES != 4 && !(T == 2 && HALVES == 2) && LV == (T == 4 ? 4 : 3)) {      // training forward: bilinear only (what RecConv2d trains with), whole-block variants, full ladder
+    if constexpr (!TRAIN && MODE == 0 && !MX && HALVES != 4 && !(T == 2 && HALVES == 2) && LV == (T == 4 ? 4 : 3)) {      // training forward: bilinear only (what RecConv2d trains with), whole-block variants, full ladder
         if (sv.base) return launch<T, HALVES, MODE, PIXB, TIO, true>(x, y, wpack, bpack, N, C, s, sv);
     }
     if (!TRAIN && sv.base) return hipErrorInvalidConfiguration;
-    auto kfn = k_recconv_cpt<T, HALVES, MODE, PIXB, TIO, TRAIN, LV, STG>;
+    auto kfn = k_recconv_cpt<T, HALVES, MODE, PIXB, TIO, TRAIN, MX, LV, STG>;
     RCX_SET_LDS_ONCE(kfn, G::LDS_BYTES);                       // once per instantiation and device
     static std::atomic<int> cus_cache{0};
     int cus = cus_cache.load(std::memory_order_relaxed);
@@ -1208,7 +1602,8 @@ static hipError_t launch(const void* x, void* y, const float* wpack, const float
     if (const char* e = rcx::opt::value(rcx::opt::CPT_GRID)) { const int g = atoi(e); if (g > 0) cap = (unsigned)g; }    // A/B knob
     cap &= ~7u;
     const unsigned grid = total <= cap || cap == 0 ? total : cap;
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(G::NT), G::LDS_BYTES, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
+    if (MX && !mxpack) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(G::NT), G::LDS_BYTES, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv, mxpack);
     return hipGetLastError();
 }
 
@@ -1218,7 +1613,7 @@ static hipError_t launch_c(const void* x, void* y, const float* wpack, const flo
 {
     constexpr int CM3 = T == 4 ? 64 : 128;
     if constexpr (LV != (T == 4 ? 4 : 3)) {                    // the shorter ladder (other resolutions, inner blocks): the run-time pitch only
-        return launch<T, HALVES, MODE, 0, TIO, false, LV>(x, y, wpack, bpack, N, C, s, sv);
+        return launch<T, HALVES, MODE, 0, TIO, false, false, LV>(x, y, wpack, bpack, N, C, s, sv);
     } else {
     if (C == CM3) return launch<T, HALVES, MODE, CM3 * (int)sizeof(TIO), TIO>(x, y, wpack, bpack, N, C, s, sv);
     if constexpr (T == 2 && HALVES == 1) {
@@ -1228,6 +1623,22 @@ static hipError_t launch_c(const void* x, void* y, const float* wpack, const flo
     }
     return launch<T, HALVES, MODE, 0, TIO>(x, y, wpack, bpack, N, C, s, sv);
     }
+}
+
+// matrix-core variant (56x56 / level 4, bf16 or float16 activations; rcx_cpt.hip decides when it applies)
+template <int MODE, typename TIO>
+static hipError_t launch_mx_c(const void* x, void* y, const float* wpack, const float* bpack, const void* mxpack, int N, int C, hipStream_t s)
+{
+    const SavedPyr sv{};
+    if (C == 64) return launch<4, 2, MODE, 64 * (int)sizeof(TIO), TIO, false, true>(x, y, wpack, bpack, N, C, s, sv, mxpack);
+    return launch<4, 2, MODE, 0, TIO, false, true>(x, y, wpack, bpack, N, C, s, sv, mxpack);
+}
+template <int DEFER = 0>                                   // a template only so that the eight instantiations are made where it is called (rcx_cpt.hip)
+static hipError_t launch_mx(const void* x, void* y, const float* wpack, const float* bpack, const void* mxpack, int N, int C, int mode, int dtype, hipStream_t s)
+{
+    if (dtype == 1) return mode == 1 ? launch_mx_c<1, bf16_t>(x, y, wpack, bpack, mxpack, N, C, s) : launch_mx_c<0, bf16_t>(x, y, wpack, bpack, mxpack, N, C, s);
+    if (dtype == 2) return mode == 1 ? launch_mx_c<1, f16_t>(x, y, wpack, bpack, mxpack, N, C, s) : launch_mx_c<0, f16_t>(x, y, wpack, bpack, mxpack, N, C, s);
+    return hipErrorInvalidConfiguration;
 }
 
 // The 56x56 block with 16-channel workgroups, two per CU (HALVES = 4), or with 32-channel workgroups (HALVES = 2).  Measured INSIDE the
