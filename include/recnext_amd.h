@@ -182,6 +182,26 @@ int rcx_linear_attention_pe_fwd(const void* qpre, const void* kpre, const void* 
                                 int B, int H, int W, int C, int heads, int dtype, void* stream);
 
 /*
+ * RecAttn2d's whole coarse level on the matrix cores, for 16-bit-activation runs (round 4): the grouped 1x1 `qk` conv (model/recattn.py:13 / :36
+ * with its BatchNorm folded, :21 / :44), the activation, k v^T, the normaliser, q kv and + pe (:22-27 / :45-50) -- what rcx_linear_attention_pe_fwd
+ * does plus the projection that used to be two library GEMMs; q and k never exist in memory.
+ *   d      : B x (H W) x C float32, the output of the stride-2 ConvNorm (:61), NHWC; also v and the input of `pe`;
+ *   wqk    : (2C) x (C/2) bf16, rows [0, C) = the q half of the conv's weight, rows [C, 2C) = the k half (BatchNorm folded in float32, then rounded);
+ *   bqk    : (2C) float32 biases; w_pe_kkc / b_pe: as rcx_linear_attention_pe_fwd (b_pe may be NULL);  out: B x (H W) x C float32;
+ *   workspace: rcx_recattn_qkcore_workspace_bytes(...) bytes, 16-byte aligned (0 bytes / may be NULL up to 64 tokens).
+ * Head dimension 32 only (C == 32 heads; 1, 2, 4, 8 or 16 heads).  Planes of at most 64 tokens whose image fits the CU's LDS: ONE launch, a workgroup
+ * per image, a wave per head (16 heads: at most 32 tokens; RecNeXt-A's stages 2 and 3 at 224 x 224).  Other planes: TWO launches (the k^T v partial
+ * sums of every image go through the workspace, summed in a fixed order: deterministic), at most 8 heads.  rcx_recattn_qkcore_launches() tells which
+ * (0: no kernel for the shape -> the call returns RCX_ERR_UNSUPPORTED).  The products run on the matrix cores with bf16 operands and float32
+ * accumulation, everything else is float32: meant for 16-bit activations (results within north_star's 1e-2 of the float32 forward); float32 callers
+ * keep rcx_linear_attention_pe_fwd.
+ */
+int rcx_recattn_qkcore_launches(int B, int H, int W, int C, int heads);
+size_t rcx_recattn_qkcore_workspace_bytes(int B, int H, int W, int C, int heads);
+int rcx_recattn_qkcore_fwd(const float* d, const void* wqk_bf16, const float* bqk, const float* w_pe_kkc, const float* b_pe, float* out,
+                           void* workspace, size_t workspace_bytes, int B, int H, int W, int C, int heads, void* stream);
+
+/*
  * Backward of rcx_linear_attention_fwd (the gradients engine.py:48-64 needs through RecAttn2d, model/recattn.py:16-28 / :39-51):
  *   given gout = dL/dout (B x n x C), writes gq = dL/dqpre, gk = dL/dkpre, gv = dL/dv (all B x n x C, `dtype`); dL/dpe = gout is the
  *   caller's.  float32 arithmetic, deterministic (fixed summation order).  C/heads at most 64.

@@ -126,6 +126,7 @@ enum StepKernel { STEP_GENERIC, STEP_LANES, STEP_CPT, STEP_CPL14, STEP_CONV5_LAN
 StepKernel pick_dwconv(int N, int C, int H, int W, int k, int stride, int in_dt, int out_dt)
 {
     if (lanes_off()) return STEP_GENERIC;
+    if (rcx::down5_cpl7_applicable(N, C, H, W, k, stride, in_dt, out_dt)) return STEP_CPL14;          // the 7 x 7 plane, whole (round 4)
     const bool lanes_ok = rcx::down5_lanes_applicable(N, C, H, W, k, stride, in_dt, out_dt);
     if (lanes_ok && !upcpt_everywhere() && !(W % 14 != 0 && C % 64 == 0)) return STEP_LANES;
     if (rcx::down5_cpt_applicable(N, C, H, W, k, stride, in_dt, out_dt)) return STEP_CPT;
@@ -175,6 +176,7 @@ hipError_t step_dwconv(const void* x, void* y, const float* w, const float* b, i
                        int in_dt, int out_dt, hipStream_t s)
 {
     switch (pick_dwconv(N, C, H, W, k, stride, in_dt, out_dt)) {
+    case STEP_CPL14: return rcx::down5_cpl7(x, y, w, b, N, C, in_dt, s);
     case STEP_LANES: return rcx::down5_lanes(x, y, w, b, N, C, H, W, in_dt, out_dt, s);
     case STEP_CPT: return rcx::down5_cpt(x, y, w, b, N, C, H, W, in_dt, out_dt, s);
     case STEP_CONV5_LANES: return rcx::conv5_lanes(x, y, w, b, N, C, H, W, in_dt, s);
@@ -186,7 +188,7 @@ hipError_t step_upadd(const void* x, const void* coarse, void* y, const float* w
                       int Hc, int Wc, int k, int mode, int x_dt, int c_dt, int out_dt, hipStream_t s)
 {
     switch (pick_upadd(N, C, H, W, Hc, Wc, k, x_dt, c_dt, out_dt, coarse != nullptr)) {
-    case STEP_CPL14: return rcx::upadd_cpl14(x, coarse, y, w, b, N, C, mode, x_dt, c_dt, s);
+    case STEP_CPL14: return rcx::upadd_cpl14(x, coarse, y, w, b, N, C, H, mode, x_dt, c_dt, s);
     case STEP_CPT: return rcx::upadd_cpt(x, coarse, y, w, b, N, C, H, W, mode, x_dt, c_dt, s);
     case STEP_LANES: return rcx::upadd_lanes(x, coarse, y, w, b, N, C, H, W, mode, x_dt, c_dt, s);
     case STEP_CONV5_LANES: return rcx::conv5_lanes(x, y, w, b, N, C, H, W, x_dt, s);
@@ -622,7 +624,7 @@ const char* rcx_upadd_dwconv_fwd_plan(int N, int C, int H, int W, int Hc, int Wc
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || (k & 1) == 0) return "invalid";
     static thread_local char desc[160];
     switch (pick_upadd(N, C, H, W, Hc, Wc, k, x_dtype, coarse_dtype, out_dtype, has_coarse != 0)) {
-    case STEP_CPL14: return "upadd_cpl14(k_upadd_cpl14)";
+    case STEP_CPL14: return H == 7 ? "upadd_cpl14(k_upadd_cpl7)" : "upadd_cpl14(k_upadd_cpl14)";
     case STEP_CPT: return rcx::upadd_cpt_describe(N, C, H, W, mode == RCX_MODE_NEAREST ? 1 : 0, x_dtype, desc, (int)sizeof(desc)) > 0 ? desc : "upadd_cpt(k_upadd_cpt)";
     case STEP_LANES: return "upadd_lanes(k_upadd_lanes)";
     case STEP_CONV5_LANES: return "conv5_lanes(k_upadd_lanes)";
@@ -718,6 +720,36 @@ int rcx_linear_attention_pe_fwd(const void* qpre, const void* kpre, const void* 
                                          "four, at most 64 (use rcx_dwconv2d_fwd + rcx_linear_attention_fwd)", D, H * W);
     hipError_t e = rcx::linattn_core(qpre, kpre, v, nullptr, out, B, H * W, C, heads, dtype, (hipStream_t)stream, w_pe_kkc, b_pe, W);
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_linear_attention_pe_fwd");
+}
+
+int rcx_recattn_qkcore_launches(int B, int H, int W, int C, int heads)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0 || C % heads) return 0;
+    return rcx::recattn_qkcore_launches(B, H, W, C, heads);
+}
+
+size_t rcx_recattn_qkcore_workspace_bytes(int B, int H, int W, int C, int heads)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0 || C % heads) return 0;
+    return rcx::recattn_qkcore_workspace_bytes(B, H, W, C, heads);
+}
+
+int rcx_recattn_qkcore_fwd(const float* d, const void* wqk_bf16, const float* bqk, const float* w_pe_kkc, const float* b_pe, float* out,
+                           void* workspace, size_t workspace_bytes, int B, int H, int W, int C, int heads, void* stream)
+{
+    if (!d || !wqk_bf16 || !bqk || !w_pe_kkc || !out) return fail(RCX_ERR_BAD_ARG, "rcx_recattn_qkcore_fwd: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive extent B=%d H=%d W=%d C=%d heads=%d", B, H, W, C, heads);
+    if (C % heads) return fail(RCX_ERR_BAD_ARG, "C=%d is not a multiple of heads=%d", C, heads);
+    if (((size_t)d & 15) || ((size_t)wqk_bf16 & 15) || ((size_t)out & 15)) return fail(RCX_ERR_BAD_ARG, "rcx_recattn_qkcore_fwd: d, wqk and out must be 16-byte aligned");
+    if (!rcx::recattn_qkcore_applicable(B, H, W, C, heads))
+        return fail(RCX_ERR_UNSUPPORTED, "rcx_recattn_qkcore_fwd: head dimension %d, %d heads, %d tokens, C=%d: the matrix-core form takes 32-wide heads, 1, 2, 4, 8 or "
+                                         "16 of them; 16 only on planes of at most 32 tokens (rcx_recattn_qkcore_launches; use the projection GEMMs + "
+                                         "rcx_linear_attention_pe_fwd)", C / heads, heads, H * W, C);
+    const size_t need = rcx::recattn_qkcore_workspace_bytes(B, H, W, C, heads);
+    if (need && (!workspace || workspace_bytes < need || ((size_t)workspace & 15)))
+        return fail(RCX_ERR_WORKSPACE, "rcx_recattn_qkcore_fwd: needs a 16-byte-aligned workspace of %zu bytes, got %zu", need, workspace ? workspace_bytes : (size_t)0);
+    hipError_t e = rcx::recattn_qkcore(d, wqk_bf16, bqk, w_pe_kkc, b_pe, out, workspace, B, H, W, C, heads, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "rcx_recattn_qkcore_fwd");
 }
 
 int rcx_linear_attention_bwd(const void* qpre, const void* kpre, const void* v, const void* gout, void* gq, void* gk, void* gv,

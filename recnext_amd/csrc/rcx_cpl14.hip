@@ -535,6 +535,109 @@ void k_upadd_cpl14(const TIO* __restrict__ x, const TC* __restrict__ coarse, TIO
     });
 }
 
+// ---- the same two single steps on the 7x7 plane (coarse 4x4): RecAttn2d's last stage (model/recattn.py:61 / :67 at 7x7; RecNeXt-A's stage 3)
+// ran them on the any-shape kernel (43.7 / 17.7 us at 256 x 512 against 20.5 / 13.6 for the 14x14 steps of four times the pixels).  The plane
+// is held whole, as in k_recconv_cpl7b.
+template <int MODE, int CT, typename TIO, typename TC>
+__global__ __launch_bounds__(64)
+void k_upadd_cpl7(const TIO* __restrict__ x, const TC* __restrict__ coarse, TIO* __restrict__ y, const float* __restrict__ w,
+                  const float* __restrict__ bias, int N, int C_rt)
+{
+    constexpr int W = 7, P = 4, W1 = 4, P1 = 2;
+    const int C = CT > 0 ? CT : C_rt;
+    const int nb = (C + 63) / 64;
+    unsigned b = blockIdx.x;
+    const unsigned G = gridDim.x;
+    if ((G & 7u) == 0) b = (b & 7u) * (G >> 3) + (b >> 3);                 // XCD-aware order, as above
+    const int n = (int)(b / (unsigned)nb), cb = (int)(b - (unsigned)n * (unsigned)nb);
+    if (n >= N) return;
+    const int c = cb * 64 + (int)threadIdx.x;
+    if (c >= C) return;
+    const size_t pix = (size_t)C * sizeof(TIO);
+    const gcptr xb = (gcptr)x + (size_t)n * W * W * pix;
+    const gcptr yb = (gcptr)y + (size_t)n * W * W * pix;
+    const unsigned vo = (unsigned)c * (unsigned)sizeof(TIO), vow = (unsigned)c * 4u;
+    const RowAddr<W, CT, TIO> ra(vo, pix);
+    uint32_t raw[W][W];
+    lanes::sfor<W>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        ra.row(xb, r, [&](auto qc, gcptr base, unsigned voff, auto immc) {
+            raw[r][decltype(qc)::value] = SafeLd<TIO>::ld(base + decltype(immc)::value + voff);
+        });
+    });
+    f32x2 C1[W1][P1];
+    {
+        const TC* q = coarse + ((size_t)n * W1 * W1) * C + c;
+#pragma unroll
+        for (int o = 0; o < W1; ++o)
+#pragma unroll
+            for (int j = 0; j < P1; ++j)
+                C1[o][j] = f32x2{elem_to_f32(q[(size_t)(o * W1 + 2 * j) * C]), elem_to_f32(q[(size_t)(o * W1 + 2 * j + 1) * C])};
+    }
+    Taps t2;
+    load_taps<CT>(t2, w, bias, 0, C, vow, bias != nullptr);
+    f32x2 X[W][P];
+#pragma unroll
+    for (int r = 0; r < W; ++r)
+#pragma unroll
+        for (int j = 0; j < P; ++j) X[r][j] = f32x2{SafeLd<TIO>::cvt(raw[r][2 * j]), 2 * j + 1 < W ? SafeLd<TIO>::cvt(raw[r][2 * j + 1]) : 0.f};
+    f32x2 H1[W1][P];
+#pragma unroll
+    for (int i = 0; i < W1; ++i) resize_row<MODE, W1, W>(C1[i], H1[i]);
+#pragma unroll
+    for (int r = 0; r < W; ++r) add_resized_row<MODE, W1, W, P>(X[r], H1, r);
+    f32x2 Y[W][P];
+    conv5_plane<W>(X, Y, t2);
+    lanes::sfor<W>([&](auto rc) {
+        constexpr int o = decltype(rc)::value;
+        typename PixSt<TIO>::packed pk[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) pk[j] = PixSt<TIO>::prep(Y[o][j]);
+        ra.row(yb, o, [&](auto qc, gcptr base, unsigned voff, auto immc) {
+            constexpr int q = decltype(qc)::value;
+            PixSt<TIO>::st(base + decltype(immc)::value + voff, pk[q >> 1], q & 1);
+        });
+    });
+}
+
+// stride-2 conv5 of the 7x7 plane -> 4x4, float32 out (the input of RecAttn2d's coarse chain)
+template <int CT, typename TIO>
+__global__ __launch_bounds__(64)
+void k_down5_cpl7(const TIO* __restrict__ x, float* __restrict__ y, const float* __restrict__ w, const float* __restrict__ bias, int N, int C_rt)
+{
+    constexpr int W = 7, P = 4, W1 = 4, P1 = 2;
+    const int C = CT > 0 ? CT : C_rt;
+    const int nb = (C + 63) / 64;
+    unsigned b = blockIdx.x;
+    const unsigned G = gridDim.x;
+    if ((G & 7u) == 0) b = (b & 7u) * (G >> 3) + (b >> 3);
+    const int n = (int)(b / (unsigned)nb), cb = (int)(b - (unsigned)n * (unsigned)nb);
+    if (n >= N) return;
+    const int c = cb * 64 + (int)threadIdx.x;
+    if (c >= C) return;
+    const size_t pix = (size_t)C * sizeof(TIO);
+    const gcptr xb = (gcptr)x + (size_t)n * W * W * pix;
+    const unsigned vo = (unsigned)c * (unsigned)sizeof(TIO), vow = (unsigned)c * 4u;
+    const RowAddr<W, CT, TIO> ra(vo, pix);
+    uint32_t raw[W][W];
+    lanes::sfor<W>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        ra.row(xb, r, [&](auto qc, gcptr base, unsigned voff, auto immc) {
+            raw[r][decltype(qc)::value] = SafeLd<TIO>::ld(base + decltype(immc)::value + voff);
+        });
+    });
+    Taps td;
+    load_taps<CT>(td, w, bias, 0, C, vow, bias != nullptr);
+    f32x2 X[W][P];
+#pragma unroll
+    for (int r = 0; r < W; ++r)
+#pragma unroll
+        for (int j = 0; j < P; ++j) X[r][j] = f32x2{SafeLd<TIO>::cvt(raw[r][2 * j]), 2 * j + 1 < W ? SafeLd<TIO>::cvt(raw[r][2 * j + 1]) : 0.f};
+    f32x2 F1[W1][P1];
+    down5<W, W1>(X, F1, td);
+    save_plane<W1>(y, 0ull, n, C, c, F1);
+}
+
 template <int MODE, int CT, typename TIO, typename TC>
 static hipError_t launch_up(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, hipStream_t s)
 {
@@ -694,17 +797,62 @@ hipError_t cpl7b_recconv(const void* x, void* y, const float* wpack, const float
 }
 
 // y = conv5(x + resize(coarse)) on the 14x14 plane: coarse in the I/O type or float32
+// RCX_UPADD_CPL=0: neither plane; RCX_UPADD_CPL=14: the 14x14 plane only (A/B of the 7x7 step kernels, round 4)
+static bool cpl7_steps()
+{
+    const char* v = rcx::opt::value(rcx::opt::UPADD_CPL);
+    return !(v && v[0] == '1' && v[1] == '4');
+}
+
 bool upadd_cpl14_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int x_dt, int c_dt, int out_dt)
 {
     (void)N;
     const char* v = rcx::opt::value(rcx::opt::UPADD_CPL);
-    return cpl14::enabled() && !(v && *v == '0') && H == 14 && W == 14 && Hc == 7 && Wc == 7 && k == 5 && C >= 1 && out_dt == x_dt &&
+    const bool plane = (H == 14 && W == 14 && Hc == 7 && Wc == 7) || (H == 7 && W == 7 && Hc == 4 && Wc == 4 && cpl7_steps());
+    return cpl14::enabled() && !(v && *v == '0') && plane && k == 5 && C >= 1 && out_dt == x_dt &&
            (x_dt == 0 || x_dt == 1 || x_dt == 2) && (c_dt == x_dt || c_dt == 0);
 }
 
-hipError_t upadd_cpl14(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int mode, int x_dt, int c_dt,
+bool down5_cpl7_applicable(int N, int C, int H, int W, int k, int stride, int in_dt, int out_dt)
+{
+    (void)N;
+    const char* v = rcx::opt::value(rcx::opt::UPADD_CPL);
+    return cpl14::enabled() && !(v && *v == '0') && cpl7_steps() && H == 7 && W == 7 && k == 5 && stride == 2 && C >= 1 && out_dt == 0 &&
+           (in_dt == 0 || in_dt == 1 || in_dt == 2);
+}
+
+hipError_t down5_cpl7(const void* x, void* y, const float* w, const float* b, int N, int C, int in_dt, hipStream_t s)
+{
+    const unsigned grid = (unsigned)(N * ((C + 63) / 64));
+#define RCX_D7(CT_, T_) hipLaunchKernelGGL((cpl14::k_down5_cpl7<CT_, T_>), dim3(grid), dim3(64), 0, s, (const T_*)x, (float*)y, w, b, N, C)
+    if (C == 512) { if (in_dt == 0) RCX_D7(512, float); else if (in_dt == 1) RCX_D7(512, bf16_t); else RCX_D7(512, f16_t); }
+    else { if (in_dt == 0) RCX_D7(0, float); else if (in_dt == 1) RCX_D7(0, bf16_t); else RCX_D7(0, f16_t); }
+#undef RCX_D7
+    return hipGetLastError();
+}
+
+namespace cpl14 {
+template <int MODE, typename TIO, typename TC>
+static hipError_t launch_up7(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, hipStream_t s)
+{
+    const unsigned grid = (unsigned)(N * ((C + 63) / 64));
+    if (C == 512) hipLaunchKernelGGL((k_upadd_cpl7<MODE, 512, TIO, TC>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (const TC*)coarse, (TIO*)y, w, b, N, C);
+    else hipLaunchKernelGGL((k_upadd_cpl7<MODE, 0, TIO, TC>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (const TC*)coarse, (TIO*)y, w, b, N, C);
+    return hipGetLastError();
+}
+}  // namespace cpl14
+
+hipError_t upadd_cpl14(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int H, int mode, int x_dt, int c_dt,
                        hipStream_t s)
 {
+    if (H == 7) {
+#define RCX_U7(MD_)                                                                                                                  \
+    (x_dt == 0 ? cpl14::launch_up7<MD_, float, float>(x, coarse, y, w, b, N, C, s)                                                   \
+     : x_dt == 1 ? (c_dt == 1 ? cpl14::launch_up7<MD_, bf16_t, bf16_t>(x, coarse, y, w, b, N, C, s) : cpl14::launch_up7<MD_, bf16_t, float>(x, coarse, y, w, b, N, C, s)) \
+                 : (c_dt == 2 ? cpl14::launch_up7<MD_, f16_t, f16_t>(x, coarse, y, w, b, N, C, s) : cpl14::launch_up7<MD_, f16_t, float>(x, coarse, y, w, b, N, C, s)))
+        return mode == 1 ? RCX_U7(1) : RCX_U7(0);
+#undef RCX_U7
+    }
 #define RCX_UC(MD_)                                                                                                                  \
     (x_dt == 0 ? cpl14::launch_up_c<MD_, float, float>(x, coarse, y, w, b, N, C, s)                                                  \
      : x_dt == 1 ? (c_dt == 1 ? cpl14::launch_up_c<MD_, bf16_t, bf16_t>(x, coarse, y, w, b, N, C, s) : cpl14::launch_up_c<MD_, bf16_t, float>(x, coarse, y, w, b, N, C, s)) \

@@ -76,8 +76,11 @@ hipError_t down7m2_cpt(const void* x, void* y, const float* w, const float* b, i
 bool down5_cpt_applicable(int N, int C, int H, int W, int k, int stride, int in_dt, int out_dt);
 hipError_t down5_cpt(const void* x, void* y, const float* w, const float* b, int N, int C, int H, int W, int in_dt, int out_dt, hipStream_t s);
 bool upadd_cpl14_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int x_dt, int c_dt, int out_dt);
-hipError_t upadd_cpl14(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int mode, int x_dt, int c_dt,
-                       hipStream_t s);
+hipError_t upadd_cpl14(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int H, int mode, int x_dt, int c_dt,
+                       hipStream_t s);            // H = 14 (coarse 7 x 7) or 7 (coarse 4 x 4)
+// the stride-2 conv5 of the 7 x 7 plane, float32 out (round 4)
+bool down5_cpl7_applicable(int N, int C, int H, int W, int k, int stride, int in_dt, int out_dt);
+hipError_t down5_cpl7(const void* x, void* y, const float* w, const float* b, int N, int C, int in_dt, hipStream_t s);
 
 bool cpl7b_applicable(int N, int C, int H, int W, int level, int k, int dtype);
 int cpl7b_describe(int N, int C, int mode, char* buf, int len);
@@ -127,6 +130,13 @@ hipError_t down5_lanes(const void* x, void* y, const float* w, const float* b, i
 hipError_t linattn_core(const void* qpre, const void* kpre, const void* v, const void* pe, void* out,
                         int B, int n, int C, int heads, int dtype, hipStream_t s, const float* pew = nullptr, const float* peb = nullptr, int Wp = 0);
 bool linattn_core_fuses_pe(int n, int C, int heads, int dtype);
+// rcx_qkcore.hip -- the qk projection + the core + pe on the matrix cores, 16-bit-activation callers: one launch (a workgroup per image, a wave
+// per head) up to 64 tokens, two launches (k^T v partial sums in the workspace, then the outputs) above
+bool recattn_qkcore_applicable(int B, int Hp, int Wp, int C, int heads);
+int recattn_qkcore_launches(int B, int Hp, int Wp, int C, int heads);          // 0: no kernel for this shape, 1 / 2: launches
+size_t recattn_qkcore_workspace_bytes(int B, int Hp, int Wp, int C, int heads);
+hipError_t recattn_qkcore(const float* d, const void* wqk_bf16, const float* bqk, const float* wpe, const float* bpe, float* out, void* workspace,
+                          int B, int Hp, int Wp, int C, int heads, hipStream_t s);
 
 hipError_t linattn_core_bwd(const void* qpre, const void* kpre, const void* v, const void* gout, void* gq, void* gk, void* gv,
                             int B, int n, int C, int heads, int dtype, hipStream_t s);

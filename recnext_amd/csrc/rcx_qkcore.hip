@@ -1,0 +1,516 @@
+// RecAttn2d's coarse level in ONE launch for the short sequences (14x14 and 7x7 planes: 49 / 16 tokens; 15 of RecNeXt-A3's 21 units): the
+// grouped 1x1 `qk` projection, the activation, k v^T, the normaliser, q kv and + pe (model/recattn.py:21-28 LinearAttention1, :44-51
+// LinearAttention2 -- the same function) -- everything between the stride-2 conv and the final conv(x + resize(.)) of RecAttn2d.forward
+// (:61-67).  It replaces two library GEMMs, their bias adds and rcx_linear_attention_pe_fwd, and the q / k tensors never exist in memory.
+//
+// ONE WORKGROUP = one image, ONE WAVE = one head: the image's d is staged in LDS once (one barrier), after which the waves share nothing.
+// Head dimension 32 (every head of the A-series), at most 64 tokens, at most 16 heads.
+//   projection  q[t][c] = sum_ci d[t][ci] Wq[c][ci] + bq[c] over the FIRST half of d's channels, k likewise over the second half (groups = 2):
+//               v_mfma_f32_32x32x16_bf16, A = d rows (float32 from the LDS image, rounded to bf16 in registers), B = the head's 32 rows of the bf16
+//               weight pack, float32 accumulation -- C / 32 k-steps per 32-token tile.  The accumulator tile has the CHANNEL on the lane and
+//               the tokens in its registers, which is exactly the A operand k^T of the next product;
+//   kv          kv[c1][c2] = (1/n) sum_t k[t][c1] v[t][c2]: A = k straight from the accumulator registers (registers 8s .. 8s+7 = k-step s: the
+//               token order they imply is the order the v fragment is gathered in), B = v = the head's 32 channels of d (LDS, float32 -> bf16);
+//   out         out[t][c2] = sum_c1 q[t][c1] kv[c1][c2]: B = kv straight from ITS accumulator registers, A = q through a wave-private
+//               float32 image in LDS (the one transpose), read in the permuted c1 order the kv registers imply; the normaliser
+//               q . kbar + 1e-6 in float32 from the same image;
+//   + pe        the depthwise 3x3 of d (float32, from the LDS image) where it is added; a is stored as float32.
+// Numerics: the MFMA operands are bf16 (d, the weights, k, v, q, kv), every accumulation, the activation, the normaliser and pe are float32.
+// That form holds north_star's flat 1e-2 for 16-bit activations (tests/test_recconv_gpu.py: the recattn goldens and A3 stages 2 / 3 run it;
+// profiles/r04_recattn_qk_gemm_operands.txt measured the projection with bf16 operands alone); float32 activations keep the float32 GEMMs and
+// rcx_linear_attention_pe_fwd (their bar is 1e-3).
+#include "rcx_common.h"
+#include "rcx_launch.h"
+#include "rcx_opts.h"
+
+namespace rcx {
+namespace qkc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
+typedef float f32x4q __attribute__((ext_vector_type(4)));
+
+constexpr int LROW = 36;          // floats per row of a wave's q image (32 + 4: 16-byte aligned rows that spread over the banks)
+constexpr int DPAD = 4;           // floats added to a row of the shared d image (rows of C + 4: the 32 token rows of a fragment read fall on different banks)
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.f : __expf(x); }
+__device__ __forceinline__ void wave_sync()
+{
+    // LDS operations of one wave execute in order; this only keeps the compiler from moving accesses across the hand-off
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// token of accumulator register i (0..15) of lane half h in a 32-row tile
+__device__ __forceinline__ constexpr int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+
+// rows [row0, row0 + nrows) of an image's d (float32, C channels) -> LDS rows of DROW floats, 16 bytes per lane and EIGHT requests in flight per lane
+// (one request per iteration costs a memory round trip per 16 bytes: 8 round trips for a 49 x 256 image).  Rows outside the image read 0.
+__device__ __forceinline__ void stage_rows(float* Ld, __amdgpu_buffer_rsrc_t dsrc, int row0, int nrows, int C, int DROW, int nthr)
+{
+    constexpr int UN = 8;
+    const int cq = C / 4, chunks = nrows * cq;
+    for (int i0 = threadIdx.x; i0 < chunks; i0 += UN * nthr) {
+        u32x4q v[UN];
+        int dst[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = i0 + u * nthr, t = i / cq, q4 = i - t * cq;
+            dst[u] = i < chunks ? t * DROW + q4 * 4 : -1;
+            v[u] = __builtin_bit_cast(u32x4q, __builtin_amdgcn_raw_buffer_load_b128(dsrc, i < chunks ? ((row0 + t) * C + q4 * 4) * 4 : -16, 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (dst[u] >= 0) *reinterpret_cast<u32x4q*>(Ld + dst[u]) = v[u];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// LONG sequences (the 56x56 and 28x28 stages: 784 / 196 tokens, 2 / 4 heads; any token count): the same function in TWO launches, because k v^T sums
+// over every token of the image before the first output can be formed and an image's d (200 KB of float32 at 784 x 64) is not LDS-sized:
+//   k_recattn_kv   grid (G, B): a workgroup projects k for its range of 32-token tiles (a wave = (head, split)), accumulates k^T v on the matrix cores
+//                  and leaves ONE partial 32 x 32 sum + column sums per (image, range, head) in the workspace (fixed order: deterministic);
+//   k_recattn_out  grid (G, B): stages the range's rows of d + one plane row and one token either side in LDS (the 3x3 of pe), sums the G partials,
+//                  projects q^T = Wq d^T (the OPERANDS SWAPPED against the short kernel: the accumulator then has the TOKEN on the lane and c1 in the
+//                  registers, which is the B operand of out^T = kv^T q^T as it stands, kv^T being the kv accumulator as it stands: no transpose
+//                  through LDS), the normaliser (lane partial + its partner lane), pe as float4s of the lane's token, 16-byte stores.
+// A lane of out^T holds channels 8 g + 4 h + (0..3), g = 0..3, of its token: registers 4 g .. 4 g + 3.
+
+// The end of a 32-token tile once q^T is accumulated (aq: rows c1 in the registers, column = the lane's token t): bias + activation, the normaliser
+// (the lane's 16 channels + its partner lane's), out^T = kv^T q^T, pe as float4s of the lane's token and 16-byte stores.  drow = the token's row of
+// the LDS image, at the lane's first channel (rows above / below the plane hold zeros: they are outside the buffer the image was staged from), zrow = a row of zeros for the taps
+// that would wrap to the neighbouring plane row, Lwc / outp already point at the lane's first channel (head * 32 + 4 h).
+template <int C>
+__device__ __forceinline__ void out_epilogue(const f32x16& aq, bf16x8 kv0, bf16x8 kv1, const float* Lbq, const float* Lkb, const float4* drow,
+                                             const float4* zrow, const float4* Lwc, int t, int n, int Wp, int h, float* outp)
+{
+    constexpr int DROW4 = (C + DPAD) / 4;
+    float dpart = 0.f;
+    bf16x8 q0, q1;
+    int hop = 4 * h;                               // opaque: or the 32 biases / kbar values of a lane are hoisted out of the caller's tile loop into registers
+    asm volatile("" : "+v"(hop));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float qq = elu1(aq[i] + Lbq[acc_row(i, 0) + hop]);
+        dpart = fmaf(qq, Lkb[acc_row(i, 0) + hop], dpart);
+        if (i < 8) q0[i] = (__bf16)qq; else q1[i - 8] = (__bf16)qq;
+    }
+    const float dn = dpart + __shfl_xor(dpart, 32) + 1e-6f;
+    f32x16 o;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = 0.f;
+    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv0, q0, o, 0, 0, 0);                  // out^T[c2][t] = sum_c1 kv[c1][c2] q^T[c1][t]
+    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv1, q1, o, 0, 0, 0);
+    if (t < n) {
+        const float rdn = 1.f / dn;
+        const int y = t / Wp, x = t - y * Wp;
+        const float4* nb[9];
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const bool wrap = (dx < 0 && x == 0) || (dx > 0 && x == Wp - 1);
+                nb[(dy + 1) * 3 + dx + 1] = wrap ? zrow : drow + (dy * Wp + dx) * DROW4;
+            }
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            float4 pe = Lwc[(9 * C) / 4 + 2 * gq];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const float4 w4 = Lwc[(j * C) / 4 + 2 * gq];
+                const float4 dv = nb[j][2 * gq];
+                pe.x = fmaf(w4.x, dv.x, pe.x); pe.y = fmaf(w4.y, dv.y, pe.y); pe.z = fmaf(w4.z, dv.z, pe.z); pe.w = fmaf(w4.w, dv.w, pe.w);
+            }
+            float4 res;
+            res.x = fmaf(o[4 * gq + 0], rdn, pe.x); res.y = fmaf(o[4 * gq + 1], rdn, pe.y);
+            res.z = fmaf(o[4 * gq + 2], rdn, pe.z); res.w = fmaf(o[4 * gq + 3], rdn, pe.w);
+            *reinterpret_cast<float4*>(outp + (size_t)t * C + 8 * gq) = res;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// SHORT sequences (at most 64 tokens: the 14x14 and 7x7 stages), ONE launch: a WORKGROUP = one image, a WAVE = one head.  The image's d is staged
+// in LDS once (with a plane row + a token of zeros either side for the 3x3 of pe; one barrier), after which the waves share nothing:
+//   1. k = elu1(Wk d + bk) tile by tile (lane = channel, tokens in the registers), its column sums, kv += k^T v (A = the k accumulators as they
+//      stand, B = v gathered from the LDS image in the token order those registers imply);
+//   2. q^T = Wq d^T (lane = token), then the shared tile epilogue (out_epilogue: normaliser, out^T = kv^T q^T, pe, 16-byte stores).
+// The first version kept q in the lane = channel form and took it through a wave-private LDS image for the second product, computed pe with 9
+// bounds-checked 4-byte LDS reads per output and divided per output: 26-28 us at 256 x 49 x 256, of which pe 8.5 (profiles/r04_recattn_one_launch.txt).
+// Weight fragments come from global memory (L2) through a ring PF k-steps deep; NT = 32-token tiles, KS = C / 32 = heads.
+template <int NT, int KS>
+__global__ void __launch_bounds__(NT == 1 ? 1024 : 512)
+k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, const float* __restrict__ bqk, const float* __restrict__ wpe,
+                const float* __restrict__ bpe, float* __restrict__ out, int Hp, int Wp)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds_s[];
+    constexpr int C = 32 * KS, K = C / 2, DROW = C + DPAD, DROW4 = DROW / 4, NTHR = 64 * KS, PF = KS < 4 ? KS : 4;
+    const int hd = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x, n = Hp * Wp, rows = NT * 32 + 2 * Wp + 2, R0 = -Wp - 1;
+    float* const Ld = lds_s;                                  // [rows + 1][DROW]: tokens R0 .. of the image (zeros outside it), then a row of zeros
+    const float4* const Ld4 = reinterpret_cast<const float4*>(lds_s);
+    float* const Lw = Ld + (size_t)(rows + 1) * DROW;         // [9][C] pe taps, [C] pe bias, [C] q biases, [C] kbar
+    const float* dimg = d + (size_t)b * n * C;
+    const __amdgpu_buffer_rsrc_t dsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dimg, 0, n * C * 4, 0x00020000);
+
+    const bf16_t* wq_row = wqk + (size_t)(hd * 32 + r) * K + 8 * h;            // this lane's output channel, its 8 inputs of k-step 0
+    const bf16_t* wk_row = wqk + (size_t)(C + hd * 32 + r) * K + 8 * h;
+    u32x4q wf[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) wf[j] = *reinterpret_cast<const u32x4q*>(wk_row + 16 * j);
+
+    stage_rows(Ld, dsrc, R0, rows, C, DROW, NTHR);
+    for (int i = threadIdx.x; i < DROW; i += NTHR) Ld[(size_t)rows * DROW + i] = 0.f;
+    for (int i = threadIdx.x; i < 9 * C; i += NTHR) Lw[i] = wpe[i];
+    for (int i = threadIdx.x; i < C; i += NTHR) { Lw[9 * C + i] = bpe ? bpe[i] : 0.f; Lw[10 * C + i] = bqk[i]; }
+    __syncthreads();
+
+    // ---- 1. k tiles (lane = channel hd * 32 + r, tokens in the registers), kv
+    f32x16 acc[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tt][i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const bf16x8 bk8 = __builtin_bit_cast(bf16x8, wf[s % PF]);
+        if (s + PF < KS) wf[s % PF] = *reinterpret_cast<const u32x4q*>(wk_row + 16 * (s + PF));
+        else wf[s % PF] = *reinterpret_cast<const u32x4q*>(wq_row + 16 * (s + PF - KS));          // the ring rolls over into the q weights
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const float4* pa = Ld4 + (32 * tt + r - R0) * DROW4 + K / 4 + 4 * s + 2 * h;      // token 32 tt + r, inputs 16 s + 8 h .. + 7 of the k half
+            const float4 x0 = pa[0], x1 = pa[1];
+            bf16x8 fa;
+            fa[0] = (__bf16)x0.x; fa[1] = (__bf16)x0.y; fa[2] = (__bf16)x0.z; fa[3] = (__bf16)x0.w;
+            fa[4] = (__bf16)x1.x; fa[5] = (__bf16)x1.y; fa[6] = (__bf16)x1.z; fa[7] = (__bf16)x1.w;
+            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, bk8, acc[tt], 0, 0, 0);
+        }
+    }
+    const float bk = bqk[C + hd * 32 + r];
+    const float* const Lv = Ld + hd * 32 + r;                 // this lane's channel of d: v
+    f32x16 kv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kv[i] = 0.f;
+    float ksum = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 fa, fb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = 8 * s2 + j, t = 32 * tt + acc_row(i, h);
+                const float kk = t < n ? elu1(acc[tt][i] + bk) : 0.f;
+                ksum += kk;
+                fa[j] = (__bf16)kk;
+                fb[j] = (__bf16)Lv[(t - R0) * DROW];
+            }
+            kv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, kv, 0, 0, 0);
+        }
+    const float inv_n = 1.f / (float)n;
+    const float kbar_mine = (ksum + __shfl_xor(ksum, 32)) * inv_n;          // lane (r, h): kbar of channel r of the head
+    float* const Lkb = Lw + 11 * C + hd * 32;
+    if (h == 0) Lkb[r] = kbar_mine;
+    bf16x8 kv0, kv1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { kv0[j] = (__bf16)(kv[j] * inv_n); kv1[j] = (__bf16)(kv[8 + j] * inv_n); }
+    wave_sync();
+
+    // ---- 2. q^T tiles (lane = token), epilogue
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tt][i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const bf16x8 bq8 = __builtin_bit_cast(bf16x8, wf[(s + KS) % PF]);
+        if (s + PF < KS) wf[(s + KS) % PF] = *reinterpret_cast<const u32x4q*>(wq_row + 16 * (s + PF));
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const float4* pa = Ld4 + (32 * tt + r - R0) * DROW4 + 4 * s + 2 * h;              // token 32 tt + r, inputs 16 s + 8 h .. + 7 of the q half
+            const float4 x0 = pa[0], x1 = pa[1];
+            bf16x8 fb;
+            fb[0] = (__bf16)x0.x; fb[1] = (__bf16)x0.y; fb[2] = (__bf16)x0.z; fb[3] = (__bf16)x0.w;
+            fb[4] = (__bf16)x1.x; fb[5] = (__bf16)x1.y; fb[6] = (__bf16)x1.z; fb[7] = (__bf16)x1.w;
+            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq8, fb, acc[tt], 0, 0, 0);
+        }
+    }
+    const float4* const zrow = Ld4 + (size_t)rows * DROW4 + (hd * 32 + 4 * h) / 4;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+        const int t = 32 * tt + r;
+        out_epilogue<C>(acc[tt], kv0, kv1, Lw + 10 * C + hd * 32, Lkb, Ld4 + (t - R0) * DROW4 + (hd * 32 + 4 * h) / 4, zrow, reinterpret_cast<const float4*>(Lw) + (hd * 32 + 4 * h) / 4,
+                        t, n, Wp, h, out + (size_t)b * n * C + hd * 32 + 4 * h);
+    }
+}
+
+static inline size_t short_lds_bytes(int NT, int Wp, int C) { return sizeof(float) * ((size_t)(NT * 32 + 2 * Wp + 3) * (C + DPAD) + 12 * (size_t)C); }
+
+
+constexpr int TILE_TOK = 32;
+constexpr int PART_FLOATS = 17 * 64;       // per (image, range, head): 16 accumulator registers + the column-sum partial of each lane
+
+struct LongGeo { int ntiles, tpg, G, rows, waves, S; size_t lds_out; int tpgA, GA, SA; size_t lds_kv, ws_bytes; };
+static inline LongGeo long_geo(int B, int Hp, int Wp, int C, int heads)
+{
+    LongGeo g{};
+    const int n = Hp * Wp;
+    g.ntiles = (n + TILE_TOK - 1) / TILE_TOK;
+    // second kernel: ranges whose rows (+ halo) take at most half a CU's LDS
+    const int halo = 2 * Wp + 2;
+    int tpg = ((int)((80 * 1024 - 48 * (size_t)C) / (4 * (size_t)(C + DPAD))) - halo - 1) / TILE_TOK;
+    if (tpg < 1) tpg = 1;
+    if (tpg > g.ntiles) tpg = g.ntiles;
+    g.G = (g.ntiles + tpg - 1) / tpg;
+    g.tpg = (g.ntiles + g.G - 1) / g.G;
+    g.G = (g.ntiles + g.tpg - 1) / g.tpg;
+    g.rows = g.tpg * TILE_TOK + halo;
+    g.waves = 8;
+    g.S = g.waves / heads;
+    g.lds_out = sizeof(float) * ((size_t)(g.rows + 1) * (C + DPAD) + 12 * (size_t)C);      // rows of d, 9 + 1 rows of pe taps / bias, the q biases, kbar
+    // first kernel: 16 waves, as few ranges per image as keeps a wave's serial tiles short (every range's partial is read by every workgroup of the second)
+    g.SA = 16 / heads;
+    g.GA = (g.ntiles + 63) / 64;
+    g.tpgA = (g.ntiles + g.GA - 1) / g.GA;
+    g.GA = (g.ntiles + g.tpgA - 1) / g.tpgA;
+    g.lds_kv = sizeof(float) * 16 * (size_t)PART_FLOATS;
+    g.ws_bytes = sizeof(float) * (size_t)B * g.GA * heads * PART_FLOATS;
+    return g;
+}
+
+template <int KS>
+__global__ void __launch_bounds__(1024)
+k_recattn_kv(const float* __restrict__ d, const bf16_t* __restrict__ wqk, const float* __restrict__ bqk, float* __restrict__ part,
+             int n, int C_, int heads, int S, int tpg, int ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds_kv[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int hd = wv % heads, sp = wv / heads;
+    constexpr int C = 32 * KS;                    // C / heads == 32 and 16 inputs per k-step of each half: a compile-time C makes every offset an immediate
+    const int g = blockIdx.x, b = blockIdx.y, G = gridDim.x, K = C / 2;
+    const float* dimg = d + (size_t)b * n * C;
+    const __amdgpu_buffer_rsrc_t dsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dimg, 0, n * C * 4, 0x00020000);
+    const bf16_t* wk_row = wqk + (size_t)(C + hd * 32 + r) * K + 8 * h;
+    bf16x8 wk[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) wk[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4q*>(wk_row + 16 * s));
+    const float bk = bqk[C + hd * 32 + r];
+    f32x16 kv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kv[i] = 0.f;
+    float ksum = 0.f;
+    const int t_end = min((g + 1) * tpg, ntiles);
+    for (int tt = g * tpg + sp; tt < t_end; tt += S) {
+        f32x16 ak;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ak[i] = 0.f;
+        // v of this tile, in the token order of the accumulator registers (requested first: the longest wait)
+        float vv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) vv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dsrc, ((32 * tt + acc_row(i, h)) * C + hd * 32 + r) * 4, 0, 0));
+        f32x4q xlo[KS], xhi[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int off = ((32 * tt + r) * C + K + 16 * s + 8 * h) * 4;          // token 32 tt + r, inputs 16 s + 8 h .. + 7 of the k half
+            xlo[s] = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(dsrc, off, 0, 0));
+            xhi[s] = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(dsrc, off + 16, 0, 0));
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 fa;
+            fa[0] = (__bf16)xlo[s].x; fa[1] = (__bf16)xlo[s].y; fa[2] = (__bf16)xlo[s].z; fa[3] = (__bf16)xlo[s].w;
+            fa[4] = (__bf16)xhi[s].x; fa[5] = (__bf16)xhi[s].y; fa[6] = (__bf16)xhi[s].z; fa[7] = (__bf16)xhi[s].w;
+            ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, wk[s], ak, 0, 0, 0);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 fa, fb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = 8 * s2 + j, t = 32 * tt + acc_row(i, h);
+                const float kk = t < n ? elu1(ak[i] + bk) : 0.f;
+                ksum += kk;
+                fa[j] = (__bf16)kk;
+                fb[j] = (__bf16)vv[i];
+            }
+            kv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, kv, 0, 0, 0);
+        }
+    }
+    // the splits of a head -> one partial per (image, range, head), summed in split order
+    float* mine = lds_kv + (size_t)wv * PART_FLOATS;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mine[i * 64 + lane] = kv[i];
+    mine[16 * 64 + lane] = ksum;
+    __syncthreads();
+    if (sp == 0) {
+        float* dst = part + (((size_t)b * G + g) * heads + hd) * PART_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 17; ++i) {
+            float a = 0.f;
+            for (int q = 0; q < S; ++q) a += lds_kv[(size_t)(q * heads + hd) * PART_FLOATS + i * 64 + lane];
+            dst[i * 64 + lane] = a;
+        }
+    }
+}
+
+template <int KS, int NTHR>
+__global__ void __launch_bounds__(NTHR, KS <= 4 ? 4 : 2)          // two workgroups per CU (128 registers) where the weights leave room
+k_recattn_out(const float* __restrict__ d, const bf16_t* __restrict__ wqk, const float* __restrict__ bqk, const float* __restrict__ wpe,
+              const float* __restrict__ bpe, const float* __restrict__ part, float* __restrict__ out,
+              int Hp, int Wp, int C_, int heads, int S, int tpg, int ntiles, int rows, int GA)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds_o[];
+    constexpr int C = 32 * KS;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int hd = wv % heads, sp = wv / heads;
+    constexpr int K = C / 2, DROW = C + DPAD;
+    const int g = blockIdx.x, b = blockIdx.y, n = Hp * Wp;
+    float* const Ld = lds_o;                      // [rows][DROW]: tokens R0 .. R0 + rows - 1 of the image (zeros outside it)
+    const float4* const zrow = reinterpret_cast<const float4*>(lds_o) + (size_t)rows * (DROW / 4) + (hd * 32 + 4 * h) / 4;      // row `rows`: zeros
+    float* const Lw = Ld + (size_t)(rows + 1) * DROW;   // [9][C] pe taps, then [C] pe bias, [C] q biases, [C] kbar (a lane's 16 of each would be 32 registers)
+    float* const Lbq = Lw + 10 * C + hd * 32;
+    float* const Lkb = Lw + 11 * C + hd * 32;
+    const float4* const Lw4 = reinterpret_cast<const float4*>(Lw);
+    const int T0 = g * tpg * TILE_TOK, R0 = T0 - Wp - 1;
+    const float* dimg = d + (size_t)b * n * C;
+    const __amdgpu_buffer_rsrc_t dsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dimg, 0, n * C * 4, 0x00020000);
+
+    stage_rows(Ld, dsrc, R0, rows, C, DROW, NTHR);
+    __builtin_amdgcn_sched_barrier(0);            // keep the loads below from being hoisted among the staging requests (register pressure)
+    for (int i = threadIdx.x; i < DROW; i += NTHR) Ld[(size_t)rows * DROW + i] = 0.f;
+    for (int i = threadIdx.x; i < 9 * C; i += NTHR) Lw[i] = wpe[i];
+    for (int i = threadIdx.x; i < C; i += NTHR) { Lw[9 * C + i] = bpe ? bpe[i] : 0.f; Lw[10 * C + i] = bqk[i]; }
+    // this head's weights and the partial sums (requested after the staging loop, whose eight 16-byte requests per lane would otherwise be live with them: 166-202 registers; waited for at the barrier)
+    const bf16_t* wq_row = wqk + (size_t)(hd * 32 + r) * K + 8 * h;
+    bf16x8 wq[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) wq[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4q*>(wq_row + 16 * s));
+    float kvs[16], ks = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kvs[i] = 0.f;
+    for (int q = 0; q < GA; ++q) {
+        const float* src = part + (((size_t)b * GA + q) * heads + hd) * PART_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) kvs[i] += src[i * 64 + lane];
+        ks += src[16 * 64 + lane];
+    }
+    const float inv_n = 1.f / (float)n;
+    // kbar: channel c of the head = lane c's partial + lane 32 + c's
+    const float kbar_mine = (ks + __shfl_xor(ks, 32)) * inv_n;       // lane (r, h): kbar of channel r
+    bf16x8 kv0, kv1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { kv0[j] = (__bf16)(kvs[j] * inv_n); kv1[j] = (__bf16)(kvs[8 + j] * inv_n); }
+    if (sp == 0 && h == 0) Lkb[r] = kbar_mine;
+    __syncthreads();
+
+    const int t_end = min((g + 1) * tpg, ntiles);
+    for (int tt = g * tpg + sp; tt < t_end; tt += S) {
+        const int t = 32 * tt + r;                                    // this lane's token
+        const float4* drow = reinterpret_cast<const float4*>(lds_o) + (t - R0) * (DROW / 4);
+        f32x16 aq;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) aq[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 x0 = drow[4 * s + 2 * h], x1 = drow[4 * s + 2 * h + 1];
+            bf16x8 fb;
+            fb[0] = (__bf16)x0.x; fb[1] = (__bf16)x0.y; fb[2] = (__bf16)x0.z; fb[3] = (__bf16)x0.w;
+            fb[4] = (__bf16)x1.x; fb[5] = (__bf16)x1.y; fb[6] = (__bf16)x1.z; fb[7] = (__bf16)x1.w;
+            aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s], fb, aq, 0, 0, 0);          // q^T: rows c1 (registers), column = this lane's token
+        }
+        out_epilogue<C>(aq, kv0, kv1, Lbq, Lkb, drow + (hd * 32 + 4 * h) / 4, zrow, Lw4 + (hd * 32 + 4 * h) / 4, t, n, Wp, h, out + (size_t)b * n * C + hd * 32 + 4 * h);
+    }
+}
+
+}  // namespace qkc
+
+// 16-bit-activation callers only (the operands of the products are bf16): head dimension 32 (so C = 32 heads, heads a power of two up to 16),
+// 16-byte-aligned d.  ONE launch when the plane has at most 64 tokens and its image (+ halo) fits the CU's LDS (at most 8 heads above 32 tokens);
+// else two launches and a workspace (at most 8 heads).  RCX_ATTN_FUSED=0: off, RCX_ATTN_FUSED=short: the one-launch form only (A/B).
+static bool pow2_heads(int heads) { return heads > 0 && heads <= 16 && !(heads & (heads - 1)); }
+static bool qkc_short(int Hp, int Wp, int C, int heads)
+{
+    const int n = Hp * Wp;
+    if (n > 64 || (n > 32 && heads > 8)) return false;
+    return qkc::short_lds_bytes(n <= 32 ? 1 : 2, Wp, C) <= 160 * 1024;
+}
+bool recattn_qkcore_applicable(int B, int Hp, int Wp, int C, int heads)
+{
+    const char* v = rcx::opt::value(rcx::opt::ATTN_FUSED);
+    if (v && *v == '0') return false;
+    if (!(B > 0 && Hp > 0 && Wp > 0 && pow2_heads(heads) && C == 32 * heads)) return false;
+    if (qkc_short(Hp, Wp, C, heads)) return true;
+    if ((v && *v == 's') || heads > 8) return false;
+    if ((size_t)Hp * Wp * C * 4 >= (size_t)1 << 31 || B > 65535) return false;
+    const qkc::LongGeo g = qkc::long_geo(B, Hp, Wp, C, heads);
+    return g.lds_out <= 160 * 1024 && g.G <= 65535;
+}
+
+int recattn_qkcore_launches(int B, int Hp, int Wp, int C, int heads)
+{
+    if (!recattn_qkcore_applicable(B, Hp, Wp, C, heads)) return 0;
+    return qkc_short(Hp, Wp, C, heads) ? 1 : 2;
+}
+
+size_t recattn_qkcore_workspace_bytes(int B, int Hp, int Wp, int C, int heads)
+{
+    if (!recattn_qkcore_applicable(B, Hp, Wp, C, heads) || qkc_short(Hp, Wp, C, heads)) return 0;
+    return qkc::long_geo(B, Hp, Wp, C, heads).ws_bytes;
+}
+
+template <int KS>
+static hipError_t launch_long(const float* d, const bf16_t* wqk, const float* bqk, const float* wpe, const float* bpe, float* out, float* ws,
+                              int B, int Hp, int Wp, int C, int heads, hipStream_t s)
+{
+    const qkc::LongGeo g = qkc::long_geo(B, Hp, Wp, C, heads);
+    {
+        auto kfn = qkc::k_recattn_kv<KS>;
+        RCX_SET_LDS_ONCE(kfn, g.lds_kv);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)g.GA, (unsigned)B), dim3(1024), g.lds_kv, s, d, wqk, bqk, ws, Hp * Wp, C, heads, g.SA, g.tpgA, g.ntiles);
+    }
+    {
+        auto kfn = qkc::k_recattn_out<KS, 512>;
+        RCX_SET_LDS_ONCE(kfn, g.lds_out);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)g.G, (unsigned)B), dim3(512), g.lds_out, s, d, wqk, bqk, wpe, bpe, ws, out, Hp, Wp, C, heads, g.S, g.tpg, g.ntiles, g.rows, g.GA);
+    }
+    return hipGetLastError();
+}
+
+template <int NT, int KS>
+static hipError_t launch_short(const float* d, const bf16_t* wqk, const float* bqk, const float* wpe, const float* bpe, float* out, int B, int Hp, int Wp, hipStream_t s)
+{
+    const size_t lds = qkc::short_lds_bytes(NT, Wp, 32 * KS);
+    auto kfn = qkc::k_recattn_short<NT, KS>;
+    RCX_SET_LDS_ONCE(kfn, lds);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(64 * KS), lds, s, d, wqk, bqk, wpe, bpe, out, Hp, Wp);
+    return hipGetLastError();
+}
+
+hipError_t recattn_qkcore(const float* d, const void* wqk_bf16, const float* bqk, const float* wpe, const float* bpe, float* out, void* workspace,
+                          int B, int Hp, int Wp, int C, int heads, hipStream_t s)
+{
+    const bf16_t* w = (const bf16_t*)wqk_bf16;
+    if (qkc_short(Hp, Wp, C, heads)) {
+        const bool one = Hp * Wp <= 32;
+        switch (heads) {                  // = C / 32 = the k-steps of the projection (C / 2 inputs, 16 per step)
+            case 1: return one ? launch_short<1, 1>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, s) : launch_short<2, 1>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, s);
+            case 2: return one ? launch_short<1, 2>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, s) : launch_short<2, 2>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, s);
+            case 4: return one ? launch_short<1, 4>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, s) : launch_short<2, 4>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, s);
+            case 8: return one ? launch_short<1, 8>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, s) : launch_short<2, 8>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, s);
+            case 16: return one ? launch_short<1, 16>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, s) : hipErrorInvalidConfiguration;
+            default: return hipErrorInvalidConfiguration;
+        }
+    }
+    float* ws = (float*)workspace;
+    switch (heads) {
+        case 1: return launch_long<1>(d, w, bqk, wpe, bpe, out, ws, B, Hp, Wp, C, heads, s);
+        case 2: return launch_long<2>(d, w, bqk, wpe, bpe, out, ws, B, Hp, Wp, C, heads, s);
+        case 4: return launch_long<4>(d, w, bqk, wpe, bpe, out, ws, B, Hp, Wp, C, heads, s);
+        case 8: return launch_long<8>(d, w, bqk, wpe, bpe, out, ws, B, Hp, Wp, C, heads, s);
+        default: return hipErrorInvalidConfiguration;
+    }
+}
+
+}  // namespace rcx

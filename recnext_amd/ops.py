@@ -365,6 +365,35 @@ def linear_attention_core_pe(qpre, kpre, v, w_pe_kkc, b_pe, heads):
     return out
 
 
+def recattn_qkcore_supported(c, heads, h, w):
+    """Whether recattn_qkcore has a kernel for this coarse plane (rcx_recattn_qkcore_launches: 32-wide heads, 1/2/4/8/16 of them; one launch for
+    planes of at most 64 tokens that fit the LDS, two launches otherwise)."""
+    return _lib.load().rcx_recattn_qkcore_launches(1, h, w, c, heads) > 0
+
+
+def recattn_qkcore(d, wqk_bf16, bqk, w_pe_kkc, b_pe, heads):
+    """RecAttn2d's coarse level on the matrix cores (rcx_recattn_qkcore_fwd; one launch up to 64 tokens, two above): d float32 N x C x h x w channels_last; wqk_bf16 (2C, C/2) bfloat16, bqk (2C)
+    float32, the pe packs as linear_attention_core_pe.  Returns the attention output + pe, float32 channels_last like d."""
+    d = _nhwc(d, "d")
+    b, c, h, w = d.shape
+    if d.dtype != torch.float32:
+        raise ValueError("d must be float32 (the coarse chain of RecAttn2d)")
+    if wqk_bf16.dtype != torch.bfloat16 or tuple(wqk_bf16.shape) != (2 * c, c // 2) or not wqk_bf16.is_contiguous():
+        raise ValueError(f"wqk_bf16 must be a contiguous ({2 * c}, {c // 2}) bfloat16 tensor")
+    if bqk.dtype != torch.float32 or bqk.numel() != 2 * c:
+        raise ValueError("bqk must be float32 of 2C elements")
+    out = _empty_nhwc(b, c, h, w, torch.float32, d.device)
+    lib = _lib.load()
+    need = lib.rcx_recattn_qkcore_workspace_bytes(b, h, w, c, heads)               # the k^T v partial sums of the two-launch form (> 64 tokens)
+    ws = torch.empty(need, dtype=torch.uint8, device=d.device) if need else None
+    with _on(d.device):
+        rc = lib.rcx_recattn_qkcore_fwd(d.data_ptr(), wqk_bf16.data_ptr(), bqk.data_ptr(), w_pe_kkc.data_ptr(),
+                                        b_pe.data_ptr() if b_pe is not None else None, out.data_ptr(),
+                                        ws.data_ptr() if ws is not None else None, need, b, h, w, c, heads, _stream(d.device))
+    _lib.check(rc, "rcx_recattn_qkcore_fwd")
+    return out
+
+
 def linear_attention_core_backward(qpre, kpre, v, gout, heads):
     """Gradients of linear_attention_core with respect to qpre, kpre (B, n, C) and v (N x C x h x w); dL/dpe = gout."""
     v = _nhwc(v, "v")

@@ -149,7 +149,8 @@ class RecAttn2d(nn.Module):
                               ops.pack_dw_weight(wc.float()), None if bc is None else ops.pack_bias(bc.float()),
                               wqk[:c, :, 0, 0].float().contiguous(), zeros(bqk, 2 * c)[:c].contiguous(),        # float32 GEMM operands: the coarse chain is float32
                               wqk[c:, :, 0, 0].float().contiguous(), zeros(bqk, 2 * c)[c:].contiguous(),
-                              ops.pack_dw_weight(wpe.float()), None if bpe is None else ops.pack_bias(bpe.float()))
+                              ops.pack_dw_weight(wpe.float()), None if bpe is None else ops.pack_bias(bpe.float()),
+                              wqk[:, :, 0, 0].float().to(torch.bfloat16).contiguous(), zeros(bqk, 2 * c).contiguous())     # the one-launch form's operands
             self._pack_key = key
         return self._pack
 
@@ -162,7 +163,7 @@ class RecAttn2d(nn.Module):
             d = _conv_norm_train(self.down[0], x, 2)
             a = self.down[1](d)
             return _conv_norm_train(self.conv, x + F.interpolate(a, size=x.shape[2:], mode=self.mode), 1)
-        wd, bd, wc, bc, wq, bq, wk, bk, wpe, bpe = self.packed_params()
+        wd, bd, wc, bc, wq, bq, wk, bk, wpe, bpe, wqk16, bqk = self.packed_params()
         k = self.kernel_size
         la = self.down[1]
         if x.shape[1] % la.num_heads or not head_dim_supported(x.shape[1] // la.num_heads):
@@ -170,6 +171,11 @@ class RecAttn2d(nn.Module):
         # the coarse chain in float32 (quarter-size tensors: ~1/4 of x's bytes per tensor even at twice the element size)
         d = ops.dwconv2d(x, wd, bd, k=k, stride=2, out_dtype=torch.float32)        # ConvNorm(dw k5 s2), :61
         b, c, h, w = d.shape
+        if x.dtype != torch.float32 and ops.recattn_qkcore_supported(c, la.num_heads, h, w):
+            # 16-bit activations, short sequences (the 14 x 14 and 7 x 7 stages): projection + core + pe in ONE launch, one wave per (image, head),
+            # bf16 operands on the matrix cores with float32 accumulation (rcx_recattn_qkcore_fwd, round 4); :21-27 / :44-50
+            a = ops.recattn_qkcore(d, wqk16, bqk, wpe, bpe, la.num_heads)
+            return ops.upadd_dwconv(x, a, wc, bc, k=k, mode=self.mode)              # conv(x + resize(.)), :67
         tok = d.permute(0, 2, 3, 1).reshape(b * h * w, c)                           # NHWC storage viewed token-major, no copy
         qpre = F.linear(tok[:, :c // 2], wq, bq).view(b, h * w, c)                  # grouped 1x1 conv = two GEMMs, :21 / :44
         kpre = F.linear(tok[:, c // 2:], wk, bk).view(b, h * w, c)

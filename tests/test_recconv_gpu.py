@@ -402,6 +402,42 @@ def test_upadd_dwconv_piece(mode, shape, cdtype):
     assert np.allclose(y0.cpu().numpy(), c_oracle.dwconv2d(x, wt, None, 1), atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("mode", ["bilinear", "nearest"])
+@pytest.mark.parametrize("c", [16, 100, 512])
+@pytest.mark.parametrize("dts", [(torch.bfloat16, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32), (torch.float16, torch.float32)],
+                         ids=["bf16+f32", "bf16+bf16", "f32", "f16+f32"])
+def test_7x7_whole_plane_step_kernels(mode, c, dts, monkeypatch):
+    """The two single steps of RecAttn2d's last stage on their own kernels (k_down5_cpl7, k_upadd_cpl7, round 4; model/recattn.py:61 / :67 on a
+    7 x 7 plane): against the C oracle, and -- float32, where both are exact to round-off -- against the any-shape kernel they replace
+    (RCX_UPADD_CPL=14).  Ragged channel counts (16, 100) and the compile-time C = 512 of RecNeXt-A3."""
+    xdt, cdt = dts
+    rng = np.random.default_rng(c + len(mode))
+    x = bf16_round_np(rng.standard_normal((3, c, 7, 7)).astype(np.float32))
+    cs = bf16_round_np(rng.standard_normal((3, c, 4, 4)).astype(np.float32))
+    wt = (rng.standard_normal((c, 1, 5, 5)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(c).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev())
+    wp, bp = ops.pack_dw_weight(t(wt)), ops.pack_bias(t(b))
+    assert ops.upadd_dwconv_plan(3, c, 7, 7, 4, 4, 5, mode, xdt, cdt, xdt) == "upadd_cpl14(k_upadd_cpl7)"
+    ref = c_oracle.dwconv2d(c_oracle.add_resized(x, cs, mode), wt, b, 1)
+    y = ops.upadd_dwconv(t(x).to(xdt), t(cs).to(cdt), wp, bp, k=5, mode=mode)
+    assert y.dtype == xdt
+    tol = dict(atol=2e-5, rtol=1e-5) if xdt == torch.float32 else dict(atol=BF16_ATOL, rtol=BF16_RTOL)
+    assert np.allclose(y.float().cpu().numpy(), ref, **tol), np.abs(y.float().cpu().numpy() - ref).max()
+    nob = ops.upadd_dwconv(t(x).to(xdt), t(cs).to(cdt), wp, None, k=5, mode=mode)
+    assert np.allclose(nob.float().cpu().numpy(), ref - b[None, :, None, None], **tol)
+    dref = c_oracle.dwconv2d(x, wt, b, 2)
+    dd = ops.dwconv2d(t(x).to(xdt), wp, bp, k=5, stride=2, out_dtype=torch.float32)
+    assert dd.dtype == torch.float32 and tuple(dd.shape) == dref.shape
+    assert np.allclose(dd.cpu().numpy(), dref, atol=2e-5, rtol=1e-5), np.abs(dd.cpu().numpy() - dref).max()
+    monkeypatch.setenv("RCX_UPADD_CPL", "14")
+    assert ops.upadd_dwconv_plan(3, c, 7, 7, 4, 4, 5, mode, xdt, cdt, xdt) != "upadd_cpl14(k_upadd_cpl7)"
+    y_any = ops.upadd_dwconv(t(x).to(xdt), t(cs).to(cdt), wp, bp, k=5, mode=mode)
+    d_any = ops.dwconv2d(t(x).to(xdt), wp, bp, k=5, stride=2, out_dtype=torch.float32)
+    assert torch.allclose(d_any, dd, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(y_any.float(), y.float(), **tol)
+
+
 # ---- full BASELINE sizes: size-independent properties + spot checks against the oracle ----
 FULL = [
     ("M1 cfg2 stage1", 256, 96, 28, 28, 3),
@@ -643,6 +679,48 @@ def test_linear_attention_core(case, dtype):
         pe0 = ops.dwconv2d(dd, ops.pack_dw_weight(t(w_pe)), None, k=3, stride=1)
         want0 = ops.linear_attention_core(qpre, kpre, dd, pe0, heads)
         assert torch.allclose(nob.float(), want0.float(), atol=2e-2 if dtype != torch.float32 else 1e-4, rtol=1e-2)
+
+
+@pytest.mark.parametrize("case", [(3, 256, 8, 7, 7), (2, 512, 16, 4, 4), (5, 64, 2, 7, 7), (1, 128, 4, 8, 8), (2, 256, 8, 5, 9), (9, 32, 1, 3, 3),
+                                  (3, 64, 2, 28, 28), (2, 128, 4, 14, 14), (2, 64, 2, 9, 11), (1, 32, 1, 10, 10), (2, 256, 8, 10, 9), (1, 64, 2, 65, 1),
+                                  (2, 64, 2, 56, 56), (1, 128, 4, 1, 130)], ids=lambda c: "x".join(map(str, c)))
+def test_recattn_qkcore_one_launch_against_the_two_step_path_and_the_oracle(case):
+    """rcx_recattn_qkcore_fwd (round 4): the qk projection + the attention core + pe on the matrix cores (bf16 operands, float32 accumulation) against
+    (a) the NumPy restatement of model/recattn.py:16-28 in float64 and (b) the float32 two-step HIP path (float32 GEMMs + rcx_linear_attention_pe_fwd)
+    -- both within north_star's 1e-2 for 16-bit-activation runs.  Up to 64 tokens one launch (one wave per (image, head)): 49 / 16 tokens are
+    RecNeXt-A3's stages 2 and 3, the others ragged token counts (64 = two full tiles, 45, 9) and head counts.  Above 64 tokens two launches (k^T v
+    partial sums, then the outputs): 784 / 196 tokens are A3's stages 0 and 1, 3 136 the first stage of a 448 x 448 input (several ranges in both
+    kernels), the others ragged counts, one-row and one-column planes (the 3x3 of pe at every border)."""
+    from oracle import recconv_np
+    b, c, heads, h, w = case
+    rng = np.random.default_rng(c * 31 + h)
+    d = rng.standard_normal((b, c, h, w)).astype(np.float32)
+    w_qk = (rng.standard_normal((2 * c, c // 2, 1, 1)) * (2.0 / c) ** 0.5).astype(np.float32)
+    b_qk = (rng.standard_normal(2 * c) * 0.1).astype(np.float32)
+    w_pe = (rng.standard_normal((c, 1, 3, 3)) * 0.2).astype(np.float32)
+    b_pe = (rng.standard_normal(c) * 0.1).astype(np.float32)
+    ref = recconv_np.linear_attention(d.astype(np.float64), w_qk, b_qk, w_pe, b_pe, heads, variant=1)
+    t = lambda a: torch.from_numpy(a).to(dev())
+    dd = t(d).contiguous(memory_format=torch.channels_last)
+    assert ops.recattn_qkcore_supported(c, heads, h, w)
+    wpe, bpe = ops.pack_dw_weight(t(w_pe)), ops.pack_bias(t(b_pe))
+    got = ops.recattn_qkcore(dd, t(w_qk[:, :, 0, 0]).to(torch.bfloat16).contiguous(), t(b_qk), wpe, bpe, heads)
+    assert got.dtype == torch.float32 and got.shape == dd.shape
+    assert torch.equal(got, ops.recattn_qkcore(dd, t(w_qk[:, :, 0, 0]).to(torch.bfloat16).contiguous(), t(b_qk), wpe, bpe, heads)), "not deterministic"
+    g = got.cpu().numpy()
+    tok = dd.permute(0, 2, 3, 1).reshape(b * h * w, c)
+    qpre = torch.nn.functional.linear(tok[:, :c // 2], t(w_qk[:c, :, 0, 0]), t(b_qk[:c])).view(b, h * w, c)
+    kpre = torch.nn.functional.linear(tok[:, c // 2:], t(w_qk[c:, :, 0, 0]), t(b_qk[c:])).view(b, h * w, c)
+    two = ops.linear_attention_core_pe(qpre, kpre, dd, wpe, bpe, heads)
+    if two is None:                                                        # sequences the pe-fusing core does not take: pe as its own launch
+        two = ops.linear_attention_core(qpre, kpre, dd, ops.dwconv2d(dd, wpe, bpe, k=3, stride=1), heads)
+    two = two.cpu().numpy()
+    print(f"{'x'.join(map(str, case))}: one launch vs float64 oracle max|err| {np.abs(g - ref).max():.3e} (two-step float32 path: {np.abs(two - ref).max():.3e}), "
+          f"worst err/tol {(np.abs(g - ref) / (BF16_ATOL + BF16_RTOL * np.abs(ref))).max():.2f}")
+    assert np.allclose(g, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
+    assert np.allclose(g, two, atol=BF16_ATOL, rtol=BF16_RTOL)
+    nob = ops.recattn_qkcore(dd, t(w_qk[:, :, 0, 0]).to(torch.bfloat16).contiguous(), t(b_qk), wpe, None, heads).cpu().numpy()      # no pe bias pack
+    assert np.allclose(nob, g - b_pe[None, :, None, None], atol=1e-5, rtol=1e-5)
 
 
 @pytest.mark.parametrize("name", recattn_cases())

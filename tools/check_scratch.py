@@ -51,7 +51,7 @@ for (path, r), name in zip(rows, names):
     gated = False
     if m:
         gated = m.group(6) == "false" and not fp16
-    elif re.match(r"(cpl14::k_recconv_cpl14|cpl14::k_recconv_cpl7b|cpl14::k_upadd_cpl14|upcpt::k_upadd_cpt|upcpt::k_down5_cpt|upcpt::k_down7m2_cpt)<", short):
+    elif re.match(r"(cpl14::k_recconv_cpl14|cpl14::k_recconv_cpl7b|cpl14::k_upadd_cpl14|cpl14::k_upadd_cpl7|cpl14::k_down5_cpl7|upcpt::k_upadd_cpt|upcpt::k_down5_cpt|upcpt::k_down7m2_cpt)<", short):
         gated = not fp16
     flag = ""
     if priv:
