@@ -740,7 +740,8 @@ int rcx_recattn_qkcore_fwd(const float* d, const void* wqk_bf16, const float* bq
     if (!d || !wqk_bf16 || !bqk || !w_pe_kkc || !out) return fail(RCX_ERR_BAD_ARG, "rcx_recattn_qkcore_fwd: null pointer");
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive extent B=%d H=%d W=%d C=%d heads=%d", B, H, W, C, heads);
     if (C % heads) return fail(RCX_ERR_BAD_ARG, "C=%d is not a multiple of heads=%d", C, heads);
-    if (((size_t)d & 15) || ((size_t)wqk_bf16 & 15) || ((size_t)out & 15)) return fail(RCX_ERR_BAD_ARG, "rcx_recattn_qkcore_fwd: d, wqk and out must be 16-byte aligned");
+    if (((size_t)d & 15) || ((size_t)wqk_bf16 & 15) || ((size_t)out & 15) || ((size_t)bqk & 15) || ((size_t)w_pe_kkc & 15) || ((size_t)b_pe & 15))
+        return fail(RCX_ERR_BAD_ARG, "rcx_recattn_qkcore_fwd: d, wqk, bqk, w_pe_kkc, b_pe and out must be 16-byte aligned");
     if (!rcx::recattn_qkcore_applicable(B, H, W, C, heads))
         return fail(RCX_ERR_UNSUPPORTED, "rcx_recattn_qkcore_fwd: head dimension %d, %d heads, %d tokens, C=%d: the matrix-core form takes 32-wide heads, 1, 2, 4, 8 or "
                                          "16 of them; 16 only on planes of at most 32 tokens (rcx_recattn_qkcore_launches; use the projection GEMMs + "

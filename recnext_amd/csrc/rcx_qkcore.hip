@@ -46,11 +46,11 @@ __device__ __forceinline__ void wave_sync()
 __device__ __forceinline__ constexpr int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
 
-// rows [row0, row0 + nrows) of an image's d (float32, C channels) -> LDS rows of DROW floats, 16 bytes per lane and EIGHT requests in flight per lane
+// rows [row0, row0 + nrows) of an image's d (float32, C channels) -> LDS rows of DROW floats, 16 bytes per lane and UN requests in flight per lane
 // (one request per iteration costs a memory round trip per 16 bytes: 8 round trips for a 49 x 256 image).  Rows outside the image read 0.
+template <int UN = 8>
 __device__ __forceinline__ void stage_rows(float* Ld, __amdgpu_buffer_rsrc_t dsrc, int row0, int nrows, int C, int DROW, int nthr)
 {
-    constexpr int UN = 8;
     const int cq = C / 4, chunks = nrows * cq;
     for (int i0 = threadIdx.x; i0 < chunks; i0 += UN * nthr) {
         u32x4q v[UN];
@@ -77,6 +77,26 @@ __device__ __forceinline__ void stage_rows(float* Ld, __amdgpu_buffer_rsrc_t dsr
 //                  registers, which is the B operand of out^T = kv^T q^T as it stands, kv^T being the kv accumulator as it stands: no transpose
 //                  through LDS), the normaliser (lane partial + its partner lane), pe as float4s of the lane's token, 16-byte stores.
 // A lane of out^T holds channels 8 g + 4 h + (0..3), g = 0..3, of its token: registers 4 g .. 4 g + 3.
+
+// the pe taps (9 x C), the pe bias and the q biases -> Lw[0, 11 C): 16 bytes per lane, every request issued before the first store (the plain loops
+// were four to five dependent L2 round trips).  9 C / 4 <= 2 NTHR and C / 4 <= NTHR for every instantiation (C = 32 KS, NTHR >= 64 KS or 512).
+template <int C, int NTHR>
+__device__ __forceinline__ void stage_small(float* Lw, const float* __restrict__ wpe, const float* __restrict__ bpe, const float* __restrict__ bqk)
+{
+    static_assert(9 * C / 4 <= 2 * NTHR && C / 4 <= NTHR, "stage_small: one or two requests per lane");
+    const int i = threadIdx.x;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* w4 = reinterpret_cast<const float4*>(wpe);
+    float4 a0 = z, a1 = z, b0 = z, c0 = z;              // (`cond ? p[i] : z` selects between ADDRESSES and puts z in scratch)
+    if (i < 9 * C / 4) a0 = w4[i];
+    if (i + NTHR < 9 * C / 4) a1 = w4[i + NTHR];
+    if (bpe && i < C / 4) b0 = reinterpret_cast<const float4*>(bpe)[i];
+    if (i < C / 4) c0 = reinterpret_cast<const float4*>(bqk)[i];
+    float4* L4 = reinterpret_cast<float4*>(Lw);
+    if (i < 9 * C / 4) L4[i] = a0;
+    if (i + NTHR < 9 * C / 4) L4[i + NTHR] = a1;
+    if (i < C / 4) { L4[9 * C / 4 + i] = b0; L4[10 * C / 4 + i] = c0; }
+}
 
 // The end of a 32-token tile once q^T is accumulated (aq: rows c1 in the registers, column = the lane's token t): bias + activation, the normaliser
 // (the lane's 16 channels + its partner lane's), out^T = kv^T q^T, pe as float4s of the lane's token and 16-byte stores.  drow = the token's row of
@@ -146,7 +166,7 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
                 const float* __restrict__ bpe, float* __restrict__ out, int Hp, int Wp)
 {
     extern __shared__ __attribute__((aligned(16))) float lds_s[];
-    constexpr int C = 32 * KS, K = C / 2, DROW = C + DPAD, DROW4 = DROW / 4, NTHR = 64 * KS, PF = KS < 4 ? KS : 4;
+    constexpr int C = 32 * KS, K = C / 2, DROW = C + DPAD, DROW4 = DROW / 4, NTHR = 64 * KS, PF = KS < 8 ? KS : 8;        // weight fragments in flight: a ring 4 deep left ~0.4 us of L2 latency exposed at every refill
     const int hd = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int b = blockIdx.x, n = Hp * Wp, rows = NT * 32 + 2 * Wp + 2, R0 = -Wp - 1;
     float* const Ld = lds_s;                                  // [rows + 1][DROW]: tokens R0 .. of the image (zeros outside it), then a row of zeros
@@ -161,10 +181,10 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
 #pragma unroll
     for (int j = 0; j < PF; ++j) wf[j] = *reinterpret_cast<const u32x4q*>(wk_row + 16 * j);
 
-    stage_rows(Ld, dsrc, R0, rows, C, DROW, NTHR);
+    const float bk = bqk[C + hd * 32 + r];
+    stage_rows<NT == 2 ? 12 : 6>(Ld, dsrc, R0, rows, C, DROW, NTHR);      // rows / 8 requests per lane: the whole image in one round trip up to 14 x 14 / 7 x 7 planes
     for (int i = threadIdx.x; i < DROW; i += NTHR) Ld[(size_t)rows * DROW + i] = 0.f;
-    for (int i = threadIdx.x; i < 9 * C; i += NTHR) Lw[i] = wpe[i];
-    for (int i = threadIdx.x; i < C; i += NTHR) { Lw[9 * C + i] = bpe ? bpe[i] : 0.f; Lw[10 * C + i] = bqk[i]; }
+    stage_small<C, NTHR>(Lw, wpe, bpe, bqk);
     __syncthreads();
 
     // ---- 1. k tiles (lane = channel hd * 32 + r, tokens in the registers), kv
@@ -173,6 +193,14 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
     for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[tt][i] = 0.f;
+    // the d fragments of k-step s + 1 are read from LDS before the products of k-step s are issued (the compiler waits for every read in
+    // front of the product that uses it: ~190 cycles a step instead of the product's 64)
+    float4 xf[2][NT][2];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+        const float4* pa = Ld4 + (32 * tt + r - R0) * DROW4 + K / 4 + 2 * h;
+        xf[0][tt][0] = pa[0]; xf[0][tt][1] = pa[1];
+    }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const bf16x8 bk8 = __builtin_bit_cast(bf16x8, wf[s % PF]);
@@ -180,15 +208,19 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
         else wf[s % PF] = *reinterpret_cast<const u32x4q*>(wq_row + 16 * (s + PF - KS));          // the ring rolls over into the q weights
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
-            const float4* pa = Ld4 + (32 * tt + r - R0) * DROW4 + K / 4 + 4 * s + 2 * h;      // token 32 tt + r, inputs 16 s + 8 h .. + 7 of the k half
-            const float4 x0 = pa[0], x1 = pa[1];
+            // next: k-step s + 1 of the k half, or k-step 0 of the q half
+            const float4* pa = Ld4 + (32 * tt + r - R0) * DROW4 + (s + 1 < KS ? K / 4 + 4 * (s + 1) : 0) + 2 * h;
+            xf[(s + 1) & 1][tt][0] = pa[0]; xf[(s + 1) & 1][tt][1] = pa[1];
+        }
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const float4 x0 = xf[s & 1][tt][0], x1 = xf[s & 1][tt][1];          // token 32 tt + r, inputs 16 s + 8 h .. + 7 of the k half
             bf16x8 fa;
             fa[0] = (__bf16)x0.x; fa[1] = (__bf16)x0.y; fa[2] = (__bf16)x0.z; fa[3] = (__bf16)x0.w;
             fa[4] = (__bf16)x1.x; fa[5] = (__bf16)x1.y; fa[6] = (__bf16)x1.z; fa[7] = (__bf16)x1.w;
             acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, bk8, acc[tt], 0, 0, 0);
         }
     }
-    const float bk = bqk[C + hd * 32 + r];
     const float* const Lv = Ld + hd * 32 + r;                 // this lane's channel of d: v
     f32x16 kv;
 #pragma unroll
@@ -227,10 +259,16 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
     for (int s = 0; s < KS; ++s) {
         const bf16x8 bq8 = __builtin_bit_cast(bf16x8, wf[(s + KS) % PF]);
         if (s + PF < KS) wf[(s + KS) % PF] = *reinterpret_cast<const u32x4q*>(wq_row + 16 * (s + PF));
+        if (s + 1 < KS) {
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                const float4* pa = Ld4 + (32 * tt + r - R0) * DROW4 + 4 * (s + 1) + 2 * h;
+                xf[(s + 1 + KS) & 1][tt][0] = pa[0]; xf[(s + 1 + KS) & 1][tt][1] = pa[1];
+            }
+        }
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
-            const float4* pa = Ld4 + (32 * tt + r - R0) * DROW4 + 4 * s + 2 * h;              // token 32 tt + r, inputs 16 s + 8 h .. + 7 of the q half
-            const float4 x0 = pa[0], x1 = pa[1];
+            const float4 x0 = xf[(s + KS) & 1][tt][0], x1 = xf[(s + KS) & 1][tt][1];          // token 32 tt + r, inputs 16 s + 8 h .. + 7 of the q half
             bf16x8 fb;
             fb[0] = (__bf16)x0.x; fb[1] = (__bf16)x0.y; fb[2] = (__bf16)x0.z; fb[3] = (__bf16)x0.w;
             fb[4] = (__bf16)x1.x; fb[5] = (__bf16)x1.y; fb[6] = (__bf16)x1.z; fb[7] = (__bf16)x1.w;
@@ -380,8 +418,7 @@ k_recattn_out(const float* __restrict__ d, const bf16_t* __restrict__ wqk, const
     stage_rows(Ld, dsrc, R0, rows, C, DROW, NTHR);
     __builtin_amdgcn_sched_barrier(0);            // keep the loads below from being hoisted among the staging requests (register pressure)
     for (int i = threadIdx.x; i < DROW; i += NTHR) Ld[(size_t)rows * DROW + i] = 0.f;
-    for (int i = threadIdx.x; i < 9 * C; i += NTHR) Lw[i] = wpe[i];
-    for (int i = threadIdx.x; i < C; i += NTHR) { Lw[9 * C + i] = bpe ? bpe[i] : 0.f; Lw[10 * C + i] = bqk[i]; }
+    stage_small<C, NTHR>(Lw, wpe, bpe, bqk);
     // this head's weights and the partial sums (requested after the staging loop, whose eight 16-byte requests per lane would otherwise be live with them: 166-202 registers; waited for at the barrier)
     const bf16_t* wq_row = wqk + (size_t)(hd * 32 + r) * K + 8 * h;
     bf16x8 wq[KS];
