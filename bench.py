@@ -83,7 +83,7 @@ def parse_args():
 
 class MixerTimers:
     """HIP events around token-mixer calls (recorded on the stream the kernels are launched on): RecConv2d is one kernel
-    launch; RecAttn2d (A family) is a unit of four HIP kernels and two GEMMs and is reported as such.
+    launch; RecAttn2d (A family) is a unit of three or four HIP kernels (or four and two GEMMs) and is reported as such.
 
     Every event pair costs the stream ~2.5 us (the marker packets keep the next kernel from starting early): 40 pairs a step are
     2.7 % of RecNeXt-M3's step (tools/graph_probe.py: 63.8 k img/s without any, 62.1 k with all).  So the warm-up steps bracket
@@ -135,7 +135,7 @@ class MixerTimers:
             avg_ms = ent["ms"] / ent["calls"]
             if level is None:                 # RecAttn2d: compulsory bytes of its depthwise pieces, 3.5 * S per block
                 alg = int(3.5 * n * c * h * w * elem_bytes)
-                plan = "recattn2d(conv5 stride 2 + qk GEMMs + pe conv + k_linattn_core4 + conv5(x + resize))"
+                plan = "recattn2d(conv5 stride 2 + qk projection / attention core / pe [rcx_recattn_qkcore_fwd: 1-2 launches; or 2 GEMMs + k_linattn_core4] + conv5(x + resize))"
             else:
                 alg = 2 * n * c * h * w * elem_bytes + (level + 2) * c * k * k * elem_bytes
                 plan = plan_of(n, c, h, w, level, k)

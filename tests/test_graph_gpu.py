@@ -6,7 +6,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["recnext_m0", "recnext_a0"])
+@pytest.mark.parametrize("name", ["recnext_m0", "recnext_a0", "recnext_a3"])          # a3: the matrix-core RecAttn2d kernels and their workspace inside a capture
 def test_graph_replay_equals_eager(name):
     from recnext_amd.graph import GraphedInference
     from recnext_amd.speed import build_inference_model, synthetic_batch
