@@ -202,6 +202,16 @@ int rcx_recattn_qkcore_fwd(const float* d, const void* wqk_bf16, const float* bq
                            void* workspace, size_t workspace_bytes, int B, int H, int W, int C, int heads, void* stream);
 
 /*
+ * The same preceded by RecAttn2d's stride-2 depthwise 5x5 ConvNorm (model/recattn.py:12 / :61, BatchNorm folded) in the same launch: x -> d stays in
+ * LDS, d never exists in memory.  x: B x H x W x C bf16 / f16 NHWC; w_down_kkc (5,5,C) / b_down (C, may be NULL) float32 as rcx_dwconv2d_fwd takes
+ * them; the rest as rcx_recattn_qkcore_fwd; out: B x ceil(H/2) x ceil(W/2) x C float32.  Planes 14 x 14 (1 .. 8 heads) and 7 x 7 (1 .. 16 heads) only --
+ * RecNeXt-A's stages 2 and 3 at 224 x 224 -- rcx_recattn_down_qkcore_supported() says (1 / 0); else RCX_ERR_UNSUPPORTED.
+ */
+int rcx_recattn_down_qkcore_supported(int B, int H, int W, int C, int heads, int x_dtype);
+int rcx_recattn_down_qkcore_fwd(const void* x, const float* w_down_kkc, const float* b_down, const void* wqk_bf16, const float* bqk,
+                                const float* w_pe_kkc, const float* b_pe, float* out, int B, int H, int W, int C, int heads, int x_dtype, void* stream);
+
+/*
  * Backward of rcx_linear_attention_fwd (the gradients engine.py:48-64 needs through RecAttn2d, model/recattn.py:16-28 / :39-51):
  *   given gout = dL/dout (B x n x C), writes gq = dL/dqpre, gk = dL/dkpre, gv = dL/dv (all B x n x C, `dtype`); dL/dpe = gout is the
  *   caller's.  float32 arithmetic, deterministic (fixed summation order).  C/heads at most 64.

@@ -176,7 +176,7 @@ hipError_t step_dwconv(const void* x, void* y, const float* w, const float* b, i
                        int in_dt, int out_dt, hipStream_t s)
 {
     switch (pick_dwconv(N, C, H, W, k, stride, in_dt, out_dt)) {
-    case STEP_CPL14: return rcx::down5_cpl7(x, y, w, b, N, C, in_dt, s);
+    case STEP_CPL14: return rcx::down5_cpl7(x, y, w, b, N, C, H, in_dt, s);
     case STEP_LANES: return rcx::down5_lanes(x, y, w, b, N, C, H, W, in_dt, out_dt, s);
     case STEP_CPT: return rcx::down5_cpt(x, y, w, b, N, C, H, W, in_dt, out_dt, s);
     case STEP_CONV5_LANES: return rcx::conv5_lanes(x, y, w, b, N, C, H, W, in_dt, s);
@@ -751,6 +751,29 @@ int rcx_recattn_qkcore_fwd(const float* d, const void* wqk_bf16, const float* bq
         return fail(RCX_ERR_WORKSPACE, "rcx_recattn_qkcore_fwd: needs a 16-byte-aligned workspace of %zu bytes, got %zu", need, workspace ? workspace_bytes : (size_t)0);
     hipError_t e = rcx::recattn_qkcore(d, wqk_bf16, bqk, w_pe_kkc, b_pe, out, workspace, B, H, W, C, heads, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_recattn_qkcore_fwd");
+}
+
+int rcx_recattn_down_qkcore_supported(int B, int H, int W, int C, int heads, int x_dtype)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0 || C % heads) return 0;
+    return rcx::recattn_down_qkcore_applicable(B, H, W, C, heads, x_dtype) ? 1 : 0;
+}
+
+int rcx_recattn_down_qkcore_fwd(const void* x, const float* w_down_kkc, const float* b_down, const void* wqk_bf16, const float* bqk,
+                                const float* w_pe_kkc, const float* b_pe, float* out, int B, int H, int W, int C, int heads, int x_dtype, void* stream)
+{
+    if (!x || !w_down_kkc || !wqk_bf16 || !bqk || !w_pe_kkc || !out) return fail(RCX_ERR_BAD_ARG, "rcx_recattn_down_qkcore_fwd: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive extent B=%d H=%d W=%d C=%d heads=%d", B, H, W, C, heads);
+    if (C % heads) return fail(RCX_ERR_BAD_ARG, "C=%d is not a multiple of heads=%d", C, heads);
+    if (!known_dtype(x_dtype)) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", x_dtype);
+    if (((size_t)wqk_bf16 & 15) || ((size_t)out & 15) || ((size_t)bqk & 15) || ((size_t)w_pe_kkc & 15) || ((size_t)b_pe & 15))
+        return fail(RCX_ERR_BAD_ARG, "rcx_recattn_down_qkcore_fwd: wqk, bqk, w_pe_kkc, b_pe and out must be 16-byte aligned");
+    if (!rcx::recattn_down_qkcore_applicable(B, H, W, C, heads, x_dtype))
+        return fail(RCX_ERR_UNSUPPORTED, "rcx_recattn_down_qkcore_fwd: %d x %d plane, %d heads of %d, dtype %d: the one-launch form takes the 14 x 14 plane (1 .. 8 heads) "
+                                         "and the 7 x 7 plane (1 .. 16 heads) of bf16 / f16 activations, 32-wide heads (use rcx_dwconv2d_fwd + rcx_recattn_qkcore_fwd)",
+                    H, W, heads, C / heads, x_dtype);
+    hipError_t e = rcx::recattn_down_qkcore(x, w_down_kkc, b_down, wqk_bf16, bqk, w_pe_kkc, b_pe, out, B, H, C, heads, x_dtype, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "rcx_recattn_down_qkcore_fwd");
 }
 
 int rcx_linear_attention_bwd(const void* qpre, const void* kpre, const void* v, const void* gout, void* gq, void* gk, void* gv,

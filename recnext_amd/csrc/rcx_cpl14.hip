@@ -600,12 +600,12 @@ void k_upadd_cpl7(const TIO* __restrict__ x, const TC* __restrict__ coarse, TIO*
     });
 }
 
-// stride-2 conv5 of the 7x7 plane -> 4x4, float32 out (the input of RecAttn2d's coarse chain)
-template <int CT, typename TIO>
+// stride-2 conv5 of the 7x7 plane -> 4x4 (W = 7) or of the 14x14 plane -> 7x7 (W = 14), float32 out (the input of RecAttn2d's coarse chain)
+template <int W, int CT, typename TIO>
 __global__ __launch_bounds__(64)
 void k_down5_cpl7(const TIO* __restrict__ x, float* __restrict__ y, const float* __restrict__ w, const float* __restrict__ bias, int N, int C_rt)
 {
-    constexpr int W = 7, P = 4, W1 = 4, P1 = 2;
+    constexpr int P = (W + 1) / 2, W1 = (W + 1) / 2, P1 = (W1 + 1) / 2;
     const int C = CT > 0 ? CT : C_rt;
     const int nb = (C + 63) / 64;
     unsigned b = blockIdx.x;
@@ -813,20 +813,25 @@ bool upadd_cpl14_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, i
            (x_dt == 0 || x_dt == 1 || x_dt == 2) && (c_dt == x_dt || c_dt == 0);
 }
 
+// RCX_UPADD_CPL=7: the 14x14 -> 7x7 step stays on the lanes kernel (A/B)
 bool down5_cpl7_applicable(int N, int C, int H, int W, int k, int stride, int in_dt, int out_dt)
 {
     (void)N;
     const char* v = rcx::opt::value(rcx::opt::UPADD_CPL);
-    return cpl14::enabled() && !(v && *v == '0') && cpl7_steps() && H == 7 && W == 7 && k == 5 && stride == 2 && C >= 1 && out_dt == 0 &&
+    const bool plane = (H == 7 && W == 7) || (H == 14 && W == 14 && !(v && *v == '7') && in_dt != 0);
+    return cpl14::enabled() && !(v && *v == '0') && cpl7_steps() && plane && k == 5 && stride == 2 && C >= 1 && out_dt == 0 &&
            (in_dt == 0 || in_dt == 1 || in_dt == 2);
 }
 
-hipError_t down5_cpl7(const void* x, void* y, const float* w, const float* b, int N, int C, int in_dt, hipStream_t s)
+hipError_t down5_cpl7(const void* x, void* y, const float* w, const float* b, int N, int C, int H, int in_dt, hipStream_t s)
 {
     const unsigned grid = (unsigned)(N * ((C + 63) / 64));
-#define RCX_D7(CT_, T_) hipLaunchKernelGGL((cpl14::k_down5_cpl7<CT_, T_>), dim3(grid), dim3(64), 0, s, (const T_*)x, (float*)y, w, b, N, C)
-    if (C == 512) { if (in_dt == 0) RCX_D7(512, float); else if (in_dt == 1) RCX_D7(512, bf16_t); else RCX_D7(512, f16_t); }
-    else { if (in_dt == 0) RCX_D7(0, float); else if (in_dt == 1) RCX_D7(0, bf16_t); else RCX_D7(0, f16_t); }
+#define RCX_D7(W_, CT_, T_) hipLaunchKernelGGL((cpl14::k_down5_cpl7<W_, CT_, T_>), dim3(grid), dim3(64), 0, s, (const T_*)x, (float*)y, w, b, N, C)
+    if (H == 14) {
+        if (C == 256) { if (in_dt == 1) RCX_D7(14, 256, bf16_t); else RCX_D7(14, 256, f16_t); }
+        else { if (in_dt == 1) RCX_D7(14, 0, bf16_t); else RCX_D7(14, 0, f16_t); }
+    } else if (C == 512) { if (in_dt == 0) RCX_D7(7, 512, float); else if (in_dt == 1) RCX_D7(7, 512, bf16_t); else RCX_D7(7, 512, f16_t); }
+    else { if (in_dt == 0) RCX_D7(7, 0, float); else if (in_dt == 1) RCX_D7(7, 0, bf16_t); else RCX_D7(7, 0, f16_t); }
 #undef RCX_D7
     return hipGetLastError();
 }

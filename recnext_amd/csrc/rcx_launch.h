@@ -78,9 +78,9 @@ hipError_t down5_cpt(const void* x, void* y, const float* w, const float* b, int
 bool upadd_cpl14_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int x_dt, int c_dt, int out_dt);
 hipError_t upadd_cpl14(const void* x, const void* coarse, void* y, const float* w, const float* b, int N, int C, int H, int mode, int x_dt, int c_dt,
                        hipStream_t s);            // H = 14 (coarse 7 x 7) or 7 (coarse 4 x 4)
-// the stride-2 conv5 of the 7 x 7 plane, float32 out (round 4)
+// the stride-2 conv5 of the 7 x 7 plane (and of the 14 x 14 plane of 16-bit activations), float32 out (round 4)
 bool down5_cpl7_applicable(int N, int C, int H, int W, int k, int stride, int in_dt, int out_dt);
-hipError_t down5_cpl7(const void* x, void* y, const float* w, const float* b, int N, int C, int in_dt, hipStream_t s);
+hipError_t down5_cpl7(const void* x, void* y, const float* w, const float* b, int N, int C, int H, int in_dt, hipStream_t s);
 
 bool cpl7b_applicable(int N, int C, int H, int W, int level, int k, int dtype);
 int cpl7b_describe(int N, int C, int mode, char* buf, int len);
@@ -135,6 +135,10 @@ bool linattn_core_fuses_pe(int n, int C, int heads, int dtype);
 bool recattn_qkcore_applicable(int B, int Hp, int Wp, int C, int heads);
 int recattn_qkcore_launches(int B, int Hp, int Wp, int C, int heads);          // 0: no kernel for this shape, 1 / 2: launches
 size_t recattn_qkcore_workspace_bytes(int B, int Hp, int Wp, int C, int heads);
+// ... and with RecAttn2d's stride-2 conv inside (x = the 14 x 14 / 7 x 7 plane of 16-bit activations): one launch from x to the attention output
+bool recattn_down_qkcore_applicable(int B, int H, int W, int C, int heads, int x_dt);
+hipError_t recattn_down_qkcore(const void* x, const float* wdn, const float* bdn, const void* wqk_bf16, const float* bqk, const float* wpe, const float* bpe,
+                               float* out, int B, int H, int C, int heads, int x_dt, hipStream_t s);
 hipError_t recattn_qkcore(const float* d, const void* wqk_bf16, const float* bqk, const float* wpe, const float* bpe, float* out, void* workspace,
                           int B, int Hp, int Wp, int C, int heads, hipStream_t s);
 

@@ -160,10 +160,14 @@ __device__ __forceinline__ void out_epilogue(const f32x16& aq, bf16x8 kv0, bf16x
 // The first version kept q in the lane = channel form and took it through a wave-private LDS image for the second product, computed pe with 9
 // bounds-checked 4-byte LDS reads per output and divided per output: 26-28 us at 256 x 49 x 256, of which pe 8.5 (profiles/r04_recattn_one_launch.txt).
 // Weight fragments come from global memory (L2) through a ring PF k-steps deep; NT = 32-token tiles, KS = C / 32 = heads.
-template <int NT, int KS>
+// XW > 0: d is not read from memory but computed here, d = conv5 stride 2 (x) + bias of RecAttn2d.forward (model/recattn.py:61), from the image's XW x XW
+// plane of 16-bit activations (XW = 14 / 7: Hp = Wp = 7 / 4): two lanes per channel, each the upper / lower output rows, every x row loaded once and
+// scattered into the output rows it touches (float32).  Saves the stand-alone step's launch and d's trip through memory.
+template <int NT, int KS, int XW = 0, typename TX = bf16_t>
 __global__ void __launch_bounds__(NT == 1 ? 1024 : 512)
 k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, const float* __restrict__ bqk, const float* __restrict__ wpe,
-                const float* __restrict__ bpe, float* __restrict__ out, int Hp, int Wp)
+                const float* __restrict__ bpe, float* __restrict__ out, int Hp, int Wp,
+                const TX* __restrict__ x, const float* __restrict__ wdn, const float* __restrict__ bdn)
 {
     extern __shared__ __attribute__((aligned(16))) float lds_s[];
     constexpr int C = 32 * KS, K = C / 2, DROW = C + DPAD, DROW4 = DROW / 4, NTHR = 64 * KS, PF = KS < 8 ? KS : 8;        // weight fragments in flight: a ring 4 deep left ~0.4 us of L2 latency exposed at every refill
@@ -178,12 +182,65 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
     const bf16_t* wq_row = wqk + (size_t)(hd * 32 + r) * K + 8 * h;            // this lane's output channel, its 8 inputs of k-step 0
     const bf16_t* wk_row = wqk + (size_t)(C + hd * 32 + r) * K + 8 * h;
     u32x4q wf[PF];
+    if constexpr (XW == 0) {                                  // (with the conv inside: requested after it -- its 70 live registers leave no room at 16 waves)
 #pragma unroll
-    for (int j = 0; j < PF; ++j) wf[j] = *reinterpret_cast<const u32x4q*>(wk_row + 16 * j);
+        for (int j = 0; j < PF; ++j) wf[j] = *reinterpret_cast<const u32x4q*>(wk_row + 16 * j);
+    }
 
     const float bk = bqk[C + hd * 32 + r];
-    stage_rows<NT == 2 ? 12 : 6>(Ld, dsrc, R0, rows, C, DROW, NTHR);      // rows / 8 requests per lane: the whole image in one round trip up to 14 x 14 / 7 x 7 planes
-    for (int i = threadIdx.x; i < DROW; i += NTHR) Ld[(size_t)rows * DROW + i] = 0.f;
+    if constexpr (XW == 0) {
+        stage_rows<NT == 2 ? 12 : 6>(Ld, dsrc, R0, rows, C, DROW, NTHR);      // rows / 8 requests per lane: the whole image in one round trip up to 14 x 14 / 7 x 7 planes
+        for (int i = threadIdx.x; i < DROW; i += NTHR) Ld[(size_t)rows * DROW + i] = 0.f;
+    } else {
+        constexpr int WO = (XW + 1) / 2, RPP = (WO + 1) / 2, NXR = 2 * RPP + 3;          // output plane, output rows per lane, x rows they touch
+        static_assert(NTHR == 2 * C, "two lanes per channel");
+        const int c = threadIdx.x < C ? threadIdx.x : threadIdx.x - C, o0 = threadIdx.x < C ? 0 : WO - RPP;      // (per wave for C >= 64; C = 32 has both halves in its one wave)
+        const TX* xc = x + (size_t)b * XW * XW * C + c;
+        float wt[25];
+#pragma unroll
+        for (int j = 0; j < 25; ++j) wt[j] = wdn[j * C + c];
+        const float bias = bdn ? bdn[c] : 0.f;
+        // rows of the LDS image that are not tokens: zeros (the halo of pe, the rows of tokens past the plane, the zero row)
+        {
+            float4* L4 = reinterpret_cast<float4*>(lds_s);
+            const int tok0 = (Wp + 1) * DROW4, tok1 = (Wp + 1 + n) * DROW4, total = (rows + 1) * DROW4;
+            for (int i = threadIdx.x; i < total; i += NTHR)
+                if (i < tok0 || i >= tok1) L4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float a[RPP][WO];
+#pragma unroll
+        for (int o = 0; o < RPP; ++o)
+#pragma unroll
+            for (int j = 0; j < WO; ++j) a[o][j] = bias;
+#pragma unroll
+        for (int i = 0; i < NXR; ++i) {
+            const int y = 2 * o0 - 2 + i;
+            if (y >= 0 && y < XW) {
+                float xr[XW];
+#pragma unroll
+                for (int xx = 0; xx < XW; ++xx) xr[xx] = elem_to_f32(xc[(size_t)(y * XW + xx) * C]);
+#pragma unroll
+                for (int o = 0; o < RPP; ++o) {
+                    const int dy = i - 2 * o;                  // compile time after unrolling
+                    if (dy >= 0 && dy < 5) {
+#pragma unroll
+                        for (int j = 0; j < WO; ++j)
+#pragma unroll
+                            for (int dx = 0; dx < 5; ++dx) {
+                                const int xx = 2 * j - 2 + dx;
+                                if (xx >= 0 && xx < XW) a[o][j] = fmaf(wt[dy * 5 + dx], xr[xx], a[o][j]);
+                            }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < RPP; ++o)
+#pragma unroll
+            for (int j = 0; j < WO; ++j) Ld[(size_t)(Wp + 1 + (o0 + o) * Wp + j) * DROW + c] = a[o][j];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) wf[j] = *reinterpret_cast<const u32x4q*>(wk_row + 16 * j);
+    }
     stage_small<C, NTHR>(Lw, wpe, bpe, bqk);
     __syncthreads();
 
@@ -521,8 +578,55 @@ static hipError_t launch_short(const float* d, const bf16_t* wqk, const float* b
     const size_t lds = qkc::short_lds_bytes(NT, Wp, 32 * KS);
     auto kfn = qkc::k_recattn_short<NT, KS>;
     RCX_SET_LDS_ONCE(kfn, lds);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(64 * KS), lds, s, d, wqk, bqk, wpe, bpe, out, Hp, Wp);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(64 * KS), lds, s, d, wqk, bqk, wpe, bpe, out, Hp, Wp, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
     return hipGetLastError();
+}
+
+// the same with the stride-2 conv inside (XW = 14: 49 tokens, two tiles; XW = 7: 16 tokens, one tile)
+template <int NT, int KS, int XW, typename TX>
+static hipError_t launch_short_x(const void* x, const float* wdn, const float* bdn, const bf16_t* wqk, const float* bqk, const float* wpe, const float* bpe,
+                                 float* out, int B, hipStream_t s)
+{
+    constexpr int WO = (XW + 1) / 2;
+    const size_t lds = qkc::short_lds_bytes(NT, WO, 32 * KS);
+    auto kfn = qkc::k_recattn_short<NT, KS, XW, TX>;
+    RCX_SET_LDS_ONCE(kfn, lds);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(64 * KS), lds, s, (const float*)nullptr, wqk, bqk, wpe, bpe, out, WO, WO, (const TX*)x, wdn, bdn);
+    return hipGetLastError();
+}
+
+// RecAttn2d's stride-2 conv + coarse level in one launch: the 14 x 14 plane with 1 .. 8 heads, the 7 x 7 plane with 1 .. 16; 16-bit x.
+// RCX_ATTN_FUSED=nodown: off (A/B)
+bool recattn_down_qkcore_applicable(int B, int H, int W, int C, int heads, int x_dt)
+{
+    const char* v = rcx::opt::value(rcx::opt::ATTN_FUSED);
+    if (v && (*v == '0' || *v == 'n')) return false;
+    if (!(B > 0 && pow2_heads(heads) && C == 32 * heads && (x_dt == 1 || x_dt == 2))) return false;
+    if (!((H == 14 && W == 14 && heads <= 8) || (H == 7 && W == 7))) return false;
+    const int wo = (W + 1) / 2;
+    return qkc_short(wo, wo, C, heads);
+}
+
+hipError_t recattn_down_qkcore(const void* x, const float* wdn, const float* bdn, const void* wqk_bf16, const float* bqk, const float* wpe, const float* bpe,
+                               float* out, int B, int H, int C, int heads, int x_dt, hipStream_t s)
+{
+    const bf16_t* w = (const bf16_t*)wqk_bf16;
+#define RCX_DX(KS_)                                                                                                                            \
+    (H == 14 ? (x_dt == 1 ? launch_short_x<2, KS_, 14, bf16_t>(x, wdn, bdn, w, bqk, wpe, bpe, out, B, s)                                       \
+                          : launch_short_x<2, KS_, 14, f16_t>(x, wdn, bdn, w, bqk, wpe, bpe, out, B, s))                                       \
+             : (x_dt == 1 ? launch_short_x<1, KS_, 7, bf16_t>(x, wdn, bdn, w, bqk, wpe, bpe, out, B, s)                                        \
+                          : launch_short_x<1, KS_, 7, f16_t>(x, wdn, bdn, w, bqk, wpe, bpe, out, B, s)))
+    switch (heads) {
+        case 1: return RCX_DX(1);
+        case 2: return RCX_DX(2);
+        case 4: return RCX_DX(4);
+        case 8: return RCX_DX(8);
+        case 16: return H == 7 ? (x_dt == 1 ? launch_short_x<1, 16, 7, bf16_t>(x, wdn, bdn, w, bqk, wpe, bpe, out, B, s)
+                                            : launch_short_x<1, 16, 7, f16_t>(x, wdn, bdn, w, bqk, wpe, bpe, out, B, s))
+                               : hipErrorInvalidConfiguration;
+        default: return hipErrorInvalidConfiguration;
+    }
+#undef RCX_DX
 }
 
 hipError_t recattn_qkcore(const float* d, const void* wqk_bf16, const float* bqk, const float* wpe, const float* bpe, float* out, void* workspace,

@@ -394,6 +394,30 @@ def recattn_qkcore(d, wqk_bf16, bqk, w_pe_kkc, b_pe, heads):
     return out
 
 
+def recattn_down_qkcore_supported(c, heads, h, w, x_dtype):
+    """Whether RecAttn2d's stride-2 conv + coarse level run as ONE launch from x (rcx_recattn_down_qkcore_fwd: the 14 x 14 and 7 x 7 planes of 16-bit
+    activations, 32-wide heads)."""
+    return x_dtype in _DT and _lib.load().rcx_recattn_down_qkcore_supported(1, h, w, c, heads, _DT[x_dtype]) > 0
+
+
+def recattn_down_qkcore(x, w_down_kkc, b_down, wqk_bf16, bqk, w_pe_kkc, b_pe, heads):
+    """a = LinearAttention(ConvNorm_k5s2(x)) of RecAttn2d.forward (model/recattn.py:61-66) in one launch: x N x C x H x W channels_last, 16-bit; the conv's
+    packs as dwconv2d takes them, the rest as recattn_qkcore.  Returns float32 N x C x ceil(H/2) x ceil(W/2), channels_last."""
+    x = _nhwc(x, "x")
+    b, c, h, w = x.shape
+    if wqk_bf16.dtype != torch.bfloat16 or tuple(wqk_bf16.shape) != (2 * c, c // 2) or not wqk_bf16.is_contiguous():
+        raise ValueError(f"wqk_bf16 must be a contiguous ({2 * c}, {c // 2}) bfloat16 tensor")
+    if bqk.dtype != torch.float32 or bqk.numel() != 2 * c:
+        raise ValueError("bqk must be float32 of 2C elements")
+    out = _empty_nhwc(b, c, (h + 1) // 2, (w + 1) // 2, torch.float32, x.device)
+    with _on(x.device):
+        rc = _lib.load().rcx_recattn_down_qkcore_fwd(x.data_ptr(), w_down_kkc.data_ptr(), b_down.data_ptr() if b_down is not None else None,
+                                                     wqk_bf16.data_ptr(), bqk.data_ptr(), w_pe_kkc.data_ptr(),
+                                                     b_pe.data_ptr() if b_pe is not None else None, out.data_ptr(), b, h, w, c, heads, _dt(x), _stream(x.device))
+    _lib.check(rc, "rcx_recattn_down_qkcore_fwd")
+    return out
+
+
 def linear_attention_core_backward(qpre, kpre, v, gout, heads):
     """Gradients of linear_attention_core with respect to qpre, kpre (B, n, C) and v (N x C x h x w); dL/dpe = gout."""
     v = _nhwc(v, "v")

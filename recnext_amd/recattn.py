@@ -168,6 +168,10 @@ class RecAttn2d(nn.Module):
         la = self.down[1]
         if x.shape[1] % la.num_heads or not head_dim_supported(x.shape[1] // la.num_heads):
             raise NotImplementedError(f"RecAttn2d: the HIP attention core takes head sizes up to 32, or multiples of 4 up to 64; got dim {x.shape[1]}, {la.num_heads} heads")
+        if k == 5 and ops.recattn_down_qkcore_supported(x.shape[1], la.num_heads, x.shape[2], x.shape[3], x.dtype):
+            # the 14 x 14 / 7 x 7 stages of a 16-bit run: the stride-2 conv, the projection, the core and pe in ONE launch (d stays in LDS), :61-66
+            a = ops.recattn_down_qkcore(x, wd, bd, wqk16, bqk, wpe, bpe, la.num_heads)
+            return ops.upadd_dwconv(x, a, wc, bc, k=k, mode=self.mode)              # conv(x + resize(.)), :67
         # the coarse chain in float32 (quarter-size tensors: ~1/4 of x's bytes per tensor even at twice the element size)
         d = ops.dwconv2d(x, wd, bd, k=k, stride=2, out_dtype=torch.float32)        # ConvNorm(dw k5 s2), :61
         b, c, h, w = d.shape

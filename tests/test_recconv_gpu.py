@@ -438,6 +438,29 @@ def test_7x7_whole_plane_step_kernels(mode, c, dts, monkeypatch):
     assert torch.allclose(y_any.float(), y.float(), **tol)
 
 
+@pytest.mark.parametrize("c", [16, 100, 256])
+@pytest.mark.parametrize("xdt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_14x14_whole_plane_down_step(c, xdt, monkeypatch):
+    """RecAttn2d's stride-2 conv on the 14 x 14 plane of 16-bit activations (k_down5_cpl7<14, ...>, round 4; model/recattn.py:61) against the C oracle
+    and against the lanes kernel it replaces (RCX_UPADD_CPL=7): both accumulate in float32 from the same rounded inputs."""
+    rng = np.random.default_rng(c)
+    rnd = bf16_round_np if xdt == torch.bfloat16 else (lambda a: a.astype(np.float16).astype(np.float32))
+    x = rnd(rng.standard_normal((3, c, 14, 14)).astype(np.float32))
+    wt = (rng.standard_normal((c, 1, 5, 5)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(c).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev())
+    wp, bp = ops.pack_dw_weight(t(wt)), ops.pack_bias(t(b))
+    ref = c_oracle.dwconv2d(x, wt, b, 2)
+    got = ops.dwconv2d(t(x).to(xdt), wp, bp, k=5, stride=2, out_dtype=torch.float32)
+    assert got.dtype == torch.float32 and tuple(got.shape) == ref.shape
+    assert np.allclose(got.cpu().numpy(), ref, atol=2e-5, rtol=1e-5), np.abs(got.cpu().numpy() - ref).max()
+    nob = ops.dwconv2d(t(x).to(xdt), wp, None, k=5, stride=2, out_dtype=torch.float32)
+    assert np.allclose(nob.cpu().numpy(), ref - b[None, :, None, None], atol=2e-5, rtol=1e-5)
+    monkeypatch.setenv("RCX_UPADD_CPL", "7")
+    other = ops.dwconv2d(t(x).to(xdt), wp, bp, k=5, stride=2, out_dtype=torch.float32)
+    assert torch.allclose(other, got, atol=2e-5, rtol=1e-5)
+
+
 # ---- full BASELINE sizes: size-independent properties + spot checks against the oracle ----
 FULL = [
     ("M1 cfg2 stage1", 256, 96, 28, 28, 3),
@@ -721,6 +744,44 @@ def test_recattn_qkcore_one_launch_against_the_two_step_path_and_the_oracle(case
     assert np.allclose(g, two, atol=BF16_ATOL, rtol=BF16_RTOL)
     nob = ops.recattn_qkcore(dd, t(w_qk[:, :, 0, 0]).to(torch.bfloat16).contiguous(), t(b_qk), wpe, None, heads).cpu().numpy()      # no pe bias pack
     assert np.allclose(nob, g - b_pe[None, :, None, None], atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("case", [(3, 256, 8, 14), (2, 512, 16, 7), (2, 64, 2, 14), (5, 32, 1, 7), (1, 128, 4, 14), (2, 128, 4, 7)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("xdt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_recattn_down_qkcore_one_launch_from_x(case, xdt):
+    """rcx_recattn_down_qkcore_fwd (round 4): RecAttn2d's stride-2 conv + qk projection + core + pe in ONE launch from x (model/recattn.py:61-66 on
+    the 14 x 14 / 7 x 7 planes) against (a) the oracle chain -- C oracle conv, then the NumPy restatement of LinearAttention in float64 -- and (b) the
+    two launches it replaces (rcx_dwconv2d_fwd + rcx_recattn_qkcore_fwd), which compute the same sums in another order."""
+    from oracle import recconv_np
+    b, c, heads, hw = case
+    rng = np.random.default_rng(c + hw)
+    rnd = bf16_round_np if xdt == torch.bfloat16 else (lambda a: a.astype(np.float16).astype(np.float32))
+    x = rnd(rng.standard_normal((b, c, hw, hw)).astype(np.float32))
+    w_dn = (rng.standard_normal((c, 1, 5, 5)) * 0.2).astype(np.float32)
+    b_dn = (rng.standard_normal(c) * 0.1).astype(np.float32)
+    w_qk = (rng.standard_normal((2 * c, c // 2, 1, 1)) * (2.0 / c) ** 0.5).astype(np.float32)
+    b_qk = (rng.standard_normal(2 * c) * 0.1).astype(np.float32)
+    w_pe = (rng.standard_normal((c, 1, 3, 3)) * 0.2).astype(np.float32)
+    b_pe = (rng.standard_normal(c) * 0.1).astype(np.float32)
+    d_ref = c_oracle.dwconv2d(x, w_dn, b_dn, 2)
+    ref = recconv_np.linear_attention(d_ref.astype(np.float64), w_qk, b_qk, w_pe, b_pe, heads, variant=1)
+    t = lambda a: torch.from_numpy(a).to(dev())
+    xx = t(x).to(xdt).contiguous(memory_format=torch.channels_last)
+    assert ops.recattn_down_qkcore_supported(c, heads, hw, hw, xdt)
+    wdn, bdn, wpe, bpe = ops.pack_dw_weight(t(w_dn)), ops.pack_bias(t(b_dn)), ops.pack_dw_weight(t(w_pe)), ops.pack_bias(t(b_pe))
+    wqk16 = t(w_qk[:, :, 0, 0]).to(torch.bfloat16).contiguous()
+    got = ops.recattn_down_qkcore(xx, wdn, bdn, wqk16, t(b_qk), wpe, bpe, heads)
+    assert got.dtype == torch.float32 and tuple(got.shape) == ref.shape
+    assert torch.equal(got, ops.recattn_down_qkcore(xx, wdn, bdn, wqk16, t(b_qk), wpe, bpe, heads)), "not deterministic"
+    g = got.cpu().numpy()
+    print(f"{'x'.join(map(str, case))}: worst err/tol vs the float64 oracle chain {(np.abs(g - ref) / (BF16_ATOL + BF16_RTOL * np.abs(ref))).max():.2f}")
+    assert np.allclose(g, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
+    two = ops.recattn_qkcore(ops.dwconv2d(xx, wdn, bdn, k=5, stride=2, out_dtype=torch.float32), wqk16, t(b_qk), wpe, bpe, heads)
+    assert torch.allclose(got, two, atol=2e-3, rtol=2e-3), (got - two).abs().max().item()
+    nob = ops.recattn_down_qkcore(xx, wdn, None, wqk16, t(b_qk), wpe, None, heads)                    # no bias packs
+    two0 = ops.recattn_qkcore(ops.dwconv2d(xx, wdn, None, k=5, stride=2, out_dtype=torch.float32), wqk16, t(b_qk), wpe, None, heads)
+    assert torch.allclose(nob, two0, atol=2e-3, rtol=2e-3)
+    assert not ops.recattn_down_qkcore_supported(c, heads, 28, 28, xdt) and not ops.recattn_down_qkcore_supported(c, heads, hw, hw, torch.float32)
 
 
 @pytest.mark.parametrize("name", recattn_cases())

@@ -40,7 +40,10 @@ for stage, (b, c, h) in enumerate([(256, 64, 56), (256, 128, 28), (256, 256, 14)
         t_down = timed(lambda x: ops.dwconv2d(x, wd, bd, k=mod.kernel_size, stride=2, out_dtype=torch.float32), xs)
         fused = ops.recattn_qkcore_supported(c, heads, h // 2, h // 2)
         t_core = timed(lambda d: ops.recattn_qkcore(d, wqk16, bqk, wpe, bpe, heads), ds) if fused else None
+        one = ops.recattn_down_qkcore_supported(c, heads, h, h, xs[0].dtype)        # stride-2 conv + coarse level in ONE launch (14 x 14 / 7 x 7 planes)
+        t_one = timed(lambda x: ops.recattn_down_qkcore(x, wd, bd, wqk16, bqk, wpe, bpe, heads), xs) if one else None
         a = ops.recattn_qkcore(ds[0], wqk16, bqk, wpe, bpe, heads) if fused else torch.randn_like(ds[0])
         t_up = timed(lambda x: ops.upadd_dwconv(x, a, wc, bc, k=mod.kernel_size, mode=mod.mode), xs)
     print(json.dumps({"stage": stage, "B": b, "C": c, "plane": h, "heads": heads, "tokens": (h // 2) ** 2, "unit_us": round(unit, 1),
-                      "down_us": round(t_down, 1), "qk_core_pe_us": None if t_core is None else round(t_core, 1), "upadd_conv_us": round(t_up, 1)}))
+                      "down_us": round(t_down, 1), "qk_core_pe_us": None if t_core is None else round(t_core, 1),
+                      "down_qk_core_pe_one_launch_us": None if t_one is None else round(t_one, 1), "upadd_conv_us": round(t_up, 1)}))
