@@ -212,6 +212,18 @@ int rcx_recattn_down_qkcore_fwd(const void* x, const float* w_down_kkc, const fl
                                 const float* w_pe_kkc, const float* b_pe, float* out, int B, int H, int W, int C, int heads, int x_dtype, void* stream);
 
 /*
+ * RecAttn2d.forward whole (model/recattn.py:54-67 in eval mode, BatchNorms folded): y = ConvNorm_k5(x + interpolate(LinearAttention(ConvNorm_k5s2(x)),
+ * size = x's, mode = nearest)) in ONE launch -- a workgroup per image, x's plane read twice (the stride-2 conv, the final conv), d and the attention
+ * output only ever in LDS.  x, y: B x H x W x C bf16 / f16 NHWC; w_down_kkc / b_down, w_conv_kkc / b_conv: (5,5,C) / (C) float32 packs (biases may be
+ * NULL); wqk / bqk / w_pe_kkc / b_pe as rcx_recattn_qkcore_fwd.  Planes 14 x 14 and 7 x 7, 1 .. 8 heads of 32 channels, RCX_MODE_NEAREST;
+ * rcx_recattn2d_fwd_supported() says (1 / 0); else RCX_ERR_UNSUPPORTED -- the caller then chains the entry points above and rcx_upadd_dwconv_fwd.
+ */
+int rcx_recattn2d_fwd_supported(int B, int H, int W, int C, int heads, int mode, int dtype);
+int rcx_recattn2d_fwd(const void* x, void* y, const float* w_down_kkc, const float* b_down, const void* wqk_bf16, const float* bqk,
+                      const float* w_pe_kkc, const float* b_pe, const float* w_conv_kkc, const float* b_conv,
+                      int B, int H, int W, int C, int heads, int mode, int dtype, void* stream);
+
+/*
  * Backward of rcx_linear_attention_fwd (the gradients engine.py:48-64 needs through RecAttn2d, model/recattn.py:16-28 / :39-51):
  *   given gout = dL/dout (B x n x C), writes gq = dL/dqpre, gk = dL/dkpre, gv = dL/dv (all B x n x C, `dtype`); dL/dpe = gout is the
  *   caller's.  float32 arithmetic, deterministic (fixed summation order).  C/heads at most 64.

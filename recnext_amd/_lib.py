@@ -46,6 +46,8 @@ SIGNATURES = {
     "rcx_recattn_qkcore_fwd": (_i, [_vp] * 7 + [_sz] + [_i] * 5 + [_vp]),
     "rcx_recattn_down_qkcore_supported": (_i, [_i] * 6),
     "rcx_recattn_down_qkcore_fwd": (_i, [_vp] * 8 + [_i] * 6 + [_vp]),
+    "rcx_recattn2d_fwd_supported": (_i, [_i] * 7),
+    "rcx_recattn2d_fwd": (_i, [_vp] * 10 + [_i] * 7 + [_vp]),
     "rcx_dwconv2d_bwd_workspace_bytes": (ctypes.c_size_t, [_i, _i]),
     "rcx_dwconv2d_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t] + [_i] * 7 + [_vp]),
     "rcx_dwconv2d_mult2_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t] + [_i] * 6 + [_vp]),

@@ -776,6 +776,31 @@ int rcx_recattn_down_qkcore_fwd(const void* x, const float* w_down_kkc, const fl
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_recattn_down_qkcore_fwd");
 }
 
+int rcx_recattn2d_fwd_supported(int B, int H, int W, int C, int heads, int mode, int dtype)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0 || C % heads) return 0;
+    return rcx::recattn2d_unit_applicable(B, H, W, C, heads, dtype, mode == RCX_MODE_NEAREST ? 1 : 0) ? 1 : 0;
+}
+
+int rcx_recattn2d_fwd(const void* x, void* y, const float* w_down_kkc, const float* b_down, const void* wqk_bf16, const float* bqk,
+                      const float* w_pe_kkc, const float* b_pe, const float* w_conv_kkc, const float* b_conv,
+                      int B, int H, int W, int C, int heads, int mode, int dtype, void* stream)
+{
+    if (!x || !y || !w_down_kkc || !wqk_bf16 || !bqk || !w_pe_kkc || !w_conv_kkc) return fail(RCX_ERR_BAD_ARG, "rcx_recattn2d_fwd: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive extent B=%d H=%d W=%d C=%d heads=%d", B, H, W, C, heads);
+    if (C % heads) return fail(RCX_ERR_BAD_ARG, "C=%d is not a multiple of heads=%d", C, heads);
+    if (!known_dtype(dtype)) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
+    if (mode != RCX_MODE_BILINEAR && mode != RCX_MODE_NEAREST) return fail(RCX_ERR_BAD_ARG, "unknown mode %d", mode);
+    if (((size_t)wqk_bf16 & 15) || ((size_t)bqk & 15) || ((size_t)w_pe_kkc & 15) || ((size_t)b_pe & 15))
+        return fail(RCX_ERR_BAD_ARG, "rcx_recattn2d_fwd: wqk, bqk, w_pe_kkc and b_pe must be 16-byte aligned");
+    if (!rcx::recattn2d_unit_applicable(B, H, W, C, heads, dtype, mode == RCX_MODE_NEAREST ? 1 : 0))
+        return fail(RCX_ERR_UNSUPPORTED, "rcx_recattn2d_fwd: %d x %d plane, %d heads of %d, mode %d, dtype %d: the one-launch unit takes the 14 x 14 and 7 x 7 planes of bf16 / f16 "
+                                         "activations, 1 .. 8 heads of 32, nearest resize (use rcx_recattn_down_qkcore_fwd / rcx_dwconv2d_fwd + rcx_recattn_qkcore_fwd, then "
+                                         "rcx_upadd_dwconv_fwd)", H, W, heads, C / heads, mode, dtype);
+    hipError_t e = rcx::recattn2d_unit(x, w_down_kkc, b_down, wqk_bf16, bqk, w_pe_kkc, b_pe, w_conv_kkc, b_conv, y, B, H, C, heads, dtype, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "rcx_recattn2d_fwd");
+}
+
 int rcx_linear_attention_bwd(const void* qpre, const void* kpre, const void* v, const void* gout, void* gq, void* gk, void* gv,
                              int B, int n, int C, int heads, int dtype, void* stream)
 {

@@ -139,6 +139,10 @@ size_t recattn_qkcore_workspace_bytes(int B, int Hp, int Wp, int C, int heads);
 bool recattn_down_qkcore_applicable(int B, int H, int W, int C, int heads, int x_dt);
 hipError_t recattn_down_qkcore(const void* x, const float* wdn, const float* bdn, const void* wqk_bf16, const float* bqk, const float* wpe, const float* bpe,
                                float* out, int B, int H, int C, int heads, int x_dt, hipStream_t s);
+// ... and RecAttn2d.forward whole (nearest resize): + the final conv(x + resize(a)), one launch from x to y
+bool recattn2d_unit_applicable(int B, int H, int W, int C, int heads, int x_dt, int mode);
+hipError_t recattn2d_unit(const void* x, const float* wdn, const float* bdn, const void* wqk_bf16, const float* bqk, const float* wpe, const float* bpe,
+                          const float* wcv, const float* bcv, void* y, int B, int H, int C, int heads, int x_dt, hipStream_t s);
 hipError_t recattn_qkcore(const float* d, const void* wqk_bf16, const float* bqk, const float* wpe, const float* bpe, float* out, void* workspace,
                           int B, int Hp, int Wp, int C, int heads, hipStream_t s);
 

@@ -102,7 +102,7 @@ __device__ __forceinline__ void stage_small(float* Lw, const float* __restrict__
 // (the lane's 16 channels + its partner lane's), out^T = kv^T q^T, pe as float4s of the lane's token and 16-byte stores.  drow = the token's row of
 // the LDS image, at the lane's first channel (rows above / below the plane hold zeros: they are outside the buffer the image was staged from), zrow = a row of zeros for the taps
 // that would wrap to the neighbouring plane row, Lwc / outp already point at the lane's first channel (head * 32 + 4 h).
-template <int C>
+template <int C, int OSTR = C>
 __device__ __forceinline__ void out_epilogue(const f32x16& aq, bf16x8 kv0, bf16x8 kv1, const float* Lbq, const float* Lkb, const float4* drow,
                                              const float4* zrow, const float4* Lwc, int t, int n, int Wp, int h, float* outp)
 {
@@ -146,7 +146,7 @@ __device__ __forceinline__ void out_epilogue(const f32x16& aq, bf16x8 kv0, bf16x
             float4 res;
             res.x = fmaf(o[4 * gq + 0], rdn, pe.x); res.y = fmaf(o[4 * gq + 1], rdn, pe.y);
             res.z = fmaf(o[4 * gq + 2], rdn, pe.z); res.w = fmaf(o[4 * gq + 3], rdn, pe.w);
-            *reinterpret_cast<float4*>(outp + (size_t)t * C + 8 * gq) = res;
+            *reinterpret_cast<float4*>(outp + (size_t)t * OSTR + 8 * gq) = res;          // OSTR floats between tokens (C in memory; a padded row when the caller keeps a in LDS)
         }
     }
 }
@@ -163,12 +163,16 @@ __device__ __forceinline__ void out_epilogue(const f32x16& aq, bf16x8 kv0, bf16x
 // XW > 0: d is not read from memory but computed here, d = conv5 stride 2 (x) + bias of RecAttn2d.forward (model/recattn.py:61), from the image's XW x XW
 // plane of 16-bit activations (XW = 14 / 7: Hp = Wp = 7 / 4): two lanes per channel, each the upper / lower output rows, every x row loaded once and
 // scattered into the output rows it touches (float32).  Saves the stand-alone step's launch and d's trip through memory.
-template <int NT, int KS, int XW = 0, typename TX = bf16_t>
-__global__ void __launch_bounds__(NT == 1 ? 1024 : 512)
+// FULL (with XW > 0): the unit's last step too, y = conv5(x + nearest-resize(a)) + bias (model/recattn.py:67): a stays in LDS (one more barrier), the
+// same two lanes per channel form the upper / lower output rows from x rows loaded once each -- RecAttn2d.forward in one launch.
+template <int NT, int KS, int XW = 0, typename TX = bf16_t, bool FULL = false>
+__global__ void __launch_bounds__(64 * KS)
 k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, const float* __restrict__ bqk, const float* __restrict__ wpe,
                 const float* __restrict__ bpe, float* __restrict__ out, int Hp, int Wp,
-                const TX* __restrict__ x, const float* __restrict__ wdn, const float* __restrict__ bdn)
+                const TX* __restrict__ x, const float* __restrict__ wdn, const float* __restrict__ bdn,
+                const float* __restrict__ wcv, const float* __restrict__ bcv, TX* __restrict__ yout)
 {
+    static_assert(!FULL || XW > 0, "the whole unit starts from x");
     extern __shared__ __attribute__((aligned(16))) float lds_s[];
     constexpr int C = 32 * KS, K = C / 2, DROW = C + DPAD, DROW4 = DROW / 4, NTHR = 64 * KS, PF = KS < 8 ? KS : 8;        // weight fragments in flight: a ring 4 deep left ~0.4 us of L2 latency exposed at every refill
     const int hd = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
@@ -336,12 +340,80 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
         const int t = 32 * tt + r;
-        out_epilogue<C>(acc[tt], kv0, kv1, Lw + 10 * C + hd * 32, Lkb, Ld4 + (t - R0) * DROW4 + (hd * 32 + 4 * h) / 4, zrow, reinterpret_cast<const float4*>(Lw) + (hd * 32 + 4 * h) / 4,
-                        t, n, Wp, h, out + (size_t)b * n * C + hd * 32 + 4 * h);
+        if constexpr (FULL)
+            out_epilogue<C, DROW>(acc[tt], kv0, kv1, Lw + 10 * C + hd * 32, Lkb, Ld4 + (t - R0) * DROW4 + (hd * 32 + 4 * h) / 4, zrow,
+                                  reinterpret_cast<const float4*>(Lw) + (hd * 32 + 4 * h) / 4, t, n, Wp, h, Lw + 12 * C + hd * 32 + 4 * h);
+        else
+            out_epilogue<C>(acc[tt], kv0, kv1, Lw + 10 * C + hd * 32, Lkb, Ld4 + (t - R0) * DROW4 + (hd * 32 + 4 * h) / 4, zrow,
+                            reinterpret_cast<const float4*>(Lw) + (hd * 32 + 4 * h) / 4, t, n, Wp, h, out + (size_t)b * n * C + hd * 32 + 4 * h);
+    }
+    if constexpr (FULL) {
+        // ---- 3. y = conv5(x + resize(a)) + bias: lane = (channel, upper / lower output rows), a[token][channel] float32 in LDS behind Lw
+        __syncthreads();
+        constexpr int ORP = (XW + 1) / 2;                      // output rows per lane (7 x 7: row 3 by both, the same value)
+        const int c = threadIdx.x < C ? threadIdx.x : threadIdx.x - C, o0 = threadIdx.x < C ? 0 : XW - ORP;
+        const TX* xc = x + (size_t)b * XW * XW * C + c;
+        const float* La = Lw + 12 * C + c;
+        float wt[25];
+#pragma unroll
+        for (int j = 0; j < 25; ++j) wt[j] = wcv[j * C + c];
+        const float bias = bcv ? bcv[c] : 0.f;
+        float a[ORP][XW];
+#pragma unroll
+        for (int o = 0; o < ORP; ++o)
+#pragma unroll
+            for (int j = 0; j < XW; ++j) a[o][j] = bias;
+        // x rows one ahead of the row being used, and no further: left alone the compiler requests all 11 rows (154 registers) up front and spills
+        TX cur[XW], nxt[XW];
+        auto load_xrow = [&](TX (&dst)[XW], int y) {
+            const int yc_ = y < 0 ? 0 : (y > XW - 1 ? XW - 1 : y);                  // rows outside the plane: a valid row, not used
+#pragma unroll
+            for (int xx = 0; xx < XW; ++xx) dst[xx] = xc[(size_t)(yc_ * XW + xx) * C];
+        };
+        load_xrow(cur, o0 - 2);
+#pragma unroll
+        for (int i = 0; i < ORP + 4; ++i) {
+            const int y = o0 - 2 + i;
+            if (i + 1 < ORP + 4) load_xrow(nxt, y + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (y >= 0 && y < XW) {
+                float tr[XW];                                  // row y of x + resize(a): nearest, source index = destination >> 1 for 14 <- 7 and 7 <- 4
+#pragma unroll
+                for (int xx = 0; xx < XW; ++xx) tr[xx] = elem_to_f32(cur[xx]) + La[((y >> 1) * Wp + (xx >> 1)) * DROW];
+#pragma unroll
+                for (int o = 0; o < ORP; ++o) {
+                    const int dy = i - o;                      // compile time after unrolling
+                    if (dy >= 0 && dy < 5) {
+#pragma unroll
+                        for (int j = 0; j < XW; ++j)
+#pragma unroll
+                            for (int dx = 0; dx < 5; ++dx) {
+                                const int xx = j - 2 + dx;
+                                if (xx >= 0 && xx < XW) a[o][j] = fmaf(wt[dy * 5 + dx], tr[xx], a[o][j]);
+                            }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int xx = 0; xx < XW; ++xx) cur[xx] = nxt[xx];
+        }
+        TX* yc = yout + (size_t)b * XW * XW * C + c;
+#pragma unroll
+        for (int o = 0; o < ORP; ++o)
+#pragma unroll
+            for (int j = 0; j < XW; ++j) {
+                const float v1[1] = {a[o][j]};
+                store_vec<1>(yc + (size_t)((o0 + o) * XW + j) * C, v1);
+            }
     }
 }
 
-static inline size_t short_lds_bytes(int NT, int Wp, int C) { return sizeof(float) * ((size_t)(NT * 32 + 2 * Wp + 3) * (C + DPAD) + 12 * (size_t)C); }
+// full = the whole-unit form: + a[Wp * Wp tokens][C + 4] behind the small arrays
+static inline size_t short_lds_bytes(int NT, int Wp, int C, bool full = false)
+{
+    return sizeof(float) * ((size_t)(NT * 32 + 2 * Wp + 3 + (full ? Wp * Wp : 0)) * (C + DPAD) + 12 * (size_t)C);
+}
 
 
 constexpr int TILE_TOK = 32;
@@ -578,7 +650,8 @@ static hipError_t launch_short(const float* d, const bf16_t* wqk, const float* b
     const size_t lds = qkc::short_lds_bytes(NT, Wp, 32 * KS);
     auto kfn = qkc::k_recattn_short<NT, KS>;
     RCX_SET_LDS_ONCE(kfn, lds);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(64 * KS), lds, s, d, wqk, bqk, wpe, bpe, out, Hp, Wp, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(64 * KS), lds, s, d, wqk, bqk, wpe, bpe, out, Hp, Wp, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -591,8 +664,51 @@ static hipError_t launch_short_x(const void* x, const float* wdn, const float* b
     const size_t lds = qkc::short_lds_bytes(NT, WO, 32 * KS);
     auto kfn = qkc::k_recattn_short<NT, KS, XW, TX>;
     RCX_SET_LDS_ONCE(kfn, lds);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(64 * KS), lds, s, (const float*)nullptr, wqk, bqk, wpe, bpe, out, WO, WO, (const TX*)x, wdn, bdn);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(64 * KS), lds, s, (const float*)nullptr, wqk, bqk, wpe, bpe, out, WO, WO, (const TX*)x, wdn, bdn,
+                       (const float*)nullptr, (const float*)nullptr, (TX*)nullptr);
     return hipGetLastError();
+}
+
+// RecAttn2d.forward in ONE launch (nearest resize): the conv inside, the attention output kept in LDS, the final conv inside
+template <int NT, int KS, int XW, typename TX>
+static hipError_t launch_unit(const void* x, const float* wdn, const float* bdn, const bf16_t* wqk, const float* bqk, const float* wpe, const float* bpe,
+                              const float* wcv, const float* bcv, void* y, int B, hipStream_t s)
+{
+    constexpr int WO = (XW + 1) / 2;
+    const size_t lds = qkc::short_lds_bytes(NT, WO, 32 * KS, true);
+    auto kfn = qkc::k_recattn_short<NT, KS, XW, TX, true>;
+    RCX_SET_LDS_ONCE(kfn, lds);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(64 * KS), lds, s, (const float*)nullptr, wqk, bqk, wpe, bpe, (float*)nullptr, WO, WO, (const TX*)x, wdn, bdn, wcv, bcv, (TX*)y);
+    return hipGetLastError();
+}
+
+// RCX_ATTN_FUSED=twostep: the unit stays conv + attention | final conv (A/B)
+bool recattn2d_unit_applicable(int B, int H, int W, int C, int heads, int x_dt, int mode)
+{
+    const char* v = rcx::opt::value(rcx::opt::ATTN_FUSED);
+    if (v && *v == 't') return false;
+    if (mode != 1 || heads > 8 || !recattn_down_qkcore_applicable(B, H, W, C, heads, x_dt)) return false;      // 16 heads = 16 waves = 128 registers: the final conv does not fit
+    const int wo = (W + 1) / 2;
+    return qkc::short_lds_bytes(wo * wo <= 32 ? 1 : 2, wo, C, true) <= 160 * 1024;
+}
+
+hipError_t recattn2d_unit(const void* x, const float* wdn, const float* bdn, const void* wqk_bf16, const float* bqk, const float* wpe, const float* bpe,
+                          const float* wcv, const float* bcv, void* y, int B, int H, int C, int heads, int x_dt, hipStream_t s)
+{
+    const bf16_t* w = (const bf16_t*)wqk_bf16;
+#define RCX_UX(KS_)                                                                                                                            \
+    (H == 14 ? (x_dt == 1 ? launch_unit<2, KS_, 14, bf16_t>(x, wdn, bdn, w, bqk, wpe, bpe, wcv, bcv, y, B, s)                                  \
+                          : launch_unit<2, KS_, 14, f16_t>(x, wdn, bdn, w, bqk, wpe, bpe, wcv, bcv, y, B, s))                                  \
+             : (x_dt == 1 ? launch_unit<1, KS_, 7, bf16_t>(x, wdn, bdn, w, bqk, wpe, bpe, wcv, bcv, y, B, s)                                   \
+                          : launch_unit<1, KS_, 7, f16_t>(x, wdn, bdn, w, bqk, wpe, bpe, wcv, bcv, y, B, s)))
+    switch (heads) {
+        case 1: return RCX_UX(1);
+        case 2: return RCX_UX(2);
+        case 4: return RCX_UX(4);
+        case 8: return RCX_UX(8);
+        default: return hipErrorInvalidConfiguration;
+    }
+#undef RCX_UX
 }
 
 // RecAttn2d's stride-2 conv + coarse level in one launch: the 14 x 14 plane with 1 .. 8 heads, the 7 x 7 plane with 1 .. 16; 16-bit x.

@@ -418,6 +418,29 @@ def recattn_down_qkcore(x, w_down_kkc, b_down, wqk_bf16, bqk, w_pe_kkc, b_pe, he
     return out
 
 
+def recattn2d_supported(c, heads, h, w, mode, dtype):
+    """Whether RecAttn2d.forward is ONE launch for this plane (rcx_recattn2d_fwd: 14 x 14 / 7 x 7, 1 .. 8 heads of 32, nearest, 16-bit)."""
+    return dtype in _DT and mode in _lib.MODES and _lib.load().rcx_recattn2d_fwd_supported(1, h, w, c, heads, _lib.MODES[mode], _DT[dtype]) > 0
+
+
+def recattn2d(x, w_down_kkc, b_down, wqk_bf16, bqk, w_pe_kkc, b_pe, w_conv_kkc, b_conv, heads, mode="nearest"):
+    """RecAttn2d.forward (eval, BatchNorms folded; model/recattn.py:54-67) in one launch: x N x C x H x W channels_last, 16-bit -> y like x."""
+    x = _nhwc(x, "x")
+    b, c, h, w = x.shape
+    if wqk_bf16.dtype != torch.bfloat16 or tuple(wqk_bf16.shape) != (2 * c, c // 2) or not wqk_bf16.is_contiguous():
+        raise ValueError(f"wqk_bf16 must be a contiguous ({2 * c}, {c // 2}) bfloat16 tensor")
+    if bqk.dtype != torch.float32 or bqk.numel() != 2 * c:
+        raise ValueError("bqk must be float32 of 2C elements")
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    p = lambda t: t.data_ptr() if t is not None else None
+    with _on(x.device):
+        rc = _lib.load().rcx_recattn2d_fwd(x.data_ptr(), y.data_ptr(), w_down_kkc.data_ptr(), p(b_down), wqk_bf16.data_ptr(), bqk.data_ptr(),
+                                           w_pe_kkc.data_ptr(), p(b_pe), w_conv_kkc.data_ptr(), p(b_conv), b, h, w, c, heads, _lib.MODES[mode], _dt(x),
+                                           _stream(x.device))
+    _lib.check(rc, "rcx_recattn2d_fwd")
+    return y
+
+
 def linear_attention_core_backward(qpre, kpre, v, gout, heads):
     """Gradients of linear_attention_core with respect to qpre, kpre (B, n, C) and v (N x C x h x w); dL/dpe = gout."""
     v = _nhwc(v, "v")

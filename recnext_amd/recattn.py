@@ -168,6 +168,9 @@ class RecAttn2d(nn.Module):
         la = self.down[1]
         if x.shape[1] % la.num_heads or not head_dim_supported(x.shape[1] // la.num_heads):
             raise NotImplementedError(f"RecAttn2d: the HIP attention core takes head sizes up to 32, or multiples of 4 up to 64; got dim {x.shape[1]}, {la.num_heads} heads")
+        if k == 5 and ops.recattn2d_supported(x.shape[1], la.num_heads, x.shape[2], x.shape[3], self.mode, x.dtype):
+            # the 14 x 14 (and, up to 8 heads, 7 x 7) stage of a 16-bit run: the WHOLE unit in one launch (rcx_recattn2d_fwd, round 4), :61-67
+            return ops.recattn2d(x, wd, bd, wqk16, bqk, wpe, bpe, wc, bc, la.num_heads, self.mode)
         if k == 5 and ops.recattn_down_qkcore_supported(x.shape[1], la.num_heads, x.shape[2], x.shape[3], x.dtype):
             # the 14 x 14 / 7 x 7 stages of a 16-bit run: the stride-2 conv, the projection, the core and pe in ONE launch (d stays in LDS), :61-66
             a = ops.recattn_down_qkcore(x, wd, bd, wqk16, bqk, wpe, bpe, la.num_heads)

@@ -784,6 +784,49 @@ def test_recattn_down_qkcore_one_launch_from_x(case, xdt):
     assert not ops.recattn_down_qkcore_supported(c, heads, 28, 28, xdt) and not ops.recattn_down_qkcore_supported(c, heads, hw, hw, torch.float32)
 
 
+@pytest.mark.parametrize("case", [(3, 256, 8, 14), (2, 64, 2, 14), (5, 32, 1, 7), (1, 128, 4, 14), (2, 128, 4, 7), (2, 256, 8, 7)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("xdt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_recattn2d_whole_unit_in_one_launch(case, xdt):
+    """rcx_recattn2d_fwd (round 4): RecAttn2d.forward (model/recattn.py:54-67, eval, nearest) in ONE launch on the 14 x 14 / 7 x 7 planes against (a) the
+    oracle chain in float64 / float32 -- C-oracle stride-2 conv, NumPy LinearAttention, C-oracle conv(x + resize(.)) -- under north_star's flat 1e-2 and
+    (b) the launches it replaces (rcx_recattn_down_qkcore_fwd + rcx_upadd_dwconv_fwd: same sums, the attention output float32 in both)."""
+    from oracle import recconv_np
+    b, c, heads, hw = case
+    rng = np.random.default_rng(3 * c + hw)
+    rnd = bf16_round_np if xdt == torch.bfloat16 else (lambda a: a.astype(np.float16).astype(np.float32))
+    x = rnd(rng.standard_normal((b, c, hw, hw)).astype(np.float32))
+    w_dn = (rng.standard_normal((c, 1, 5, 5)) * 0.2).astype(np.float32)
+    b_dn = (rng.standard_normal(c) * 0.1).astype(np.float32)
+    w_cv = (rng.standard_normal((c, 1, 5, 5)) * 0.2).astype(np.float32)
+    b_cv = (rng.standard_normal(c) * 0.1).astype(np.float32)
+    w_qk = (rng.standard_normal((2 * c, c // 2, 1, 1)) * (2.0 / c) ** 0.5).astype(np.float32)
+    b_qk = (rng.standard_normal(2 * c) * 0.1).astype(np.float32)
+    w_pe = (rng.standard_normal((c, 1, 3, 3)) * 0.2).astype(np.float32)
+    b_pe = (rng.standard_normal(c) * 0.1).astype(np.float32)
+    a_ref = recconv_np.linear_attention(c_oracle.dwconv2d(x, w_dn, b_dn, 2).astype(np.float64), w_qk, b_qk, w_pe, b_pe, heads, variant=1)
+    ref = c_oracle.dwconv2d(c_oracle.add_resized(x, a_ref.astype(np.float32), "nearest"), w_cv, b_cv, 1)
+    t = lambda a: torch.from_numpy(a).to(dev())
+    xx = t(x).to(xdt).contiguous(memory_format=torch.channels_last)
+    assert ops.recattn2d_supported(c, heads, hw, hw, "nearest", xdt)
+    assert not ops.recattn2d_supported(c, heads, hw, hw, "bilinear", xdt) and not ops.recattn2d_supported(c, heads, 28, 28, "nearest", xdt)
+    wdn, bdn, wcv, bcv = ops.pack_dw_weight(t(w_dn)), ops.pack_bias(t(b_dn)), ops.pack_dw_weight(t(w_cv)), ops.pack_bias(t(b_cv))
+    wpe, bpe = ops.pack_dw_weight(t(w_pe)), ops.pack_bias(t(b_pe))
+    wqk16 = t(w_qk[:, :, 0, 0]).to(torch.bfloat16).contiguous()
+    got = ops.recattn2d(xx, wdn, bdn, wqk16, t(b_qk), wpe, bpe, wcv, bcv, heads)
+    assert got.dtype == xdt and got.shape == xx.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, ops.recattn2d(xx, wdn, bdn, wqk16, t(b_qk), wpe, bpe, wcv, bcv, heads)), "not deterministic"
+    g = got.float().cpu().numpy()
+    print(f"{'x'.join(map(str, case))}: worst err/tol vs the oracle chain {(np.abs(g - ref) / (BF16_ATOL + BF16_RTOL * np.abs(ref))).max():.2f}")
+    assert np.allclose(g, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
+    a = ops.recattn_down_qkcore(xx, wdn, bdn, wqk16, t(b_qk), wpe, bpe, heads)
+    two = ops.upadd_dwconv(xx, a, wcv, bcv, k=5, mode="nearest")
+    ulp = 2.0 ** -7 if xdt == torch.bfloat16 else 2.0 ** -10           # one rounding step of the output type: both round the same float32 sums (+- summation order)
+    assert torch.allclose(got.float(), two.float(), atol=ulp, rtol=ulp), (got.float() - two.float()).abs().max().item()
+    nob = ops.recattn2d(xx, wdn, None, wqk16, t(b_qk), wpe, None, wcv, None, heads)                      # no bias packs
+    a0 = ops.recattn_down_qkcore(xx, wdn, None, wqk16, t(b_qk), wpe, None, heads)
+    assert torch.allclose(nob.float(), ops.upadd_dwconv(xx, a0, wcv, None, k=5, mode="nearest").float(), atol=ulp, rtol=ulp)
+
+
 @pytest.mark.parametrize("name", recattn_cases())
 def test_recattn2d_module_matches_reference_golden(name):
     from tests.util import load_recattn
