@@ -87,14 +87,22 @@ class MixerTimers:
 
     Every event pair costs the stream ~2.5 us (the marker packets keep the next kernel from starting early): 40 pairs a step are
     2.7 % of RecNeXt-M3's step (tools/graph_probe.py: 63.8 k img/s without any, 62.1 k with all).  So the warm-up steps bracket
-    EVERY mixer (the per-kernel table, and which kernel dominates), and the timed region brackets only the dominant kernel's
-    launches (`only`), which is what the roofline object is computed from."""
+    EVERY mixer (the per-kernel table, and which kernel dominates), and the timed region times only the dominant kernel's
+    launches (`only`), which is what the roofline object is computed from.
+
+    Where the dominant kernel is ONE fused launch (plans "cpt(...)" / "cpl(...)": `exact`), the timed region does not bracket the call: it hands
+    the event pair to the library (rcx_time_next_launch), which has the command processor record them AT the kernel's start and end
+    (hipExtLaunchKernelGGL) -- the duration rocprofv3 reports, without the dispatch gaps a bracket includes (+2.5 .. 4 us on a ~105 us kernel:
+    0.2325 against rocprofv3's 0.2414 in round 4's first record) and without the markers' cost to the step."""
 
     def __init__(self, net, torch, RecConv2d):
         self.torch = torch
         self.records = []          # (module_key, start, end)
         self.enabled = False
         self.only = None           # None: every mixer; else the set of (C, H, W, level, k) keys whose launches are bracketed
+        self.exact = set()         # keys (subset of `only`) whose one-kernel launches are timed by events attached to the dispatch
+        self.pool = []             # event pairs created (recorded once) before the timed region, for the exact launches
+        self.lib = None
         self.keys = {}
         for name, m in net.named_modules():
             if isinstance(m, RecConv2d):
@@ -107,17 +115,36 @@ class MixerTimers:
     def shape_key(m, shape):
         return (shape[1], shape[2], shape[3], getattr(m, "level", None), m.kernel_size)
 
+    def prepare_exact(self, keys, pairs, lib):
+        """Event pairs for `pairs` launches of the one-kernel plans `keys`: created here (an event exists once it has been recorded), outside the
+        timed region."""
+        self.exact, self.lib = set(keys), lib
+        self.pool = []
+        for _ in range(pairs if keys else 0):
+            s, e = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            s.record(); e.record()
+            self.pool.append((s, e))
+        self.torch.cuda.synchronize()
+
     def _pre(self, m, args):
         if self.enabled and (self.only is None or self.shape_key(m, args[0].shape) in self.only):
+            if self.pool and self.shape_key(m, args[0].shape) in self.exact:
+                s, e = self.pool.pop()
+                self.lib.rcx_time_next_launch(s.cuda_event, e.cuda_event)
+                self._open[m] = (s, tuple(args[0].shape), e)
+                return
             e = self.torch.cuda.Event(enable_timing=True)
             e.record()
-            self._open[m] = (e, tuple(args[0].shape))
+            self._open[m] = (e, tuple(args[0].shape), None)
 
     def _post(self, m, args, out):
         if m in self._open:
-            e = self.torch.cuda.Event(enable_timing=True)
-            e.record()
-            s, shape = self._open.pop(m)
+            s, shape, e = self._open.pop(m)
+            if e is None:
+                e = self.torch.cuda.Event(enable_timing=True)
+                e.record()
+            elif self.lib.rcx_launch_events_pending():        # the schedule did not take the pair (cannot happen for an `exact` key): refuse to report a stale pair
+                raise RuntimeError("bench.py: the timed launch did not consume its event pair")
             self.records.append((m, shape, s, e))
 
     def summarize(self, elem_bytes, plan_of):
@@ -346,6 +373,10 @@ def main():
         if survey:                                            # timed region: only the launches of the kernel with the most time in a step
             dom_name = survey[1][0]["kernel"]
             timers.only = {(rr["C"], rr["H"], rr["W"], rr["level"], rr["k"]) for rr in survey[0] if kernel_name(rr["plan"], elem) == dom_name}
+            one_kernel = {(rr["C"], rr["H"], rr["W"], rr["level"], rr["k"]) for rr in survey[0]
+                          if kernel_name(rr["plan"], elem) == dom_name and rr["level"] is not None and rr["plan"].startswith(("cpt(", "cpl("))}
+            per_step = sum(rr["calls"] for rr in survey[0] if (rr["C"], rr["H"], rr["W"], rr["level"], rr["k"]) in one_kernel) // max(survey_steps, 1)
+            timers.prepare_exact(one_kernel, per_step * args.steps + 8, recnext_amd._lib.load())
         timers.records = []
         rdist.barrier(r)
         timers.enabled = True
@@ -399,8 +430,10 @@ def main():
                          "kernel": dom["kernel"], "shapes": dom["shapes"], "avg_launch_ms": dom["avg_launch_ms"],
                          "algorithmic_bytes_per_launch": dom["algorithmic_bytes"] / dom["launches"],
                          "launches_timed": dom["launches"],
-                         "note": "HIP events on the launch stream around each launch of this kernel inside the timed region; "
-                                 "algorithmic bytes = 2*N*C*H*W*b + (level+2)*C*k*k*b per launch (SURVEY 8d)"},
+                         "timing": ("HIP events recorded by the command processor at the kernel's start and end (hipExtLaunchKernelGGL through "
+                                    "rcx_time_next_launch), every launch of this kernel inside the timed region") if timers.exact else
+                                   "HIP events recorded on the launch stream around each launch of this unit inside the timed region (dispatch gaps included)",
+                         "note": "algorithmic bytes = 2*N*C*H*W*b + (level+2)*C*k*k*b per launch (SURVEY 8d)"},
             "token_mixers": {"measured_over": (f"the last {survey_steps} warm-up steps (every mixer bracketed; the timed region brackets only the "
                                                "dominant kernel, an event pair costs the stream ~2.5 us)") if survey else "the timed region",
                              "ms_per_step": mixer_ms_per_step, "share_of_step": mixer_ms_per_step / (elapsed / args.steps * 1e3),

@@ -89,6 +89,16 @@ int rcx_recconv2d_fwd(const void* x, void* y, const float* wpack, const float* b
                       int N, int C, int H, int W, int level, int k, int mode, int dtype, void* stream);
 
 /*
+ * Measurement hook (nothing in the reference; bench.py's roofline object): the next rcx_recconv2d_fwd of this thread that runs as ONE fused kernel
+ * (plan "cpt(...)" or "cpl(...)": the 56x56 / 28x28 / 14x14 / 7x7 blocks) has the two HIP events recorded by the command processor at the kernel's
+ * start and end (hipExtLaunchKernelGGL) -- its duration as rocprofv3 sees it, without the dispatch gaps an event pair recorded around the call
+ * brackets, and without delaying the next kernel.  Either may be NULL.  Cleared when that call returns, consumed or not
+ * (rcx_launch_events_pending() == 1 after arming, 0 once consumed or cleared).
+ */
+int rcx_time_next_launch(void* start_event, void* stop_event);
+int rcx_launch_events_pending(void);
+
+/*
  * Training (engine.py:48-64): a forward that keeps the fp32 pyramid F_1..F_L, C_1..C_L in `saved`, and the backward pass.
  *   rcx_recconv2d_fwd_train   same contract as rcx_recconv2d_fwd (the blocks of RecNeXt at 224x224 run their inference launch, which then also
  *                             writes the pyramid; other shapes the per-level schedule); `saved` must hold

@@ -32,6 +32,8 @@ SIGNATURES = {
     "rcx_unpack_recconv_grads": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "rcx_recconv2d_fwd_workspace_bytes": (_sz, [_i] * 7),
     "rcx_recconv2d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 8 + [_vp]),
+    "rcx_time_next_launch": (_i, [_vp, _vp]),
+    "rcx_launch_events_pending": (_i, []),
     "rcx_recconv2d_train_saved_bytes": (_sz, [_i] * 6),
     "rcx_recconv2d_bwd_workspace_bytes": (_sz, [_i] * 6),
     "rcx_recconv2d_fwd_train": (_i, [_vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 8 + [_vp]),

@@ -299,7 +299,41 @@ size_t rcx_recconv2d_fwd_workspace_bytes(int N, int C, int H, int W, int level, 
     return make_ladder(N, C, H, W, level, k).total;
 }
 
+// ---- rcx_time_next_launch: see rcx_launch.h
+extern "C++" {
+namespace rcx {
+static thread_local LaunchEvents g_launch_events;
+LaunchEvents take_launch_events()
+{
+    const LaunchEvents e = g_launch_events;
+    g_launch_events = LaunchEvents{};
+    return e;
+}
+}  // namespace rcx
+}
+
+int rcx_time_next_launch(void* start_event, void* stop_event)
+{
+    rcx::g_launch_events.start = (hipEvent_t)start_event;
+    rcx::g_launch_events.stop = (hipEvent_t)stop_event;
+    return 0;
+}
+
+int rcx_launch_events_pending(void) { return (rcx::g_launch_events.start || rcx::g_launch_events.stop) ? 1 : 0; }
+
+static int recconv2d_fwd_impl(const void* x, void* y, const float* wpack, const float* bpack, void* workspace, size_t workspace_bytes,
+                              int N, int C, int H, int W, int level, int k, int mode, int dtype, void* stream);
+
 int rcx_recconv2d_fwd(const void* x, void* y, const float* wpack, const float* bpack,
+                      void* workspace, size_t workspace_bytes,
+                      int N, int C, int H, int W, int level, int k, int mode, int dtype, void* stream)
+{
+    const int rc = recconv2d_fwd_impl(x, y, wpack, bpack, workspace, workspace_bytes, N, C, H, W, level, k, mode, dtype, stream);
+    rcx::g_launch_events = rcx::LaunchEvents{};        // a pair the schedule did not consume (several launches, an unsupported kernel) does not wait for a later call
+    return rc;
+}
+
+static int recconv2d_fwd_impl(const void* x, void* y, const float* wpack, const float* bpack,
                       void* workspace, size_t workspace_bytes,
                       int N, int C, int H, int W, int level, int k, int mode, int dtype, void* stream)
 {

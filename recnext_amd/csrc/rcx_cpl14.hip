@@ -19,6 +19,7 @@
 // immediate, no vector address arithmetic.  Same arithmetic as the other schedules: float32 throughout, one rounding at the
 // final store.
 #include "rcx_cpl14_pieces.h"
+#include "rcx_launch.h"
 #include "rcx_opts.h"
 
 namespace rcx {
@@ -680,11 +681,11 @@ static hipError_t launch(const void* x, void* y, const float* wpack, const float
     // registers without scratch, and they keep the stash form)
     if constexpr (reload_built<CT, TIO>()) {
         if (!sv.base && use_reload(grid)) {
-            hipLaunchKernelGGL((k_recconv_cpl14<MODE, CT, TIO, false, 2, true>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
+            RCX_LAUNCH_TIMED((k_recconv_cpl14<MODE, CT, TIO, false, 2, true>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
             return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((k_recconv_cpl14<MODE, CT, TIO>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
+    RCX_LAUNCH_TIMED((k_recconv_cpl14<MODE, CT, TIO>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
     return hipGetLastError();
 }
 
@@ -708,7 +709,7 @@ template <int MODE, int CT, typename TIO>
 static hipError_t launch_xl(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv)
 {
     const unsigned grid = (unsigned)(N * (C / 64));
-    hipLaunchKernelGGL((k_recconv_cpl14<MODE, CT, TIO, true>), dim3(grid), dim3(64), 25 * 1024, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
+    RCX_LAUNCH_TIMED((k_recconv_cpl14<MODE, CT, TIO, true>), dim3(grid), dim3(64), 25 * 1024, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
     return hipGetLastError();
 }
 
@@ -730,7 +731,7 @@ template <int MODE, int CT, typename TIO>
 static hipError_t launch7(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv)
 {
     const unsigned grid = (unsigned)(N * ((C + 63) / 64));
-    hipLaunchKernelGGL((k_recconv_cpl7b<MODE, CT, TIO>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
+    RCX_LAUNCH_TIMED((k_recconv_cpl7b<MODE, CT, TIO>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
     return hipGetLastError();
 }
 
@@ -740,7 +741,7 @@ static hipError_t launch_short(const void* x, void* y, const float* wpack, const
 {
     const SavedPyr sv{};
     const unsigned grid = (unsigned)(N * ((C + 63) / 64));
-    hipLaunchKernelGGL((k_recconv_cpl14<MODE, 0, TIO, false, 1>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
+    RCX_LAUNCH_TIMED((k_recconv_cpl14<MODE, 0, TIO, false, 1>), dim3(grid), dim3(64), 0, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
     return hipGetLastError();
 }
 

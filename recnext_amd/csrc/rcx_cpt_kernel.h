@@ -1208,7 +1208,7 @@ static hipError_t launch(const void* x, void* y, const float* wpack, const float
     if (const char* e = rcx::opt::value(rcx::opt::CPT_GRID)) { const int g = atoi(e); if (g > 0) cap = (unsigned)g; }    // A/B knob
     cap &= ~7u;
     const unsigned grid = total <= cap || cap == 0 ? total : cap;
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(G::NT), G::LDS_BYTES, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
+    RCX_LAUNCH_TIMED(kfn, dim3(grid), dim3(G::NT), G::LDS_BYTES, s, (const TIO*)x, (TIO*)y, wpack, bpack, N, C, bpack != nullptr, sv);
     return hipGetLastError();
 }
 

@@ -1,6 +1,7 @@
 // Host-side launcher prototypes shared between the kernel translation units and rcx_api.hip.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stddef.h>
 
 // Raise a kernel's dynamic-LDS limit once per kernel instantiation AND DEVICE (the attribute belongs to the device's copy of the
@@ -21,6 +22,18 @@
     } while (0)
 
 namespace rcx {
+
+// rcx_time_next_launch(): a pair of HIP events the caller wants recorded by the command processor AT the start and the end of the next fused-block
+// kernel (hipExtLaunchKernelGGL), not around its launch: an event pair recorded on the stream brackets the dispatch gaps too (+2.5 .. 4 us on a
+// ~100 us kernel) and delays the next kernel.  Thread-local, consumed by the first launch that supports it, cleared when rcx_recconv2d_fwd returns.
+struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };
+LaunchEvents take_launch_events();
+#define RCX_LAUNCH_TIMED(kfn, grid, block, lds, stream, ...)                                                                       \
+    do {                                                                                                                           \
+        const rcx::LaunchEvents rcx_ev_ = rcx::take_launch_events();                                                               \
+        if (rcx_ev_.start || rcx_ev_.stop) hipExtLaunchKernelGGL(kfn, grid, block, lds, stream, rcx_ev_.start, rcx_ev_.stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kfn, grid, block, lds, stream, __VA_ARGS__);                                                       \
+    } while (0)
 
 // rcx_generic.hip
 hipError_t generic_dwconv(const void* x, void* y, const float* w, const float* b,

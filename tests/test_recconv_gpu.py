@@ -461,6 +461,41 @@ def test_14x14_whole_plane_down_step(c, xdt, monkeypatch):
     assert torch.allclose(other, got, atol=2e-5, rtol=1e-5)
 
 
+def test_timing_hook_records_the_events_at_the_kernel():
+    """rcx_time_next_launch (round 4; bench.py's roofline object): the event pair handed to the library is recorded by the command processor at the
+    start and the end of the next one-kernel block -- a plausible duration, not longer than a bracket recorded around the same call --, consumed by
+    that launch, and dropped (not left armed for a later call) when the schedule is not one fused kernel."""
+    from recnext_amd import _lib
+    lib = _lib.load()
+    mod = recnext_amd.RecConv2d(256, kernel_size=5, level=2).to(dev()).eval()
+    x = torch.randn(64, 256, 14, 14, device=dev()).bfloat16().contiguous(memory_format=torch.channels_last)
+    assert ops.recconv2d_plan(64, 256, 14, 14, 2, 5, "bilinear", torch.bfloat16).startswith("cpl(")
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    with torch.no_grad():
+        want = mod(x)
+        for e in ev:
+            e.record()                                   # an event exists once it has been recorded
+        torch.cuda.synchronize()
+        assert lib.rcx_launch_events_pending() == 0
+        lib.rcx_time_next_launch(ev[0].cuda_event, ev[1].cuda_event)
+        assert lib.rcx_launch_events_pending() == 1
+        ev[2].record()
+        got = mod(x)
+        ev[3].record()
+        torch.cuda.synchronize()
+        assert lib.rcx_launch_events_pending() == 0 and torch.equal(got, want)
+        exact, bracket = ev[0].elapsed_time(ev[1]) * 1e3, ev[2].elapsed_time(ev[3]) * 1e3
+        print(f"14x14 block, 64 x 256: kernel {exact:.1f} us, bracket around the call {bracket:.1f} us")
+        assert 2.0 < exact <= bracket + 0.5
+        odd = recnext_amd.RecConv2d(24, kernel_size=5, level=2).to(dev()).eval()          # 19 x 23: several launches
+        xo = torch.randn(2, 24, 19, 23, device=dev()).contiguous(memory_format=torch.channels_last)
+        assert not ops.recconv2d_plan(2, 24, 19, 23, 2, 5, "bilinear", torch.float32).startswith(("cpt(", "cpl("))
+        lib.rcx_time_next_launch(ev[0].cuda_event, ev[1].cuda_event)
+        odd(xo)
+        assert lib.rcx_launch_events_pending() == 0
+        torch.cuda.synchronize()
+
+
 # ---- full BASELINE sizes: size-independent properties + spot checks against the oracle ----
 FULL = [
     ("M1 cfg2 stage1", 256, 96, 28, 28, 3),
