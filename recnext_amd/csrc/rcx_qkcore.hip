@@ -30,6 +30,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
 typedef float f32x4q __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// eight float32 (two 16-byte LDS reads kept WHOLE: converted element by element, the compiler re-splits the reads into 12 + 4 + 4-byte pieces whose
+// row-strided 4-byte parts hit the same bank four ways: SQ_LDS_BANK_CONFLICT 0.40 of the LDS cycles, profiles/r04_sq_wave_states.txt) -> a bf16 operand
+__device__ __forceinline__ bf16x8 to_bf16x8(f32x4q lo, f32x4q hi)
+{
+    const bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 
 constexpr int LROW = 36;          // floats per row of a wave's q image (32 + 4: 16-byte aligned rows that spread over the banks)
 constexpr int DPAD = 4;           // floats added to a row of the shared d image (rows of C + 4: the 32 token rows of a fragment read fall on different banks)
@@ -136,17 +144,13 @@ __device__ __forceinline__ void out_epilogue(const f32x16& aq, bf16x8 kv0, bf16x
             }
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-            float4 pe = Lwc[(9 * C) / 4 + 2 * gq];
+            const f32x4q* Lwv = reinterpret_cast<const f32x4q*>(Lwc);
+            f32x4q pe = Lwv[(9 * C) / 4 + 2 * gq];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const float4 w4 = Lwc[(j * C) / 4 + 2 * gq];
-                const float4 dv = nb[j][2 * gq];
-                pe.x = fmaf(w4.x, dv.x, pe.x); pe.y = fmaf(w4.y, dv.y, pe.y); pe.z = fmaf(w4.z, dv.z, pe.z); pe.w = fmaf(w4.w, dv.w, pe.w);
-            }
-            float4 res;
-            res.x = fmaf(o[4 * gq + 0], rdn, pe.x); res.y = fmaf(o[4 * gq + 1], rdn, pe.y);
-            res.z = fmaf(o[4 * gq + 2], rdn, pe.z); res.w = fmaf(o[4 * gq + 3], rdn, pe.w);
-            *reinterpret_cast<float4*>(outp + (size_t)t * OSTR + 8 * gq) = res;          // OSTR floats between tokens (C in memory; a padded row when the caller keeps a in LDS)
+            for (int j = 0; j < 9; ++j) pe = __builtin_elementwise_fma(Lwv[(j * C) / 4 + 2 * gq], reinterpret_cast<const f32x4q*>(nb[j])[2 * gq], pe);
+            const f32x4q ov = {o[4 * gq + 0], o[4 * gq + 1], o[4 * gq + 2], o[4 * gq + 3]};
+            const f32x4q res = __builtin_elementwise_fma(ov, f32x4q{rdn, rdn, rdn, rdn}, pe);
+            *reinterpret_cast<f32x4q*>(outp + (size_t)t * OSTR + 8 * gq) = res;          // OSTR floats between tokens (C in memory; a padded row when the caller keeps a in LDS)
         }
     }
 }
@@ -179,6 +183,7 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
     const int b = blockIdx.x, n = Hp * Wp, rows = NT * 32 + 2 * Wp + 2, R0 = -Wp - 1;
     float* const Ld = lds_s;                                  // [rows + 1][DROW]: tokens R0 .. of the image (zeros outside it), then a row of zeros
     const float4* const Ld4 = reinterpret_cast<const float4*>(lds_s);
+    const f32x4q* const Ldv = reinterpret_cast<const f32x4q*>(lds_s);
     float* const Lw = Ld + (size_t)(rows + 1) * DROW;         // [9][C] pe taps, [C] pe bias, [C] q biases, [C] kbar
     const float* dimg = d + (size_t)b * n * C;
     const __amdgpu_buffer_rsrc_t dsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dimg, 0, n * C * 4, 0x00020000);
@@ -256,10 +261,10 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
         for (int i = 0; i < 16; ++i) acc[tt][i] = 0.f;
     // the d fragments of k-step s + 1 are read from LDS before the products of k-step s are issued (the compiler waits for every read in
     // front of the product that uses it: ~190 cycles a step instead of the product's 64)
-    float4 xf[2][NT][2];
+    f32x4q xf[2][NT][2];
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
-        const float4* pa = Ld4 + (32 * tt + r - R0) * DROW4 + K / 4 + 2 * h;
+        const f32x4q* pa = Ldv + (32 * tt + r - R0) * DROW4 + K / 4 + 2 * h;
         xf[0][tt][0] = pa[0]; xf[0][tt][1] = pa[1];
     }
 #pragma unroll
@@ -270,15 +275,12 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
             // next: k-step s + 1 of the k half, or k-step 0 of the q half
-            const float4* pa = Ld4 + (32 * tt + r - R0) * DROW4 + (s + 1 < KS ? K / 4 + 4 * (s + 1) : 0) + 2 * h;
+            const f32x4q* pa = Ldv + (32 * tt + r - R0) * DROW4 + (s + 1 < KS ? K / 4 + 4 * (s + 1) : 0) + 2 * h;
             xf[(s + 1) & 1][tt][0] = pa[0]; xf[(s + 1) & 1][tt][1] = pa[1];
         }
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
-            const float4 x0 = xf[s & 1][tt][0], x1 = xf[s & 1][tt][1];          // token 32 tt + r, inputs 16 s + 8 h .. + 7 of the k half
-            bf16x8 fa;
-            fa[0] = (__bf16)x0.x; fa[1] = (__bf16)x0.y; fa[2] = (__bf16)x0.z; fa[3] = (__bf16)x0.w;
-            fa[4] = (__bf16)x1.x; fa[5] = (__bf16)x1.y; fa[6] = (__bf16)x1.z; fa[7] = (__bf16)x1.w;
+            const bf16x8 fa = to_bf16x8(xf[s & 1][tt][0], xf[s & 1][tt][1]);          // token 32 tt + r, inputs 16 s + 8 h .. + 7 of the k half
             acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, bk8, acc[tt], 0, 0, 0);
         }
     }
@@ -323,16 +325,13 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
         if (s + 1 < KS) {
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
-                const float4* pa = Ld4 + (32 * tt + r - R0) * DROW4 + 4 * (s + 1) + 2 * h;
+                const f32x4q* pa = Ldv + (32 * tt + r - R0) * DROW4 + 4 * (s + 1) + 2 * h;
                 xf[(s + 1 + KS) & 1][tt][0] = pa[0]; xf[(s + 1 + KS) & 1][tt][1] = pa[1];
             }
         }
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
-            const float4 x0 = xf[(s + KS) & 1][tt][0], x1 = xf[(s + KS) & 1][tt][1];          // token 32 tt + r, inputs 16 s + 8 h .. + 7 of the q half
-            bf16x8 fb;
-            fb[0] = (__bf16)x0.x; fb[1] = (__bf16)x0.y; fb[2] = (__bf16)x0.z; fb[3] = (__bf16)x0.w;
-            fb[4] = (__bf16)x1.x; fb[5] = (__bf16)x1.y; fb[6] = (__bf16)x1.z; fb[7] = (__bf16)x1.w;
+            const bf16x8 fb = to_bf16x8(xf[(s + KS) & 1][tt][0], xf[(s + KS) & 1][tt][1]);          // token 32 tt + r, inputs 16 s + 8 h .. + 7 of the q half
             acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq8, fb, acc[tt], 0, 0, 0);
         }
     }
@@ -580,10 +579,8 @@ k_recattn_out(const float* __restrict__ d, const bf16_t* __restrict__ wqk, const
         for (int i = 0; i < 16; ++i) aq[i] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const float4 x0 = drow[4 * s + 2 * h], x1 = drow[4 * s + 2 * h + 1];
-            bf16x8 fb;
-            fb[0] = (__bf16)x0.x; fb[1] = (__bf16)x0.y; fb[2] = (__bf16)x0.z; fb[3] = (__bf16)x0.w;
-            fb[4] = (__bf16)x1.x; fb[5] = (__bf16)x1.y; fb[6] = (__bf16)x1.z; fb[7] = (__bf16)x1.w;
+            const f32x4q* dv4 = reinterpret_cast<const f32x4q*>(drow);
+            const bf16x8 fb = to_bf16x8(dv4[4 * s + 2 * h], dv4[4 * s + 2 * h + 1]);
             aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s], fb, aq, 0, 0, 0);          // q^T: rows c1 (registers), column = this lane's token
         }
         out_epilogue<C>(aq, kv0, kv1, Lbq, Lkb, drow + (hd * 32 + 4 * h) / 4, zrow, Lw4 + (hd * 32 + 4 * h) / 4, t, n, Wp, h, out + (size_t)b * n * C + hd * 32 + 4 * h);
