@@ -26,6 +26,7 @@ def selftest_d16(device):
     if mask:
         raise _lib.RcxError(f"D16 self-test failed on {dev} (mask {mask:#x}: bit 0 global_load_short_d16_hi, 1 buffer_load_short_d16_hi, 2 "
                             "ds_read_u16_d16_hi): this device does not zero the other half of a D16-hi load; the 16-bit kernels would return garbage")
+    _D16_CHECKED.add(dev.index if dev.index is not None else torch.cuda.current_device())
     return mask
 
 
@@ -36,10 +37,14 @@ def _dt(t):
         raise TypeError(f"recnext_amd kernels take float32, bfloat16 or float16 tensors, got {t.dtype}") from None
     if code != _lib.DTYPE_F32 and t.is_cuda:
         idx = t.device.index
-        if idx not in _D16_CHECKED:                      # once per device, before its first 16-bit launch; never while a graph is being captured
-            if not torch.cuda.is_current_stream_capturing():
-                selftest_d16(t.device)
-                _D16_CHECKED.add(idx)
+        if idx not in _D16_CHECKED:                      # once per device, before its first 16-bit launch
+            if torch.cuda.is_current_stream_capturing():
+                # the probe reads its flag back (a synchronisation), which a capturing stream cannot do -- and a captured launch that was never
+                # probed would run unguarded on every replay: refuse, loudly, instead of skipping the guard
+                raise _lib.RcxError(f"the first 16-bit recnext_amd launch on {t.device} happens while a HIP graph is being captured: call "
+                                    "recnext_amd.ops.selftest_d16(device) (or run one eager forward) before the capture")
+            selftest_d16(t.device)
+            _D16_CHECKED.add(idx)
     return code
 
 

@@ -157,6 +157,7 @@ class _RecConv2dFn(torch.autograd.Function):
         ctx.save_for_backward(x, wpack, saved, module._wflip)
         ctx.has_bias = bpack is not None
         ctx.param_dtypes = [p.dtype for p in params]
+        ctx.param_strides = [p.stride() for p in params]
         return y
 
     @staticmethod
@@ -173,4 +174,9 @@ class _RecConv2dFn(torch.autograd.Function):
             if ctx.has_bias:
                 grads.append(gb[i])
         grads = [g.to(dt) for g, dt in zip(grads, ctx.param_dtypes)]
+        # a (C, 1, k, k) parameter of a channels_last model has strides (k*k, 1, k, 1), the same memory as the contiguous (k*k, k*k, k, 1): hand the
+        # gradient back with the parameter's own strides, so that DDP's bucket views take it without a copy (its "grad strides do not match bucket
+        # view strides" warning, GPUTEST_r04).  Only size-1 dimensions may differ: no data moves.
+        grads = [g.as_strided(g.shape, ps) if g.stride() != ps and all(n == 1 or a == b for n, a, b in zip(g.shape, g.stride(), ps)) else g
+                 for g, ps in zip(grads, ctx.param_strides)]
         return (gx if ctx.needs_input_grad[0] else None, None, *grads)

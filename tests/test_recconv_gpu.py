@@ -582,6 +582,30 @@ def test_d16_selftest_passes_and_guards_the_first_16_bit_launch():
     assert dev().index in ops._D16_CHECKED
 
 
+def test_d16_selftest_is_not_skipped_by_a_graph_first_caller():
+    """a first 16-bit launch under stream capture used to skip the probe for good; now it is refused (the probe cannot run
+    inside a capture), and after an explicit ops.selftest_d16 the same capture goes through."""
+    x = torch.randn(1, 8, 14, 14, device=dev()).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = ops.pack_dw_weight(torch.randn(8, 1, 5, 5, device=dev()))
+    y_eager = ops.dwconv2d(x, w, None, k=5, stride=1)
+    torch.cuda.synchronize()
+    ops._D16_CHECKED.discard(dev().index)
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with pytest.raises(recnext_amd._lib.RcxError, match="selftest_d16"):
+        with torch.cuda.graph(g, stream=s):
+            ops.dwconv2d(x, w, None, k=5, stride=1)
+    torch.cuda.synchronize()
+    assert ops.selftest_d16(dev()) == 0 and dev().index in ops._D16_CHECKED
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=s):
+        y = ops.dwconv2d(x, w, None, k=5, stride=1)
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_eager)
+
+
 def test_errors_surface_as_exceptions():
     mod = recnext_amd.RecConv2d(8, level=1).to(dev())
     with pytest.raises(TypeError):

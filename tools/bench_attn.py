@@ -44,6 +44,6 @@ for stage, (b, c, h) in enumerate([(256, 64, 56), (256, 128, 28), (256, 256, 14)
         t_one = timed(lambda x: ops.recattn_down_qkcore(x, wd, bd, wqk16, bqk, wpe, bpe, heads), xs) if one else None
         a = ops.recattn_qkcore(ds[0], wqk16, bqk, wpe, bpe, heads) if fused else torch.randn_like(ds[0])
         t_up = timed(lambda x: ops.upadd_dwconv(x, a, wc, bc, k=mod.kernel_size, mode=mod.mode), xs)
-    print(json.dumps({"stage": stage, "B": b, "C": c, "plane": h, "heads": heads, "tokens": (h // 2) ** 2, "unit_us": round(unit, 1),
+    print(json.dumps({"stage": stage, "B": b, "C": c, "plane": h, "heads": heads, "tokens": ((h + 1) // 2) ** 2, "unit_us": round(unit, 1),
                       "down_us": round(t_down, 1), "qk_core_pe_us": None if t_core is None else round(t_core, 1),
                       "down_qk_core_pe_one_launch_us": None if t_one is None else round(t_one, 1), "upadd_conv_us": round(t_up, 1)}))
