@@ -55,22 +55,33 @@ using lanes::VT;
 #ifndef RCX_CPT_PRIO
 #define RCX_CPT_PRIO 0                     /* A/B: s_setprio 1 for the second half of the waves (the arbitration losers by age; ibid. item 4) */
 #endif
+#ifndef RCX_CPT_STG_P2
+#define RCX_CPT_STG_P2 0                   /* staged x rows (STG, diagnostic build) in pass 2 as well as in pass 1 (round 5 measured pass 1 alone: no gain either) */
+#endif
+#ifndef RCX_CPT_SKIPW
+#define RCX_CPT_SKIPW 1                    /* piece rounds of the 7- and 4-wide planes: waves none of whose tile-lanes has a row skip the round (uniform branch) */
+#endif
+#ifndef RCX_CPT_ENDBAR
+#define RCX_CPT_ENDBAR 1                   /* A/B: the barrier at the end of a unit.  The barrier behind the next unit's tap loads already orders this unit's last reads of C1
+                                              (pass 2) before the next unit's first writes of F1 (pass 1); measured equal either way (profiles/r05_cpt_unit_timeline.txt) */
+#endif
 #ifndef RCX_CPT_PF
 #define RCX_CPT_PF 0                       /* wide-load L2 prefetch ahead of pass 1: measured slower, see pass 1 */
 #endif
 
-// diagnostic build only (-DRCX_STAMPS, tools/cpt_bench.hip): lane 0 of every wave of the first workgroups writes the clock at phase boundaries
+// diagnostic build only (-DRCX_STAMPS, tools/cpt_one.hip): lane 0 of every wave of the first workgroups writes the clock at the phase boundaries of
+// its first four units (`it` = the unit loop's counter)
 #ifdef RCX_STAMPS
 static __device__ unsigned long long* g_cpt_stamps = nullptr;
 #define CPT_STAMP(id)                                                                                                    \
     do {                                                                                                                 \
         if ((threadIdx.x & 63) == 0 && g_cpt_stamps && blockIdx.x < 512)                                                 \
-            g_cpt_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (id)] = __builtin_readcyclecounter();             \
+            g_cpt_stamps[((blockIdx.x * 8 + (threadIdx.x >> 6)) * 4 + (it < 3 ? it : 3)) * 16 + (id)] = __builtin_readcyclecounter();             \
     } while (0)
 #define CPT_STAMP_RT(id)                                                                                                 \
     do {                                                                                                                 \
         if ((threadIdx.x & 63) == 0 && g_cpt_stamps && blockIdx.x < 512)                                                 \
-            g_cpt_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (id)] = __builtin_amdgcn_s_memrealtime();         \
+            g_cpt_stamps[((blockIdx.x * 8 + (threadIdx.x >> 6)) * 4 + (it < 3 ? it : 3)) * 16 + (id)] = __builtin_amdgcn_s_memrealtime();         \
     } while (0)
 #else
 #define CPT_STAMP(id) do { } while (0)
@@ -803,6 +814,11 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                 constexpr int rnd = decltype(rc)::value;
                 const int rr = q + NWORK * rnd;
                 const bool act = rr < P;
+                // the wave's smallest row of this round (its first tile-lane's; scalar): a wave with no row at all leaves the round to the others --
+                // the LDS pipe and the SIMD partner see half (7-wide planes at T = 4) or a quarter (4-wide) of the instructions
+                if constexpr (RCX_CPT_SKIPW != 0 && !TRAIN) {
+                    if (tr * T + tcb + NWORK * rnd >= P) return;
+                }
                 f(rc, IC<0>{}, IC<P>{}, act ? rr : 0, act);
             });
         }
@@ -919,23 +935,30 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         };
         constexpr bool LANE_PARITY = HALVES > 1 && WPR == 1;      // the tiles of a wave are neighbours: both column parities in one wave
         const int cpar = LANE_PARITY ? 0 : __builtin_amdgcn_readfirstlane(d0 & 1);
-        auto form = [&](auto parc) {
-            constexpr int PAR = decltype(parc)::value;
+        auto form = [&](auto parc, auto rparc) {
+            constexpr int PAR = decltype(parc)::value, RPAR = decltype(rparc)::value;      // parities of the tile's first column / first row (7 tc, 7 tr)
+            // the tile's 7 rows interpolate from the five C2 rows ib .. ib + 4 (clamped), ib = (7 tr - 1) >> 1: five rows of five values, read once and
+            // all of them before the first use (one LDS latency instead of one per row)
+            const int ib = (7 * tr - 1) >> 1;                  // uniform
+            float C2v[5][5];
+#pragma unroll
+            for (int m = 0; m < 5; ++m) {
+                int im = ib + m;
+                im = im < 0 ? 0 : (im > P2 - 1 ? P2 - 1 : im);
+                const float* rm_ = L2 + im * (P2 * PIXF);
+#pragma unroll
+                for (int k = 0; k < 5; ++k) C2v[m][k] = rm_[cofs[k]];
+            }
 #pragma unroll
             for (int r = 0; r < 7; ++r) {
-                const int dr = 7 * tr + r;                      // uniform
-                int i0, i1;
-                float lam;
-                if (MODE == 1) { i0 = i1 = dr >> 1; lam = 0.f; }
-                else if (dr & 1) { i0 = (dr - 1) >> 1; i1 = i0 + 1; lam = 0.25f; }
-                else { i0 = (dr >> 1) - 1; i1 = i0 + 1; lam = 0.75f; }
-                i0 = i0 < 0 ? 0 : (i0 > P2 - 1 ? P2 - 1 : i0);
-                i1 = i1 < 0 ? 0 : (i1 > P2 - 1 ? P2 - 1 : i1);
-                const float* r0 = L2 + i0 * (P2 * PIXF);
-                const float* r1 = L2 + i1 * (P2 * PIXF);
+                // row 7 tr + r: odd -> C2 rows ((d - 1)/2, (d + 1)/2), weight 0.25; even -> (d/2 - 1, d/2), weight 0.75; nearest: d >> 1 -- relative to ib
+                const bool odd = ((RPAR + r) & 1) != 0;
+                const int m0 = MODE == 1 ? (RPAR ? (r + 1) >> 1 : 1 + (r >> 1)) : (RPAR ? (odd ? r / 2 : (r - 1) / 2) : (odd ? (r + 1) / 2 : r / 2));
+                const int m1 = MODE == 1 ? m0 : m0 + 1;
+                const float lam = MODE == 1 ? 0.f : (odd ? 0.25f : 0.75f);
                 float V[5];
 #pragma unroll
-                for (int k = 0; k < 5; ++k) V[k] = MODE == 1 ? r0[cofs[k]] : fmaf(lam, r1[cofs[k]], (1.f - lam) * r0[cofs[k]]);
+                for (int k = 0; k < 5; ++k) V[k] = MODE == 1 ? C2v[m0][k] : fmaf(lam, C2v[m1][k], (1.f - lam) * C2v[m0][k]);
                 sfor<7>([&](auto cic) {
                     constexpr int cI = decltype(cic)::value;
                     constexpr Rel rl = rel2(MODE, PAR, cI);
@@ -944,8 +967,10 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                 });
             }
         };
+        const int rpar = __builtin_amdgcn_readfirstlane((7 * tr) & 1);
         if constexpr (LANE_PARITY) form_lane();
-        else if (cpar) form(IC<1>{}); else form(IC<0>{});
+        else if (cpar) { if (rpar) form(IC<1>{}, IC<1>{}); else form(IC<1>{}, IC<0>{}); }
+        else { if (rpar) form(IC<0>{}, IC<1>{}); else form(IC<0>{}, IC<0>{}); }
         float* dst = L1 + ((7 * tr) * P1 + 7 * tc) * PIXF;
 #pragma unroll
         for (int r = 0; r < 7; ++r)
@@ -1075,13 +1100,14 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             Hs[0] = Hs[0] * splat(lmaskG);
             Hs[8] = Hs[8] * splat(rmaskG);
         };
-        if constexpr (STG > 0) sfor<SAH>([&](auto rc) { stg_request(IC<decltype(rc)::value % (STG > 0 ? STG : 1)>{}, R0 + decltype(rc)::value); });
+        constexpr bool STG2 = STG > 0 && RCX_CPT_STG_P2 != 0;
+        if constexpr (STG2) sfor<SAH>([&](auto rc) { stg_request(IC<decltype(rc)::value % (STG > 0 ? STG : 1)>{}, R0 + decltype(rc)::value); });
         else sfor<AHEAD>([&](auto rc) { load_row(raw[decltype(rc)::value], R0 + decltype(rc)::value); });
         build_H(H[0], -2);
         build_H(H[1], -1);
         sfor<NR>([&](auto rc) {
             constexpr int ri = decltype(rc)::value, t = R0 + ri;
-            if constexpr (STG > 0) {
+            if constexpr (STG2) {
                 if constexpr (ri + SAH < NR) stg_request(IC<(ri + SAH) % (STG > 0 ? STG : 1)>{}, t + SAH);
             } else if constexpr (ri + AHEAD < NR) load_row(raw[ri + AHEAD], t + AHEAD);
             // vertical source rows (tile origin is even): t even -> (t/2 - 1, t/2) weight 0.75; t odd -> ((t-1)/2, (t+1)/2) weight 0.25
@@ -1096,14 +1122,14 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             // end of the iterations in between (14 stores each; iteration i stores a row for 4 <= i <= 17); the counter holds 63
             constexpr int NLD = NR - 1 - ri < AHEAD ? NR - 1 - ri : AHEAD;
             constexpr int NST = [] { int k = 0; for (int j = 1; j <= AHEAD; ++j) k += (ri - j >= 4 && ri - j <= 17) ? 1 : 0; return k; }();
-            if constexpr (STG > 0) {
+            if constexpr (STG2) {
                 // younger: the pieces of the rows requested since (3 each) and the output rows stored at the end of the iterations in between
                 constexpr int SLD = NR - 1 - ri < SAH ? NR - 1 - ri : SAH;
                 constexpr int SST = [] { int k = 0; for (int j = 1; j <= SAH; ++j) k += (ri - j >= 4 && ri - j <= 17) ? 1 : 0; return k; }();
                 constexpr int SNY = 3 * SLD + (sizeof(TIO) == 2 ? 14 : 14) * SST;
                 fetch_row<TIO, (SNY > 63 ? 63 : SNY), (ri % (STG > 0 ? STG : 1)) * G::SLOTB>(raw[ri], stg_tra);
             }
-            if constexpr (STG == 0) pin_row<(18 * NLD + 14 * NST > 63 ? 63 : 18 * NLD + 14 * NST)>(raw[ri]);
+            if constexpr (!STG2) pin_row<(18 * NLD + 14 * NST > 63 ? 63 : 18 * NLD + 14 * NST)>(raw[ri]);
             if (row_valid(t)) {
                 f32x2 row[9], odd[8];
 #pragma unroll
@@ -1149,7 +1175,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     }
     CPT_STAMP(8);
     CPT_STAMP_RT(10);
-    __syncthreads();                                         // the next unit's pass 1 writes F1 where this unit's pass 2 read C1
+    if constexpr (RCX_CPT_ENDBAR != 0) __syncthreads();      // the next unit's pass 1 writes F1 where this unit's pass 2 read C1
   }
 }
 
