@@ -7,6 +7,7 @@ namespace rcx {
 namespace cpt {
 hipError_t launch_t2(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s, const SavedPyr& sv);
 hipError_t launch_lv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int H, int mode, int dtype, hipStream_t s);   // rcx_cpt3.hip
+hipError_t launch_ts16(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int mode, int dtype, hipStream_t s);        // rcx_cpt4.hip
 }  // namespace cpt
 
 // RCX_CPT=0 gives both blocks back to the banded lanes kernels.  The 28x28 block with a channel count that is not a multiple of 64
@@ -31,6 +32,9 @@ bool cpt_applicable(int N, int C, int H, int W, int level, int k, int dtype)
     if (!cpt::enabled() || k != 5 || C < 1 || !(dtype == 0 || dtype == 1 || dtype == 2)) return false;
     if (H == 56 && W == 56 && level == 4) return true;
     if (H == 28 && W == 28 && level == 3) return C % 64 == 0 || cpt28_ragged(N, C);
+    // 64 x 64 / level 3 on 16-pixel tiles (round 5; RCX_CPT16=0: the banded lanes kernel).  Chosen by the plane alone, never by N: a unit's chain of
+    // phases (~40 us) is shorter than the lanes kernel's one wave per four channel planes (~58 us) at every batch size
+    if (H == 64 && W == 64 && level == 3) return !rcx::opt::is_zero(rcx::opt::CPT16);
     // one level less (round 3): stages 1 and 2 of a 448 x 448 input, inner blocks of the nested schedule; RCX_CPT=full: not these
     const char* v = rcx::opt::value(rcx::opt::CPT);
     if (v && *v == 'f') return false;
@@ -42,11 +46,13 @@ bool cpt_applicable(int N, int C, int H, int W, int level, int k, int dtype)
 // the training forward has the bilinear, whole-block instantiations only
 bool cpt_train_applicable(int N, int C, int H, int W, int level, int k, int mode, int dtype)
 {
-    return mode == 0 && cpt_applicable(N, C, H, W, level, k, dtype) && !(H == 28 && C % 64 != 0) && level == (H == 56 ? 4 : 3);
+    return mode == 0 && H != 64 && cpt_applicable(N, C, H, W, level, k, dtype) && !(H == 28 && C % 64 != 0) && level == (H == 56 ? 4 : 3);
 }
 
 int cpt_describe(int N, int C, int H, int level, int mode, int dtype, char* buf, int len)
 {
+    if (H == 64)
+        return snprintf(buf, len, "cpt(k_recconv_cpt<4, 4, %d, 0, ts=16>,cb=16,nt=256,units=%d,lds=%d)", mode, N * ((C + 15) / 16), cpt::Geo<4, 4, 0, float, 3, 0, 16>::LDS_BYTES);
     const int T = H / 14, halves = T == 4 ? (cpt::cb16(N, C) ? 4 : 2) : (C % 64 != 0 ? 2 : 1), pixf = 64 / halves;
     const bool full = level == (T == 4 ? 4 : 3);
     const int pixb = full && C == (T == 4 ? 64 : 128) ? C * (dtype == 0 ? 4 : 2) : 0;
@@ -60,6 +66,7 @@ int cpt_describe(int N, int C, int H, int level, int mode, int dtype, char* buf,
 hipError_t cpt_recconv(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, int H, int level, int mode, int dtype, hipStream_t s,
                        float* saved, const size_t* f_off, const size_t* c_off)
 {
+    if (H == 64) return saved ? hipErrorInvalidConfiguration : cpt::launch_ts16(x, y, wpack, bpack, N, C, mode, dtype, s);
     if (level != (H == 56 ? 4 : 3)) return saved ? hipErrorInvalidConfiguration : cpt::launch_lv(x, y, wpack, bpack, N, C, H, mode, dtype, s);
     cpt::SavedPyr sv{};
     sv.base = saved;

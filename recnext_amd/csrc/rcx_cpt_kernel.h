@@ -55,6 +55,9 @@ using lanes::VT;
 #ifndef RCX_CPT_PRIO
 #define RCX_CPT_PRIO 0                     /* A/B: s_setprio 1 for the second half of the waves (the arbitration losers by age; ibid. item 4) */
 #endif
+#ifndef RCX_CPT16_ALIAS
+#define RCX_CPT16_ALIAS 0                  /* A/B: 16-pixel tiles with the small planes aliased into the level-1 plane (two workgroups per CU); see Geo::ALIAS */
+#endif
 #ifndef RCX_CPT_STG_P2
 #define RCX_CPT_STG_P2 0                   /* staged x rows (STG, diagnostic build) in pass 2 as well as in pass 1 (round 5 measured pass 1 alone: no gain either) */
 #endif
@@ -297,6 +300,86 @@ __device__ __forceinline__ void pin_row20(uint32_t (&v)[20])
                  "+v"(v[17]), "+v"(v[18]), "+v"(v[19]) : "n"(PENDING));
 }
 
+// ---- 16-pixel tiles (TS = 16: the 16 * 2^k planes of a 512 x 512 input): a row of 20 columns = -2, -1 (vl), 0 .. 15 (vm), 16, 17 (vr), and a row of 16
+// outputs; float32 rows as well (the inner block of the split schedule reads the float32 F1 of its outer step)
+#define CPT_ROW20_IMM(OP)                                                                                                            \
+    "s_add_i32 %[t], %[rb], 0\n\t"                                                                                                  \
+    CPT_LI(OP, 0, "vl", "t", 0) CPT_LI(OP, 1, "vl", "t", 1)                                                                          \
+    CPT_LI(OP, 2, "vm", "t", 0) CPT_LI(OP, 3, "vm", "t", 1) CPT_LI(OP, 4, "vm", "t", 2) CPT_LI(OP, 5, "vm", "t", 3)                  \
+    CPT_LI(OP, 6, "vm", "t", 4) CPT_LI(OP, 7, "vm", "t", 5) CPT_LI(OP, 8, "vm", "t", 6) CPT_LI(OP, 9, "vm", "t", 7)                  \
+    CPT_LI(OP, 10, "vm", "t", 8) CPT_LI(OP, 11, "vm", "t", 9) CPT_LI(OP, 12, "vm", "t", 10) CPT_LI(OP, 13, "vm", "t", 11)            \
+    CPT_LI(OP, 14, "vm", "t", 12) CPT_LI(OP, 15, "vm", "t", 13) CPT_LI(OP, 16, "vm", "t", 14) CPT_LI(OP, 17, "vm", "t", 15)          \
+    CPT_LI(OP, 18, "vr", "t", 0) CPT_LI(OP, 19, "vr", "t", 1)
+#define CPT_ROW20_GEN(OP)                                                                                                            \
+    "s_add_i32 %[t], %[rb], 0\n\ts_add_i32 %[t2], %[rb], %[pix]\n\t"                                                                \
+    CPT_LG(OP, 0, "vl", "t") CPT_LG(OP, 1, "vl", "t2") CPT_LG(OP, 18, "vr", "t") CPT_LG(OP, 19, "vr", "t2")                          \
+    CPT_LG(OP, 2, "vm", "t") CPT_LG(OP, 3, "vm", "t2")                                                                               \
+    CPT_LGN(OP, 4) CPT_LGN(OP, 5) CPT_LGN(OP, 6) CPT_LGN(OP, 7) CPT_LGN(OP, 8) CPT_LGN(OP, 9) CPT_LGN(OP, 10) CPT_LGN(OP, 11)         \
+    CPT_LGN(OP, 12) CPT_LGN(OP, 13) CPT_LGN(OP, 14) CPT_LGN(OP, 15) CPT_LGN(OP, 16) CPT_LGN(OP, 17)
+template <typename TIO, int PIXB>
+__device__ __forceinline__ void row_load20(uint32_t (&v)[20], unsigned vl, unsigned vm, unsigned vr, i32x4 rs, int rb, int pix)
+{
+    int t, t2;
+    if constexpr (PIXB > 0 && PIXB * 15 <= 4095) {
+        (void)pix; (void)t2;
+        if constexpr (std::is_same<TIO, f16_t>::value)
+            asm volatile(CPT_ROW20_IMM(CPT_LDH) : CPT_OUT20(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+        else if constexpr (sizeof(TIO) == 2)
+            asm volatile(CPT_ROW20_IMM(CPT_LD16) : CPT_OUT20(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+        else
+            asm volatile(CPT_ROW20_IMM(CPT_LD32) : CPT_OUT20(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+    } else {
+        if constexpr (std::is_same<TIO, f16_t>::value)
+            asm volatile(CPT_ROW20_GEN(CPT_LDH) : CPT_OUT20(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+        else if constexpr (sizeof(TIO) == 2)
+            asm volatile(CPT_ROW20_GEN(CPT_LD16) : CPT_OUT20(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+        else
+            asm volatile(CPT_ROW20_GEN(CPT_LD32) : CPT_OUT20(v), [t] "=&s"(t), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+    }
+}
+// an output row of 16 pixels (run-time pitch: t2 walks along the row)
+template <typename TIO>
+__device__ __forceinline__ void row_store16(const f32x2 (&a)[8], unsigned vo, i32x4 rs, int rb, int pix)
+{
+    int t2;
+    if constexpr (sizeof(TIO) == 2) {
+        uint32_t p[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (std::is_same<TIO, f16_t>::value) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p[j]) : "v"(a[j].x), "v"(a[j].y));
+            else asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p[j]) : "v"(a[j].x), "v"(a[j].y));
+        }
+        asm volatile("s_add_i32 %[t2], %[rb], 0\n\t"
+                     CPT_SG("buffer_store_short", 0, "t2") CPT_SGN("buffer_store_short_d16_hi", 0) CPT_SGN("buffer_store_short", 1) CPT_SGN("buffer_store_short_d16_hi", 1)
+                     CPT_SGN("buffer_store_short", 2) CPT_SGN("buffer_store_short_d16_hi", 2) CPT_SGN("buffer_store_short", 3) CPT_SGN("buffer_store_short_d16_hi", 3)
+                     CPT_SGN("buffer_store_short", 4) CPT_SGN("buffer_store_short_d16_hi", 4) CPT_SGN("buffer_store_short", 5) CPT_SGN("buffer_store_short_d16_hi", 5)
+                     CPT_SGN("buffer_store_short", 6) CPT_SGN("buffer_store_short_d16_hi", 6) CPT_SGN("buffer_store_short", 7) CPT_SGN("buffer_store_short_d16_hi", 7)
+                     : [t2] "=&s"(t2)
+                     : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [p4] "v"(p[4]), [p5] "v"(p[5]), [p6] "v"(p[6]), [p7] "v"(p[7]),
+                       [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc", "memory");
+    } else {
+        float p[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { p[2 * j] = a[j].x; p[2 * j + 1] = a[j].y; }
+        asm volatile("s_add_i32 %[t2], %[rb], 0\n\t"
+                     CPT_SG("buffer_store_dword", 0, "t2") CPT_SGN("buffer_store_dword", 1) CPT_SGN("buffer_store_dword", 2) CPT_SGN("buffer_store_dword", 3)
+                     CPT_SGN("buffer_store_dword", 4) CPT_SGN("buffer_store_dword", 5) CPT_SGN("buffer_store_dword", 6) CPT_SGN("buffer_store_dword", 7)
+                     CPT_SGN("buffer_store_dword", 8) CPT_SGN("buffer_store_dword", 9) CPT_SGN("buffer_store_dword", 10) CPT_SGN("buffer_store_dword", 11)
+                     CPT_SGN("buffer_store_dword", 12) CPT_SGN("buffer_store_dword", 13) CPT_SGN("buffer_store_dword", 14) CPT_SGN("buffer_store_dword", 15)
+                     : [t2] "=&s"(t2)
+                     : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [p4] "v"(p[4]), [p5] "v"(p[5]), [p6] "v"(p[6]), [p7] "v"(p[7]),
+                       [p8] "v"(p[8]), [p9] "v"(p[9]), [p10] "v"(p[10]), [p11] "v"(p[11]), [p12] "v"(p[12]), [p13] "v"(p[13]), [p14] "v"(p[14]), [p15] "v"(p[15]),
+                       [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc", "memory");
+    }
+}
+// the tile-width-generic faces of the row statements
+template <typename TIO, int PIXB> __device__ __forceinline__ void trow_load(uint32_t (&v)[18], unsigned vl, unsigned vm, unsigned vr, i32x4 rs, int rb, int pix) { row_load<TIO, PIXB>(v, vl, vm, vr, rs, rb, pix); }
+template <typename TIO, int PIXB> __device__ __forceinline__ void trow_load(uint32_t (&v)[20], unsigned vl, unsigned vm, unsigned vr, i32x4 rs, int rb, int pix) { row_load20<TIO, PIXB>(v, vl, vm, vr, rs, rb, pix); }
+template <int PENDING> __device__ __forceinline__ void trow_pin(uint32_t (&v)[18]) { pin_row<PENDING>(v); }
+template <int PENDING> __device__ __forceinline__ void trow_pin(uint32_t (&v)[20]) { pin_row20<PENDING>(v); }
+template <typename TIO, int PIXB> __device__ __forceinline__ void trow_store(const f32x2 (&a)[7], unsigned vo, i32x4 rs, int rb, int pix) { RowSt<TIO, PIXB>::st(a, vo, rs, rb, pix); }
+template <typename TIO, int PIXB> __device__ __forceinline__ void trow_store(const f32x2 (&a)[8], unsigned vo, i32x4 rs, int rb, int pix) { row_store16<TIO>(a, vo, rs, rb, pix); }
+
 // two float32 -> one register of two TIO, low half = the first (RNE, NaN stays NaN): v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 through the compiler
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
@@ -395,7 +478,7 @@ struct SavedPyr {
     unsigned long long f_off[5], c_off[5];
 };
 
-constexpr int plane_size(int T, int l) { return l == 0 ? 14 * T : (plane_size(T, l - 1) + 1) / 2; }
+constexpr int plane_size(int T, int l, int TS = 14) { return l == 0 ? TS * T : (plane_size(T, l - 1, TS) + 1) / 2; }
 
 // ---- pieces: one output row segment of a small plane, gathered from LDS.  L* point at this lane's channel column; a pixel is
 // PIXF floats.  Rows outside the plane read the zero row; columns outside are compile-time zeros.
@@ -500,9 +583,13 @@ constexpr Rel rel2(int mode, int par, int c)
 
 // NL_ = levels of the block: the full ladder down to 4 x 4 (56 x 56 / level 4, 28 x 28 / level 3: RecNeXt at 224 x 224) or one level less
 // (56 x 56 / level 3, 28 x 28 / level 2: the same stages of a 448 x 448 input, and the inner blocks of the nested schedule)
-template <int T_, int HALVES, int MODE, typename TIO, int NL_ = (T_ == 4 ? 4 : 3), int STG_ = 0>
+// TS_ = pixels per tile side: 14 (the 7 * 2^k planes of a 224 x 224 input) or 16 (round 5: the 64 x 64 / level 3 block of a 512 x 512 input, 16-channel
+// workgroups; every plane of its ladder is even, 64 -> 32 -> 16 -> 8)
+template <int T_, int HALVES, int MODE, typename TIO, int NL_ = (T_ == 4 ? 4 : 3), int STG_ = 0, int TS_ = 14>
 struct Geo {
     static constexpr int T = T_;
+    static constexpr int TS = TS_, TH = TS_ / 2;
+    static_assert(TS == 14 || (TS == 16 && T == 4 && HALVES == 4 && NL_ == 3 && STG_ == 0), "16-pixel tiles: 64 x 64 / level 3, 16-channel workgroups");
     static constexpr int NL = NL_;
     static_assert(NL == (T == 4 ? 4 : 3) || NL == (T == 4 ? 3 : 2), "levels");
     static constexpr int NW = T * T / HALVES;
@@ -510,14 +597,21 @@ struct Geo {
     static constexpr int CB = 64 / HALVES;                 // channels of a workgroup's block
     static constexpr int PIXF = CB;                        // floats between two pixels of an LDS plane
     static constexpr int NWORK = T * T;
-    static constexpr int P0 = 14 * T, P1 = 7 * T, P2 = plane_size(T, 2), P3 = plane_size(T, 3), P4 = plane_size(T, 4);
+    static constexpr int P0 = TS * T, P1 = TH * T, P2 = plane_size(T, 2, TS), P3 = plane_size(T, 3, TS), P4 = plane_size(T, 4, TS);
     // LDS, in pixels: zero row | guard | L1 | guard | L2 | L3 | L4
     static constexpr int ZR = P1;
     static constexpr int O1 = ZR + 2;
-    static constexpr int O2 = O1 + P1 * P1 + 2;
+    // ALIAS (A/B, round 5; off): the planes of levels >= 2 INSIDE the level-1 plane's region.  A lane keeps its F1 tile in registers until T1 is formed, so the
+    // LDS copy of F1 is dead once F2 = down(F1) has been read (compute, barrier, write), and T1 overwrites C2 only after every lane has read it (read, barrier,
+    // write): 68 KB instead of 88 KB per workgroup = two workgroups per CU with 16-pixel tiles -- at 256 registers instead of 512 per wave, one row less in
+    // flight and two more barriers.  Measured slower at every batch size (profiles/r05_cpt16_64x64.txt): 67.3 against 62.5 us at 32 images, 88.5 against
+    // 105.5 at 64 (the banded lanes kernel: 63.8)
+    static constexpr bool ALIAS = TS == 16 && RCX_CPT16_ALIAS != 0;
+    static constexpr int O2 = ALIAS ? O1 : O1 + P1 * P1 + 2;
     static constexpr int O3 = O2 + P2 * P2;
     static constexpr int O4 = O3 + P3 * P3;
-    static constexpr int NPIX = O4 + (NL >= 4 ? P4 * P4 : 0);
+    static constexpr int NPIX = ALIAS ? O1 + P1 * P1 + 2 : O4 + (NL >= 4 ? P4 * P4 : 0);
+    static_assert(!ALIAS || (NL == 3 && O4 <= O1 + P1 * P1), "aliased small planes must fit the level-1 plane");
     // STG (round 4): the two streaming passes fetch their x rows by LDS-DMA into per-wave slots behind the level-1 plane -- over the planes of
     // the levels below, dead during both passes -- and read them back with the transposing read.  A slot = one row of the wave's window:
     // two sub-images [18 pixels: tile columns -2 .. 15][64 bytes = 32 channels] (the wave's two tiles at T = 4, the two channel halves of its
@@ -538,15 +632,18 @@ struct Geo {
 // workgroup = four waves = 16 channels of an image with 69 KB of LDS -- TWO workgroups per CU, which run different units and so are
 // in different phases: one's barrier-bound small-plane phases and load waits fill with the other's passes (a 32-channel workgroup
 // alone on its CU serialises ~105 k cycles of phases that each leave most of the CU idle).  Used where cb16() says so.
-template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool TRAIN = false, int LV = (T == 4 ? 4 : 3), int STG = 0>
-__global__ __launch_bounds__(T * T / HALVES * 64, (T == 4 && HALVES == 2) ? 1 : 2)          // 256 registers either way: 8 waves per CU
+template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool TRAIN = false, int LV = (T == 4 ? 4 : 3), int STG = 0, int TS = 14>
+__global__ __launch_bounds__(T * T / HALVES * 64, ((T == 4 && HALVES == 2) || (TS == 16 && RCX_CPT16_ALIAS == 0)) ? 1 : 2)   // 256 registers, 8 waves per CU (16-pixel tiles:
+                                                                                              // one 4-wave workgroup per CU -- 88 KB of LDS -- with up to 512 registers a wave)
 void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* __restrict__ wpack, const float* __restrict__ bpack,
                    int N, int C, int has_bias, SavedPyr sv)
 {
-    using G = Geo<T, HALVES, MODE, TIO, LV, STG>;
+    using G = Geo<T, HALVES, MODE, TIO, LV, STG, TS>;
     static_assert(LV == (T == 4 ? 4 : 3) || !TRAIN, "the shorter ladder: inference");
+    static_assert(TS == 14 || !TRAIN, "16-pixel tiles: inference");
     constexpr int NL = G::NL, PIXF = G::PIXF, NWORK = G::NWORK, P0 = G::P0, P1 = G::P1, P2 = G::P2, P3 = G::P3, P4 = G::P4;
-    constexpr int NCOL = 18;                                       // columns of a level-0 input row held by a lane
+    constexpr int TH = TS / 2;                                     // a tile of the level-1 plane is TH x TH
+    constexpr int NCOL = TS + 4;                                   // columns of a level-0 input row held by a lane
     constexpr int ESZ = (int)sizeof(TIO);
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -637,19 +734,22 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     // recomputed, not kept live (or spilled: the training-forward instantiation did) across the chain of small-plane phases in between
     unsigned voffM, voffL, voffR;
     auto set_voffs = [&](int tcg, int ccg) {
-        voffM = (unsigned)((14 * tcg) * pix + ccg * ESZ);
+        voffM = (unsigned)((TS * tcg) * pix + ccg * ESZ);
         voffL = tcg == 0 ? OOB : voffM - 2u * (unsigned)pix;               // columns -2, -1 of the tile
-        voffR = tcg == T - 1 ? OOB : voffM + 14u * (unsigned)pix;          // columns 14, 15
+        voffR = tcg == T - 1 ? OOB : voffM + (unsigned)TS * (unsigned)pix; // columns TS, TS + 1
     };
     set_voffs(tcG, ccG);
     // row r (tile-local, -2 .. 15), all 18 columns; rows outside the image are redirected to a valid row (loaded, not used)
+    // trp = the tile row as the PASS sees it: pass 2 hands in an opaque copy, or the row bases of pass 1 (one multiply each, the same rows) are kept live
+    // -- spilled, with 16-pixel tiles -- across the chain of small-plane phases for pass 2 to reuse
+    int trp = tr;
     auto load_row = [&](uint32_t (&raw)[NCOL], int r) {
-        int ar = 14 * tr + r;
+        int ar = TS * trp + r;
         ar = ar < 0 ? 0 : (ar > P0 - 1 ? P0 - 1 : ar);
         const int rb = __builtin_amdgcn_readfirstlane(ar * (P0 * pix));     // uniform by construction; the asm below needs it in an SGPR
-        row_load<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
+        trow_load<TIO, PIXB>(raw, voffL, voffM, voffR, rsrc, rb, pix);
     };
-    auto row_valid = [&](int r) -> bool { const int ar = 14 * tr + r; return ar >= 0 && ar < P0; };   // uniform
+    auto row_valid = [&](int r) -> bool { const int ar = TS * tr + r; return ar >= 0 && ar < P0; };   // uniform
     // STG: this lane's three source offsets (piece j, lane i = chunk 64 j + i of the row image: sub-image s = chunk / 72, pixel (chunk % 72) / 4 =
     // tile column - 2, 16-byte quarter chunk % 4 of the sub-image's 32 channels; s = the wave's tile (T = 4) or the channel half (T = 2)), the
     // LDS byte address of the wave's first slot, and this lane's address for the transposing reads
@@ -670,13 +770,14 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         stg_tra = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(reinterpret_cast<char*>(lds) + lbase + (g >> 1) * (18 * 64) + ((lane >> 2) & 3) * 64 + (g & 1) * 32 + (lane & 3) * 8);
     }
     auto stg_request = [&](auto sc, int r) {                      // request row r (tile-local) into slot sc
-        int ar = 14 * tr + r;
+        int ar = TS * tr + r;
         ar = ar < 0 ? 0 : (ar > P0 - 1 ? P0 - 1 : ar);
         const int rb = __builtin_amdgcn_readfirstlane(ar * (P0 * pix));
         stage_row(dv[0], dv[1], dv[2], rsrc, rb, stg_lds + decltype(sc)::value * G::SLOTB);
     };
     // pass 1's first rows are requested before the taps, the LDS clearing's tail and the barrier: their HBM latency runs behind those
-    constexpr int AHEAD1 = RCX_CPT_PF > 0 ? 2 : RCX_CPT_AHEAD1, R01 = -2, NR1 = 17;
+    constexpr int AHEAD1 = TS == 16 && RCX_CPT16_ALIAS != 0 ? 1 : (RCX_CPT_PF > 0 ? 2 : RCX_CPT_AHEAD1), R01 = -2, NR1 = TS + 3;     // 16-pixel tiles: 20-register rows, one row less in flight
+
     uint32_t raw1[NR1][NCOL];
     constexpr int SAH = STG > 0 ? STG - 1 : 0;                 // staged rows in flight in front of the row being used
     if constexpr (STG > 0) sfor<SAH>([&](auto rc) { stg_request(IC<decltype(rc)::value % (STG > 0 ? STG : 1)>{}, R01 + decltype(rc)::value); });
@@ -692,12 +793,12 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     if constexpr (RCX_CPT_STAGGER > 0) { if (w >= G::NW / 2) __builtin_amdgcn_s_sleep(RCX_CPT_STAGGER); }
 
     // ================= pass 1: F1 tile = down(x), rows -2 .. 14 of the tile, input-row stationary (tap pairs) =================
-    float f1[7][7];                                          // this lane's F1 tile stays in registers until T1 is formed
+    float f1[TH][TH];                                        // this lane's F1 tile stays in registers until T1 is formed
     {
         constexpr int AHEAD = AHEAD1, R0 = R01, NR = NR1;
         const f32x2 b0 = f32x2{td.bias, 0.f};
-        uint32_t (&raw)[NR][18] = raw1;
-        f32x2 facc[3][7];
+        uint32_t (&raw)[NR][NCOL] = raw1;
+        f32x2 facc[3][TH];
         // The per-lane loads move 2 bytes each and a wave holds at most 63 memory operations: 3 rows in flight do not cover the HBM
         // latency (stamps: this pass takes 20 k cycles for 11 k cycles of issue).  Tried (-DRCX_CPT_PF=2): pull each row into L2 first
         // with a few WIDE loads (16 bytes per lane, results discarded) PF rows ahead of the element loads.  Measured slower (pass 1:
@@ -706,19 +807,19 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         constexpr int PF = RCX_CPT_PF;
         constexpr int CPP = PIXF * ESZ / 16;                   // 16-byte chunks per pixel of the block
         constexpr int PPI = (64 / HALVES) / CPP;               // pixels per instruction and tile
-        constexpr int NPF = PF > 0 ? (18 + PPI - 1) / PPI : 0; // instructions per row
+        constexpr int NPF = PF > 0 ? (NCOL + PPI - 1) / PPI : 0; // instructions per row
         u32x4pf sink = {0u, 0u, 0u, 0u};                       // destination of the wide loads: kept live to the end of the pass
         const int pj = (lane & (64 / HALVES - 1)) / CPP, pchunk = lane & (CPP - 1);
         unsigned pvo[NPF > 0 ? NPF : 1];                       // this lane's offsets inside a row, one per instruction
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
-            int colp = 14 * tc - 2 + i * PPI + pj;             // columns left of the image: re-read column 0; right of it: the next row or out of range
+            int colp = TS * tc - 2 + i * PPI + pj;             // columns left of the image: re-read column 0; right of it: the next row or out of range
             colp = colp < 0 ? 0 : colp;
             pvo[i] = (unsigned)(colp * pix + (cb * PIXF) * ESZ + pchunk * 16);
         }
         auto prefetch_row = [&](int r) {
             if constexpr (PF > 0) {
-                int ar = 14 * tr + r;
+                int ar = TS * tr + r;
                 ar = ar < 0 ? 0 : (ar > P0 - 1 ? P0 - 1 : ar);
                 const int rb = __builtin_amdgcn_readfirstlane(ar * (P0 * pix));
 #pragma unroll
@@ -744,48 +845,48 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             // younger memory operations: what the iterations since row ri was requested have issued (wide loads first, then a row)
             constexpr int NY = [] {
                 int k = 0;
-                for (int j = 1; j <= AHEAD; ++j) k += (ri + j < NR ? 18 : 0) + (ri + j + PF < NR ? NPF : 0);
+                for (int j = 1; j <= AHEAD; ++j) k += (ri + j < NR ? NCOL : 0) + (ri + j + PF < NR ? NPF : 0);
                 return k > 63 ? 63 : k;
             }();
-            pin_row<NY>(raw[ri]);
+            trow_pin<NY>(raw[ri]);
             }
-            f32x2 xr[9];
+            f32x2 xr[NCOL / 2];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) xr[k] = f32x2{raw_f32<TIO>(raw[ri][2 * k]), raw_f32<TIO>(raw[ri][2 * k + 1])};
+            for (int k = 0; k < NCOL / 2; ++k) xr[k] = f32x2{raw_f32<TIO>(raw[ri][2 * k]), raw_f32<TIO>(raw[ri][2 * k + 1])};
             const bool rv = row_valid(r);
 #pragma unroll
-            for (int o = 0; o < 7; ++o) {
+            for (int o = 0; o < TH; ++o) {
                 const int u = r - 2 * o + 2;
                 if (u < 0 || u > 4) continue;
-                f32x2(&a)[7] = facc[o % 3];
+                f32x2(&a)[TH] = facc[o % 3];
                 if (rv) {
                     // u == 0: the first contribution of output row o carries the initial value (bias, 0) as its addend
 #pragma unroll
-                    for (int i = 0; i < 7; ++i) a[i] = pfma(xr[i], td.p[u][0], u == 0 ? b0 : a[i]);
+                    for (int i = 0; i < TH; ++i) a[i] = pfma(xr[i], td.p[u][0], u == 0 ? b0 : a[i]);
 #pragma unroll
-                    for (int i = 0; i < 7; ++i) a[i] = pfma(xr[i + 1], td.p[u][1], a[i]);
+                    for (int i = 0; i < TH; ++i) a[i] = pfma(xr[i + 1], td.p[u][1], a[i]);
 #pragma unroll
-                    for (int i = 0; i < 7; ++i) a[i].x = fmaf(xr[i + 2].x, td.p[u][2].x, a[i].x);
+                    for (int i = 0; i < TH; ++i) a[i].x = fmaf(xr[i + 2].x, td.p[u][2].x, a[i].x);
                 } else if (u == 0) {
 #pragma unroll
-                    for (int i = 0; i < 7; ++i) a[i] = b0;
+                    for (int i = 0; i < TH; ++i) a[i] = b0;
                 }
                 if (u == 4) {
-                    float* dst = L1 + ((7 * tr + o) * P1 + 7 * tc) * PIXF;
+                    float* dst = L1 + ((TH * tr + o) * P1 + TH * tc) * PIXF;
 #pragma unroll
-                    for (int i = 0; i < 7; ++i) {
+                    for (int i = 0; i < TH; ++i) {
                         f1[o][i] = a[i].x + a[i].y;
                         dst[i * PIXF] = f1[o][i];
                     }
                     if constexpr (TRAIN) if (svon) {
 #pragma unroll
-                        for (int i = 0; i < 7; ++i) *sv_ptr(sv.f_off[1], P1, 7 * tr + o, 7 * tc + i) = f1[o][i];
+                        for (int i = 0; i < TH; ++i) *sv_ptr(sv.f_off[1], P1, TH * tr + o, TH * tc + i) = f1[o][i];
                     }
                     pin(f1[o]);
                 }
             }
 #pragma unroll
-            for (int o = 0; o < 7; ++o) if (r - 2 * o + 2 >= 0 && r - 2 * o + 2 < 4) pin(facc[o % 3]);
+            for (int o = 0; o < TH; ++o) if (r - 2 * o + 2 >= 0 && r - 2 * o + 2 < 4) pin(facc[o % 3]);
             CPT_FENCE;
         });
         asm volatile("" : "+v"(sink));                         // every wide load has landed by now (the last rows' waits were vmcnt(0))
@@ -798,16 +899,16 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     // conv j of the pack: 0 = down, 1 + (NL - l) = the conv of level l, 1 + NL = the final conv
     constexpr int PL[5] = {P0, P1, P2, P3, P4};
     float* const LP[5] = {nullptr, L1, L2, L3, L4};
-    // piece rounds of a P-wide plane: P == 14 (16 workers): two rounds = the two 7-wide column segments, row = q; else full rows,
+    // piece rounds of a P-wide plane: P == 14 or 16 (16 workers): two rounds = the two P / 2-wide column segments, row = q; else full rows,
     // row = q + NWORK * round
     auto for_pieces = [&](auto pc, auto&& f) {
         constexpr int P = decltype(pc)::value;
-        if constexpr (P == 14) {
-            static_assert(NWORK == 16, "14-wide piece planes are dealt over 16 workers");
-            const bool act = q < 14;
+        if constexpr (P > 8) {
+            static_assert(NWORK == 16 && P <= 16 && (P & 1) == 0, "14- and 16-wide piece planes are dealt over 16 workers");
+            const bool act = q < P;
             const int row = act ? q : 0;
-            f(IC<0>{}, IC<0>{}, IC<7>{}, row, act);
-            f(IC<1>{}, IC<7>{}, IC<7>{}, row, act);
+            f(IC<0>{}, IC<0>{}, IC<P / 2>{}, row, act);
+            f(IC<1>{}, IC<P / 2>{}, IC<P / 2>{}, row, act);
         } else {
             constexpr int RNDS = (P + NWORK - 1) / NWORK;
             sfor<RNDS>([&](auto rc) {
@@ -827,6 +928,22 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     sfor<NL - 1>([&](auto lc) {
         constexpr int l = 2 + decltype(lc)::value;
         constexpr int PIN = PL[l - 1], PO = PL[l];
+        if constexpr (G::ALIAS && l == 2) {
+            // F2 lands where F1 was read from: every piece is computed before the first one is written
+            static_assert(PO > 8, "two column segments");
+            float o2[2][PO / 2];
+            for_pieces(IC<PO>{}, [&](auto rc, auto col0c, auto noutc, int row, bool) {
+                down_piece<PIN, decltype(col0c)::value, decltype(noutc)::value, PIXF>(LP[1], Lzero, row, td, o2[decltype(rc)::value]);
+            });
+            __syncthreads();
+            for_pieces(IC<PO>{}, [&](auto rc, auto col0c, auto noutc, int row, bool act) {
+                if (act) {
+                    float* dst = LP[2] + (row * PO + decltype(col0c)::value) * PIXF;
+#pragma unroll
+                    for (int i = 0; i < decltype(noutc)::value; ++i) dst[i * PIXF] = o2[decltype(rc)::value][i];
+                }
+            });
+        } else
         for_pieces(IC<PO>{}, [&](auto, auto col0c, auto noutc, int row, bool act) {
             constexpr int COL0 = decltype(col0c)::value, NOUT = decltype(noutc)::value;
             float out[NOUT];
@@ -858,7 +975,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             });
             __syncthreads();
         }
-        constexpr int RN = P == 14 ? 2 : (P + NWORK - 1) / NWORK;
+        constexpr int RN = P > 8 ? 2 : (P + NWORK - 1) / NWORK;
         f32x2 res[RN][4];
         for_pieces(IC<P>{}, [&](auto rc, auto col0c, auto noutc, int row, bool) {
             constexpr int COL0 = decltype(col0c)::value, NOUT = decltype(noutc)::value;
@@ -890,11 +1007,12 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
     load_taps(t1, wsrc, bsrc, NL, C, cc);         // conv of level 1 = pack 1 + (NL - 1)
     {
         // columns: run of 7 starting at absolute column 7*tc (parity uniform), source columns b .. b+4 of C2, clamped
-        const int d0 = 7 * tc;
+        const int d0 = TH * tc;
         const int bcol = MODE == 1 ? (d0 >> 1) : ((d0 - 1) >> 1);
-        int cofs[5];
+        constexpr int NV = TH / 2 + 2;                           // source columns (and rows) of C2 a run of TH interpolates from
+        int cofs[NV];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
+        for (int k = 0; k < NV; ++k) {
             int cx = bcol + k;
             cx = cx < 0 ? 0 : (cx > P2 - 1 ? P2 - 1 : cx);
             cofs[k] = cx * PIXF;
@@ -904,8 +1022,8 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             const bool par = (d0 & 1) != 0;
             const float le = MODE == 1 ? 0.f : (par ? 0.25f : 0.75f), lo = MODE == 1 ? 0.f : (par ? 0.75f : 0.25f);
 #pragma unroll
-            for (int r = 0; r < 7; ++r) {
-                const int dr = 7 * tr + r;                      // uniform
+            for (int r = 0; r < TH; ++r) {
+                const int dr = TH * tr + r;                     // uniform
                 int i0, i1;
                 float lam;
                 if (MODE == 1) { i0 = i1 = dr >> 1; lam = 0.f; }
@@ -915,11 +1033,11 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                 i1 = i1 < 0 ? 0 : (i1 > P2 - 1 ? P2 - 1 : i1);
                 const float* r0 = L2 + i0 * (P2 * PIXF);
                 const float* r1 = L2 + i1 * (P2 * PIXF);
-                float V[5];
+                float V[NV];
 #pragma unroll
-                for (int k = 0; k < 5; ++k) V[k] = MODE == 1 ? r0[cofs[k]] : fmaf(lam, r1[cofs[k]], (1.f - lam) * r0[cofs[k]]);
+                for (int k = 0; k < NV; ++k) V[k] = MODE == 1 ? r0[cofs[k]] : fmaf(lam, r1[cofs[k]], (1.f - lam) * r0[cofs[k]]);
 #pragma unroll
-                for (int cI = 0; cI < 7; ++cI) {
+                for (int cI = 0; cI < TH; ++cI) {
                     float up;
                     if (cI & 1) {                                // rel2: par 0 -> (m, m+1; 0.25), par 1 -> (m-1, m; 0.75), m = (cI + 1) / 2
                         const int m = (cI + 1) / 2;
@@ -933,33 +1051,33 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                 }
             }
         };
-        constexpr bool LANE_PARITY = HALVES > 1 && WPR == 1;      // the tiles of a wave are neighbours: both column parities in one wave
+        constexpr bool LANE_PARITY = HALVES > 1 && WPR == 1 && (TH & 1) != 0;      // the tiles of a wave are neighbours: both column parities in one wave (odd tile width)
         const int cpar = LANE_PARITY ? 0 : __builtin_amdgcn_readfirstlane(d0 & 1);
         auto form = [&](auto parc, auto rparc) {
-            constexpr int PAR = decltype(parc)::value, RPAR = decltype(rparc)::value;      // parities of the tile's first column / first row (7 tc, 7 tr)
-            // the tile's 7 rows interpolate from the five C2 rows ib .. ib + 4 (clamped), ib = (7 tr - 1) >> 1: five rows of five values, read once and
+            constexpr int PAR = decltype(parc)::value, RPAR = decltype(rparc)::value;      // parities of the tile's first column / first row (TH tc, TH tr)
+            // the tile's TH rows interpolate from the NV C2 rows ib .. ib + NV - 1 (clamped), ib = (TH tr - 1) >> 1: NV rows of NV values, read once and
             // all of them before the first use (one LDS latency instead of one per row)
-            const int ib = (7 * tr - 1) >> 1;                  // uniform
-            float C2v[5][5];
+            const int ib = (TH * tr - 1) >> 1;                 // uniform
+            float C2v[NV][NV];
 #pragma unroll
-            for (int m = 0; m < 5; ++m) {
+            for (int m = 0; m < NV; ++m) {
                 int im = ib + m;
                 im = im < 0 ? 0 : (im > P2 - 1 ? P2 - 1 : im);
                 const float* rm_ = L2 + im * (P2 * PIXF);
 #pragma unroll
-                for (int k = 0; k < 5; ++k) C2v[m][k] = rm_[cofs[k]];
+                for (int k = 0; k < NV; ++k) C2v[m][k] = rm_[cofs[k]];
             }
 #pragma unroll
-            for (int r = 0; r < 7; ++r) {
+            for (int r = 0; r < TH; ++r) {
                 // row 7 tr + r: odd -> C2 rows ((d - 1)/2, (d + 1)/2), weight 0.25; even -> (d/2 - 1, d/2), weight 0.75; nearest: d >> 1 -- relative to ib
                 const bool odd = ((RPAR + r) & 1) != 0;
                 const int m0 = MODE == 1 ? (RPAR ? (r + 1) >> 1 : 1 + (r >> 1)) : (RPAR ? (odd ? r / 2 : (r - 1) / 2) : (odd ? (r + 1) / 2 : r / 2));
                 const int m1 = MODE == 1 ? m0 : m0 + 1;
                 const float lam = MODE == 1 ? 0.f : (odd ? 0.25f : 0.75f);
-                float V[5];
+                float V[NV];
 #pragma unroll
-                for (int k = 0; k < 5; ++k) V[k] = MODE == 1 ? C2v[m0][k] : fmaf(lam, C2v[m1][k], (1.f - lam) * C2v[m0][k]);
-                sfor<7>([&](auto cic) {
+                for (int k = 0; k < NV; ++k) V[k] = MODE == 1 ? C2v[m0][k] : fmaf(lam, C2v[m1][k], (1.f - lam) * C2v[m0][k]);
+                sfor<TH>([&](auto cic) {
                     constexpr int cI = decltype(cic)::value;
                     constexpr Rel rl = rel2(MODE, PAR, cI);
                     const float up = MODE == 1 ? V[rl.idx] : fmaf(rl.l, V[rl.idx + 1], (1.f - rl.l) * V[rl.idx]);
@@ -967,46 +1085,47 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                 });
             }
         };
-        const int rpar = __builtin_amdgcn_readfirstlane((7 * tr) & 1);
+        const int rpar = __builtin_amdgcn_readfirstlane((TH * tr) & 1);
         if constexpr (LANE_PARITY) form_lane();
         else if (cpar) { if (rpar) form(IC<1>{}, IC<1>{}); else form(IC<1>{}, IC<0>{}); }
         else { if (rpar) form(IC<0>{}, IC<1>{}); else form(IC<0>{}, IC<0>{}); }
-        float* dst = L1 + ((7 * tr) * P1 + 7 * tc) * PIXF;
+        if constexpr (G::ALIAS) __syncthreads();             // C2 lives inside the level-1 plane: every lane has read it (form() reads it up front) before T1 overwrites it
+        float* dst = L1 + ((TH * tr) * P1 + TH * tc) * PIXF;
 #pragma unroll
-        for (int r = 0; r < 7; ++r)
+        for (int r = 0; r < TH; ++r)
 #pragma unroll
-            for (int cI = 0; cI < 7; ++cI) dst[(r * P1 + cI) * PIXF] = f1[r][cI];
+            for (int cI = 0; cI < TH; ++cI) dst[(r * P1 + cI) * PIXF] = f1[r][cI];
     }
     __syncthreads();
     CPT_STAMP(6);
     // halo masks of the tile (per lane): columns outside the plane contribute nothing
     const float lmask = ledge ? 0.f : 1.f, rmask = redge ? 0.f : 1.f;
     {
-        // C1 tile, input-row stationary over T1 rows -2 .. 8, columns -2 .. 8 (the guards before and after the plane make every
+        // C1 tile, input-row stationary over T1 rows -2 .. TH + 1, columns -2 .. TH + 1 (the guards before and after the plane make every
         // address valid; what a masked column reads is finite)
-        f32x2 c1[7][4];
+        f32x2 c1[TH][4];
         const f32x2 b1 = splat(t1.bias);
-        const float* base = L1 + ((7 * tr) * P1 + 7 * tc) * PIXF;
+        const float* base = L1 + ((TH * tr) * P1 + TH * tc) * PIXF;
 #pragma unroll
-        for (int t = -2; t <= 8; ++t) {
-            const int ar = 7 * tr + t;
+        for (int t = -2; t <= TH + 1; ++t) {
+            const int ar = TH * tr + t;
             if (ar >= 0 && ar < P1) {                        // uniform
                 const float* rp = base + t * (P1 * PIXF);
                 f32x2 in[6], odd[5];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
                     in[k].x = rp[(2 * k - 2) * PIXF];
-                    in[k].y = k < 5 ? rp[(2 * k - 1) * PIXF] : 0.f;
+                    in[k].y = 2 * k - 1 <= TH + 1 ? rp[(2 * k - 1) * PIXF] : 0.f;
                 }
                 in[0] = in[0] * splat(lmask);
-                in[4].y *= rmask;                            // column 7
-                in[5].x *= rmask;                            // column 8
+                if constexpr (TH & 1) { in[(TH + 2) / 2].y *= rmask; in[(TH + 3) / 2].x *= rmask; }     // columns TH, TH + 1: (4, y), (5, x) at TH = 7
+                else in[(TH + 2) / 2] = in[(TH + 2) / 2] * splat(rmask);                                 // one pair at an even tile width
 #pragma unroll
                 for (int j = 0; j < 5; ++j) odd[j] = pkmov<1, 0>(in[j], in[j + 1]);       // one v_pk_mov_b32 (the compiler: two v_mov_b32 on LDS data)
 #pragma unroll
                 for (int u = 0; u < 5; ++u) {
                     const int o = t - u + 2;
-                    if (o < 0 || o > 6) continue;
+                    if (o < 0 || o > TH - 1) continue;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) c1[o][j] = pfma(in[j], splat(t1.at(u, 0)), u == 0 ? b1 : c1[o][j]);     // u == 0: first contribution of row o
 #pragma unroll
@@ -1018,23 +1137,23 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) c1[o][j] = pfma(in[j + 2], splat(t1.at(u, 4)), c1[o][j]);
                 }
-            } else if (t + 2 <= 6) {                         // a row above the plane: the output row it would have opened starts from the bias
+            } else if (t + 2 <= TH - 1) {                    // a row above the plane: the output row it would have opened starts from the bias
 #pragma unroll
                 for (int j = 0; j < 4; ++j) c1[t + 2][j] = b1;
             }
             CPT_FENCE;
         }
         __syncthreads();                                     // every read of T1 is done
-        float* dst = L1 + ((7 * tr) * P1 + 7 * tc) * PIXF;
+        float* dst = L1 + ((TH * tr) * P1 + TH * tc) * PIXF;
 #pragma unroll
-        for (int o = 0; o < 7; ++o)
+        for (int o = 0; o < TH; ++o)
 #pragma unroll
-            for (int cI = 0; cI < 7; ++cI) dst[(o * P1 + cI) * PIXF] = (cI & 1) ? c1[o][cI >> 1].y : c1[o][cI >> 1].x;
+            for (int cI = 0; cI < TH; ++cI) dst[(o * P1 + cI) * PIXF] = (cI & 1) ? c1[o][cI >> 1].y : c1[o][cI >> 1].x;
         if constexpr (TRAIN) if (svon) {
 #pragma unroll
-            for (int o = 0; o < 7; ++o)
+            for (int o = 0; o < TH; ++o)
 #pragma unroll
-                for (int cI = 0; cI < 7; ++cI) *sv_ptr(sv.c_off[1], P1, 7 * tr + o, 7 * tc + cI) = (cI & 1) ? c1[o][cI >> 1].y : c1[o][cI >> 1].x;
+                for (int cI = 0; cI < TH; ++cI) *sv_ptr(sv.c_off[1], P1, TH * tr + o, TH * tc + cI) = (cI & 1) ? c1[o][cI >> 1].y : c1[o][cI >> 1].x;
         }
     }
     Taps tf;
@@ -1045,25 +1164,27 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
 
     // ================= pass 2: y tile = conv(x + resize(C1)), input rows -2 .. 15, five accumulator rows in flight =================
     {
-        constexpr int AHEAD = std::is_same<TIO, f16_t>::value && RCX_CPT_AHEAD2 > 1 ? 1 : RCX_CPT_AHEAD2, R0 = -2, NR = 18;   // float16: one row less in flight (its
+        constexpr int AHEAD = (std::is_same<TIO, f16_t>::value || (TS == 16 && RCX_CPT16_ALIAS != 0)) && RCX_CPT_AHEAD2 > 1 ? 1 : RCX_CPT_AHEAD2, R0 = -2, NR = TS + 4;   // float16: one row less in flight (its
                                                                                   // per-element conversions otherwise spill eight registers at 256)
         {                                                     // see set_voffs
             int l2 = lane;
             asm volatile("" : "+v"(l2));
             const int h2 = HALVES == 4 ? (l2 >> 4) : (HALVES == 2 ? (l2 >> 5) : 0), c2 = cb * CHB + (l2 & (G::CB - 1));
             set_voffs(tcb + WPR * h2, c2 < C ? c2 : C - 1);
+            if constexpr (TS == 16) asm volatile("" : "+s"(trp));
         }
         // C1 columns -2 .. 8 of the tile: the two on each side may lie outside the plane (clamped: ATen's border rule)
-        const int cb0 = 7 * tcG;
+        const int cb0 = TH * tcG;
         const int cL0 = (ledgeG ? 0 : cb0 - 2) * PIXF, cL1 = (ledgeG ? 0 : cb0 - 1) * PIXF;
-        const int cR0 = (redgeG ? P1 - 1 : cb0 + 7) * PIXF, cR1 = (redgeG ? P1 - 1 : cb0 + 8) * PIXF;
+        const int cR0 = (redgeG ? P1 - 1 : cb0 + TH) * PIXF, cR1 = (redgeG ? P1 - 1 : cb0 + TH + 1) * PIXF;
         const float lmaskG = ledgeG ? 0.f : 1.f, rmaskG = redgeG ? 0.f : 1.f;
         const float* const L1G = L + G::O1 * PIXF;
         // horizontal weights; the pairs that lie outside the image (columns -2, -1 at the left edge, 14, 15 at the right) are zeroed here
         const f32x2 wq = MODE == 1 ? splat(0.f) : splat(0.25f), wt = MODE == 1 ? splat(1.f) : splat(0.75f);
         uint32_t raw[NR][NCOL];
-        f32x2 H[2][9];
-        f32x2 acc[5][7];
+        constexpr int NHP = NCOL / 2;                            // pairs of columns of the window
+        f32x2 H[2][NHP];
+        f32x2 acc[5][TH];
         const f32x2 bf = splat(tf.bias);
         i32x4 ysrc;                                           // y image as a raw buffer; lanes past the last channel store out of range (dropped)
         {
@@ -1075,21 +1196,21 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
         }
         const unsigned yoff = cvalidG ? voffM : OOB;          // a valid lane's own column 0 = where its row loads start
         // H[i]: C1 row i (tile-local, -2 .. 8; clamped into the plane) resized horizontally to the 18 columns -2 .. 15
-        auto build_H = [&](f32x2 (&Hs)[9], int i) {
-            int ar = 7 * tr + i;
+        auto build_H = [&](f32x2 (&Hs)[NHP], int i) {
+            int ar = TH * tr + i;
             ar = ar < 0 ? 0 : (ar > P1 - 1 ? P1 - 1 : ar);
             const float* rp = L1G + ar * (P1 * PIXF);
-            float cv[11];
+            float cv[TH + 4];
             cv[0] = rp[cL0];
             cv[1] = rp[cL1];
 #pragma unroll
-            for (int k = 0; k < 7; ++k) cv[2 + k] = rp[(cb0 + k) * PIXF];
-            cv[9] = rp[cR0];
-            cv[10] = rp[cR1];
+            for (int k = 0; k < TH; ++k) cv[2 + k] = rp[(cb0 + k) * PIXF];
+            cv[TH + 2] = rp[cR0];
+            cv[TH + 3] = rp[cR1];
             f32x2 P[6], Pq[6];                                   // pairs of C1 pixels, and the same times the outer weight (0.25)
 #pragma unroll
-            for (int m = 0; m < 6; ++m) { P[m] = f32x2{cv[2 * m], m < 5 ? cv[2 * m + 1] : 0.f}; Pq[m] = P[m] * wq; }
-            sfor<9>([&](auto jc) {
+            for (int m = 0; m < 6; ++m) { P[m] = f32x2{cv[2 * m], 2 * m + 1 < TH + 4 ? cv[2 * m + 1] : 0.f}; Pq[m] = P[m] * wq; }
+            sfor<NHP>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 // columns 2j-2 (even) and 2j-1 (odd): 0.25 c[j] + 0.75 c[j+1] and 0.75 c[j+1] + 0.25 c[j+2]; nearest: c[j+1] twice.
                 // (c[j], c[j+2]) = the same halves of two neighbouring pairs: one v_pk_mov_b32
@@ -1098,7 +1219,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                 Hs[j] = pfma(splat(mid), wt, e);
             });
             Hs[0] = Hs[0] * splat(lmaskG);
-            Hs[8] = Hs[8] * splat(rmaskG);
+            Hs[NHP - 1] = Hs[NHP - 1] * splat(rmaskG);
         };
         constexpr bool STG2 = STG > 0 && RCX_CPT_STG_P2 != 0;
         if constexpr (STG2) sfor<SAH>([&](auto rc) { stg_request(IC<decltype(rc)::value % (STG > 0 ? STG : 1)>{}, R0 + decltype(rc)::value); });
@@ -1121,7 +1242,7 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
             // younger memory operations at this point: the rows requested since (18 loads each) and the output rows stored at the
             // end of the iterations in between (14 stores each; iteration i stores a row for 4 <= i <= 17); the counter holds 63
             constexpr int NLD = NR - 1 - ri < AHEAD ? NR - 1 - ri : AHEAD;
-            constexpr int NST = [] { int k = 0; for (int j = 1; j <= AHEAD; ++j) k += (ri - j >= 4 && ri - j <= 17) ? 1 : 0; return k; }();
+            constexpr int NST = [] { int k = 0; for (int j = 1; j <= AHEAD; ++j) k += (ri - j >= 4 && ri - j <= TS + 3) ? 1 : 0; return k; }();
             if constexpr (STG2) {
                 // younger: the pieces of the rows requested since (3 each) and the output rows stored at the end of the iterations in between
                 constexpr int SLD = NR - 1 - ri < SAH ? NR - 1 - ri : SAH;
@@ -1129,45 +1250,45 @@ void k_recconv_cpt(const TIO* __restrict__ x, TIO* __restrict__ y, const float* 
                 constexpr int SNY = 3 * SLD + (sizeof(TIO) == 2 ? 14 : 14) * SST;
                 fetch_row<TIO, (SNY > 63 ? 63 : SNY), (ri % (STG > 0 ? STG : 1)) * G::SLOTB>(raw[ri], stg_tra);
             }
-            if constexpr (!STG2) pin_row<(18 * NLD + 14 * NST > 63 ? 63 : 18 * NLD + 14 * NST)>(raw[ri]);
+            if constexpr (!STG2) trow_pin<(NCOL * NLD + TS * NST > 63 ? 63 : NCOL * NLD + TS * NST)>(raw[ri]);
             if (row_valid(t)) {
-                f32x2 row[9], odd[8];
+                f32x2 row[NHP], odd[NHP - 1];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
+                for (int k = 0; k < NHP; ++k) {
                     const f32x2 xv = f32x2{raw_f32<TIO>(raw[ri][2 * k]), raw_f32<TIO>(raw[ri][2 * k + 1])};
                     if (MODE == 1) row[k] = xv + H[(i0 + 2) & 1][k];
                     else row[k] = pfma(splat(lam), H[(i1 + 2) & 1][k], pfma(splat(1.f - lam), H[(i0 + 2) & 1][k], xv));
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) odd[j] = shift1(row[j], row[j + 1]);
+                for (int j = 0; j < NHP - 1; ++j) odd[j] = shift1(row[j], row[j + 1]);
 #pragma unroll
                 for (int u = 0; u < 5; ++u) {
                     const int o = t - u + 2;
-                    if (o < 0 || o > 13) continue;
-                    f32x2(&a)[7] = acc[o % 5];
+                    if (o < 0 || o > TS - 1) continue;
+                    f32x2(&a)[TH] = acc[o % 5];
 #pragma unroll
-                    for (int j = 0; j < 7; ++j) a[j] = pfma(row[j], splat(tf.at(u, 0)), u == 0 ? bf : a[j]);     // u == 0: output row t + 2 enters the window
+                    for (int j = 0; j < TH; ++j) a[j] = pfma(row[j], splat(tf.at(u, 0)), u == 0 ? bf : a[j]);     // u == 0: output row t + 2 enters the window
 #pragma unroll
-                    for (int j = 0; j < 7; ++j) a[j] = pfma(odd[j], splat(tf.at(u, 1)), a[j]);
+                    for (int j = 0; j < TH; ++j) a[j] = pfma(odd[j], splat(tf.at(u, 1)), a[j]);
 #pragma unroll
-                    for (int j = 0; j < 7; ++j) a[j] = pfma(row[j + 1], splat(tf.at(u, 2)), a[j]);
+                    for (int j = 0; j < TH; ++j) a[j] = pfma(row[j + 1], splat(tf.at(u, 2)), a[j]);
 #pragma unroll
-                    for (int j = 0; j < 7; ++j) a[j] = pfma(odd[j + 1], splat(tf.at(u, 3)), a[j]);
+                    for (int j = 0; j < TH; ++j) a[j] = pfma(odd[j + 1], splat(tf.at(u, 3)), a[j]);
 #pragma unroll
-                    for (int j = 0; j < 7; ++j) a[j] = pfma(row[j + 2], splat(tf.at(u, 4)), a[j]);
+                    for (int j = 0; j < TH; ++j) a[j] = pfma(row[j + 2], splat(tf.at(u, 4)), a[j]);
                 }
-            } else if constexpr (t + 2 >= 0 && t + 2 <= 13) {  // a row outside the image: the output row it would have opened starts from the bias
+            } else if constexpr (t + 2 >= 0 && t + 2 <= TS - 1) {  // a row outside the image: the output row it would have opened starts from the bias
 #pragma unroll
-                for (int j = 0; j < 7; ++j) acc[(t + 2) % 5][j] = bf;
+                for (int j = 0; j < TH; ++j) acc[(t + 2) % 5][j] = bf;
             }
             // output row t - 2 has seen its last input row
-            if constexpr (t - 2 >= 0 && t - 2 <= 13) {
+            if constexpr (t - 2 >= 0 && t - 2 <= TS - 1) {
                 constexpr int o = t - 2;
-                const int yrb = __builtin_amdgcn_readfirstlane((14 * tr + o) * (P0 * pix));
-                RowSt<TIO, PIXB>::st(acc[o % 5], yoff, ysrc, yrb, pix);
+                const int yrb = __builtin_amdgcn_readfirstlane((TS * trp + o) * (P0 * pix));
+                trow_store<TIO, PIXB>(acc[o % 5], yoff, ysrc, yrb, pix);
             }
 #pragma unroll
-            for (int o = 0; o < 14; ++o) if (o > t - 2 && o <= t + 2) pin(acc[o % 5]);
+            for (int o = 0; o < TS; ++o) if (o > t - 2 && o <= t + 2) pin(acc[o % 5]);
             pin(H[0]);
             pin(H[1]);
             CPT_FENCE;
@@ -1204,19 +1325,19 @@ template <int T, int HALVES, typename TIO, bool TRAIN> constexpr int stg_slots()
 }
 static inline bool stg_enabled() { return !rcx::opt::is_zero(rcx::opt::CPT_STG); }
 
-template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool TRAIN = false, int LV = (T == 4 ? 4 : 3), int STG = 0>
+template <int T, int HALVES, int MODE, int PIXB, typename TIO, bool TRAIN = false, int LV = (T == 4 ? 4 : 3), int STG = 0, int TS = 14>
 static hipError_t launch(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s, const SavedPyr& sv)
 {
-    using G = Geo<T, HALVES, MODE, TIO, LV, STG>;
-    if constexpr (STG == 0 && stg_slots<T, HALVES, TIO, TRAIN>() > 0) {
+    using G = Geo<T, HALVES, MODE, TIO, LV, STG, TS>;
+    if constexpr (TS == 14 && STG == 0 && stg_slots<T, HALVES, TIO, TRAIN>() > 0) {
         if (!sv.base && C % 8 == 0 && ((size_t)x & 15) == 0 && stg_enabled())
             return launch<T, HALVES, MODE, PIXB, TIO, TRAIN, LV, stg_slots<T, HALVES, TIO, TRAIN>()>(x, y, wpack, bpack, N, C, s, sv);
     }
-    if constexpr (!TRAIN && MODE == 0 && HALVES != 4 && !(T == 2 && HALVES == 2) && LV == (T == 4 ? 4 : 3)) {      // training forward: bilinear only (what RecConv2d trains with), whole-block variants, full ladder
+    if constexpr (TS == 14 && !TRAIN && MODE == 0 && HALVES != 4 && !(T == 2 && HALVES == 2) && LV == (T == 4 ? 4 : 3)) {      // training forward: bilinear only (what RecConv2d trains with), whole-block variants, full ladder
         if (sv.base) return launch<T, HALVES, MODE, PIXB, TIO, true>(x, y, wpack, bpack, N, C, s, sv);
     }
     if (!TRAIN && sv.base) return hipErrorInvalidConfiguration;
-    auto kfn = k_recconv_cpt<T, HALVES, MODE, PIXB, TIO, TRAIN, LV, STG>;
+    auto kfn = k_recconv_cpt<T, HALVES, MODE, PIXB, TIO, TRAIN, LV, STG, TS>;
     RCX_SET_LDS_ONCE(kfn, G::LDS_BYTES);                       // once per instantiation and device
     static std::atomic<int> cus_cache{0};
     int cus = cus_cache.load(std::memory_order_relaxed);
@@ -1228,7 +1349,7 @@ static hipError_t launch(const void* x, void* y, const float* wpack, const float
     }
     const unsigned total = (unsigned)(N * ((C + G::CB - 1) / G::CB));
     // workgroups resident at once: 8 waves per CU (256 registers each) and 160 KB of LDS
-    constexpr unsigned PER_CU = (T == 4 && HALVES == 2) ? 1u : ((T == 2 && HALVES == 2) ? 4u : 2u);
+    constexpr unsigned PER_CU = ((T == 4 && HALVES == 2) || (TS == 16 && RCX_CPT16_ALIAS == 0)) ? 1u : ((T == 2 && HALVES == 2) ? 4u : 2u);
     static_assert(PER_CU * G::LDS_BYTES <= 160 * 1024 && PER_CU * G::NW <= 8, "residency");
     unsigned cap = (unsigned)cus * PER_CU;
     if (const char* e = rcx::opt::value(rcx::opt::CPT_GRID)) { const int g = atoi(e); if (g > 0) cap = (unsigned)g; }    // A/B knob
@@ -1275,6 +1396,14 @@ static hipError_t launch_md(const void* x, void* y, const float* wpack, const fl
     if (dtype == 1) return mode == 1 ? launch_c<T, HALVES, 1, bf16_t, LV>(x, y, wpack, bpack, N, C, s, sv) : launch_c<T, HALVES, 0, bf16_t, LV>(x, y, wpack, bpack, N, C, s, sv);
     if (dtype == 2) return mode == 1 ? launch_c<T, HALVES, 1, f16_t, LV>(x, y, wpack, bpack, N, C, s, sv) : launch_c<T, HALVES, 0, f16_t, LV>(x, y, wpack, bpack, N, C, s, sv);
     return mode == 1 ? launch_c<T, HALVES, 1, float, LV>(x, y, wpack, bpack, N, C, s, sv) : launch_c<T, HALVES, 0, float, LV>(x, y, wpack, bpack, N, C, s, sv);
+}
+
+// the 64 x 64 / level 3 block on 16-pixel tiles (TS = 16; rcx_cpt4.hip): 16-channel workgroups of four waves, run-time pixel pitch
+template <int MODE, typename TIO>
+static hipError_t launch16(const void* x, void* y, const float* wpack, const float* bpack, int N, int C, hipStream_t s)
+{
+    const SavedPyr sv{};
+    return launch<4, 4, MODE, 0, TIO, false, 3, 0, 16>(x, y, wpack, bpack, N, C, s, sv);
 }
 
 }  // namespace cpt

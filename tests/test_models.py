@@ -163,7 +163,9 @@ def test_full_model_at_512_hip_vs_eager_gpu():
     # the plans of the four stage shapes at this resolution (what the forward above ran)
     from recnext_amd import ops
     plans = [ops.recconv2d_plan(2, c, hw, hw, lv, 5, "bilinear", torch.bfloat16) for c, hw, lv in ((64, 128, 4), (128, 64, 3), (256, 32, 2), (512, 16, 1))]
-    assert plans[0].startswith("split(") and all(p.startswith("lanes(") for p in plans[1:]), plans
+    # 128 x 128: split (whose inner 64 x 64 block is the 16-pixel-tile kernel, in float32); 64 x 64: that kernel itself (round 5); 32 x 32 and 16 x 16: lanes
+    assert plans[0].startswith("split(") and "ts=16" in plans[0] and plans[1].startswith("cpt(k_recconv_cpt<4, 4, 0, 0, ts=16>") and \
+        all(p.startswith("lanes(") for p in plans[2:]), plans
 
 
 def test_fold_token_mixer_norms_counts_and_is_noop_for_other_mixers():

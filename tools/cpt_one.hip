@@ -3,7 +3,8 @@
 // read-only x (tools/cpt_bench.hip) ranks some variants the other way round (profiles/r03_cpt_cb16.txt, r03_cpt_fresh_sweep.txt).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -DVARIANT=0 [-DRCX_CPT_AHEAD1=4 ...] tools/cpt_one.hip -o tools/cpt_one_v0
 //   tools/cpt_one_v0 [N=256] [iters=40] [fresh=1]
-// VARIANT 0: <4, 2, 0, 128, bf16> (56x56x64), 1: <4, 4, 0, 128, bf16>, 2: <2, 1, 0, 256, bf16> (28x28x128), 3: <2, 2, 0, 0, bf16> (28x28x96)
+// VARIANT 0: <4, 2, 0, 128, bf16> (56x56x64), 1: <4, 4, 0, 128, bf16>, 2: <2, 1, 0, 256, bf16> (28x28x128), 3: <2, 2, 0, 0, bf16> (28x28x96),
+//         4: 16-pixel tiles, 64x64x128 / level 3 (config 5, default N = 32)
 //   -DSTGN=3 (56x56) / 2 (28x28): x rows by LDS-DMA (with -DRCX_CPT_STG_P2=0/1: pass 1 only / both passes); -DRCX_STAMPS: the phase timeline of the last unit
 #include "../recnext_amd/csrc/rcx_cpt_kernel.h"
 namespace rcx { LaunchEvents take_launch_events() { return LaunchEvents{}; } }
@@ -30,7 +31,7 @@ int main(int argc, char** argv)
 {
     using namespace rcx;
     const int N = argc > 1 ? atoi(argv[1]) : 256, iters = argc > 2 ? atoi(argv[2]) : 40, fresh = argc > 3 ? atoi(argv[3]) : 1;
-    constexpr int H = VARIANT < 2 ? 56 : 28, C = VARIANT < 2 ? 64 : (VARIANT == 2 ? 128 : 96), level = VARIANT < 2 ? 4 : 3;
+    constexpr int H = VARIANT == 4 ? 64 : (VARIANT < 2 ? 56 : 28), C = VARIANT == 4 ? 128 : (VARIANT < 2 ? 64 : (VARIANT == 2 ? 128 : 96)), level = VARIANT < 2 ? 4 : 3;
     const size_t elems = (size_t)N * C * H * H;
     std::vector<unsigned short> hx(elems);
     srand(1);
@@ -50,6 +51,9 @@ int main(int argc, char** argv)
         return cpt::launch<4, 4, 0, 128, bf16_t, false, 4, STGN>(x, y, w, nullptr, N, C, s, sv);
 #elif VARIANT == 2
         return cpt::launch<2, 1, 0, 256, bf16_t, false, 3, STGN>(x, y, w, nullptr, N, C, s, sv);
+#elif VARIANT == 4
+        (void)sv;
+        return cpt::launch16<0, bf16_t>(x, y, w, nullptr, N, C, s);
 #else
         return cpt::launch<2, 2, 0, 0, bf16_t, false, 3, STGN>(x, y, w, nullptr, N, C, s, sv);
 #endif
@@ -95,7 +99,7 @@ int main(int argc, char** argv)
     std::vector<unsigned long long> h(nst);
     CK(hipMemcpy(h.data(), st, nst * 8, hipMemcpyDeviceToHost));
     const char* names[9] = {"start", "taps, barrier", "pass 1", "barrier", "down ladder", "up pieces", "T1", "C1", "pass 2"};
-    const int nw = VARIANT == 0 ? 8 : (VARIANT == 3 ? 2 : 4);
+    const int nw = VARIANT == 0 ? 8 : (VARIANT == 3 ? 2 : 4);        // waves per workgroup
     unsigned long long r0 = ~0ull;                       // the first wave's start on the 100 MHz clock
     for (size_t k = 0; k < nst / 16; ++k) if (h[k * 16 + 9]) r0 = std::min(r0, h[k * 16 + 9]);
     for (int it = 0; it < 4; ++it) {
