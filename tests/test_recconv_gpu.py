@@ -232,6 +232,37 @@ def test_56_block_with_16_and_32_channel_workgroups_is_the_same_function(mode, d
 
 @pytest.mark.parametrize("mode", ["bilinear", "nearest"])
 @pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("shape", [(2, 128), (3, 64), (1, 40), (2, 8), (5, 18)], ids=lambda v: "x".join(map(str, v)))
+def test_64_block_on_16_pixel_tiles_against_oracle_and_lanes_kernel(mode, bias, dtype, shape, monkeypatch):
+    """Round 5: the 64 x 64 / level 3 block (stage 1 of a 512 x 512 input, BASELINE config 5) on the tiled channel-per-lane kernel with 16-pixel tiles
+    (k_recconv_cpt<4, 4, ., 0, ts=16>): against the float64 C oracle and against the schedule it replaces (RCX_CPT16=0: float32 round-off apart).
+    Whole and ragged 16-channel blocks (128, 64 / 40, 8, 18), both resize modes, bias."""
+    n, c = shape
+    k, hw, level = 5, 64, 3
+    rng = np.random.default_rng(zlib.crc32(repr(("ts16", mode, bias, str(dtype), shape)).encode()))
+    x, wd, wc, bd, bc = _rand_case(rng, n, c, hw, hw, level, k, bias)
+    if dtype != torch.float32:
+        x = bf16_round_np(x) if dtype == torch.bfloat16 else x.astype(np.float16).astype(np.float32)
+    ref = c_oracle.recconv2d(x, wd, wc, bd, bc, level, mode)
+    assert ops.recconv2d_plan(n, c, hw, hw, level, k, mode, dtype).startswith("cpt(k_recconv_cpt<4, 4, %d, 0, ts=16>" % (1 if mode == "nearest" else 0))
+    got = _run_hip(x, wd, wc, bd, bc, level, k, mode, dtype)
+    if dtype == torch.float32:
+        assert np.abs(got - ref).max() < F32_TIGHT
+    elif dtype == torch.float16:
+        assert np.allclose(got, ref, atol=1e-3, rtol=1e-3)
+    else:
+        assert np.allclose(got, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
+        assert np.all(np.abs(got - ref) <= np.abs(ref) * 2 ** -8 + 1e-5)          # one rounding, at the store
+    monkeypatch.setenv("RCX_CPT16", "0")
+    assert not ops.recconv2d_plan(n, c, hw, hw, level, k, mode, dtype).startswith("cpt(")       # lanes( for float32 / bfloat16, nested( for float16
+    other = _run_hip(x, wd, wc, bd, bc, level, k, mode, dtype)
+    if dtype == torch.float32:
+        assert np.abs(got - other).max() < 2e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("mode", ["bilinear", "nearest"])
+@pytest.mark.parametrize("bias", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 64, 56, 4), (1, 48, 56, 4), (2, 80, 56, 4), (1, 8, 56, 4), (2, 128, 28, 3), (1, 96, 28, 3), (3, 160, 28, 3),
                                    (2, 40, 28, 3), (3, 96, 28, 3), (1, 72, 28, 3),
