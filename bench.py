@@ -199,11 +199,14 @@ def kernel_name(plan, elem_bytes):
         return f"rcx::lanes::{kern}, {t}>"
     if plan.startswith("cpt(k_recconv_cpt"):
         kern = plan[len("cpt("):plan.index(">")]
-        # template arguments after the type: training, levels (4 / 3 = the full ladder of a 56 / 28 plane; one less: "levels-1"), staged rows
-        # (diagnostic build)
+        # template arguments after the type: training, levels (4 / 3 = the full ladder of a 56 / 28 plane; one less: "levels-1"; the 64 x 64 block on
+        # 16-pixel tiles: 3), staged rows (diagnostic build), pixels per tile side (14; "ts=16" in the plan: 16)
+        ts = 14
+        if kern.endswith(", ts=16"):
+            kern, ts = kern[:-len(", ts=16")], 16
         t_ = int(kern[len("k_recconv_cpt<"):].split(",")[0])
-        lv = (4 if t_ == 4 else 3) - (1 if ">,levels-1," in plan else 0)
-        return f"rcx::cpt::{kern}, {t}, false, {lv}, 0>"
+        lv = 3 if ts == 16 else (4 if t_ == 4 else 3) - (1 if ">,levels-1," in plan else 0)
+        return f"rcx::cpt::{kern}, {t}, false, {lv}, 0, {ts}>"
     if plan.startswith("cpl(k_recconv_cpl"):
         kern = plan[len("cpl("):plan.index(">")]
         ns = "cpl14"                                                          # rcx_cpl14.hip

@@ -50,3 +50,26 @@ def test_traffic_is_quoted_only_for_the_sources_it_was_measured_on(tmp_path):
         assert json.load(open(os.path.join(ROOT, src)))["library_sources_sha256"] == build.source_fingerprint()
     else:
         assert "re-run tools/collect_profiles.sh" in note
+
+
+def test_plan_strings_map_to_the_device_kernel_names_rocprofv3_reports():
+    """bench.py matches its per-mixer times to the committed PMC profiles by kernel name: the mapping from rcx_recconv2d_fwd_plan's strings has to
+    follow the kernels' template arguments (round 5 added the tile side to k_recconv_cpt)."""
+    bench = _load("_rcx_bench_t3", "bench.py")
+    kn = bench.kernel_name
+    assert kn("cpt(k_recconv_cpt<4, 2, 0, 128>,cb=32,nt=512,units=512,lds=137856)", 2) == "rcx::cpt::k_recconv_cpt<4, 2, 0, 128, unsigned short, false, 4, 0, 14>"
+    assert kn("cpt(k_recconv_cpt<2, 1, 0, 256>,cb=64,nt=256,units=512,lds=71424)", 2) == "rcx::cpt::k_recconv_cpt<2, 1, 0, 256, unsigned short, false, 3, 0, 14>"
+    assert kn("cpt(k_recconv_cpt<4, 4, 0, 0>,levels-1,cb=16,nt=256,units=8,lds=68928)", 4) == "rcx::cpt::k_recconv_cpt<4, 4, 0, 0, float, false, 3, 0, 14>"
+    assert kn("cpt(k_recconv_cpt<4, 4, 0, 0, ts=16>,cb=16,nt=256,units=256,lds=88320)", 2) == "rcx::cpt::k_recconv_cpt<4, 4, 0, 0, unsigned short, false, 3, 0, 16>"
+    assert kn("cpl(k_recconv_cpl14<0, 256>,cb=64,nt=64,blocks=1024,lds=0)", 2) == "rcx::cpl14::k_recconv_cpl14<0, 256, unsigned short, false, 2, false>"
+
+
+def test_every_mixer_of_the_five_baseline_configs_has_a_traffic_record_in_this_rounds_profiles():
+    """`roofline.traffic` must not be null for any BASELINE configuration -- every token-mixer kernel (or multi-launch unit) that the
+    round's profiled bench lines name has HBM bytes per launch in the traffic file of the same run."""
+    for tag in ("r05", "r05_m1", "r05_m5", "r05_a3", "r05_512"):
+        line = json.loads(open(os.path.join(ROOT, "profiles", f"{tag}_bench.json")).read().strip().split("\n")[-1])
+        traffic = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_traffic.json")))
+        have = {k["kernel"] for k in traffic["kernels"] if k.get("hbm_bytes_per_launch") is not None}
+        for ent in line["token_mixers"]["per_kernel"]:
+            assert ent["kernel"] in have, (tag, ent["kernel"])

@@ -18,3 +18,4 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $CMD > "$O
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $CMD > "$OUT/pmc_write.log" 2>&1
 python3 tools/profile_summary.py "$TAG" "$OUT" "$ROOT/gpurun_out/profiles_$TAG"
 ls -la "$ROOT/gpurun_out/profiles_$TAG"
+rm -rf "$OUT/kt" "$OUT/pmc_fetch" "$OUT/pmc_write"      # the raw traces are tens of MB per configuration: gpurun copies back at most 64 MiB

@@ -51,6 +51,38 @@ for k, d in sorted(pmc.items()):
         rec["correction"] = ("2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes (gfx950: FETCH_SIZE tallies 128-B requests at 64 B; checked on the "
                              "whole-plane kernels, which read x exactly once: 1.02-1.05 x their algorithmic bytes)")
     kernels.append(rec)
+# Composite units (what bench.py lists as ONE token mixer but the device runs as several launches: a RecAttn2d unit, the three-launch split schedule of
+# 128 x 128 / level 4): HBM bytes per UNIT = sum over the unit's device kernels of bytes per launch x launches, divided by the units of the run.  The unit
+# names and their counts come from the bench line of the same profiled run; passes = launches of a kernel that runs once per forward pass (Downsample's
+# k_down7m2_cpt) or steps + warm-up + 1.
+import re
+bench_line = None
+p_log = os.path.join(raw, "kt_bench.log")
+if os.path.exists(p_log):
+    for line in open(p_log):
+        if line.startswith('{"metric"'):
+            bench_line = json.loads(line)
+if bench_line and "token_mixers" in bench_line:
+    tm = bench_line["token_mixers"]
+    m = re.search(r"last (\d+) warm-up steps", tm.get("measured_over", ""))
+    survey = int(m.group(1)) if m else 8
+    once = [k for k in kernels if "k_down7m2_cpt" in k["kernel"] and k["launches_sampled"]]
+    passes = once[0]["launches_sampled"] if once else 31
+    for ent in tm.get("per_kernel", []):
+        name = ent["kernel"]
+        if name.startswith("RecAttn2d token mixer"):
+            pat = r"rcx::qkc::|rcx::lanes::k_down5_lanes|rcx::lanes::k_upadd_lanes|rcx::upcpt::k_upadd_cpt|rcx::upcpt::k_down5_cpt|rcx::cpl14::k_upadd_cpl|rcx::cpl14::k_down5_cpl|rcx::k_linattn|rcx::k_conv_generic"
+        elif name.startswith("rcx split schedule"):
+            pat = r"rcx::upcpt::k_down5_cpt<|rcx::upcpt::k_upadd_cpt<|rcx::lanes::k_down5_lanes|rcx::lanes::k_upadd_lanes|float, false, 3, 0, 16>|rcx::lanes::k_recconv_lanes_banded<64, 3, 16, \d, \d, \d, float>"
+        else:
+            continue
+        comp = [k for k in kernels if re.search(pat, k["kernel"]) and k.get("hbm_bytes_per_launch") is not None]
+        units = ent["launches"] / float(survey) * passes
+        if comp and units > 0:
+            kernels.append({"kernel": name, "composite": True, "units_in_run": units, "passes": passes,
+                            "composed_of": [{"kernel": k["kernel"], "launches": k["launches_sampled"], "hbm_bytes_per_launch": k["hbm_bytes_per_launch"]} for k in comp],
+                            "hbm_bytes_per_launch": sum(k["hbm_bytes_per_launch"] * k["launches_sampled"] for k in comp) / units,
+                            "correction": "sum over the unit's device kernels of (2*FETCH_SIZE + WRITE_SIZE) x launches, divided by the units of the run"})
 import importlib.util
 _spec = importlib.util.spec_from_file_location("_rcx_build", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "recnext_amd", "build.py"))
 _build = importlib.util.module_from_spec(_spec)
