@@ -22,6 +22,7 @@
 #include "rcx_common.h"
 #include "rcx_launch.h"
 #include "rcx_opts.h"
+#include "rcx_cpl14_pieces.h"          // the packed-FMA row pieces of the channel-per-lane kernels: the whole unit's final conv (round 5)
 
 namespace rcx {
 namespace qkc {
@@ -353,6 +354,93 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
         const int c = threadIdx.x < C ? threadIdx.x : threadIdx.x - C, o0 = threadIdx.x < C ? 0 : XW - ORP;
         const TX* xc = x + (size_t)b * XW * XW * C + c;
         const float* La = Lw + 12 * C + c;
+      if constexpr (XW == 14 && C >= 64) {
+        // Round 5: the 14 x 14 plane on PIXEL PAIRS -- v_pk_fma_f32 throughout, input-row stationary with five accumulator rows in
+        // flight (70 registers instead of 98), the 35 values of a the lane's rows interpolate from read from LDS once (the scalar form read 14 per x row)
+        // -- the row pieces of rcx_cpl14_pieces.h.  The upper / lower half is the wave's (C >= 64): rows and edge cases are compile-time in each branch.
+        using cpl14::f32x2;
+        cpl14::Taps t2;
+        cpl14::load_taps<0>(t2, wcv, bcv, 0, C, (unsigned)c * 4u, bcv != nullptr);
+        auto half = [&](auto hc) {
+            constexpr int O0 = decltype(hc)::value ? XW - ORP : 0, T0 = O0 - 2 < 0 ? 0 : O0 - 2, T1 = O0 + ORP + 1 > XW - 1 ? XW - 1 : O0 + ORP + 1;   // input rows T0 .. T1
+            constexpr int A0 = T0 >> 1, NA = (T1 >> 1) - A0 + 1;                   // rows of a (nearest: source = destination >> 1)
+            float av[NA][7];
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int j = 0; j < 7; ++j) av[i][j] = La[((A0 + i) * Wp + j) * DROW];
+            TX cur[XW], nxt[XW];
+            auto load_xrow = [&](TX (&dst)[XW], int y) {
+#pragma unroll
+                for (int xx = 0; xx < XW; ++xx) dst[xx] = xc[(size_t)(y * XW + xx) * C];
+            };
+            load_xrow(cur, T0);
+            f32x2 acc[5][7];
+            TX* yc = yout + (size_t)b * XW * XW * C + c;
+            lanes::sfor<T1 - T0 + 1>([&](auto tcn) {
+                constexpr int t = T0 + decltype(tcn)::value;
+                if constexpr (t < T1) load_xrow(nxt, t + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                // output rows that this input row opens start from the bias
+#pragma unroll
+                for (int o = O0; o < O0 + ORP; ++o) {
+                    const bool opens = (o - 2 <= T0) ? (t == T0) : (t == o - 2);
+                    if (opens && o >= t - 2 && o <= t + 2) {
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) acc[o % 5][j] = cpl14::splat(t2.bias);
+                    }
+                }
+                f32x2 row[7];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const float a_ = av[(t >> 1) - A0][j];
+                    row[j] = f32x2{elem_to_f32(cur[2 * j]) + a_, elem_to_f32(cur[2 * j + 1]) + a_};
+                }
+                // one input row into the accumulator rows of THIS half it feeds (cpl14::conv5_row restricted to O0 .. O0 + ORP - 1)
+                {
+                    f32x2 odd[8];
+                    const f32x2 zero = f32x2{0.f, 0.f};
+                    odd[0] = cpl14::shift1(zero, row[0]);
+#pragma unroll
+                    for (int j = 1; j < 7; ++j) odd[j] = cpl14::shift1(row[j - 1], row[j]);
+                    odd[7] = cpl14::shift1(row[6], zero);
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) {
+                        const int o = t - u + 2;
+                        if (o < O0 || o >= O0 + ORP) continue;
+                        f32x2(&a)[7] = acc[o % 5];
+#pragma unroll
+                        for (int j = 1; j < 7; ++j) a[j] = cpl14::pfma(row[j - 1], cpl14::splat(t2.at(u, 0)), a[j]);
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) a[j] = cpl14::pfma(odd[j], cpl14::splat(t2.at(u, 1)), a[j]);
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) a[j] = cpl14::pfma(row[j], cpl14::splat(t2.at(u, 2)), a[j]);
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) a[j] = cpl14::pfma(odd[j + 1], cpl14::splat(t2.at(u, 3)), a[j]);
+#pragma unroll
+                        for (int j = 0; j + 1 < 7; ++j) a[j] = cpl14::pfma(row[j + 1], cpl14::splat(t2.at(u, 4)), a[j]);
+                    }
+                }
+                // output row t - 2 has seen its last input row (the plane's last rows: with the last input row)
+#pragma unroll
+                for (int o = O0; o < O0 + ORP; ++o) {
+                    const bool done = (o + 2 >= T1) ? (t == T1) : (t == o + 2);
+                    if (done) {
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) {
+                            const float v2[1] = {acc[o % 5][j].x}, v3[1] = {acc[o % 5][j].y};
+                            store_vec<1>(yc + (size_t)(o * XW + 2 * j) * C, v2);
+                            store_vec<1>(yc + (size_t)(o * XW + 2 * j + 1) * C, v3);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int xx = 0; xx < XW; ++xx) cur[xx] = nxt[xx];
+            });
+        };
+        if (threadIdx.x < C) half(lanes::IC<0>{}); else half(lanes::IC<1>{});
+      } else {
         float wt[25];
 #pragma unroll
         for (int j = 0; j < 25; ++j) wt[j] = wcv[j * C + c];
@@ -405,6 +493,7 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
                 const float v1[1] = {a[o][j]};
                 store_vec<1>(yc + (size_t)((o0 + o) * XW + j) * C, v1);
             }
+      }
     }
 }
 
