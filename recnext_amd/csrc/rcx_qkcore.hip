@@ -40,7 +40,24 @@ __device__ __forceinline__ bf16x8 to_bf16x8(f32x4q lo, f32x4q hi)
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-constexpr int LROW = 36;          // floats per row of a wave's q image (32 + 4: 16-byte aligned rows that spread over the banks)
+// ---- head dimensions below 32 (round 5: RecNeXt-A0 / A1 / A2, 20 / 24 / 28 channels per head; model/recattn.py:382-396).  Everything INSIDE the kernels stays
+// 32 wide per head: the LDS images of d, a, the pe taps and the biases are PADDED (head hd at columns 32 hd .. 32 hd + D - 1, the rest zeros -- or -100 for the
+// q / k biases: elu1 of it is 0, so a padded channel neither projects nor normalises), the weights of a padded output row or input column are zeros.  Only the
+// faces to memory know the compact layout (C = D heads channels per token): the staging of d, x, the small arrays, the weight fragments and the stores of the
+// attention output.  D is a multiple of 4 (16-byte groups never straddle a head) and a q / k half is whole heads (heads even).
+typedef unsigned u32x2q __attribute__((ext_vector_type(2)));
+constexpr float QK_PAD_BIAS = -100.f;
+// the 8 bf16 weights of one output row (row = its first compact input) for the padded input columns pcol .. pcol + 7 of the row's half (pcol % 8 == 0)
+template <bool PAD>
+__device__ __forceinline__ u32x4q wfrag(const bf16_t* row, bool rvalid, int pcol, int D)
+{
+    if constexpr (!PAD) return rvalid ? *reinterpret_cast<const u32x4q*>(row + pcol) : u32x4q{0u, 0u, 0u, 0u};
+    const int off = pcol & 31, ci = (pcol >> 5) * D + off;
+    // (unconditional loads from an address that always exists, then a select: a branch per fragment otherwise)
+    const bool vl = rvalid && off < D, vh = rvalid && off + 4 < D;
+    const u32x2q lo = *reinterpret_cast<const u32x2q*>(row + (vl ? ci : 0)), hi = *reinterpret_cast<const u32x2q*>(row + (vh ? ci + 4 : 0));
+    return u32x4q{vl ? lo.x : 0u, vl ? lo.y : 0u, vh ? hi.x : 0u, vh ? hi.y : 0u};
+}
 constexpr int DPAD = 4;           // floats added to a row of the shared d image (rows of C + 4: the 32 token rows of a fragment read fall on different banks)
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.f : __expf(x); }
@@ -58,21 +75,30 @@ __device__ __forceinline__ constexpr int acc_row(int i, int h) { return (i & 3) 
 // rows [row0, row0 + nrows) of an image's d (float32, C channels) -> LDS rows of DROW floats, 16 bytes per lane and UN requests in flight per lane
 // (one request per iteration costs a memory round trip per 16 bytes: 8 round trips for a 49 x 256 image).  Rows outside the image read 0.
 template <int UN = 8>
-__device__ __forceinline__ void stage_rows(float* Ld, __amdgpu_buffer_rsrc_t dsrc, int row0, int nrows, int C, int DROW, int nthr)
+__device__ __forceinline__ void stage_rows(float* Ld, __amdgpu_buffer_rsrc_t dsrc, int row0, int nrows, int Cg, int D, int heads, int DROW, int nthr)
 {
-    const int cq = C / 4, chunks = nrows * cq;
+    // Cg = D heads channels per token in memory; the LDS row has head hd at columns 32 hd .. (D == 32: the same thing)
+    const int cq = Cg / 4, chunks = nrows * cq;
     for (int i0 = threadIdx.x; i0 < chunks; i0 += UN * nthr) {
         u32x4q v[UN];
         int dst[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int i = i0 + u * nthr, t = i / cq, q4 = i - t * cq;
-            dst[u] = i < chunks ? t * DROW + q4 * 4 : -1;
-            v[u] = __builtin_bit_cast(u32x4q, __builtin_amdgcn_raw_buffer_load_b128(dsrc, i < chunks ? ((row0 + t) * C + q4 * 4) * 4 : -16, 0, 0));
+            const int hdq = D == 32 ? 0 : (4 * q4) / D, col = D == 32 ? 4 * q4 : 32 * hdq + (4 * q4 - hdq * D);
+            dst[u] = i < chunks ? t * DROW + col : -1;
+            v[u] = __builtin_bit_cast(u32x4q, __builtin_amdgcn_raw_buffer_load_b128(dsrc, i < chunks ? ((row0 + t) * Cg + q4 * 4) * 4 : -16, 0, 0));
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u)
             if (dst[u] >= 0) *reinterpret_cast<u32x4q*>(Ld + dst[u]) = v[u];
+    }
+    if (D != 32) {                                            // the padding columns of every row: zeros
+        const int pq = (32 - D) / 4, per = heads * pq;
+        for (int i = threadIdx.x; i < nrows * per; i += nthr) {
+            const int t = i / per, e = i - t * per, hdq = e / pq, q = e - hdq * pq;
+            *reinterpret_cast<float4*>(Ld + t * DROW + 32 * hdq + D + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
 }
 
@@ -89,32 +115,58 @@ __device__ __forceinline__ void stage_rows(float* Ld, __amdgpu_buffer_rsrc_t dsr
 
 // the pe taps (9 x C), the pe bias and the q biases -> Lw[0, 11 C): 16 bytes per lane, every request issued before the first store (the plain loops
 // were four to five dependent L2 round trips).  9 C / 4 <= 2 NTHR and C / 4 <= NTHR for every instantiation (C = 32 KS, NTHR >= 64 KS or 512).
-template <int C, int NTHR>
-__device__ __forceinline__ void stage_small(float* Lw, const float* __restrict__ wpe, const float* __restrict__ bpe, const float* __restrict__ bqk)
+template <int C, int NTHR, bool PAD>
+__device__ __forceinline__ void stage_small(float* Lw, const float* __restrict__ wpe, const float* __restrict__ bpe, const float* __restrict__ bqk, int D)
 {
-    static_assert(9 * C / 4 <= 2 * NTHR && C / 4 <= NTHR, "stage_small: one or two requests per lane");
-    const int i = threadIdx.x;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4* w4 = reinterpret_cast<const float4*>(wpe);
-    float4 a0 = z, a1 = z, b0 = z, c0 = z;              // (`cond ? p[i] : z` selects between ADDRESSES and puts z in scratch)
-    if (i < 9 * C / 4) a0 = w4[i];
-    if (i + NTHR < 9 * C / 4) a1 = w4[i + NTHR];
-    if (bpe && i < C / 4) b0 = reinterpret_cast<const float4*>(bpe)[i];
-    if (i < C / 4) c0 = reinterpret_cast<const float4*>(bqk)[i];
-    float4* L4 = reinterpret_cast<float4*>(Lw);
-    if (i < 9 * C / 4) L4[i] = a0;
-    if (i + NTHR < 9 * C / 4) L4[i + NTHR] = a1;
-    if (i < C / 4) { L4[9 * C / 4 + i] = b0; L4[10 * C / 4 + i] = c0; }
+    if constexpr (!PAD) {
+        static_assert(9 * C / 4 <= 2 * NTHR && C / 4 <= NTHR, "stage_small: one or two requests per lane");
+        const int i = threadIdx.x;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4* w4 = reinterpret_cast<const float4*>(wpe);
+        float4 a0 = z, a1 = z, b0 = z, c0 = z;              // (`cond ? p[i] : z` selects between ADDRESSES and puts z in scratch)
+        if (i < 9 * C / 4) a0 = w4[i];
+        if (i + NTHR < 9 * C / 4) a1 = w4[i + NTHR];
+        if (bpe && i < C / 4) b0 = reinterpret_cast<const float4*>(bpe)[i];
+        if (i < C / 4) c0 = reinterpret_cast<const float4*>(bqk)[i];
+        float4* L4 = reinterpret_cast<float4*>(Lw);
+        if (i < 9 * C / 4) L4[i] = a0;
+        if (i + NTHR < 9 * C / 4) L4[i + NTHR] = a1;
+        if (i < C / 4) { L4[9 * C / 4 + i] = b0; L4[10 * C / 4 + i] = c0; }
+    } else {
+        // C = 32 heads (padded); memory holds D heads channels per row: group i of the 11 C / 4 is row i / (C / 4) (9 tap rows, the pe bias, the q biases),
+        // padded column 4 (i % (C / 4)).  One or two groups per lane, both requests issued before the first store; padding = 0 (-100 for the q biases).
+        static_assert(11 * C / 4 <= 2 * NTHR, "stage_small: at most two requests per lane");
+        const int Cg = (C / 32) * D;
+        f32x4q v0, v1;
+        auto fetch = [&](int i, f32x4q& v) {
+            const int row = i / (C / 4), cp = 4 * (i - row * (C / 4)), c = (cp >> 5) * D + (cp & 31);
+            const float pad = row == 10 ? QK_PAD_BIAS : 0.f;
+            v = f32x4q{pad, pad, pad, pad};
+            const float* src = row < 9 ? wpe + (size_t)row * Cg + c : (row == 9 ? bpe + c : bqk + c);
+            if (i < 11 * C / 4 && (cp & 31) < D && (row != 9 || bpe != nullptr)) v = *reinterpret_cast<const f32x4q*>(src);
+        };
+        fetch(threadIdx.x, v0);
+        fetch(threadIdx.x + NTHR, v1);
+        f32x4q* L4 = reinterpret_cast<f32x4q*>(Lw);
+        if (threadIdx.x < 11 * C / 4) L4[threadIdx.x] = v0;
+        if (threadIdx.x + NTHR < 11 * C / 4) L4[threadIdx.x + NTHR] = v1;
+    }
 }
 
 // The end of a 32-token tile once q^T is accumulated (aq: rows c1 in the registers, column = the lane's token t): bias + activation, the normaliser
 // (the lane's 16 channels + its partner lane's), out^T = kv^T q^T, pe as float4s of the lane's token and 16-byte stores.  drow = the token's row of
 // the LDS image, at the lane's first channel (rows above / below the plane hold zeros: they are outside the buffer the image was staged from), zrow = a row of zeros for the taps
 // that would wrap to the neighbouring plane row, Lwc / outp already point at the lane's first channel (head * 32 + 4 h).
-template <int C, int OSTR = C>
+// ostr = floats between tokens at outp (the compact C in memory; the padded row when the caller keeps a in LDS), dvalid = channels of this head that exist
+// past the lane's first one (D - 4 h; 32: all four groups): a group of four is stored when its first channel exists
+template <int C, bool MASK>
 __device__ __forceinline__ void out_epilogue(const f32x16& aq, bf16x8 kv0, bf16x8 kv1, const float* Lbq, const float* Lkb, const float4* drow,
-                                             const float4* zrow, const float4* Lwc, int t, int n, int Wp, int h, float* outp)
+                                             const float4* zrow, const float4* Lwc, int t, int n, int Wp, int h, float* outp, int ooff, int ostr, int dvalid)
 {
+    // MASK (head dimension < 32): outp + ostr n floats is the image's output; a group past the head's D channels goes to an out-of-range buffer offset, which the
+    // hardware drops (a branch around the store cost the tile loop 35 registers and spilled)
+    __amdgpu_buffer_rsrc_t osrc;
+    if constexpr (MASK) osrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, n * ostr * 4, 0x00020000);
     constexpr int DROW4 = (C + DPAD) / 4;
     float dpart = 0.f;
     bf16x8 q0, q1;
@@ -151,7 +203,8 @@ __device__ __forceinline__ void out_epilogue(const f32x16& aq, bf16x8 kv0, bf16x
             for (int j = 0; j < 9; ++j) pe = __builtin_elementwise_fma(Lwv[(j * C) / 4 + 2 * gq], reinterpret_cast<const f32x4q*>(nb[j])[2 * gq], pe);
             const f32x4q ov = {o[4 * gq + 0], o[4 * gq + 1], o[4 * gq + 2], o[4 * gq + 3]};
             const f32x4q res = __builtin_elementwise_fma(ov, f32x4q{rdn, rdn, rdn, rdn}, pe);
-            *reinterpret_cast<f32x4q*>(outp + (size_t)t * OSTR + 8 * gq) = res;          // OSTR floats between tokens (C in memory; a padded row when the caller keeps a in LDS)
+            if constexpr (MASK) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4q, res), osrc, 8 * gq < dvalid ? (t * ostr + ooff + 8 * gq) * 4 : -16, 0, 0);
+            else *reinterpret_cast<f32x4q*>(outp + (size_t)t * ostr + ooff + 8 * gq) = res;
         }
     }
 }
@@ -170,14 +223,15 @@ __device__ __forceinline__ void out_epilogue(const f32x16& aq, bf16x8 kv0, bf16x
 // scattered into the output rows it touches (float32).  Saves the stand-alone step's launch and d's trip through memory.
 // FULL (with XW > 0): the unit's last step too, y = conv5(x + nearest-resize(a)) + bias (model/recattn.py:67): a stays in LDS (one more barrier), the
 // same two lanes per channel form the upper / lower output rows from x rows loaded once each -- RecAttn2d.forward in one launch.
-template <int NT, int KS, int XW = 0, typename TX = bf16_t, bool FULL = false>
+template <int NT, int KS, int XW = 0, typename TX = bf16_t, bool FULL = false, bool PAD = false>      // PAD: head dimension < 32 (Dr); else every mask below folds away
 __global__ void __launch_bounds__(64 * KS)
 k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, const float* __restrict__ bqk, const float* __restrict__ wpe,
                 const float* __restrict__ bpe, float* __restrict__ out, int Hp, int Wp,
                 const TX* __restrict__ x, const float* __restrict__ wdn, const float* __restrict__ bdn,
-                const float* __restrict__ wcv, const float* __restrict__ bcv, TX* __restrict__ yout)
+                const float* __restrict__ wcv, const float* __restrict__ bcv, TX* __restrict__ yout, int Dr)
 {
     static_assert(!FULL || XW > 0, "the whole unit starts from x");
+    const int D = PAD ? Dr : 32;
     extern __shared__ __attribute__((aligned(16))) float lds_s[];
     constexpr int C = 32 * KS, K = C / 2, DROW = C + DPAD, DROW4 = DROW / 4, NTHR = 64 * KS, PF = KS < 8 ? KS : 8;        // weight fragments in flight: a ring 4 deep left ~0.4 us of L2 latency exposed at every refill
     const int hd = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
@@ -186,29 +240,34 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
     const float4* const Ld4 = reinterpret_cast<const float4*>(lds_s);
     const f32x4q* const Ldv = reinterpret_cast<const f32x4q*>(lds_s);
     float* const Lw = Ld + (size_t)(rows + 1) * DROW;         // [9][C] pe taps, [C] pe bias, [C] q biases, [C] kbar
-    const float* dimg = d + (size_t)b * n * C;
-    const __amdgpu_buffer_rsrc_t dsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dimg, 0, n * C * 4, 0x00020000);
+    // C, K = the PADDED channel count and half (32 per head); Cg, Kg = what memory holds (D per head)
+    const int Cg = KS * D, Kg = Cg / 2;
+    const float* dimg = d + (size_t)b * n * Cg;
+    const __amdgpu_buffer_rsrc_t dsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dimg, 0, n * Cg * 4, 0x00020000);
 
-    const bf16_t* wq_row = wqk + (size_t)(hd * 32 + r) * K + 8 * h;            // this lane's output channel, its 8 inputs of k-step 0
-    const bf16_t* wk_row = wqk + (size_t)(C + hd * 32 + r) * K + 8 * h;
+    const bool rvalid = r < D;                                                 // this lane's output channel of the head exists
+    const bf16_t* wq_row = wqk + (size_t)(hd * D + (rvalid ? r : 0)) * Kg;      // its weight row (compact); wfrag picks the 8 inputs of a k-step
+    const bf16_t* wk_row = wqk + (size_t)(Cg + hd * D + (rvalid ? r : 0)) * Kg;
     u32x4q wf[PF];
     if constexpr (XW == 0) {                                  // (with the conv inside: requested after it -- its 70 live registers leave no room at 16 waves)
 #pragma unroll
-        for (int j = 0; j < PF; ++j) wf[j] = *reinterpret_cast<const u32x4q*>(wk_row + 16 * j);
+        for (int j = 0; j < PF; ++j) wf[j] = wfrag<PAD>(wk_row, rvalid, 16 * j + 8 * h, D);
     }
 
-    const float bk = bqk[C + hd * 32 + r];
+    const float bk = rvalid ? bqk[Cg + hd * D + r] : QK_PAD_BIAS;
     if constexpr (XW == 0) {
-        stage_rows<NT == 2 ? 12 : 6>(Ld, dsrc, R0, rows, C, DROW, NTHR);      // rows / 8 requests per lane: the whole image in one round trip up to 14 x 14 / 7 x 7 planes
+        stage_rows<NT == 2 ? 12 : 6>(Ld, dsrc, R0, rows, Cg, D, KS, DROW, NTHR);      // rows / 8 requests per lane: the whole image in one round trip up to 14 x 14 / 7 x 7 planes
         for (int i = threadIdx.x; i < DROW; i += NTHR) Ld[(size_t)rows * DROW + i] = 0.f;
     } else {
         constexpr int WO = (XW + 1) / 2, RPP = (WO + 1) / 2, NXR = 2 * RPP + 3;          // output plane, output rows per lane, x rows they touch
         static_assert(NTHR == 2 * C, "two lanes per channel");
-        const int c = threadIdx.x < C ? threadIdx.x : threadIdx.x - C, o0 = threadIdx.x < C ? 0 : WO - RPP;      // (per wave for C >= 64; C = 32 has both halves in its one wave)
-        const TX* xc = x + (size_t)b * XW * XW * C + c;
+        const int cp = threadIdx.x < C ? threadIdx.x : threadIdx.x - C, o0 = threadIdx.x < C ? 0 : WO - RPP;      // padded channel (per wave for C >= 64; C = 32 has both halves in its one wave)
+        const bool cvalid = (cp & 31) < D;                                     // a padding lane runs on channel 0 and leaves zeros
+        const int c = cvalid ? (cp >> 5) * D + (cp & 31) : 0;
+        const TX* xc = x + (size_t)b * XW * XW * Cg + c;
         float wt[25];
 #pragma unroll
-        for (int j = 0; j < 25; ++j) wt[j] = wdn[j * C + c];
+        for (int j = 0; j < 25; ++j) wt[j] = wdn[j * Cg + c];
         const float bias = bdn ? bdn[c] : 0.f;
         // rows of the LDS image that are not tokens: zeros (the halo of pe, the rows of tokens past the plane, the zero row)
         {
@@ -228,7 +287,7 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
             if (y >= 0 && y < XW) {
                 float xr[XW];
 #pragma unroll
-                for (int xx = 0; xx < XW; ++xx) xr[xx] = elem_to_f32(xc[(size_t)(y * XW + xx) * C]);
+                for (int xx = 0; xx < XW; ++xx) xr[xx] = elem_to_f32(xc[(size_t)(y * XW + xx) * Cg]);
 #pragma unroll
                 for (int o = 0; o < RPP; ++o) {
                     const int dy = i - 2 * o;                  // compile time after unrolling
@@ -247,11 +306,11 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
 #pragma unroll
         for (int o = 0; o < RPP; ++o)
 #pragma unroll
-            for (int j = 0; j < WO; ++j) Ld[(size_t)(Wp + 1 + (o0 + o) * Wp + j) * DROW + c] = a[o][j];
+            for (int j = 0; j < WO; ++j) Ld[(size_t)(Wp + 1 + (o0 + o) * Wp + j) * DROW + cp] = cvalid ? a[o][j] : 0.f;
 #pragma unroll
-        for (int j = 0; j < PF; ++j) wf[j] = *reinterpret_cast<const u32x4q*>(wk_row + 16 * j);
+        for (int j = 0; j < PF; ++j) wf[j] = wfrag<PAD>(wk_row, rvalid, 16 * j + 8 * h, D);
     }
-    stage_small<C, NTHR>(Lw, wpe, bpe, bqk);
+    stage_small<C, NTHR, PAD>(Lw, wpe, bpe, bqk, D);
     __syncthreads();
 
     // ---- 1. k tiles (lane = channel hd * 32 + r, tokens in the registers), kv
@@ -271,8 +330,8 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const bf16x8 bk8 = __builtin_bit_cast(bf16x8, wf[s % PF]);
-        if (s + PF < KS) wf[s % PF] = *reinterpret_cast<const u32x4q*>(wk_row + 16 * (s + PF));
-        else wf[s % PF] = *reinterpret_cast<const u32x4q*>(wq_row + 16 * (s + PF - KS));          // the ring rolls over into the q weights
+        if (s + PF < KS) wf[s % PF] = wfrag<PAD>(wk_row, rvalid, 16 * (s + PF) + 8 * h, D);
+        else wf[s % PF] = wfrag<PAD>(wq_row, rvalid, 16 * (s + PF - KS) + 8 * h, D);          // the ring rolls over into the q weights
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
             // next: k-step s + 1 of the k half, or k-step 0 of the q half
@@ -322,7 +381,7 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const bf16x8 bq8 = __builtin_bit_cast(bf16x8, wf[(s + KS) % PF]);
-        if (s + PF < KS) wf[(s + KS) % PF] = *reinterpret_cast<const u32x4q*>(wq_row + 16 * (s + PF));
+        if (s + PF < KS) wf[(s + KS) % PF] = wfrag<PAD>(wq_row, rvalid, 16 * (s + PF) + 8 * h, D);
         if (s + 1 < KS) {
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
@@ -340,27 +399,30 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
         const int t = 32 * tt + r;
-        if constexpr (FULL)
-            out_epilogue<C, DROW>(acc[tt], kv0, kv1, Lw + 10 * C + hd * 32, Lkb, Ld4 + (t - R0) * DROW4 + (hd * 32 + 4 * h) / 4, zrow,
-                                  reinterpret_cast<const float4*>(Lw) + (hd * 32 + 4 * h) / 4, t, n, Wp, h, Lw + 12 * C + hd * 32 + 4 * h);
+        if constexpr (FULL)             // a stays in LDS, padded like d (its padding columns come out as zeros: zero kv columns, zero pe)
+            out_epilogue<C, false>(acc[tt], kv0, kv1, Lw + 10 * C + hd * 32, Lkb, Ld4 + (t - R0) * DROW4 + (hd * 32 + 4 * h) / 4, zrow,
+                                   reinterpret_cast<const float4*>(Lw) + (hd * 32 + 4 * h) / 4, t, n, Wp, h, Lw + 12 * C + hd * 32 + 4 * h, 0, DROW, 32);
         else
-            out_epilogue<C>(acc[tt], kv0, kv1, Lw + 10 * C + hd * 32, Lkb, Ld4 + (t - R0) * DROW4 + (hd * 32 + 4 * h) / 4, zrow,
-                            reinterpret_cast<const float4*>(Lw) + (hd * 32 + 4 * h) / 4, t, n, Wp, h, out + (size_t)b * n * C + hd * 32 + 4 * h);
+            out_epilogue<C, PAD>(acc[tt], kv0, kv1, Lw + 10 * C + hd * 32, Lkb, Ld4 + (t - R0) * DROW4 + (hd * 32 + 4 * h) / 4, zrow,
+                                 reinterpret_cast<const float4*>(Lw) + (hd * 32 + 4 * h) / 4, t, n, Wp, h, out + (size_t)b * n * Cg, hd * D + 4 * h, Cg, D - 4 * h);
     }
     if constexpr (FULL) {
         // ---- 3. y = conv5(x + resize(a)) + bias: lane = (channel, upper / lower output rows), a[token][channel] float32 in LDS behind Lw
         __syncthreads();
         constexpr int ORP = (XW + 1) / 2;                      // output rows per lane (7 x 7: row 3 by both, the same value)
-        const int c = threadIdx.x < C ? threadIdx.x : threadIdx.x - C, o0 = threadIdx.x < C ? 0 : XW - ORP;
-        const TX* xc = x + (size_t)b * XW * XW * C + c;
-        const float* La = Lw + 12 * C + c;
+        const int cp = threadIdx.x < C ? threadIdx.x : threadIdx.x - C, o0 = threadIdx.x < C ? 0 : XW - ORP;      // padded channel, as in the conv above
+        const bool cvalid = (cp & 31) < D;
+        const int c = cvalid ? (cp >> 5) * D + (cp & 31) : 0;
+        const TX* xc = x + (size_t)b * XW * XW * Cg + c;
+        const float* La = Lw + 12 * C + cp;
+      if (cvalid) {                                            // (Cg = the pitch of x, y and the tap packs in memory)
       if constexpr (XW == 14 && C >= 64) {
         // Round 5: the 14 x 14 plane on PIXEL PAIRS -- v_pk_fma_f32 throughout, input-row stationary with five accumulator rows in
         // flight (70 registers instead of 98), the 35 values of a the lane's rows interpolate from read from LDS once (the scalar form read 14 per x row)
         // -- the row pieces of rcx_cpl14_pieces.h.  The upper / lower half is the wave's (C >= 64): rows and edge cases are compile-time in each branch.
         using cpl14::f32x2;
         cpl14::Taps t2;
-        cpl14::load_taps<0>(t2, wcv, bcv, 0, C, (unsigned)c * 4u, bcv != nullptr);
+        cpl14::load_taps<0>(t2, wcv, bcv, 0, Cg, (unsigned)c * 4u, bcv != nullptr);
         auto half = [&](auto hc) {
             constexpr int O0 = decltype(hc)::value ? XW - ORP : 0, T0 = O0 - 2 < 0 ? 0 : O0 - 2, T1 = O0 + ORP + 1 > XW - 1 ? XW - 1 : O0 + ORP + 1;   // input rows T0 .. T1
             constexpr int A0 = T0 >> 1, NA = (T1 >> 1) - A0 + 1;                   // rows of a (nearest: source = destination >> 1)
@@ -372,11 +434,11 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
             TX cur[XW], nxt[XW];
             auto load_xrow = [&](TX (&dst)[XW], int y) {
 #pragma unroll
-                for (int xx = 0; xx < XW; ++xx) dst[xx] = xc[(size_t)(y * XW + xx) * C];
+                for (int xx = 0; xx < XW; ++xx) dst[xx] = xc[(size_t)(y * XW + xx) * Cg];
             };
             load_xrow(cur, T0);
             f32x2 acc[5][7];
-            TX* yc = yout + (size_t)b * XW * XW * C + c;
+            TX* yc = yout + (size_t)b * XW * XW * Cg + c;
             lanes::sfor<T1 - T0 + 1>([&](auto tcn) {
                 constexpr int t = T0 + decltype(tcn)::value;
                 if constexpr (t < T1) load_xrow(nxt, t + 1);
@@ -429,8 +491,8 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
 #pragma unroll
                         for (int j = 0; j < 7; ++j) {
                             const float v2[1] = {acc[o % 5][j].x}, v3[1] = {acc[o % 5][j].y};
-                            store_vec<1>(yc + (size_t)(o * XW + 2 * j) * C, v2);
-                            store_vec<1>(yc + (size_t)(o * XW + 2 * j + 1) * C, v3);
+                            store_vec<1>(yc + (size_t)(o * XW + 2 * j) * Cg, v2);
+                            store_vec<1>(yc + (size_t)(o * XW + 2 * j + 1) * Cg, v3);
                         }
                     }
                 }
@@ -443,7 +505,7 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
       } else {
         float wt[25];
 #pragma unroll
-        for (int j = 0; j < 25; ++j) wt[j] = wcv[j * C + c];
+        for (int j = 0; j < 25; ++j) wt[j] = wcv[j * Cg + c];
         const float bias = bcv ? bcv[c] : 0.f;
         float a[ORP][XW];
 #pragma unroll
@@ -455,7 +517,7 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
         auto load_xrow = [&](TX (&dst)[XW], int y) {
             const int yc_ = y < 0 ? 0 : (y > XW - 1 ? XW - 1 : y);                  // rows outside the plane: a valid row, not used
 #pragma unroll
-            for (int xx = 0; xx < XW; ++xx) dst[xx] = xc[(size_t)(yc_ * XW + xx) * C];
+            for (int xx = 0; xx < XW; ++xx) dst[xx] = xc[(size_t)(yc_ * XW + xx) * Cg];
         };
         load_xrow(cur, o0 - 2);
 #pragma unroll
@@ -485,14 +547,15 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
 #pragma unroll
             for (int xx = 0; xx < XW; ++xx) cur[xx] = nxt[xx];
         }
-        TX* yc = yout + (size_t)b * XW * XW * C + c;
+        TX* yc = yout + (size_t)b * XW * XW * Cg + c;
 #pragma unroll
         for (int o = 0; o < ORP; ++o)
 #pragma unroll
             for (int j = 0; j < XW; ++j) {
                 const float v1[1] = {a[o][j]};
-                store_vec<1>(yc + (size_t)((o0 + o) * XW + j) * C, v1);
+                store_vec<1>(yc + (size_t)((o0 + o) * XW + j) * Cg, v1);
             }
+      }
       }
     }
 }
@@ -535,23 +598,36 @@ static inline LongGeo long_geo(int B, int Hp, int Wp, int C, int heads)
     return g;
 }
 
-template <int KS>
+template <int KS, bool PAD = false>
 __global__ void __launch_bounds__(1024)
 k_recattn_kv(const float* __restrict__ d, const bf16_t* __restrict__ wqk, const float* __restrict__ bqk, float* __restrict__ part,
-             int n, int C_, int heads, int S, int tpg, int ntiles)
+             int n, int Dr, int heads, int S, int tpg, int ntiles)
 {
+    const int D = PAD ? Dr : 32;
     extern __shared__ __attribute__((aligned(16))) float lds_kv[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int hd = wv % heads, sp = wv / heads;
     constexpr int C = 32 * KS;                    // C / heads == 32 and 16 inputs per k-step of each half: a compile-time C makes every offset an immediate
     const int g = blockIdx.x, b = blockIdx.y, G = gridDim.x, K = C / 2;
-    const float* dimg = d + (size_t)b * n * C;
-    const __amdgpu_buffer_rsrc_t dsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dimg, 0, n * C * 4, 0x00020000);
-    const bf16_t* wk_row = wqk + (size_t)(C + hd * 32 + r) * K + 8 * h;
+    const int Cg = KS * D, Kg = Cg / 2;             // C, K: padded (32 per head); Cg, Kg: what memory holds (see wfrag)
+    const bool rvalid = r < D;
+    const float* dimg = d + (size_t)b * n * Cg;
+    const __amdgpu_buffer_rsrc_t dsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dimg, 0, n * Cg * 4, 0x00020000);
+    const bf16_t* wk_row = wqk + (size_t)(Cg + hd * D + (rvalid ? r : 0)) * Kg;
     bf16x8 wk[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) wk[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4q*>(wk_row + 16 * s));
-    const float bk = bqk[C + hd * 32 + r];
+    for (int s = 0; s < KS; ++s) wk[s] = __builtin_bit_cast(bf16x8, wfrag<PAD>(wk_row, rvalid, 16 * s + 8 * h, D));
+    const float bk = rvalid ? bqk[Cg + hd * D + r] : QK_PAD_BIAS;
+    // the 8 inputs of k-step s of the k half for this lane: padded columns K + 16 s + 8 h .. = compact channels ci[s] .. (two groups of four, each real or padding)
+    // as byte offsets within a token's row; a padding group: 2^31, which puts the request past the buffer whatever the token (the image is below 2^31 bytes) -- reads 0
+    unsigned sl[KS], sh[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int pc = K + 16 * s + 8 * h, off = pc & 31, ci = (pc >> 5) * D + off;
+        sl[s] = off < D ? 4u * ci : 0x80000000u;
+        sh[s] = off + 4 < D ? 4u * ci + 16u : 0x80000000u;
+    }
+    const unsigned vlane = rvalid ? 4u * (4 * h * Cg + hd * D + r) : 0x80000000u;      // v of this lane's channel; a padding channel: past the buffer, reads 0
     f32x16 kv;
 #pragma unroll
     for (int i = 0; i < 16; ++i) kv[i] = 0.f;
@@ -564,20 +640,28 @@ k_recattn_kv(const float* __restrict__ d, const bf16_t* __restrict__ wqk, const 
         // v of this tile, in the token order of the accumulator registers (requested first: the longest wait)
         float vv[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) vv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dsrc, ((32 * tt + acc_row(i, h)) * C + hd * 32 + r) * 4, 0, 0));
-        f32x4q xlo[KS], xhi[KS];
+        for (int i = 0; i < 16; ++i)              // (a uniform row offset + the lane's part: with Cg a run-time value the 16 products would otherwise be 16 loop-invariant registers)
+            vv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dsrc, (int)((unsigned)((32 * tt + acc_row(i, 0)) * Cg) * 4u + vlane), 0, 0));
+        // (8 heads of fewer than 32 channels: the 16 requests of a tile in four rounds -- their 16 selected offsets on top of the 64 registers of data do not fit the 128 of a
+        // 1024-thread workgroup; 7 of the offsets still live in scratch, 44 B, reloaded once per tile)
+        constexpr int SB = PAD && KS == 8 ? 2 : KS;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int off = ((32 * tt + r) * C + K + 16 * s + 8 * h) * 4;          // token 32 tt + r, inputs 16 s + 8 h .. + 7 of the k half
-            xlo[s] = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(dsrc, off, 0, 0));
-            xhi[s] = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(dsrc, off + 16, 0, 0));
-        }
+        for (int s0 = 0; s0 < KS; s0 += SB) {
+            f32x4q xlo[SB], xhi[SB];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            bf16x8 fa;
-            fa[0] = (__bf16)xlo[s].x; fa[1] = (__bf16)xlo[s].y; fa[2] = (__bf16)xlo[s].z; fa[3] = (__bf16)xlo[s].w;
-            fa[4] = (__bf16)xhi[s].x; fa[5] = (__bf16)xhi[s].y; fa[6] = (__bf16)xhi[s].z; fa[7] = (__bf16)xhi[s].w;
-            ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, wk[s], ak, 0, 0, 0);
+            for (int s = 0; s < SB; ++s) {
+                const unsigned trow = (unsigned)((32 * tt + r) * Cg) * 4u;              // token 32 tt + r, inputs 16 s + 8 h .. + 7 of the k half
+                xlo[s] = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(dsrc, (int)(trow + sl[s0 + s]), 0, 0));
+                xhi[s] = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(dsrc, (int)(trow + sh[s0 + s]), 0, 0));
+            }
+#pragma unroll
+            for (int s = 0; s < SB; ++s) {
+                bf16x8 fa;
+                fa[0] = (__bf16)xlo[s].x; fa[1] = (__bf16)xlo[s].y; fa[2] = (__bf16)xlo[s].z; fa[3] = (__bf16)xlo[s].w;
+                fa[4] = (__bf16)xhi[s].x; fa[5] = (__bf16)xhi[s].y; fa[6] = (__bf16)xhi[s].z; fa[7] = (__bf16)xhi[s].w;
+                ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, wk[s0 + s], ak, 0, 0, 0);
+            }
+            if constexpr (SB < KS) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -610,17 +694,18 @@ k_recattn_kv(const float* __restrict__ d, const bf16_t* __restrict__ wqk, const 
     }
 }
 
-template <int KS, int NTHR>
+template <int KS, int NTHR, bool PAD = false>
 __global__ void __launch_bounds__(NTHR, KS <= 4 ? 4 : 2)          // two workgroups per CU (128 registers) where the weights leave room
 k_recattn_out(const float* __restrict__ d, const bf16_t* __restrict__ wqk, const float* __restrict__ bqk, const float* __restrict__ wpe,
               const float* __restrict__ bpe, const float* __restrict__ part, float* __restrict__ out,
-              int Hp, int Wp, int C_, int heads, int S, int tpg, int ntiles, int rows, int GA)
+              int Hp, int Wp, int Dr, int heads, int S, int tpg, int ntiles, int rows, int GA)
 {
+    const int D = PAD ? Dr : 32;
     extern __shared__ __attribute__((aligned(16))) float lds_o[];
     constexpr int C = 32 * KS;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int hd = wv % heads, sp = wv / heads;
-    constexpr int K = C / 2, DROW = C + DPAD;
+    constexpr int DROW = C + DPAD;
     const int g = blockIdx.x, b = blockIdx.y, n = Hp * Wp;
     float* const Ld = lds_o;                      // [rows][DROW]: tokens R0 .. R0 + rows - 1 of the image (zeros outside it)
     const float4* const zrow = reinterpret_cast<const float4*>(lds_o) + (size_t)rows * (DROW / 4) + (hd * 32 + 4 * h) / 4;      // row `rows`: zeros
@@ -629,18 +714,20 @@ k_recattn_out(const float* __restrict__ d, const bf16_t* __restrict__ wqk, const
     float* const Lkb = Lw + 11 * C + hd * 32;
     const float4* const Lw4 = reinterpret_cast<const float4*>(Lw);
     const int T0 = g * tpg * TILE_TOK, R0 = T0 - Wp - 1;
-    const float* dimg = d + (size_t)b * n * C;
-    const __amdgpu_buffer_rsrc_t dsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dimg, 0, n * C * 4, 0x00020000);
+    const int Cg = KS * D, Kg = Cg / 2;             // C, K: padded; Cg, Kg: in memory
+    const bool rvalid = r < D;
+    const float* dimg = d + (size_t)b * n * Cg;
+    const __amdgpu_buffer_rsrc_t dsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dimg, 0, n * Cg * 4, 0x00020000);
 
-    stage_rows(Ld, dsrc, R0, rows, C, DROW, NTHR);
+    stage_rows(Ld, dsrc, R0, rows, Cg, D, KS, DROW, NTHR);
     __builtin_amdgcn_sched_barrier(0);            // keep the loads below from being hoisted among the staging requests (register pressure)
     for (int i = threadIdx.x; i < DROW; i += NTHR) Ld[(size_t)rows * DROW + i] = 0.f;
-    stage_small<C, NTHR>(Lw, wpe, bpe, bqk);
+    stage_small<C, NTHR, PAD>(Lw, wpe, bpe, bqk, D);
     // this head's weights and the partial sums (requested after the staging loop, whose eight 16-byte requests per lane would otherwise be live with them: 166-202 registers; waited for at the barrier)
-    const bf16_t* wq_row = wqk + (size_t)(hd * 32 + r) * K + 8 * h;
+    const bf16_t* wq_row = wqk + (size_t)(hd * D + (rvalid ? r : 0)) * Kg;
     bf16x8 wq[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) wq[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4q*>(wq_row + 16 * s));
+    for (int s = 0; s < KS; ++s) wq[s] = __builtin_bit_cast(bf16x8, wfrag<PAD>(wq_row, rvalid, 16 * s + 8 * h, D));
     float kvs[16], ks = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) kvs[i] = 0.f;
@@ -672,7 +759,7 @@ k_recattn_out(const float* __restrict__ d, const bf16_t* __restrict__ wqk, const
             const bf16x8 fb = to_bf16x8(dv4[4 * s + 2 * h], dv4[4 * s + 2 * h + 1]);
             aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s], fb, aq, 0, 0, 0);          // q^T: rows c1 (registers), column = this lane's token
         }
-        out_epilogue<C>(aq, kv0, kv1, Lbq, Lkb, drow + (hd * 32 + 4 * h) / 4, zrow, Lw4 + (hd * 32 + 4 * h) / 4, t, n, Wp, h, out + (size_t)b * n * C + hd * 32 + 4 * h);
+        out_epilogue<C, PAD>(aq, kv0, kv1, Lbq, Lkb, drow + (hd * 32 + 4 * h) / 4, zrow, Lw4 + (hd * 32 + 4 * h) / 4, t, n, Wp, h, out + (size_t)b * n * Cg, hd * D + 4 * h, Cg, D - 4 * h);
     }
 }
 
@@ -682,6 +769,14 @@ k_recattn_out(const float* __restrict__ d, const bf16_t* __restrict__ wqk, const
 // 16-byte-aligned d.  ONE launch when the plane has at most 64 tokens and its image (+ halo) fits the CU's LDS (at most 8 heads above 32 tokens);
 // else two launches and a workspace (at most 8 heads).  RCX_ATTN_FUSED=0: off, RCX_ATTN_FUSED=short: the one-launch form only (A/B).
 static bool pow2_heads(int heads) { return heads > 0 && heads <= 16 && !(heads & (heads - 1)); }
+// head dimension 32, or (round 5) 4 .. 28 in steps of 4 with an even number of heads (a q / k half is whole heads): RecNeXt-A0 / A1 / A2's 20 / 24 / 28.
+// Inside the kernels a head is 32 wide either way (padded): LDS sizes and tile counts follow 32 heads, memory follows C.
+static bool heads_ok(int C, int heads)
+{
+    if (!pow2_heads(heads) || C % heads) return false;
+    const int D = C / heads;
+    return D == 32 || (D >= 4 && D < 32 && D % 4 == 0 && heads % 2 == 0);
+}
 static bool qkc_short(int Hp, int Wp, int C, int heads)
 {
     const int n = Hp * Wp;
@@ -692,80 +787,108 @@ bool recattn_qkcore_applicable(int B, int Hp, int Wp, int C, int heads)
 {
     const char* v = rcx::opt::value(rcx::opt::ATTN_FUSED);
     if (v && *v == '0') return false;
-    if (!(B > 0 && Hp > 0 && Wp > 0 && pow2_heads(heads) && C == 32 * heads)) return false;
-    if (qkc_short(Hp, Wp, C, heads)) return true;
+    if (!(B > 0 && Hp > 0 && Wp > 0 && heads_ok(C, heads))) return false;
+    if (qkc_short(Hp, Wp, 32 * heads, heads)) return true;
     if ((v && *v == 's') || heads > 8) return false;
     if ((size_t)Hp * Wp * C * 4 >= (size_t)1 << 31 || B > 65535) return false;
-    const qkc::LongGeo g = qkc::long_geo(B, Hp, Wp, C, heads);
+    const qkc::LongGeo g = qkc::long_geo(B, Hp, Wp, 32 * heads, heads);
     return g.lds_out <= 160 * 1024 && g.G <= 65535;
 }
 
 int recattn_qkcore_launches(int B, int Hp, int Wp, int C, int heads)
 {
     if (!recattn_qkcore_applicable(B, Hp, Wp, C, heads)) return 0;
-    return qkc_short(Hp, Wp, C, heads) ? 1 : 2;
+    return qkc_short(Hp, Wp, 32 * heads, heads) ? 1 : 2;
 }
 
 size_t recattn_qkcore_workspace_bytes(int B, int Hp, int Wp, int C, int heads)
 {
-    if (!recattn_qkcore_applicable(B, Hp, Wp, C, heads) || qkc_short(Hp, Wp, C, heads)) return 0;
-    return qkc::long_geo(B, Hp, Wp, C, heads).ws_bytes;
+    if (!recattn_qkcore_applicable(B, Hp, Wp, C, heads) || qkc_short(Hp, Wp, 32 * heads, heads)) return 0;
+    return qkc::long_geo(B, Hp, Wp, 32 * heads, heads).ws_bytes;
 }
 
+// PAD = the head dimension is below 32 (D = C / heads at run time); the D == 32 instantiations keep every offset and mask a compile-time constant
+template <int KS, bool PAD>
+static hipError_t launch_long_p(const float* d, const bf16_t* wqk, const float* bqk, const float* wpe, const float* bpe, float* out, float* ws,
+                                int B, int Hp, int Wp, int C, int heads, hipStream_t s)
+{
+    const int D = C / heads;
+    const qkc::LongGeo g = qkc::long_geo(B, Hp, Wp, 32 * heads, heads);
+    {
+        auto kfn = qkc::k_recattn_kv<KS, PAD>;
+        RCX_SET_LDS_ONCE(kfn, g.lds_kv);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)g.GA, (unsigned)B), dim3(1024), g.lds_kv, s, d, wqk, bqk, ws, Hp * Wp, D, heads, g.SA, g.tpgA, g.ntiles);
+    }
+    {
+        auto kfn = qkc::k_recattn_out<KS, 512, PAD>;
+        RCX_SET_LDS_ONCE(kfn, g.lds_out);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)g.G, (unsigned)B), dim3(512), g.lds_out, s, d, wqk, bqk, wpe, bpe, ws, out, Hp, Wp, D, heads, g.S, g.tpg, g.ntiles, g.rows, g.GA);
+    }
+    return hipGetLastError();
+}
 template <int KS>
 static hipError_t launch_long(const float* d, const bf16_t* wqk, const float* bqk, const float* wpe, const float* bpe, float* out, float* ws,
                               int B, int Hp, int Wp, int C, int heads, hipStream_t s)
 {
-    const qkc::LongGeo g = qkc::long_geo(B, Hp, Wp, C, heads);
-    {
-        auto kfn = qkc::k_recattn_kv<KS>;
-        RCX_SET_LDS_ONCE(kfn, g.lds_kv);
-        hipLaunchKernelGGL(kfn, dim3((unsigned)g.GA, (unsigned)B), dim3(1024), g.lds_kv, s, d, wqk, bqk, ws, Hp * Wp, C, heads, g.SA, g.tpgA, g.ntiles);
-    }
-    {
-        auto kfn = qkc::k_recattn_out<KS, 512>;
-        RCX_SET_LDS_ONCE(kfn, g.lds_out);
-        hipLaunchKernelGGL(kfn, dim3((unsigned)g.G, (unsigned)B), dim3(512), g.lds_out, s, d, wqk, bqk, wpe, bpe, ws, out, Hp, Wp, C, heads, g.S, g.tpg, g.ntiles, g.rows, g.GA);
-    }
-    return hipGetLastError();
+    return C == 32 * heads ? launch_long_p<KS, false>(d, wqk, bqk, wpe, bpe, out, ws, B, Hp, Wp, C, heads, s)
+                           : launch_long_p<KS, true>(d, wqk, bqk, wpe, bpe, out, ws, B, Hp, Wp, C, heads, s);
 }
 
-template <int NT, int KS>
-static hipError_t launch_short(const float* d, const bf16_t* wqk, const float* bqk, const float* wpe, const float* bpe, float* out, int B, int Hp, int Wp, hipStream_t s)
+template <int NT, int KS, bool PAD>
+static hipError_t launch_short_p(const float* d, const bf16_t* wqk, const float* bqk, const float* wpe, const float* bpe, float* out, int B, int Hp, int Wp, int D, hipStream_t s)
 {
     const size_t lds = qkc::short_lds_bytes(NT, Wp, 32 * KS);
-    auto kfn = qkc::k_recattn_short<NT, KS>;
+    auto kfn = qkc::k_recattn_short<NT, KS, 0, bf16_t, false, PAD>;
     RCX_SET_LDS_ONCE(kfn, lds);
     hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(64 * KS), lds, s, d, wqk, bqk, wpe, bpe, out, Hp, Wp, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr);
+                       (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, D);
     return hipGetLastError();
+}
+template <int NT, int KS>
+static hipError_t launch_short(const float* d, const bf16_t* wqk, const float* bqk, const float* wpe, const float* bpe, float* out, int B, int Hp, int Wp, int D, hipStream_t s)
+{
+    return D == 32 ? launch_short_p<NT, KS, false>(d, wqk, bqk, wpe, bpe, out, B, Hp, Wp, D, s) : launch_short_p<NT, KS, true>(d, wqk, bqk, wpe, bpe, out, B, Hp, Wp, D, s);
 }
 
 // the same with the stride-2 conv inside (XW = 14: 49 tokens, two tiles; XW = 7: 16 tokens, one tile)
-template <int NT, int KS, int XW, typename TX>
-static hipError_t launch_short_x(const void* x, const float* wdn, const float* bdn, const bf16_t* wqk, const float* bqk, const float* wpe, const float* bpe,
-                                 float* out, int B, hipStream_t s)
+template <int NT, int KS, int XW, typename TX, bool PAD>
+static hipError_t launch_short_x_p(const void* x, const float* wdn, const float* bdn, const bf16_t* wqk, const float* bqk, const float* wpe, const float* bpe,
+                                   float* out, int B, int D, hipStream_t s)
 {
     constexpr int WO = (XW + 1) / 2;
     const size_t lds = qkc::short_lds_bytes(NT, WO, 32 * KS);
-    auto kfn = qkc::k_recattn_short<NT, KS, XW, TX>;
+    auto kfn = qkc::k_recattn_short<NT, KS, XW, TX, false, PAD>;
     RCX_SET_LDS_ONCE(kfn, lds);
     hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(64 * KS), lds, s, (const float*)nullptr, wqk, bqk, wpe, bpe, out, WO, WO, (const TX*)x, wdn, bdn,
-                       (const float*)nullptr, (const float*)nullptr, (TX*)nullptr);
+                       (const float*)nullptr, (const float*)nullptr, (TX*)nullptr, D);
     return hipGetLastError();
+}
+template <int NT, int KS, int XW, typename TX>
+static hipError_t launch_short_x(const void* x, const float* wdn, const float* bdn, const bf16_t* wqk, const float* bqk, const float* wpe, const float* bpe,
+                                 float* out, int B, int D, hipStream_t s)
+{
+    return D == 32 ? launch_short_x_p<NT, KS, XW, TX, false>(x, wdn, bdn, wqk, bqk, wpe, bpe, out, B, D, s)
+                   : launch_short_x_p<NT, KS, XW, TX, true>(x, wdn, bdn, wqk, bqk, wpe, bpe, out, B, D, s);
 }
 
 // RecAttn2d.forward in ONE launch (nearest resize): the conv inside, the attention output kept in LDS, the final conv inside
-template <int NT, int KS, int XW, typename TX>
-static hipError_t launch_unit(const void* x, const float* wdn, const float* bdn, const bf16_t* wqk, const float* bqk, const float* wpe, const float* bpe,
-                              const float* wcv, const float* bcv, void* y, int B, hipStream_t s)
+template <int NT, int KS, int XW, typename TX, bool PAD>
+static hipError_t launch_unit_p(const void* x, const float* wdn, const float* bdn, const bf16_t* wqk, const float* bqk, const float* wpe, const float* bpe,
+                                const float* wcv, const float* bcv, void* y, int B, int D, hipStream_t s)
 {
     constexpr int WO = (XW + 1) / 2;
     const size_t lds = qkc::short_lds_bytes(NT, WO, 32 * KS, true);
-    auto kfn = qkc::k_recattn_short<NT, KS, XW, TX, true>;
+    auto kfn = qkc::k_recattn_short<NT, KS, XW, TX, true, PAD>;
     RCX_SET_LDS_ONCE(kfn, lds);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(64 * KS), lds, s, (const float*)nullptr, wqk, bqk, wpe, bpe, (float*)nullptr, WO, WO, (const TX*)x, wdn, bdn, wcv, bcv, (TX*)y);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(64 * KS), lds, s, (const float*)nullptr, wqk, bqk, wpe, bpe, (float*)nullptr, WO, WO, (const TX*)x, wdn, bdn, wcv, bcv, (TX*)y, D);
     return hipGetLastError();
+}
+template <int NT, int KS, int XW, typename TX>
+static hipError_t launch_unit(const void* x, const float* wdn, const float* bdn, const bf16_t* wqk, const float* bqk, const float* wpe, const float* bpe,
+                              const float* wcv, const float* bcv, void* y, int B, int D, hipStream_t s)
+{
+    return D == 32 ? launch_unit_p<NT, KS, XW, TX, false>(x, wdn, bdn, wqk, bqk, wpe, bpe, wcv, bcv, y, B, D, s)
+                   : launch_unit_p<NT, KS, XW, TX, true>(x, wdn, bdn, wqk, bqk, wpe, bpe, wcv, bcv, y, B, D, s);
 }
 
 // RCX_ATTN_FUSED=twostep: the unit stays conv + attention | final conv (A/B)
@@ -775,7 +898,7 @@ bool recattn2d_unit_applicable(int B, int H, int W, int C, int heads, int x_dt, 
     if (v && *v == 't') return false;
     if (mode != 1 || heads > 8 || !recattn_down_qkcore_applicable(B, H, W, C, heads, x_dt)) return false;      // 16 heads = 16 waves = 128 registers: the final conv does not fit
     const int wo = (W + 1) / 2;
-    return qkc::short_lds_bytes(wo * wo <= 32 ? 1 : 2, wo, C, true) <= 160 * 1024;
+    return qkc::short_lds_bytes(wo * wo <= 32 ? 1 : 2, wo, 32 * heads, true) <= 160 * 1024;
 }
 
 hipError_t recattn2d_unit(const void* x, const float* wdn, const float* bdn, const void* wqk_bf16, const float* bqk, const float* wpe, const float* bpe,
@@ -783,10 +906,10 @@ hipError_t recattn2d_unit(const void* x, const float* wdn, const float* bdn, con
 {
     const bf16_t* w = (const bf16_t*)wqk_bf16;
 #define RCX_UX(KS_)                                                                                                                            \
-    (H == 14 ? (x_dt == 1 ? launch_unit<2, KS_, 14, bf16_t>(x, wdn, bdn, w, bqk, wpe, bpe, wcv, bcv, y, B, s)                                  \
-                          : launch_unit<2, KS_, 14, f16_t>(x, wdn, bdn, w, bqk, wpe, bpe, wcv, bcv, y, B, s))                                  \
-             : (x_dt == 1 ? launch_unit<1, KS_, 7, bf16_t>(x, wdn, bdn, w, bqk, wpe, bpe, wcv, bcv, y, B, s)                                   \
-                          : launch_unit<1, KS_, 7, f16_t>(x, wdn, bdn, w, bqk, wpe, bpe, wcv, bcv, y, B, s)))
+    (H == 14 ? (x_dt == 1 ? launch_unit<2, KS_, 14, bf16_t>(x, wdn, bdn, w, bqk, wpe, bpe, wcv, bcv, y, B, C / heads, s)                                  \
+                          : launch_unit<2, KS_, 14, f16_t>(x, wdn, bdn, w, bqk, wpe, bpe, wcv, bcv, y, B, C / heads, s))                                  \
+             : (x_dt == 1 ? launch_unit<1, KS_, 7, bf16_t>(x, wdn, bdn, w, bqk, wpe, bpe, wcv, bcv, y, B, C / heads, s)                                   \
+                          : launch_unit<1, KS_, 7, f16_t>(x, wdn, bdn, w, bqk, wpe, bpe, wcv, bcv, y, B, C / heads, s)))
     switch (heads) {
         case 1: return RCX_UX(1);
         case 2: return RCX_UX(2);
@@ -803,10 +926,10 @@ bool recattn_down_qkcore_applicable(int B, int H, int W, int C, int heads, int x
 {
     const char* v = rcx::opt::value(rcx::opt::ATTN_FUSED);
     if (v && (*v == '0' || *v == 'n')) return false;
-    if (!(B > 0 && pow2_heads(heads) && C == 32 * heads && (x_dt == 1 || x_dt == 2))) return false;
+    if (!(B > 0 && heads_ok(C, heads) && (x_dt == 1 || x_dt == 2))) return false;
     if (!((H == 14 && W == 14 && heads <= 8) || (H == 7 && W == 7))) return false;
     const int wo = (W + 1) / 2;
-    return qkc_short(wo, wo, C, heads);
+    return qkc_short(wo, wo, 32 * heads, heads);
 }
 
 hipError_t recattn_down_qkcore(const void* x, const float* wdn, const float* bdn, const void* wqk_bf16, const float* bqk, const float* wpe, const float* bpe,
@@ -814,17 +937,17 @@ hipError_t recattn_down_qkcore(const void* x, const float* wdn, const float* bdn
 {
     const bf16_t* w = (const bf16_t*)wqk_bf16;
 #define RCX_DX(KS_)                                                                                                                            \
-    (H == 14 ? (x_dt == 1 ? launch_short_x<2, KS_, 14, bf16_t>(x, wdn, bdn, w, bqk, wpe, bpe, out, B, s)                                       \
-                          : launch_short_x<2, KS_, 14, f16_t>(x, wdn, bdn, w, bqk, wpe, bpe, out, B, s))                                       \
-             : (x_dt == 1 ? launch_short_x<1, KS_, 7, bf16_t>(x, wdn, bdn, w, bqk, wpe, bpe, out, B, s)                                        \
-                          : launch_short_x<1, KS_, 7, f16_t>(x, wdn, bdn, w, bqk, wpe, bpe, out, B, s)))
+    (H == 14 ? (x_dt == 1 ? launch_short_x<2, KS_, 14, bf16_t>(x, wdn, bdn, w, bqk, wpe, bpe, out, B, C / heads, s)                                       \
+                          : launch_short_x<2, KS_, 14, f16_t>(x, wdn, bdn, w, bqk, wpe, bpe, out, B, C / heads, s))                                       \
+             : (x_dt == 1 ? launch_short_x<1, KS_, 7, bf16_t>(x, wdn, bdn, w, bqk, wpe, bpe, out, B, C / heads, s)                                        \
+                          : launch_short_x<1, KS_, 7, f16_t>(x, wdn, bdn, w, bqk, wpe, bpe, out, B, C / heads, s)))
     switch (heads) {
         case 1: return RCX_DX(1);
         case 2: return RCX_DX(2);
         case 4: return RCX_DX(4);
         case 8: return RCX_DX(8);
-        case 16: return H == 7 ? (x_dt == 1 ? launch_short_x<1, 16, 7, bf16_t>(x, wdn, bdn, w, bqk, wpe, bpe, out, B, s)
-                                            : launch_short_x<1, 16, 7, f16_t>(x, wdn, bdn, w, bqk, wpe, bpe, out, B, s))
+        case 16: return H == 7 ? (x_dt == 1 ? launch_short_x<1, 16, 7, bf16_t>(x, wdn, bdn, w, bqk, wpe, bpe, out, B, C / heads, s)
+                                            : launch_short_x<1, 16, 7, f16_t>(x, wdn, bdn, w, bqk, wpe, bpe, out, B, C / heads, s))
                                : hipErrorInvalidConfiguration;
         default: return hipErrorInvalidConfiguration;
     }
@@ -835,14 +958,14 @@ hipError_t recattn_qkcore(const float* d, const void* wqk_bf16, const float* bqk
                           int B, int Hp, int Wp, int C, int heads, hipStream_t s)
 {
     const bf16_t* w = (const bf16_t*)wqk_bf16;
-    if (qkc_short(Hp, Wp, C, heads)) {
+    if (qkc_short(Hp, Wp, 32 * heads, heads)) {
         const bool one = Hp * Wp <= 32;
         switch (heads) {                  // = C / 32 = the k-steps of the projection (C / 2 inputs, 16 per step)
-            case 1: return one ? launch_short<1, 1>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, s) : launch_short<2, 1>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, s);
-            case 2: return one ? launch_short<1, 2>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, s) : launch_short<2, 2>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, s);
-            case 4: return one ? launch_short<1, 4>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, s) : launch_short<2, 4>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, s);
-            case 8: return one ? launch_short<1, 8>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, s) : launch_short<2, 8>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, s);
-            case 16: return one ? launch_short<1, 16>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, s) : hipErrorInvalidConfiguration;
+            case 1: return one ? launch_short<1, 1>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, C / heads, s) : launch_short<2, 1>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, C / heads, s);
+            case 2: return one ? launch_short<1, 2>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, C / heads, s) : launch_short<2, 2>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, C / heads, s);
+            case 4: return one ? launch_short<1, 4>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, C / heads, s) : launch_short<2, 4>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, C / heads, s);
+            case 8: return one ? launch_short<1, 8>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, C / heads, s) : launch_short<2, 8>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, C / heads, s);
+            case 16: return one ? launch_short<1, 16>(d, w, bqk, wpe, bpe, out, B, Hp, Wp, C / heads, s) : hipErrorInvalidConfiguration;
             default: return hipErrorInvalidConfiguration;
         }
     }

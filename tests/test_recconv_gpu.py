@@ -796,7 +796,11 @@ def test_linear_attention_core(case, dtype):
 
 @pytest.mark.parametrize("case", [(3, 256, 8, 7, 7), (2, 512, 16, 4, 4), (5, 64, 2, 7, 7), (1, 128, 4, 8, 8), (2, 256, 8, 5, 9), (9, 32, 1, 3, 3),
                                   (3, 64, 2, 28, 28), (2, 128, 4, 14, 14), (2, 64, 2, 9, 11), (1, 32, 1, 10, 10), (2, 256, 8, 10, 9), (1, 64, 2, 65, 1),
-                                  (2, 64, 2, 56, 56), (1, 128, 4, 1, 130)], ids=lambda c: "x".join(map(str, c)))
+                                  (2, 64, 2, 56, 56), (1, 128, 4, 1, 130),
+                                  # round 5: head dimensions 20 / 24 / 28 (RecNeXt-A0 / A1 / A2; model/recattn.py:382-396) -- padded to 32 inside the kernels
+                                  (3, 160, 8, 7, 7), (2, 320, 16, 4, 4), (2, 40, 2, 28, 28), (2, 80, 4, 14, 14), (2, 48, 2, 28, 28), (3, 192, 8, 7, 7),
+                                  (2, 112, 4, 14, 14), (2, 224, 8, 7, 7), (2, 40, 2, 9, 11), (1, 56, 2, 56, 56), (2, 16, 2, 5, 5), (1, 96, 4, 1, 70)],
+                         ids=lambda c: "x".join(map(str, c)))
 def test_recattn_qkcore_one_launch_against_the_two_step_path_and_the_oracle(case):
     """rcx_recattn_qkcore_fwd (round 4): the qk projection + the attention core + pe on the matrix cores (bf16 operands, float32 accumulation) against
     (a) the NumPy restatement of model/recattn.py:16-28 in float64 and (b) the float32 two-step HIP path (float32 GEMMs + rcx_linear_attention_pe_fwd)
@@ -836,7 +840,8 @@ def test_recattn_qkcore_one_launch_against_the_two_step_path_and_the_oracle(case
     assert np.allclose(nob, g - b_pe[None, :, None, None], atol=1e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("case", [(3, 256, 8, 14), (2, 512, 16, 7), (2, 64, 2, 14), (5, 32, 1, 7), (1, 128, 4, 14), (2, 128, 4, 7)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("case", [(3, 256, 8, 14), (2, 512, 16, 7), (2, 64, 2, 14), (5, 32, 1, 7), (1, 128, 4, 14), (2, 128, 4, 7),
+                                  (3, 160, 8, 14), (2, 320, 16, 7), (2, 192, 8, 14), (2, 112, 4, 7), (2, 224, 8, 14)], ids=lambda c: "x".join(map(str, c)))     # head dimensions 20 / 24 / 28
 @pytest.mark.parametrize("xdt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 def test_recattn_down_qkcore_one_launch_from_x(case, xdt):
     """rcx_recattn_down_qkcore_fwd (round 4): RecAttn2d's stride-2 conv + qk projection + core + pe in ONE launch from x (model/recattn.py:61-66 on
@@ -874,7 +879,8 @@ def test_recattn_down_qkcore_one_launch_from_x(case, xdt):
     assert not ops.recattn_down_qkcore_supported(c, heads, 28, 28, xdt) and not ops.recattn_down_qkcore_supported(c, heads, hw, hw, torch.float32)
 
 
-@pytest.mark.parametrize("case", [(3, 256, 8, 14), (2, 64, 2, 14), (5, 32, 1, 7), (1, 128, 4, 14), (2, 128, 4, 7), (2, 256, 8, 7)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("case", [(3, 256, 8, 14), (2, 64, 2, 14), (5, 32, 1, 7), (1, 128, 4, 14), (2, 128, 4, 7), (2, 256, 8, 7),
+                                  (3, 160, 8, 14), (2, 224, 8, 14), (2, 96, 4, 7), (2, 40, 2, 14)], ids=lambda c: "x".join(map(str, c)))     # head dimensions 20 / 28 / 24 / 20
 @pytest.mark.parametrize("xdt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 def test_recattn2d_whole_unit_in_one_launch(case, xdt):
     """rcx_recattn2d_fwd (round 4): RecAttn2d.forward (model/recattn.py:54-67, eval, nearest) in ONE launch on the 14 x 14 / 7 x 7 planes against (a) the

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Development probe: repeat the one-launch RecAttn2d unit on one case and report where repeated calls differ (determinism check)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from recnext_amd import ops
+
+dev = torch.device("cuda:0")
+b, c, heads, hw = (int(v) for v in (sys.argv[1:5] if len(sys.argv) > 4 else (2, 128, 4, 7)))
+xdt = torch.float16 if (len(sys.argv) > 5 and sys.argv[5] == "f16") or len(sys.argv) <= 5 else torch.bfloat16
+g = torch.Generator(device="cpu").manual_seed(3 * c + hw)
+r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+x = r(b, c, hw, hw).to(xdt).contiguous(memory_format=torch.channels_last)
+wdn, bdn = ops.pack_dw_weight(r(c, 1, 5, 5, sc=0.2)), ops.pack_bias(r(c, sc=0.1))
+wcv, bcv = ops.pack_dw_weight(r(c, 1, 5, 5, sc=0.2)), ops.pack_bias(r(c, sc=0.1))
+wpe, bpe = ops.pack_dw_weight(r(c, 1, 3, 3, sc=0.2)), ops.pack_bias(r(c, sc=0.1))
+wqk = r(2 * c, c // 2, sc=(2.0 / c) ** 0.5).to(torch.bfloat16).contiguous()
+bqk = r(2 * c, sc=0.1)
+outs = []
+junk = torch.empty(64 << 20, device=dev)
+
+
+def other(c2, h2, hw2, dt):          # a different unit in between: different LDS leftovers
+    x2 = r(3, c2, hw2, hw2).to(dt).contiguous(memory_format=torch.channels_last)
+    a = (ops.pack_dw_weight(r(c2, 1, 5, 5, sc=0.2)), ops.pack_bias(r(c2, sc=0.1)), r(2 * c2, c2 // 2).to(torch.bfloat16).contiguous(), r(2 * c2, sc=0.1),
+         ops.pack_dw_weight(r(c2, 1, 3, 3, sc=0.2)), ops.pack_bias(r(c2, sc=0.1)), ops.pack_dw_weight(r(c2, 1, 5, 5, sc=0.2)), ops.pack_bias(r(c2, sc=0.1)))
+    return lambda: ops.recattn2d(x2, *a, h2)
+
+
+others = [other(256, 8, 14, torch.bfloat16), other(160, 8, 14, torch.float16), other(64, 2, 7, torch.float16), other(96, 4, 7, torch.bfloat16)]
+for i in range(40):
+    if i % 3 == 0:
+        junk.normal_()
+    if i % 2 == 0:
+        others[(i // 2) % 4]()
+    outs.append(ops.recattn2d(x, wdn, bdn, wqk, bqk, wpe, bpe, wcv, bcv, heads).float())
+torch.cuda.synchronize()
+ref = torch.stack(outs).median(0).values
+for i, o in enumerate(outs):
+    bad = (o != ref).nonzero()
+    if len(bad):
+        n, ch, yy, xx = bad.T
+        print(f"call {i}: {len(bad)} differ; images {sorted(set(n.tolist()))} channels {sorted(set(ch.tolist()))[:40]} rows {sorted(set(yy.tolist()))} cols {sorted(set(xx.tolist()))} max |d| {float((o - ref).abs().max()):.3g}")
+print("done")
