@@ -199,7 +199,8 @@ int rcx_linear_attention_pe_fwd(const void* qpre, const void* kpre, const void* 
  *   wqk    : (2C) x (C/2) bf16, rows [0, C) = the q half of the conv's weight, rows [C, 2C) = the k half (BatchNorm folded in float32, then rounded);
  *   bqk    : (2C) float32 biases; w_pe_kkc / b_pe: as rcx_linear_attention_pe_fwd (b_pe may be NULL);  out: B x (H W) x C float32;
  *   workspace: rcx_recattn_qkcore_workspace_bytes(...) bytes (0 bytes / may be NULL when one launch does it).  Every pointer 16-byte aligned.
- * Head dimension 32 only (C == 32 heads; 1, 2, 4, 8 or 16 heads).  Planes of at most 64 tokens whose image fits the CU's LDS: ONE launch, a workgroup
+ * 1, 2, 4, 8 or 16 heads of dimension C / heads = 32, or of 4, 8 .. 28 when heads is even (a head is padded to 32 inside the kernels; memory stays
+ * compact: RecNeXt-A0 / A1 / A2's 20 / 24 / 28).  Planes of at most 64 tokens whose image fits the CU's LDS: ONE launch, a workgroup
  * per image, a wave per head (16 heads: at most 32 tokens; RecNeXt-A's stages 2 and 3 at 224 x 224).  Other planes: TWO launches (the k^T v partial
  * sums of every image go through the workspace, summed in a fixed order: deterministic), at most 8 heads.  rcx_recattn_qkcore_launches() tells which
  * (0: no kernel for the shape -> the call returns RCX_ERR_UNSUPPORTED).  The products run on the matrix cores with bf16 operands and float32

@@ -4,7 +4,7 @@
 // (:61-67).  It replaces two library GEMMs, their bias adds and rcx_linear_attention_pe_fwd, and the q / k tensors never exist in memory.
 //
 // ONE WORKGROUP = one image, ONE WAVE = one head: the image's d is staged in LDS once (one barrier), after which the waves share nothing.
-// Head dimension 32 (every head of the A-series), at most 64 tokens, at most 16 heads.
+// Head dimension 32 (RecNeXt-A3 / A4) or, padded to 32 inside the kernel, 4 .. 28 in steps of 4 (A0 / A1 / A2: 20 / 24 / 28; see `wfrag`); at most 64 tokens, at most 16 heads.
 //   projection  q[t][c] = sum_ci d[t][ci] Wq[c][ci] + bq[c] over the FIRST half of d's channels, k likewise over the second half (groups = 2):
 //               v_mfma_f32_32x32x16_bf16, A = d rows (float32 from the LDS image, rounded to bf16 in registers), B = the head's 32 rows of the bf16
 //               weight pack, float32 accumulation -- C / 32 k-steps per 32-token tile.  The accumulator tile has the CHANNEL on the lane and
@@ -765,7 +765,7 @@ k_recattn_out(const float* __restrict__ d, const bf16_t* __restrict__ wqk, const
 
 }  // namespace qkc
 
-// 16-bit-activation callers only (the operands of the products are bf16): head dimension 32 (so C = 32 heads, heads a power of two up to 16),
+// 16-bit-activation callers only (the operands of the products are bf16): heads a power of two up to 16, head dimension as heads_ok() below,
 // 16-byte-aligned d.  ONE launch when the plane has at most 64 tokens and its image (+ halo) fits the CU's LDS (at most 8 heads above 32 tokens);
 // else two launches and a workspace (at most 8 heads).  RCX_ATTN_FUSED=0: off, RCX_ATTN_FUSED=short: the one-launch form only (A/B).
 static bool pow2_heads(int heads) { return heads > 0 && heads <= 16 && !(heads & (heads - 1)); }

@@ -371,7 +371,7 @@ def linear_attention_core_pe(qpre, kpre, v, w_pe_kkc, b_pe, heads):
 
 
 def recattn_qkcore_supported(c, heads, h, w):
-    """Whether recattn_qkcore has a kernel for this coarse plane (rcx_recattn_qkcore_launches: 32-wide heads, 1/2/4/8/16 of them; one launch for
+    """Whether recattn_qkcore has a kernel for this coarse plane (rcx_recattn_qkcore_launches: 1/2/4/8/16 heads of 32 channels, or of 4 .. 28 in fours when heads is even; one launch for
     planes of at most 64 tokens that fit the LDS, two launches otherwise)."""
     return _lib.load().rcx_recattn_qkcore_launches(1, h, w, c, heads) > 0
 
