@@ -119,25 +119,27 @@ template <int C, int NTHR, bool PAD>
 __device__ __forceinline__ void stage_small(float* Lw, const float* __restrict__ wpe, const float* __restrict__ bpe, const float* __restrict__ bqk, int D)
 {
     if constexpr (!PAD) {
-        static_assert(9 * C / 4 <= 2 * NTHR && C / 4 <= NTHR, "stage_small: one or two requests per lane");
+        static_assert(9 * C / 4 <= 3 * NTHR && C / 4 <= NTHR, "stage_small: at most three requests per lane");
         const int i = threadIdx.x;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4* w4 = reinterpret_cast<const float4*>(wpe);
-        float4 a0 = z, a1 = z, b0 = z, c0 = z;              // (`cond ? p[i] : z` selects between ADDRESSES and puts z in scratch)
+        float4 a0 = z, a1 = z, a2 = z, b0 = z, c0 = z;      // (`cond ? p[i] : z` selects between ADDRESSES and puts z in scratch)
         if (i < 9 * C / 4) a0 = w4[i];
         if (i + NTHR < 9 * C / 4) a1 = w4[i + NTHR];
+        if constexpr (9 * C / 4 > 2 * NTHR) { if (i + 2 * NTHR < 9 * C / 4) a2 = w4[i + 2 * NTHR]; }          // (two heads per wave: NTHR = C)
         if (bpe && i < C / 4) b0 = reinterpret_cast<const float4*>(bpe)[i];
         if (i < C / 4) c0 = reinterpret_cast<const float4*>(bqk)[i];
         float4* L4 = reinterpret_cast<float4*>(Lw);
         if (i < 9 * C / 4) L4[i] = a0;
         if (i + NTHR < 9 * C / 4) L4[i + NTHR] = a1;
+        if constexpr (9 * C / 4 > 2 * NTHR) { if (i + 2 * NTHR < 9 * C / 4) L4[i + 2 * NTHR] = a2; }
         if (i < C / 4) { L4[9 * C / 4 + i] = b0; L4[10 * C / 4 + i] = c0; }
     } else {
         // C = 32 heads (padded); memory holds D heads channels per row: group i of the 11 C / 4 is row i / (C / 4) (9 tap rows, the pe bias, the q biases),
         // padded column 4 (i % (C / 4)).  One or two groups per lane, both requests issued before the first store; padding = 0 (-100 for the q biases).
-        static_assert(11 * C / 4 <= 2 * NTHR, "stage_small: at most two requests per lane");
+        static_assert(11 * C / 4 <= 3 * NTHR, "stage_small: at most three requests per lane");
         const int Cg = (C / 32) * D;
-        f32x4q v0, v1;
+        f32x4q v0, v1, v2;
         auto fetch = [&](int i, f32x4q& v) {
             const int row = i / (C / 4), cp = 4 * (i - row * (C / 4)), c = (cp >> 5) * D + (cp & 31);
             const float pad = row == 10 ? QK_PAD_BIAS : 0.f;
@@ -147,9 +149,11 @@ __device__ __forceinline__ void stage_small(float* Lw, const float* __restrict__
         };
         fetch(threadIdx.x, v0);
         fetch(threadIdx.x + NTHR, v1);
+        if constexpr (11 * C / 4 > 2 * NTHR) fetch(threadIdx.x + 2 * NTHR, v2);
         f32x4q* L4 = reinterpret_cast<f32x4q*>(Lw);
         if (threadIdx.x < 11 * C / 4) L4[threadIdx.x] = v0;
         if (threadIdx.x + NTHR < 11 * C / 4) L4[threadIdx.x + NTHR] = v1;
+        if constexpr (11 * C / 4 > 2 * NTHR) { if (threadIdx.x + 2 * NTHR < 11 * C / 4) L4[threadIdx.x + 2 * NTHR] = v2; }
     }
 }
 
@@ -223,18 +227,21 @@ __device__ __forceinline__ void out_epilogue(const f32x16& aq, bf16x8 kv0, bf16x
 // scattered into the output rows it touches (float32).  Saves the stand-alone step's launch and d's trip through memory.
 // FULL (with XW > 0): the unit's last step too, y = conv5(x + nearest-resize(a)) + bias (model/recattn.py:67): a stays in LDS (one more barrier), the
 // same two lanes per channel form the upper / lower output rows from x rows loaded once each -- RecAttn2d.forward in one launch.
-template <int NT, int KS, int XW = 0, typename TX = bf16_t, bool FULL = false, bool PAD = false>      // PAD: head dimension < 32 (Dr); else every mask below folds away
-__global__ void __launch_bounds__(64 * KS)
+// HPW = heads per wave (2: the 7 x 7 plane with 16 heads as ONE launch -- 8 waves with 256 registers hold the final conv, 16 waves with 128 do not; the heads of a
+// wave run one after the other through the same code, the next head's first weight fragments requested while the current one's epilogue runs)
+template <int NT, int KS, int XW = 0, typename TX = bf16_t, bool FULL = false, bool PAD = false, int HPW = 1>      // PAD: head dimension < 32 (Dr); else every mask below folds away
+__global__ void __launch_bounds__(64 * KS / HPW)
 k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, const float* __restrict__ bqk, const float* __restrict__ wpe,
                 const float* __restrict__ bpe, float* __restrict__ out, int Hp, int Wp,
                 const TX* __restrict__ x, const float* __restrict__ wdn, const float* __restrict__ bdn,
                 const float* __restrict__ wcv, const float* __restrict__ bcv, TX* __restrict__ yout, int Dr)
 {
     static_assert(!FULL || XW > 0, "the whole unit starts from x");
+    static_assert(HPW == 1 || (HPW == 2 && FULL && KS % 2 == 0 && (2 * KS) % (KS < 8 ? KS : 8) == 0), "two heads per wave: the whole-unit form only");
     const int D = PAD ? Dr : 32;
     extern __shared__ __attribute__((aligned(16))) float lds_s[];
-    constexpr int C = 32 * KS, K = C / 2, DROW = C + DPAD, DROW4 = DROW / 4, NTHR = 64 * KS, PF = KS < 8 ? KS : 8;        // weight fragments in flight: a ring 4 deep left ~0.4 us of L2 latency exposed at every refill
-    const int hd = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    constexpr int C = 32 * KS, K = C / 2, DROW = C + DPAD, DROW4 = DROW / 4, NTHR = 64 * KS / HPW, PF = KS < 8 ? KS : 8;        // weight fragments in flight: a ring 4 deep left ~0.4 us of L2 latency exposed at every refill
+    const int hd0 = (threadIdx.x >> 6) * HPW, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int b = blockIdx.x, n = Hp * Wp, rows = NT * 32 + 2 * Wp + 2, R0 = -Wp - 1;
     float* const Ld = lds_s;                                  // [rows + 1][DROW]: tokens R0 .. of the image (zeros outside it), then a row of zeros
     const float4* const Ld4 = reinterpret_cast<const float4*>(lds_s);
@@ -246,21 +253,20 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
     const __amdgpu_buffer_rsrc_t dsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dimg, 0, n * Cg * 4, 0x00020000);
 
     const bool rvalid = r < D;                                                 // this lane's output channel of the head exists
-    const bf16_t* wq_row = wqk + (size_t)(hd * D + (rvalid ? r : 0)) * Kg;      // its weight row (compact); wfrag picks the 8 inputs of a k-step
-    const bf16_t* wk_row = wqk + (size_t)(Cg + hd * D + (rvalid ? r : 0)) * Kg;
+    const bf16_t* wq_row = wqk + (size_t)(hd0 * D + (rvalid ? r : 0)) * Kg;     // its weight row (compact); wfrag picks the 8 inputs of a k-step
+    const bf16_t* wk_row = wqk + (size_t)(Cg + hd0 * D + (rvalid ? r : 0)) * Kg;
     u32x4q wf[PF];
     if constexpr (XW == 0) {                                  // (with the conv inside: requested after it -- its 70 live registers leave no room at 16 waves)
 #pragma unroll
         for (int j = 0; j < PF; ++j) wf[j] = wfrag<PAD>(wk_row, rvalid, 16 * j + 8 * h, D);
     }
 
-    const float bk = rvalid ? bqk[Cg + hd * D + r] : QK_PAD_BIAS;
     if constexpr (XW == 0) {
         stage_rows<NT == 2 ? 12 : 6>(Ld, dsrc, R0, rows, Cg, D, KS, DROW, NTHR);      // rows / 8 requests per lane: the whole image in one round trip up to 14 x 14 / 7 x 7 planes
         for (int i = threadIdx.x; i < DROW; i += NTHR) Ld[(size_t)rows * DROW + i] = 0.f;
     } else {
-        constexpr int WO = (XW + 1) / 2, RPP = (WO + 1) / 2, NXR = 2 * RPP + 3;          // output plane, output rows per lane, x rows they touch
-        static_assert(NTHR == 2 * C, "two lanes per channel");
+        constexpr int WO = (XW + 1) / 2, RPP = NTHR == C ? WO : (WO + 1) / 2, NXR = 2 * RPP + 3;          // output plane, output rows per lane (all of them with one lane per channel), x rows they touch
+        static_assert(NTHR == 2 * C || NTHR == C, "two lanes per channel, or one (two heads per wave)");
         const int cp = threadIdx.x < C ? threadIdx.x : threadIdx.x - C, o0 = threadIdx.x < C ? 0 : WO - RPP;      // padded channel (per wave for C >= 64; C = 32 has both halves in its one wave)
         const bool cvalid = (cp & 31) < D;                                     // a padding lane runs on channel 0 and leaves zeros
         const int c = cvalid ? (cp >> 5) * D + (cp & 31) : 0;
@@ -313,103 +319,111 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
     stage_small<C, NTHR, PAD>(Lw, wpe, bpe, bqk, D);
     __syncthreads();
 
-    // ---- 1. k tiles (lane = channel hd * 32 + r, tokens in the registers), kv
-    f32x16 acc[NT];
 #pragma unroll
-    for (int tt = 0; tt < NT; ++tt)
+    for (int hh = 0; hh < HPW; ++hh) {                        // the heads of this wave, one after the other
+        const int hd = hd0 + hh;
+        const bf16_t* const wq_h = wq_row + (size_t)hh * D * Kg;
+        const bf16_t* const wk_h = wk_row + (size_t)hh * D * Kg;
+        const float bk = rvalid ? bqk[Cg + hd * D + r] : QK_PAD_BIAS;
+        // ---- 1. k tiles (lane = channel hd * 32 + r, tokens in the registers), kv
+        f32x16 acc[NT];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[tt][i] = 0.f;
-    // the d fragments of k-step s + 1 are read from LDS before the products of k-step s are issued (the compiler waits for every read in
-    // front of the product that uses it: ~190 cycles a step instead of the product's 64)
-    f32x4q xf[2][NT][2];
+        for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-    for (int tt = 0; tt < NT; ++tt) {
-        const f32x4q* pa = Ldv + (32 * tt + r - R0) * DROW4 + K / 4 + 2 * h;
-        xf[0][tt][0] = pa[0]; xf[0][tt][1] = pa[1];
-    }
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const bf16x8 bk8 = __builtin_bit_cast(bf16x8, wf[s % PF]);
-        if (s + PF < KS) wf[s % PF] = wfrag<PAD>(wk_row, rvalid, 16 * (s + PF) + 8 * h, D);
-        else wf[s % PF] = wfrag<PAD>(wq_row, rvalid, 16 * (s + PF - KS) + 8 * h, D);          // the ring rolls over into the q weights
+            for (int i = 0; i < 16; ++i) acc[tt][i] = 0.f;
+        // the d fragments of k-step s + 1 are read from LDS before the products of k-step s are issued (the compiler waits for every read in
+        // front of the product that uses it: ~190 cycles a step instead of the product's 64)
+        f32x4q xf[2][NT][2];
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
-            // next: k-step s + 1 of the k half, or k-step 0 of the q half
-            const f32x4q* pa = Ldv + (32 * tt + r - R0) * DROW4 + (s + 1 < KS ? K / 4 + 4 * (s + 1) : 0) + 2 * h;
-            xf[(s + 1) & 1][tt][0] = pa[0]; xf[(s + 1) & 1][tt][1] = pa[1];
+            const f32x4q* pa = Ldv + (32 * tt + r - R0) * DROW4 + K / 4 + 2 * h;
+            xf[0][tt][0] = pa[0]; xf[0][tt][1] = pa[1];
         }
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
-            const bf16x8 fa = to_bf16x8(xf[s & 1][tt][0], xf[s & 1][tt][1]);          // token 32 tt + r, inputs 16 s + 8 h .. + 7 of the k half
-            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, bk8, acc[tt], 0, 0, 0);
-        }
-    }
-    const float* const Lv = Ld + hd * 32 + r;                 // this lane's channel of d: v
-    f32x16 kv;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) kv[i] = 0.f;
-    float ksum = 0.f;
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 fa, fb;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = 8 * s2 + j, t = 32 * tt + acc_row(i, h);
-                const float kk = t < n ? elu1(acc[tt][i] + bk) : 0.f;
-                ksum += kk;
-                fa[j] = (__bf16)kk;
-                fb[j] = (__bf16)Lv[(t - R0) * DROW];
-            }
-            kv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, kv, 0, 0, 0);
-        }
-    const float inv_n = 1.f / (float)n;
-    const float kbar_mine = (ksum + __shfl_xor(ksum, 32)) * inv_n;          // lane (r, h): kbar of channel r of the head
-    float* const Lkb = Lw + 11 * C + hd * 32;
-    if (h == 0) Lkb[r] = kbar_mine;
-    bf16x8 kv0, kv1;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { kv0[j] = (__bf16)(kv[j] * inv_n); kv1[j] = (__bf16)(kv[8 + j] * inv_n); }
-    wave_sync();
-
-    // ---- 2. q^T tiles (lane = token), epilogue
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[tt][i] = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const bf16x8 bq8 = __builtin_bit_cast(bf16x8, wf[(s + KS) % PF]);
-        if (s + PF < KS) wf[(s + KS) % PF] = wfrag<PAD>(wq_row, rvalid, 16 * (s + PF) + 8 * h, D);
-        if (s + 1 < KS) {
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 bk8 = __builtin_bit_cast(bf16x8, wf[s % PF]);
+            if (s + PF < KS) wf[s % PF] = wfrag<PAD>(wk_h, rvalid, 16 * (s + PF) + 8 * h, D);
+            else wf[s % PF] = wfrag<PAD>(wq_h, rvalid, 16 * (s + PF - KS) + 8 * h, D);          // the ring rolls over into the q weights
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
-                const f32x4q* pa = Ldv + (32 * tt + r - R0) * DROW4 + 4 * (s + 1) + 2 * h;
-                xf[(s + 1 + KS) & 1][tt][0] = pa[0]; xf[(s + 1 + KS) & 1][tt][1] = pa[1];
+                // next: k-step s + 1 of the k half, or k-step 0 of the q half
+                const f32x4q* pa = Ldv + (32 * tt + r - R0) * DROW4 + (s + 1 < KS ? K / 4 + 4 * (s + 1) : 0) + 2 * h;
+                xf[(s + 1) & 1][tt][0] = pa[0]; xf[(s + 1) & 1][tt][1] = pa[1];
+            }
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                const bf16x8 fa = to_bf16x8(xf[s & 1][tt][0], xf[s & 1][tt][1]);          // token 32 tt + r, inputs 16 s + 8 h .. + 7 of the k half
+                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, bk8, acc[tt], 0, 0, 0);
             }
         }
+        const float* const Lv = Ld + hd * 32 + r;                 // this lane's channel of d: v
+        f32x16 kv;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) kv[i] = 0.f;
+        float ksum = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 fa, fb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = 8 * s2 + j, t = 32 * tt + acc_row(i, h);
+                    const float kk = t < n ? elu1(acc[tt][i] + bk) : 0.f;
+                    ksum += kk;
+                    fa[j] = (__bf16)kk;
+                    fb[j] = (__bf16)Lv[(t - R0) * DROW];
+                }
+                kv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, kv, 0, 0, 0);
+            }
+        const float inv_n = 1.f / (float)n;
+        const float kbar_mine = (ksum + __shfl_xor(ksum, 32)) * inv_n;          // lane (r, h): kbar of channel r of the head
+        float* const Lkb = Lw + 11 * C + hd * 32;
+        if (h == 0) Lkb[r] = kbar_mine;
+        bf16x8 kv0, kv1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { kv0[j] = (__bf16)(kv[j] * inv_n); kv1[j] = (__bf16)(kv[8 + j] * inv_n); }
+        wave_sync();
+
+        // ---- 2. q^T tiles (lane = token), epilogue
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[tt][i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 bq8 = __builtin_bit_cast(bf16x8, wf[(s + KS) % PF]);
+            if (s + PF < KS) wf[(s + KS) % PF] = wfrag<PAD>(wq_h, rvalid, 16 * (s + PF) + 8 * h, D);
+            else if (hh + 1 < HPW) wf[(s + KS) % PF] = wfrag<PAD>(wk_h + (size_t)D * Kg, rvalid, 16 * (s + PF - KS) + 8 * h, D);          // ... and into the wave's next head (slot (s + KS) % PF = (s + PF - KS) % PF: 2 KS % PF == 0)
+            if (s + 1 < KS) {
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    const f32x4q* pa = Ldv + (32 * tt + r - R0) * DROW4 + 4 * (s + 1) + 2 * h;
+                    xf[(s + 1 + KS) & 1][tt][0] = pa[0]; xf[(s + 1 + KS) & 1][tt][1] = pa[1];
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                const bf16x8 fb = to_bf16x8(xf[(s + KS) & 1][tt][0], xf[(s + KS) & 1][tt][1]);          // token 32 tt + r, inputs 16 s + 8 h .. + 7 of the q half
+                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq8, fb, acc[tt], 0, 0, 0);
+            }
+        }
+        const float4* const zrow = Ld4 + (size_t)rows * DROW4 + (hd * 32 + 4 * h) / 4;
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
-            const bf16x8 fb = to_bf16x8(xf[(s + KS) & 1][tt][0], xf[(s + KS) & 1][tt][1]);          // token 32 tt + r, inputs 16 s + 8 h .. + 7 of the q half
-            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq8, fb, acc[tt], 0, 0, 0);
+            const int t = 32 * tt + r;
+            if constexpr (FULL)             // a stays in LDS, padded like d (its padding columns come out as zeros: zero kv columns, zero pe)
+                out_epilogue<C, false>(acc[tt], kv0, kv1, Lw + 10 * C + hd * 32, Lkb, Ld4 + (t - R0) * DROW4 + (hd * 32 + 4 * h) / 4, zrow,
+                                       reinterpret_cast<const float4*>(Lw) + (hd * 32 + 4 * h) / 4, t, n, Wp, h, Lw + 12 * C + hd * 32 + 4 * h, 0, DROW, 32);
+            else
+                out_epilogue<C, PAD>(acc[tt], kv0, kv1, Lw + 10 * C + hd * 32, Lkb, Ld4 + (t - R0) * DROW4 + (hd * 32 + 4 * h) / 4, zrow,
+                                     reinterpret_cast<const float4*>(Lw) + (hd * 32 + 4 * h) / 4, t, n, Wp, h, out + (size_t)b * n * Cg, hd * D + 4 * h, Cg, D - 4 * h);
         }
-    }
-    const float4* const zrow = Ld4 + (size_t)rows * DROW4 + (hd * 32 + 4 * h) / 4;
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) {
-        const int t = 32 * tt + r;
-        if constexpr (FULL)             // a stays in LDS, padded like d (its padding columns come out as zeros: zero kv columns, zero pe)
-            out_epilogue<C, false>(acc[tt], kv0, kv1, Lw + 10 * C + hd * 32, Lkb, Ld4 + (t - R0) * DROW4 + (hd * 32 + 4 * h) / 4, zrow,
-                                   reinterpret_cast<const float4*>(Lw) + (hd * 32 + 4 * h) / 4, t, n, Wp, h, Lw + 12 * C + hd * 32 + 4 * h, 0, DROW, 32);
-        else
-            out_epilogue<C, PAD>(acc[tt], kv0, kv1, Lw + 10 * C + hd * 32, Lkb, Ld4 + (t - R0) * DROW4 + (hd * 32 + 4 * h) / 4, zrow,
-                                 reinterpret_cast<const float4*>(Lw) + (hd * 32 + 4 * h) / 4, t, n, Wp, h, out + (size_t)b * n * Cg, hd * D + 4 * h, Cg, D - 4 * h);
     }
     if constexpr (FULL) {
         // ---- 3. y = conv5(x + resize(a)) + bias: lane = (channel, upper / lower output rows), a[token][channel] float32 in LDS behind Lw
         __syncthreads();
-        constexpr int ORP = (XW + 1) / 2;                      // output rows per lane (7 x 7: row 3 by both, the same value)
+        constexpr int ORP = NTHR == C ? XW : (XW + 1) / 2;     // output rows per lane (7 x 7: row 3 by both, the same value; one lane per channel: all rows)
         const int cp = threadIdx.x < C ? threadIdx.x : threadIdx.x - C, o0 = threadIdx.x < C ? 0 : XW - ORP;      // padded channel, as in the conv above
         const bool cvalid = (cp & 31) < D;
         const int c = cvalid ? (cp >> 5) * D + (cp & 31) : 0;
@@ -876,11 +890,11 @@ template <int NT, int KS, int XW, typename TX, bool PAD>
 static hipError_t launch_unit_p(const void* x, const float* wdn, const float* bdn, const bf16_t* wqk, const float* bqk, const float* wpe, const float* bpe,
                                 const float* wcv, const float* bcv, void* y, int B, int D, hipStream_t s)
 {
-    constexpr int WO = (XW + 1) / 2;
+    constexpr int WO = (XW + 1) / 2, HPW = KS == 16 ? 2 : 1;          // 16 heads: two per wave (8 waves, 256 registers)
     const size_t lds = qkc::short_lds_bytes(NT, WO, 32 * KS, true);
-    auto kfn = qkc::k_recattn_short<NT, KS, XW, TX, true, PAD>;
+    auto kfn = qkc::k_recattn_short<NT, KS, XW, TX, true, PAD, HPW>;
     RCX_SET_LDS_ONCE(kfn, lds);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(64 * KS), lds, s, (const float*)nullptr, wqk, bqk, wpe, bpe, (float*)nullptr, WO, WO, (const TX*)x, wdn, bdn, wcv, bcv, (TX*)y, D);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(64 * KS / HPW), lds, s, (const float*)nullptr, wqk, bqk, wpe, bpe, (float*)nullptr, WO, WO, (const TX*)x, wdn, bdn, wcv, bcv, (TX*)y, D);
     return hipGetLastError();
 }
 template <int NT, int KS, int XW, typename TX>
@@ -896,7 +910,7 @@ bool recattn2d_unit_applicable(int B, int H, int W, int C, int heads, int x_dt, 
 {
     const char* v = rcx::opt::value(rcx::opt::ATTN_FUSED);
     if (v && *v == 't') return false;
-    if (mode != 1 || heads > 8 || !recattn_down_qkcore_applicable(B, H, W, C, heads, x_dt)) return false;      // 16 heads = 16 waves = 128 registers: the final conv does not fit
+    if (mode != 1 || !recattn_down_qkcore_applicable(B, H, W, C, heads, x_dt)) return false;      // (16 heads, 7 x 7 only: two heads per wave -- 16 waves of 128 registers do not hold the final conv)
     const int wo = (W + 1) / 2;
     return qkc::short_lds_bytes(wo * wo <= 32 ? 1 : 2, wo, 32 * heads, true) <= 160 * 1024;
 }
@@ -915,6 +929,9 @@ hipError_t recattn2d_unit(const void* x, const float* wdn, const float* bdn, con
         case 2: return RCX_UX(2);
         case 4: return RCX_UX(4);
         case 8: return RCX_UX(8);
+        case 16: return H == 7 ? (x_dt == 1 ? launch_unit<1, 16, 7, bf16_t>(x, wdn, bdn, w, bqk, wpe, bpe, wcv, bcv, y, B, C / heads, s)
+                                            : launch_unit<1, 16, 7, f16_t>(x, wdn, bdn, w, bqk, wpe, bpe, wcv, bcv, y, B, C / heads, s))
+                               : hipErrorInvalidConfiguration;
         default: return hipErrorInvalidConfiguration;
     }
 #undef RCX_UX

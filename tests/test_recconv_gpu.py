@@ -880,7 +880,8 @@ def test_recattn_down_qkcore_one_launch_from_x(case, xdt):
 
 
 @pytest.mark.parametrize("case", [(3, 256, 8, 14), (2, 64, 2, 14), (5, 32, 1, 7), (1, 128, 4, 14), (2, 128, 4, 7), (2, 256, 8, 7),
-                                  (3, 160, 8, 14), (2, 224, 8, 14), (2, 96, 4, 7), (2, 40, 2, 14)], ids=lambda c: "x".join(map(str, c)))     # head dimensions 20 / 28 / 24 / 20
+                                  (3, 160, 8, 14), (2, 224, 8, 14), (2, 96, 4, 7), (2, 40, 2, 14),                                            # head dimensions 20 / 28 / 24 / 20
+                                  (3, 512, 16, 7), (2, 320, 16, 7), (2, 448, 16, 7)], ids=lambda c: "x".join(map(str, c)))                   # 16 heads: two per wave (A3 / A0 / A2 stage 3)
 @pytest.mark.parametrize("xdt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 def test_recattn2d_whole_unit_in_one_launch(case, xdt):
     """rcx_recattn2d_fwd (round 4): RecAttn2d.forward (model/recattn.py:54-67, eval, nearest) in ONE launch on the 14 x 14 / 7 x 7 planes against (a) the
