@@ -51,7 +51,7 @@ class GraphedInference:
         with torch.no_grad(), torch.cuda.graph(graph):
             static_y = self.module(static_x)
         # the derived packs whose addresses the graph has baked in: kept alive with it
-        packs = [getattr(m, a) for m in self.module.modules() for a in ("_pack",) if getattr(m, a, None) is not None]
+        packs = [getattr(m, a) for m in self.module.modules() for a in ("_pack", "_pad_w", "_pad_b") if getattr(m, a, None) is not None]
         return graph, static_x, static_y, packs
 
     def __call__(self, x):

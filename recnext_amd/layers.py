@@ -77,6 +77,11 @@ class PointwiseLinear(nn.Module):
     Same parameters (``weight`` (Cout,Cin,1,1), ``bias``) and same function as the ``nn.Conv2d`` it replaces; the
     only difference is the library call: on ROCm the GEMM path (hipBLASLt) applies the bias in its epilogue, whereas
     the MIOpen conv path launches a separate elementwise kernel for it.  Host-side plumbing, inference only.
+
+    ``pad(out_to=, in_to=)`` makes the GEMM run on zero-padded copies of the parameters (extra output channels with
+    zero weights and zero bias, extra input channels with zero weights): the GEMM library's tiles for RecNeXt-A's
+    hidden widths (1.875 x dim: 120, 240, 480) are far slower than for the next multiple of 64.  The parameters and
+    the ``state_dict`` stay as they are; the padded copies follow them (rebuilt when a parameter changes).
     """
 
     def __init__(self, conv):
@@ -85,9 +90,38 @@ class PointwiseLinear(nn.Module):
             raise ValueError("PointwiseLinear replaces a dense 1x1, stride-1 convolution")
         self.weight, self.bias = conv.weight, conv.bias
         self.in_channels, self.out_channels = conv.in_channels, conv.out_channels
+        self.out_padded, self.in_padded = self.out_channels, self.in_channels
+        self._pad_key, self._pad_w, self._pad_b = None, None, None
+
+    def pad(self, out_to=None, in_to=None):
+        out_to = self.out_channels if out_to is None else int(out_to)
+        in_to = self.in_channels if in_to is None else int(in_to)
+        if out_to < self.out_channels or in_to < self.in_channels:
+            raise ValueError("padding cannot shrink a layer")
+        self.out_padded, self.in_padded, self._pad_key = out_to, in_to, None
+        return self
+
+    def _operands(self):
+        w, b = self.weight, self.bias
+        if self.out_padded == self.out_channels and self.in_padded == self.in_channels:
+            return w.view(self.out_channels, self.in_channels), b
+        key = (w.data_ptr(), w._version, w.dtype, w.device, None if b is None else (b.data_ptr(), b._version))
+        if key != self._pad_key:
+            with torch.no_grad():
+                wp = w.new_zeros(self.out_padded, self.in_padded)
+                wp[:self.out_channels, :self.in_channels] = w.view(self.out_channels, self.in_channels)
+                bp = None
+                if b is not None:
+                    bp = b.new_zeros(self.out_padded)
+                    bp[:self.out_channels] = b
+            self._pad_key, self._pad_w, self._pad_b = key, wp, bp
+        return self._pad_w, self._pad_b
 
     def forward(self, x):
         n, c, h, w = x.shape
+        if c != self.in_padded:
+            raise ValueError(f"expected {self.in_padded} input channels, got {c}")
+        wt, b = self._operands()
         x2 = x.permute(0, 2, 3, 1)                       # a view when x is channels_last
-        y2 = torch.nn.functional.linear(x2.reshape(n * h * w, c), self.weight.view(self.out_channels, c), self.bias)
-        return y2.view(n, h, w, self.out_channels).permute(0, 3, 1, 2)
+        y2 = torch.nn.functional.linear(x2.reshape(n * h * w, c), wt, b)
+        return y2.view(n, h, w, self.out_padded).permute(0, 3, 1, 2)

@@ -252,6 +252,37 @@ def use_linear_pointwise(net):
     return n
 
 
+def padded_hidden_width(hidden, max_growth=0.125):
+    """The hidden width the channel mixers' GEMMs run at: the next multiple of 64 (else of 16) when that adds at most ``max_growth``, else unchanged."""
+    for mult in (64, 16):
+        hp = -(-hidden // mult) * mult
+        if hp != hidden and hp <= hidden * (1 + max_growth):
+            return hp
+    return hidden
+
+
+def pad_mlp_hidden(net):
+    """Inference-only plumbing, after ``use_linear_pointwise``: run the two GEMMs of a channel mixer at a zero-padded hidden width (RecNeXt-A's
+    1.875 x dim -- 120 / 240 / 480 -- become 128 / 256 / 512).  The same function: a padded hidden channel is act(0 + 0) = 0 and meets zero weights
+    (checked: the activation must map 0 to 0).  Parameters and ``state_dict`` are untouched (``PointwiseLinear.pad``).  Returns the mixers changed."""
+    from .layers import PointwiseLinear
+    n = 0
+    for m in net.modules():
+        if isinstance(m, (MetaNeXtBlock, Downsample)):
+            seq = m.channel_mixer
+            if len(seq) != 3 or not isinstance(seq[0], PointwiseLinear) or not isinstance(seq[2], PointwiseLinear):
+                continue
+            with torch.no_grad():
+                if float(seq[1](torch.zeros(1)).abs().max()) != 0.0:
+                    continue
+            hp = padded_hidden_width(seq[0].out_channels)
+            if hp != seq[0].out_padded or hp != seq[2].in_padded:
+                seq[0].pad(out_to=hp)
+                seq[2].pad(in_to=hp)
+                n += hp != seq[0].out_channels
+    return n
+
+
 def token_mixer_shapes(name, resolution=224):
     """[(C, H, W, level|None, count)] of every token mixer call in one forward pass (SURVEY 8 model tables)."""
     cfg = CONFIGS[name]

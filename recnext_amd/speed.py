@@ -25,12 +25,13 @@ DTYPES = {"fp32": torch.float32, "f32": torch.float32, "bf16": torch.bfloat16, "
 
 
 def build_inference_model(name, device, dtype=torch.bfloat16, token_mixer=None, seed=0, fold_mixer_norm=True,
-                          hip_downsample=True, linear_pointwise=True):
+                          hip_downsample=True, linear_pointwise=True, pad_hidden=True):
     """create_model -> replace_batchnorm -> device/eval, as speed_gpu.py:47-50 (plus dtype + channels_last).
 
     ``fold_mixer_norm`` additionally absorbs the BatchNorm after each HIP token mixer into the mixer's last
     conv (same function, one kernel less per block); it is a no-op for other token mixers.  ``hip_downsample``
-    runs the three strided depthwise Downsample convs (+ their BatchNorm) on the HIP kernels as well.
+    runs the three strided depthwise Downsample convs (+ their BatchNorm) on the HIP kernels as well.  ``pad_hidden`` lets the
+    channel mixers' GEMMs run at a zero-padded hidden width (``models.pad_mlp_hidden``: RecNeXt-A's 120 / 240 / 480 -> 128 / 256 / 512).
     """
     torch.manual_seed(seed)
     net = models.create_model(name, num_classes=1000, token_mixer=token_mixer)
@@ -45,6 +46,8 @@ def build_inference_model(name, device, dtype=torch.bfloat16, token_mixer=None, 
         net = net.to(memory_format=torch.channels_last)
         if linear_pointwise:
             models.use_linear_pointwise(net)
+            if pad_hidden:
+                models.pad_mlp_hidden(net)
     return net
 
 

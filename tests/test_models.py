@@ -215,6 +215,33 @@ def test_linear_pointwise_is_the_same_function_cpu():
         assert (net(x) - ref).abs().max() < 1e-5
 
 
+def test_padded_mlp_hidden_width_is_the_same_function_cpu():
+    """pad_mlp_hidden: RecNeXt-A3's channel mixers run their GEMMs at 128 / 256 / 512 instead of 120 / 240 / 480 -- same outputs, same state_dict,
+    and the padded operands follow a parameter that changes afterwards."""
+    assert [models.padded_hidden_width(h) for h in (120, 240, 480, 960, 150, 1200, 80, 128)] == [128, 256, 512, 960, 160, 1216, 80, 128]
+    torch.manual_seed(0)
+    net = models.create_model("recnext_a3", token_mixer=eager_token_mixer("a")).eval()
+    models.replace_batchnorm(net)
+    x = torch.randn(1, 3, 64, 64)
+    with torch.no_grad():
+        ref = net(x)
+        keys = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        models.use_linear_pointwise(net)
+        assert models.pad_mlp_hidden(net) == 3 + 4 + 14 and models.pad_mlp_hidden(net) == 0          # stages 0 - 2 incl. two Downsample mixers; idempotent
+        assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == keys
+        fc1, act, fc2 = net.stages[0].blocks[0].channel_mixer
+        assert (fc1.out_channels, fc1.out_padded, fc2.in_channels, fc2.in_padded) == (120, 128, 120, 128)
+        assert (net(x) - ref).abs().max() < 1e-6
+        fc1.weight.mul_(2.0)                                       # an optimizer step / a loaded checkpoint: the padded copy is rebuilt
+        changed = net(x)
+        assert (changed - ref).abs().max() > 1e-4
+        fc1.pad()
+        fc2.pad()
+        assert (net(x) - changed).abs().max() < 1e-6
+        with pytest.raises(ValueError):
+            fc1.pad(out_to=64)
+
+
 def test_hip_downsample_keeps_the_reference_state_dict_keys():
     """use_hip_downsample reroutes the forward only: keys equal the reference's and strict loads work in both orders."""
     _, sd = _load_tiny("m")
