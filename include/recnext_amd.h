@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RCX_ABI_VERSION 4
+#define RCX_ABI_VERSION 5
 
 enum { RCX_DTYPE_F32 = 0, RCX_DTYPE_BF16 = 1, RCX_DTYPE_F16 = 2 };   /* F16: the reference's autocast dtype (engine.py:48) */
 enum { RCX_MODE_BILINEAR = 0, RCX_MODE_NEAREST = 1 };   /* F.interpolate(mode=...), model/recnext.py:33 */
@@ -233,6 +233,23 @@ int rcx_recattn2d_fwd_supported(int B, int H, int W, int C, int heads, int mode,
 int rcx_recattn2d_fwd(const void* x, void* y, const float* w_down_kkc, const float* b_down, const void* wqk_bf16, const float* bqk,
                       const float* w_pe_kkc, const float* b_pe, const float* w_conv_kkc, const float* b_conv,
                       int B, int H, int W, int C, int heads, int mode, int dtype, void* stream);
+
+/*
+ * The channel mixer of a MetaNeXtBlock / Downsample with the residual add around it, inference, ONE launch (model/recnext.py:125-132 `mlp`,
+ * :157-158 `x + drop_path(channel_mixer(norm(token_mixer(x))))`, :169-171; model/recattn.py:171, :184), both 1x1 ConvNorms BN-folded (:75-97):
+ *     y[m][:] = x[m][:] + W2 gelu(W1 z[m][:] + b1) + b2        m = 0 .. M-1 tokens (M = N H W of an NHWC tensor), gelu = the exact (erf) form
+ *   z, x, y : M x C bf16 (z = the token mixer's output, x = the block's input; z == x for Downsample); y may alias neither;
+ *   wfrag   : rcx_channel_mlp_pack_bytes(C, H) bytes -- W1 (H x C) and W2 (C x H) rounded to bf16 and laid out as the matrix-core fragments the kernel
+ *             reads (recnext_amd/ops.py::pack_channel_mlp builds it; layout in recnext_amd/csrc/rcx_mlp.hip); 16-byte aligned;
+ *   bias    : 32 (H/32 + ceil(C/32)) floats: b1 (H), then b2 padded with zeros to a multiple of 32.
+ * H % 32 == 0 (pad the hidden layer with zero units: gelu(0) = 0 meets zero weights), C % 8 == 0, M C 2 < 2^31, the weights must fit the LDS.
+ * rcx_channel_mlp_supported() says whether there is a kernel for (C, H) (today: C = 64 / 56 with H = 128, 128 / 256, 48 / 40 with 96, 96 / 192, 80 / 160);
+ * else RCX_ERR_UNSUPPORTED and the caller keeps the GEMM library.  The products run on the matrix cores with bf16 operands (the hidden activations are
+ * rounded to bf16 once, after the GELU) and float32 accumulation.
+ */
+int rcx_channel_mlp_supported(int M, int C, int H, int dtype);
+size_t rcx_channel_mlp_pack_bytes(int C, int H);
+int rcx_channel_mlp_fwd(const void* z, const void* x, void* y, const void* wfrag, const float* bias, int M, int C, int H, int dtype, void* stream);
 
 /*
  * Backward of rcx_linear_attention_fwd (the gradients engine.py:48-64 needs through RecAttn2d, model/recattn.py:16-28 / :39-51):

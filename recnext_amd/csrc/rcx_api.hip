@@ -828,11 +828,30 @@ int rcx_recattn2d_fwd(const void* x, void* y, const float* w_down_kkc, const flo
     if (((size_t)wqk_bf16 & 15) || ((size_t)bqk & 15) || ((size_t)w_pe_kkc & 15) || ((size_t)b_pe & 15))
         return fail(RCX_ERR_BAD_ARG, "rcx_recattn2d_fwd: wqk, bqk, w_pe_kkc and b_pe must be 16-byte aligned");
     if (!rcx::recattn2d_unit_applicable(B, H, W, C, heads, dtype, mode == RCX_MODE_NEAREST ? 1 : 0))
-        return fail(RCX_ERR_UNSUPPORTED, "rcx_recattn2d_fwd: %d x %d plane, %d heads of %d, mode %d, dtype %d: the one-launch unit takes the 14 x 14 and 7 x 7 planes of bf16 / f16 "
-                                         "activations, 1 .. 8 heads of 32, nearest resize (use rcx_recattn_down_qkcore_fwd / rcx_dwconv2d_fwd + rcx_recattn_qkcore_fwd, then "
+        return fail(RCX_ERR_UNSUPPORTED, "rcx_recattn2d_fwd: %d x %d plane, %d heads of %d, mode %d, dtype %d: the one-launch unit takes the 14 x 14 (1 .. 8 heads) and 7 x 7 (1 .. 16 heads) planes of bf16 / f16 "
+                                         "activations, heads of 32 or 4 .. 28 channels, nearest resize (use rcx_recattn_down_qkcore_fwd / rcx_dwconv2d_fwd + rcx_recattn_qkcore_fwd, then "
                                          "rcx_upadd_dwconv_fwd)", H, W, heads, C / heads, mode, dtype);
     hipError_t e = rcx::recattn2d_unit(x, w_down_kkc, b_down, wqk_bf16, bqk, w_pe_kkc, b_pe, w_conv_kkc, b_conv, y, B, H, C, heads, dtype, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_recattn2d_fwd");
+}
+
+int rcx_channel_mlp_supported(int M, int C, int H, int dtype) { return rcx::channel_mlp_applicable(M, C, H, dtype) ? 1 : 0; }
+
+size_t rcx_channel_mlp_pack_bytes(int C, int H) { return rcx::channel_mlp_pack_bytes(C, H); }
+
+int rcx_channel_mlp_fwd(const void* z, const void* x, void* y, const void* wfrag, const float* bias, int M, int C, int H, int dtype, void* stream)
+{
+    if (!z || !x || !y || !wfrag || !bias) return fail(RCX_ERR_BAD_ARG, "rcx_channel_mlp_fwd: null pointer");
+    if (M <= 0 || C <= 0 || H <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive extent M=%d C=%d H=%d", M, C, H);
+    if (!known_dtype(dtype)) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
+    if (((size_t)z & 15) || ((size_t)x & 7) || ((size_t)y & 7) || ((size_t)wfrag & 15) || ((size_t)bias & 15))
+        return fail(RCX_ERR_BAD_ARG, "rcx_channel_mlp_fwd: z, wfrag and bias must be 16-byte aligned, x and y 8-byte aligned");
+    if (y == z || y == x) return fail(RCX_ERR_BAD_ARG, "rcx_channel_mlp_fwd: y must not alias its inputs");
+    if (!rcx::channel_mlp_applicable(M, C, H, dtype))
+        return fail(RCX_ERR_UNSUPPORTED, "rcx_channel_mlp_fwd: no kernel for M=%d C=%d H=%d dtype %d (bf16; C = 64 / 56 with H = 128, 128 / 256, 48 / 40 with 96, 96 / 192, 80 / 160; "
+                                         "M C 2 < 2^31)", M, C, H, dtype);
+    hipError_t e = rcx::channel_mlp(z, x, y, wfrag, bias, M, C, H, dtype, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "rcx_channel_mlp_fwd");
 }
 
 int rcx_linear_attention_bwd(const void* qpre, const void* kpre, const void* v, const void* gout, void* gq, void* gk, void* gv,

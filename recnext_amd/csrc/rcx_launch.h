@@ -153,6 +153,10 @@ bool recattn_down_qkcore_applicable(int B, int H, int W, int C, int heads, int x
 hipError_t recattn_down_qkcore(const void* x, const float* wdn, const float* bdn, const void* wqk_bf16, const float* bqk, const float* wpe, const float* bpe,
                                float* out, int B, int H, int C, int heads, int x_dt, hipStream_t s);
 // ... and RecAttn2d.forward whole (nearest resize): + the final conv(x + resize(a)), one launch from x to y
+// rcx_mlp.hip: the channel mixer + residual of a block in one launch (bf16)
+bool channel_mlp_applicable(int M, int C, int H, int dtype);
+size_t channel_mlp_pack_bytes(int C, int H);
+hipError_t channel_mlp(const void* z, const void* x, void* y, const void* wfrag, const float* bias, int M, int C, int H, int dtype, hipStream_t s);
 bool recattn2d_unit_applicable(int B, int H, int W, int C, int heads, int x_dt, int mode);
 hipError_t recattn2d_unit(const void* x, const float* wdn, const float* bdn, const void* wqk_bf16, const float* bqk, const float* wpe, const float* bpe,
                           const float* wcv, const float* bcv, void* y, int B, int H, int C, int heads, int x_dt, hipStream_t s);

@@ -125,3 +125,31 @@ class PointwiseLinear(nn.Module):
         x2 = x.permute(0, 2, 3, 1)                       # a view when x is channels_last
         y2 = torch.nn.functional.linear(x2.reshape(n * h * w, c), wt, b)
         return y2.view(n, h, w, self.out_padded).permute(0, 3, 1, 2)
+
+
+class FusedChannelMlp:
+    """The channel mixer [PointwiseLinear, GELU, PointwiseLinear] of a block and the residual add around it as ONE HIP launch (ops.channel_mlp; inference,
+    bf16, channels_last).  Not a Module: it reads the two layers' own parameters (state_dict untouched) and rebuilds its fragment pack when one changes."""
+
+    def __init__(self, fc1, fc2):
+        self.fc1, self.fc2 = fc1, fc2
+        self._key, self._pack = None, None
+
+    def supported(self, x):
+        from . import ops
+        n, c, h, w = x.shape
+        return x.is_cuda and x.dtype == torch.bfloat16 and ops.channel_mlp_supported(n * h * w, c, self.fc1.out_channels, x.dtype)
+
+    def _operands(self):
+        from . import ops
+        ts = [self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias]
+        key = tuple(None if t is None else (t.data_ptr(), t._version, t.dtype, t.device) for t in ts)
+        if key != self._key:
+            self._pack = ops.pack_channel_mlp(*ts)
+            self._key = key
+        return self._pack
+
+    def __call__(self, z, x):
+        from . import ops
+        wfrag, bias, hidden = self._operands()
+        return ops.channel_mlp(z, x, wfrag, bias, hidden)

@@ -71,6 +71,9 @@ class MetaNeXtBlock(nn.Module):
         t = self.token_mixer(x)
         if self._has_norm:
             t = self.norm(t)
+        fused = self.__dict__.get("_fused_mlp")
+        if fused is not None and not self.training and fused.supported(x):
+            return fused(t, x)                          # x + channel_mixer(t) in one launch (use_fused_mlp)
         return x + self.drop_path(self.channel_mixer(t))
 
 
@@ -102,6 +105,9 @@ class Downsample(nn.Module):
     def forward(self, x):
         hip = self._hip_path()
         x = hip(x) if hip is not None else self.norm(self.token_mixer(x))
+        fused = self.__dict__.get("_fused_mlp")
+        if fused is not None and not self.training and fused.supported(x):
+            return fused(x, x)
         return x + self.channel_mixer(x)
 
 
@@ -249,6 +255,23 @@ def use_linear_pointwise(net):
                 if isinstance(sub, nn.Conv2d) and sub.kernel_size == (1, 1) and sub.groups == 1 and sub.bias is not None:
                     seq[i] = PointwiseLinear(sub)
                     n += 1
+    return n
+
+
+def use_fused_mlp(net):
+    """Inference-only, after ``use_linear_pointwise``: evaluate ``x + channel_mixer(t)`` of every MetaNeXtBlock / Downsample whose mixer is
+    [1x1 conv, exact GELU, 1x1 conv] as ONE HIP launch where rcx_channel_mlp_fwd has a kernel (bf16; the 56 x 56 and 28 x 28 stages, where the two GEMMs
+    are memory-bound and the hidden tensor's round trips are most of their time) -- other blocks, dtypes and devices keep the GEMM library, decided per
+    call.  The layers, their parameters and the state_dict are untouched.  Returns the number of blocks given the fused path."""
+    from .layers import FusedChannelMlp, PointwiseLinear
+    n = 0
+    for m in net.modules():
+        if isinstance(m, (MetaNeXtBlock, Downsample)) and m.__dict__.get("_fused_mlp") is None:
+            seq = m.channel_mixer
+            if len(seq) == 3 and isinstance(seq[0], PointwiseLinear) and isinstance(seq[2], PointwiseLinear) and isinstance(seq[1], nn.GELU) \
+                    and getattr(seq[1], "approximate", "none") == "none":            # (drop_path is the identity in eval mode, the only mode the fused path runs in)
+                object.__setattr__(m, "_fused_mlp", FusedChannelMlp(seq[0], seq[2]))
+                n += 1
     return n
 
 

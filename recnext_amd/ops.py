@@ -446,6 +446,66 @@ def recattn2d(x, w_down_kkc, b_down, wqk_bf16, bqk, w_pe_kkc, b_pe, w_conv_kkc, 
     return y
 
 
+def _mlp_acc_unit(i, h):
+    """Hidden unit (within a 32-unit tile) that accumulator register i of lane half h holds after the first product (rcx_mlp.hip acc_row)."""
+    return (i & 3) + 8 * (i >> 2) + 4 * h
+
+
+def channel_mlp_supported(m, c, hidden, dtype):
+    """Whether rcx_channel_mlp_fwd has a kernel for M tokens of C channels and a hidden width that pads to `hidden` -> multiple of 32 (bf16 only)."""
+    hp = -(-int(hidden) // 32) * 32
+    return dtype == torch.bfloat16 and _lib.load().rcx_channel_mlp_supported(int(m), int(c), hp, _DT[dtype]) > 0
+
+
+def pack_channel_mlp(w1, b1, w2, b2):
+    """The two BN-folded 1x1 convs of a channel mixer -> (wfrag, bias, H) for channel_mlp: w1 (H0, C[, 1, 1]), b1 (H0) | None, w2 (C, H0[, 1, 1]), b2 (C) | None.
+
+    The hidden layer is padded with zero units to H = a multiple of 32, C to whole k-steps / output tiles with zero columns / rows; the weights are rounded to
+    bf16 (they already are bf16 in a bf16 model) and laid out fragment by fragment in the order the kernel's lanes read them (rcx_mlp.hip):
+      W1 fragment (ht, ks), lane (h, m), element j = W1[32 ht + m][16 ks + 8 h + j]
+      W2 fragment (ct, 2 ht + q), lane (h, m), element j = W2[32 ct + m][32 ht + unit(8 q + j, h)]      unit = _mlp_acc_unit: the order the first product leaves in the registers
+    """
+    w1 = w1.detach().reshape(w1.shape[0], -1)
+    w2 = w2.detach().reshape(w2.shape[0], -1)
+    h0, c = w1.shape
+    if tuple(w2.shape) != (c, h0):
+        raise ValueError(f"w2 must be ({c}, {h0}), got {tuple(w2.shape)}")
+    dev = w1.device
+    ks1, ht, ct = -(-c // 16), -(-h0 // 32), -(-c // 32)
+    w1p = torch.zeros(32 * ht, 16 * ks1, dtype=torch.bfloat16, device=dev)
+    w1p[:h0, :c] = w1.to(torch.bfloat16)
+    f1 = w1p.view(ht, 32, ks1, 2, 8).permute(0, 2, 3, 1, 4)                    # [ht, ks, h, m, j]
+    w2p = torch.zeros(32 * ct, 32 * ht, dtype=torch.bfloat16, device=dev)
+    w2p[:c, :h0] = w2.to(torch.bfloat16)
+    unit = torch.tensor([[[_mlp_acc_unit(8 * q + j, h) for j in range(8)] for h in range(2)] for q in range(2)], device=dev)      # [q, h, j]
+    f2 = w2p.view(ct, 32, ht, 32)[:, :, :, unit]                               # [ct, m, ht, q, h, j]
+    f2 = f2.permute(0, 2, 3, 4, 1, 5)                                          # [ct, ht, q, h, m, j]
+    wfrag = torch.cat([f1.reshape(-1), f2.reshape(-1)]).contiguous()
+    bias = torch.zeros(32 * (ht + ct), dtype=torch.float32, device=dev)
+    if b1 is not None:
+        bias[:h0] = b1.detach().float()
+    if b2 is not None:
+        bias[32 * ht:32 * ht + c] = b2.detach().float()
+    return wfrag, bias, 32 * ht
+
+
+def channel_mlp(z, x, wfrag, bias, hidden):
+    """y = x + W2 gelu(W1 z + b1) + b2 in one launch (rcx_channel_mlp_fwd; model/recnext.py:157-158): z, x N x C x H x W channels_last bf16 -> y like x."""
+    z = _nhwc(z, "z")
+    x = _nhwc(x, "x")
+    if z.shape != x.shape or z.dtype != x.dtype:
+        raise ValueError("z and x must have the same shape and dtype")
+    n, c, h, w = x.shape
+    lib = _lib.load()
+    if wfrag.dtype != torch.bfloat16 or wfrag.numel() * 2 != lib.rcx_channel_mlp_pack_bytes(c, hidden) or not wfrag.is_contiguous():
+        raise ValueError("wfrag is not the pack of pack_channel_mlp for this (C, H)")
+    y = _empty_nhwc(n, c, h, w, x.dtype, x.device)
+    with _on(x.device):
+        rc = lib.rcx_channel_mlp_fwd(z.data_ptr(), x.data_ptr(), y.data_ptr(), wfrag.data_ptr(), bias.data_ptr(), n * h * w, c, hidden, _dt(x), _stream(x.device))
+    _lib.check(rc, "rcx_channel_mlp_fwd")
+    return y
+
+
 def linear_attention_core_backward(qpre, kpre, v, gout, heads):
     """Gradients of linear_attention_core with respect to qpre, kpre (B, n, C) and v (N x C x h x w); dL/dpe = gout."""
     v = _nhwc(v, "v")

@@ -242,6 +242,43 @@ def test_padded_mlp_hidden_width_is_the_same_function_cpu():
             fc1.pad(out_to=64)
 
 
+def test_use_fused_mlp_marks_the_blocks_and_keeps_the_library_path_on_cpu():
+    """use_fused_mlp only attaches the fused path (decided per call: bf16 on a GPU with a kernel for the shape); on the CPU the forward is unchanged."""
+    torch.manual_seed(0)
+    net = models.create_model("recnext_m0", token_mixer=eager_token_mixer("m")).eval()
+    models.replace_batchnorm(net)
+    x = torch.randn(1, 3, 64, 64)
+    with torch.no_grad():
+        ref = net(x)
+        keys = list(net.state_dict())
+        assert models.use_fused_mlp(net) == 0                      # plain convs: nothing to fuse before use_linear_pointwise
+        models.use_linear_pointwise(net)
+        assert models.use_fused_mlp(net) == 14 + 3 and models.use_fused_mlp(net) == 0
+        assert list(net.state_dict()) == keys
+        assert not net.stages[0].blocks[0]._fused_mlp.supported(torch.zeros(1, 40, 16, 16))
+        assert (net(x) - ref).abs().max() < 1e-5
+
+
+def test_channel_mlp_pack_layout_cpu():
+    """pack_channel_mlp: every weight lands in the fragment slot the kernel's lane reads it from (rcx_mlp.hip), padding is zeros."""
+    from recnext_amd import ops
+    c, h0 = 40, 80
+    w1 = torch.arange(h0 * c, dtype=torch.float32).reshape(h0, c) % 251
+    w2 = (torch.arange(c * h0, dtype=torch.float32).reshape(c, h0) * 7) % 241
+    b1, b2 = torch.arange(h0, dtype=torch.float32), -torch.arange(c, dtype=torch.float32)
+    wfrag, bias, hp = ops.pack_channel_mlp(w1, b1, w2, b2)
+    ks1, ht, ct = 3, 3, 2
+    assert hp == 96 and wfrag.dtype == torch.bfloat16 and wfrag.numel() == (ht * ks1 + ct * 2 * ht) * 512 and bias.numel() == 32 * (ht + ct)
+    f = wfrag.float().view(-1, 64, 8)
+    for (t, ks, lane, j) in [(0, 0, 0, 0), (1, 2, 37, 5), (2, 1, 63, 7), (2, 2, 31, 3)]:
+        row, col = 32 * t + lane % 32, 16 * ks + 8 * (lane // 32) + j
+        assert f[t * ks1 + ks, lane, j] == (w1[row, col] if row < h0 and col < c else 0)
+    for (tc, t, q, lane, j) in [(0, 0, 0, 0, 0), (1, 2, 1, 40, 6), (0, 1, 1, 33, 2), (1, 0, 0, 31, 7)]:
+        row, col = 32 * tc + lane % 32, 32 * t + ops._mlp_acc_unit(8 * q + j, lane // 32)
+        assert f[ht * ks1 + tc * 2 * ht + 2 * t + q, lane, j] == (w2[row, col] if row < c and col < h0 else 0)
+    assert torch.equal(bias[:h0], b1) and bias[h0:96].abs().sum() == 0 and torch.equal(bias[96:96 + c], b2) and bias[96 + c:].abs().sum() == 0
+
+
 def test_hip_downsample_keeps_the_reference_state_dict_keys():
     """use_hip_downsample reroutes the forward only: keys equal the reference's and strict loads work in both orders."""
     _, sd = _load_tiny("m")
