@@ -57,7 +57,46 @@ __device__ __forceinline__ f32x2q gelu2(f32x2q v)
     return __builtin_elementwise_fma(hv, e, hv);
 }
 
-// LDS: [HT * KS1] W1 fragments, [CT * 2 HT] W2 fragments (1 KB each: 64 lanes x 16 bytes), then b1 (32 HT floats), b2 (32 CT floats)
+// One 32-unit tile of the hidden layer from its chunk of fragments in LDS (Lc: KS1 W1 fragments, then 2 CT W2 fragments in (ct, q) order):
+//   D1 = W1 tile x z^T, h = gelu(D1 + b1) -> bf16 (already the second product's B operand), D2 += W2 columns x h.
+// The fragments go through register rings RD deep, requested RD products ahead -- and the second product's first RD before the GELU: a read issued right in
+// front of its product costs the LDS latency per product (measured: 13 % of the matrix-core peak whatever the shape).
+template <int KS1, int CT, int RD>
+__device__ __forceinline__ void hidden_tile_ring(const u32x4q* Lc, const float* b1t, int lane, int h, const bf16x8 (&zb)[KS1], f32x16 (&d2)[CT])
+{
+    constexpr int R1 = KS1 < RD ? KS1 : RD, N2 = 2 * CT, R2 = N2 < RD ? N2 : RD;
+    u32x4q ring[RD];
+#pragma unroll
+    for (int j = 0; j < R1; ++j) ring[j] = Lc[j * 64 + lane];
+    f32x16 d1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d1[i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+        const bf16x8 a = __builtin_bit_cast(bf16x8, ring[ks % R1]);
+        if (ks + R1 < KS1) ring[ks % R1] = Lc[(ks + R1) * 64 + lane];
+        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, zb[ks], d1, 0, 0, 0);
+    }
+    // the second product's fragments in use order: f = q CT + ct  ->  pack slot KS1 + 2 ct + q
+#pragma unroll
+    for (int f = 0; f < R2; ++f) ring[f] = Lc[(KS1 + 2 * (f % CT) + f / CT) * 64 + lane];
+    bf16x8 hb[2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4q bb = *reinterpret_cast<const f32x4q*>(b1t + 8 * g + 4 * h);
+        const f32x2q a = gelu2(f32x2q{d1[4 * g] + bb.x, d1[4 * g + 1] + bb.y}), b = gelu2(f32x2q{d1[4 * g + 2] + bb.z, d1[4 * g + 3] + bb.w});
+        hb[g >> 1][4 * (g & 1) + 0] = (__bf16)a.x; hb[g >> 1][4 * (g & 1) + 1] = (__bf16)a.y;
+        hb[g >> 1][4 * (g & 1) + 2] = (__bf16)b.x; hb[g >> 1][4 * (g & 1) + 3] = (__bf16)b.y;
+    }
+#pragma unroll
+    for (int f = 0; f < N2; ++f) {
+        const bf16x8 a = __builtin_bit_cast(bf16x8, ring[f % R2]);
+        if (f + R2 < N2) ring[f % R2] = Lc[(KS1 + 2 * ((f + R2) % CT) + (f + R2) / CT) * 64 + lane];
+        d2[f % CT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[f / CT], d2[f % CT], 0, 0, 0);
+    }
+}
+
+// LDS: per hidden tile ht its KS1 W1 fragments and 2 CT W2 fragments (1 KB each: 64 lanes x 16 bytes; ops.pack_channel_mlp), then b1 (32 HT floats), b2 (32 CT floats)
 static inline size_t lds_bytes(int KS1, int HT, int CT) { return (size_t)(HT * KS1 + CT * 2 * HT) * 1024 + sizeof(float) * 32 * (HT + CT); }
 
 // KS1 = ceil(C / 16) k-steps of the first product, HT = H / 32 hidden tiles, CT = ceil(C / 32) output tiles; C % 8 == 0 (a lane's 8 channels of a k-step are
@@ -94,27 +133,8 @@ k_channel_mlp(const bf16_t* __restrict__ z, const bf16_t* __restrict__ xres, bf1
 #pragma unroll
         for (int g = 0; g < 4; ++g) oc[ct][g] = OX || 32 * ct + 8 * g + 4 * h < C ? 2u * (32 * ct + 8 * g + 4 * h) : 0x80000000u;
 
-    // one 32-unit tile of the hidden layer: D1 = W1 tile x z^T, h = gelu(D1 + b1) -> bf16 (already the second product's B operand), D2 += W2 columns x h
     auto hidden_tile = [&](int ht, const bf16x8 (&zb)[KS1], f32x16 (&d2)[CT]) {
-        f32x16 d1;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) d1[i] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS1; ++ks)
-            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Lf[(ht * KS1 + ks) * 64 + lane]), zb[ks], d1, 0, 0, 0);
-        bf16x8 hb[2];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4q bb = *reinterpret_cast<const f32x4q*>(Lb1 + 32 * ht + 8 * g + 4 * h);
-            const f32x2q a = gelu2(f32x2q{d1[4 * g] + bb.x, d1[4 * g + 1] + bb.y}), b = gelu2(f32x2q{d1[4 * g + 2] + bb.z, d1[4 * g + 3] + bb.w});
-            hb[g >> 1][4 * (g & 1) + 0] = (__bf16)a.x; hb[g >> 1][4 * (g & 1) + 1] = (__bf16)a.y;
-            hb[g >> 1][4 * (g & 1) + 2] = (__bf16)b.x; hb[g >> 1][4 * (g & 1) + 3] = (__bf16)b.y;
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-                d2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Lf[(HT * KS1 + ct * 2 * HT + 2 * ht + q) * 64 + lane]), hb[q], d2[ct], 0, 0, 0);
+        hidden_tile_ring<KS1, CT, 4>(Lf + (size_t)ht * (KS1 + 2 * CT) * 64, Lb1 + 32 * ht, lane, h, zb, d2);
     };
     const int stride = gridDim.x * NW;
     int tile = blockIdx.x * NW + wave;
@@ -243,6 +263,85 @@ k_channel_mlp(const bf16_t* __restrict__ z, const bf16_t* __restrict__ xres, bf1
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// The same block for channel counts whose weights do not fit the LDS (C = 256, H = 512: 512 KB): the hidden-tile chunks of the pack (KS1 + 2 CT fragments, 32 KB at
+// C = 256) are STREAMED through a two-deep LDS ring while the products of the previous chunk run -- every workgroup walks the same chunks in the same order, so they
+// come from the L2.  NW waves per workgroup, 32 tokens each, hold their tokens' channels (B fragments, 4 KS1 registers) and the output accumulators (16 CT) for the
+// whole block; one barrier per hidden tile.  With NW = 4 (one wave per SIMD) a wave has 512 registers: the accumulators sit in the AGPRs.
+template <int KS1, int HT, int CT, int NW, int WPS>
+__global__ void __launch_bounds__(64 * NW, WPS)
+k_channel_mlp_stream(const bf16_t* __restrict__ z, const bf16_t* __restrict__ xres, bf16_t* __restrict__ y, const u32x4q* __restrict__ wfrag, const float* __restrict__ bias,
+                     int M, int C, int nblocks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int NCH = KS1 + 2 * CT, NT = 64 * NW, PER = NCH * 64 / NT;          // fragments per chunk; 16-byte pieces of a chunk per thread
+    static_assert(NCH * 64 % NT == 0, "a chunk is a whole number of 16-byte pieces per thread");
+    u32x4q* const Lring = reinterpret_cast<u32x4q*>(lds_raw);                        // [2][NCH * 64]
+    float* const Lb1 = reinterpret_cast<float*>(lds_raw + (size_t)2 * NCH * 1024);
+    float* const Lb2 = Lb1 + 32 * HT;
+    for (int i = threadIdx.x; i < 32 * (HT + CT); i += NT) Lb1[i] = bias[i];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const unsigned nbytes = (unsigned)M * (unsigned)C * 2u;
+    const __amdgpu_buffer_rsrc_t zsrc = __builtin_amdgcn_make_buffer_rsrc((void*)z, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xres, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, nbytes, 0x00020000);
+    // chunk 0 -> ring slot 0; chunk 1 -> the registers of set 1.  In step ht (chunk ht in slot ht & 1) the requests for chunk ht + 2 go out first and land in
+    // register set ht & 1, the products run, then set (ht + 1) & 1 -- chunk ht + 1, requested a whole step earlier -- is written to the other slot: the L2 round
+    // trip (1.5 - 2 us under this load, longer than a step's products) has two steps to complete.  The chunk sequence is periodic, so it runs across blocks.
+    static_assert(HT % 2 == 0, "the ring alternates two register sets");
+    u32x4q cp[2][PER];
+    auto request = [&](u32x4q (&dst)[PER], int chunk) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) dst[i] = wfrag[(size_t)chunk * NCH * 64 + threadIdx.x + i * NT];
+    };
+    auto deposit = [&](const u32x4q (&src)[PER], int slot) {
+        u32x4q* const Ln = Lring + slot * NCH * 64;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) Ln[threadIdx.x + i * NT] = src[i];
+    };
+    request(cp[0], 0);
+    deposit(cp[0], 0);
+    request(cp[1], 1 % HT);
+    __syncthreads();
+    for (int block = blockIdx.x; block < nblocks; block += gridDim.x) {
+        const unsigned row = (unsigned)(32 * (block * NW + wave) + r) * (unsigned)C * 2u;      // this lane's token (past M: past the buffer -- reads 0, stores dropped)
+        bf16x8 zb[KS1];
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) zb[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(zsrc, (int)(row + 2u * (16 * ks + 8 * h)), 0, 0));
+        f32x16 d2[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d2[ct][i] = 0.f;
+#pragma unroll 1
+        for (int ht = 0; ht < HT; ht += 2) {
+            request(cp[0], (ht + 2) % HT);
+            hidden_tile_ring<KS1, CT, 8>(Lring, Lb1 + 32 * ht, lane, h, zb, d2);                               // chunk ht: slot 0
+            deposit(cp[1], 1);                                                                                  // chunk ht + 1
+            __syncthreads();                      // every wave is done with slot 0; slot 1 is complete
+            request(cp[1], (ht + 3) % HT);
+            hidden_tile_ring<KS1, CT, 8>(Lring + NCH * 64, Lb1 + 32 * (ht + 1), lane, h, zb, d2);              // chunk ht + 1: slot 1
+            deposit(cp[0], 0);                                                                                  // chunk ht + 2 (the next block's chunk 0 after the last)
+            __syncthreads();
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const unsigned off = row + 2u * (32 * ct + 8 * g + 4 * h);
+                const u32x2q xv = __builtin_bit_cast(u32x2q, __builtin_amdgcn_raw_buffer_load_b64(xsrc, (int)off, 0, 0));
+                const f32x4q bb = *reinterpret_cast<const f32x4q*>(Lb2 + 32 * ct + 8 * g + 4 * h);
+                bf16x4 o;
+                o[0] = (__bf16)(d2[ct][4 * g + 0] + bb.x + __uint_as_float(xv.x << 16));
+                o[1] = (__bf16)(d2[ct][4 * g + 1] + bb.y + __uint_as_float(xv.x & 0xffff0000u));
+                o[2] = (__bf16)(d2[ct][4 * g + 2] + bb.z + __uint_as_float(xv.y << 16));
+                o[3] = (__bf16)(d2[ct][4 * g + 3] + bb.w + __uint_as_float(xv.y & 0xffff0000u));
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2q, o), ysrc, (int)off, 0, 0);
+            }
+    }
+}
+
 }  // namespace mlp
 
 // C % 8 == 0, H % 32 == 0 (the host pads the hidden layer with zero units), the weights fit the CU's LDS, M C 2 < 2^31
@@ -258,6 +357,7 @@ bool channel_mlp_applicable(int M, int C, int H, int dtype)
     int ks1, ht, ct;
     if (dtype != 1 || M <= 0 || !mlp_shape(C, H, &ks1, &ht, &ct)) return false;
     if ((unsigned long long)M * C * 2 >= (1ull << 31)) return false;
+    if (C == 256 && ht == 16) return true;
     return (ks1 == 4 && ht == 4 && ct == 2) || (C == 128 && ht == 8) || (ks1 == 3 && ht == 3 && ct == 2) || (C == 96 && ht == 6) || (C == 80 && ht == 5);
 }
 
@@ -288,6 +388,22 @@ static hipError_t launch_mlp(const void* z, const void* x, void* y, const void* 
     return hipGetLastError();
 }
 
+// C == 16 KS1 == 32 CT exactly (no padding lanes): the streamed form
+template <int KS1, int HT, int CT>
+static hipError_t launch_mlp_stream(const void* z, const void* x, void* y, const void* wfrag, const float* bias, int M, int C, int ncu, hipStream_t s)
+{
+    constexpr int NW = 4, NCH = KS1 + 2 * CT;
+    constexpr size_t lds = (size_t)2 * NCH * 1024 + sizeof(float) * 32 * (HT + CT);
+    static_assert(lds <= 160 * 1024, "the ring must fit the LDS");
+    if (C != 16 * KS1 || C != 32 * CT) return hipErrorInvalidConfiguration;
+    auto kfn = mlp::k_channel_mlp_stream<KS1, HT, CT, NW, 1>;
+    RCX_SET_LDS_ONCE(kfn, lds);
+    const int nblocks = (M + 32 * NW - 1) / (32 * NW);
+    const int grid = nblocks < ncu ? nblocks : ncu;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(64 * NW), lds, s, (const bf16_t*)z, (const bf16_t*)x, (bf16_t*)y, (const mlp::u32x4q*)wfrag, bias, M, C, nblocks);
+    return hipGetLastError();
+}
+
 hipError_t channel_mlp(const void* z, const void* x, void* y, const void* wfrag, const float* bias, int M, int C, int H, int dtype, hipStream_t s)
 {
     int ks1, ht, ct;
@@ -302,6 +418,7 @@ hipError_t channel_mlp(const void* z, const void* x, void* y, const void* wfrag,
             cus[dev].store(ncu, std::memory_order_relaxed);
         }
     }
+    if (C == 256 && ht == 16) return launch_mlp_stream<16, 16, 8>(z, x, y, wfrag, bias, M, C, ncu, s);              // M3 / A3 stage 2
     if (ks1 == 4 && ht == 4) return C == 64 ? launch_mlp<4, 4, 2, true, true>(z, x, y, wfrag, bias, M, C, ncu, s)            // M3 / A3 stage 0 ...
                                             : launch_mlp<4, 4, 2, false, false>(z, x, y, wfrag, bias, M, C, ncu, s);         // ... M2 (56 channels)
     if (ks1 == 8 && ht == 8) return C == 128 ? launch_mlp<8, 8, 4, true, true>(z, x, y, wfrag, bias, M, C, ncu, s) : hipErrorInvalidConfiguration;

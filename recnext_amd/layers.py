@@ -138,18 +138,19 @@ class FusedChannelMlp:
     def supported(self, x):
         from . import ops
         n, c, h, w = x.shape
-        return x.is_cuda and x.dtype == torch.bfloat16 and ops.channel_mlp_supported(n * h * w, c, self.fc1.out_channels, x.dtype)
+        return x.is_cuda and x.dtype == torch.bfloat16 and ops.channel_mlp_hidden(n * h * w, c, self.fc1.out_channels, x.dtype) > 0
 
-    def _operands(self):
+    def _operands(self, hidden_to):
         from . import ops
         ts = [self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias]
-        key = tuple(None if t is None else (t.data_ptr(), t._version, t.dtype, t.device) for t in ts)
+        key = (hidden_to,) + tuple(None if t is None else (t.data_ptr(), t._version, t.dtype, t.device) for t in ts)
         if key != self._key:
-            self._pack = ops.pack_channel_mlp(*ts)
+            self._pack = ops.pack_channel_mlp(*ts, hidden_to=hidden_to)
             self._key = key
         return self._pack
 
     def __call__(self, z, x):
         from . import ops
-        wfrag, bias, hidden = self._operands()
+        n, c, h, w = x.shape
+        wfrag, bias, hidden = self._operands(ops.channel_mlp_hidden(n * h * w, c, self.fc1.out_channels, x.dtype))
         return ops.channel_mlp(z, x, wfrag, bias, hidden)

@@ -451,19 +451,32 @@ def _mlp_acc_unit(i, h):
     return (i & 3) + 8 * (i >> 2) + 4 * h
 
 
+def channel_mlp_hidden(m, c, hidden, dtype):
+    """The hidden width rcx_channel_mlp_fwd would run M tokens of C channels and `hidden` units at (the next multiple of 32, 64 or 128 it has a kernel
+    for: zero units change nothing), or 0 when it has none (bf16 only)."""
+    if dtype != torch.bfloat16:
+        return 0
+    lib = _lib.load()
+    for mult in (32, 64, 128):
+        hp = -(-int(hidden) // mult) * mult
+        if hp <= 1.125 * hidden + 31 and lib.rcx_channel_mlp_supported(int(m), int(c), hp, _DT[dtype]) > 0:
+            return hp
+    return 0
+
+
 def channel_mlp_supported(m, c, hidden, dtype):
-    """Whether rcx_channel_mlp_fwd has a kernel for M tokens of C channels and a hidden width that pads to `hidden` -> multiple of 32 (bf16 only)."""
-    hp = -(-int(hidden) // 32) * 32
-    return dtype == torch.bfloat16 and _lib.load().rcx_channel_mlp_supported(int(m), int(c), hp, _DT[dtype]) > 0
+    return channel_mlp_hidden(m, c, hidden, dtype) > 0
 
 
-def pack_channel_mlp(w1, b1, w2, b2):
-    """The two BN-folded 1x1 convs of a channel mixer -> (wfrag, bias, H) for channel_mlp: w1 (H0, C[, 1, 1]), b1 (H0) | None, w2 (C, H0[, 1, 1]), b2 (C) | None.
+def pack_channel_mlp(w1, b1, w2, b2, hidden_to=None):
+    """The two BN-folded 1x1 convs of a channel mixer -> (wfrag, bias, H) for channel_mlp: w1 (H0, C[, 1, 1]), b1 (H0) | None, w2 (C, H0[, 1, 1]), b2 (C) | None;
+    hidden_to: the padded hidden width H (channel_mlp_hidden; default the next multiple of 32).
 
     The hidden layer is padded with zero units to H = a multiple of 32, C to whole k-steps / output tiles with zero columns / rows; the weights are rounded to
     bf16 (they already are bf16 in a bf16 model) and laid out fragment by fragment in the order the kernel's lanes read them (rcx_mlp.hip):
       W1 fragment (ht, ks), lane (h, m), element j = W1[32 ht + m][16 ks + 8 h + j]
-      W2 fragment (ct, 2 ht + q), lane (h, m), element j = W2[32 ct + m][32 ht + unit(8 q + j, h)]      unit = _mlp_acc_unit: the order the first product leaves in the registers
+      W2 fragment (ht, ct, q), lane (h, m), element j = W2[32 ct + m][32 ht + unit(8 q + j, h)]      unit = _mlp_acc_unit: the order the first product leaves in the registers
+    stored hidden tile by hidden tile: [W1 (ht, 0 .. KS1-1)] [W2 (ht, ct, q) for ct, q] for ht = 0 .. H/32 - 1, 1 KB (64 lanes x 8 bf16) per fragment.
     """
     w1 = w1.detach().reshape(w1.shape[0], -1)
     w2 = w2.detach().reshape(w2.shape[0], -1)
@@ -471,7 +484,10 @@ def pack_channel_mlp(w1, b1, w2, b2):
     if tuple(w2.shape) != (c, h0):
         raise ValueError(f"w2 must be ({c}, {h0}), got {tuple(w2.shape)}")
     dev = w1.device
-    ks1, ht, ct = -(-c // 16), -(-h0 // 32), -(-c // 32)
+    hp = -(-h0 // 32) * 32 if hidden_to is None else int(hidden_to)
+    if hp % 32 or hp < h0:
+        raise ValueError(f"hidden_to={hidden_to} must be a multiple of 32 and at least {h0}")
+    ks1, ht, ct = -(-c // 16), hp // 32, -(-c // 32)
     w1p = torch.zeros(32 * ht, 16 * ks1, dtype=torch.bfloat16, device=dev)
     w1p[:h0, :c] = w1.to(torch.bfloat16)
     f1 = w1p.view(ht, 32, ks1, 2, 8).permute(0, 2, 3, 1, 4)                    # [ht, ks, h, m, j]
@@ -480,7 +496,11 @@ def pack_channel_mlp(w1, b1, w2, b2):
     unit = torch.tensor([[[_mlp_acc_unit(8 * q + j, h) for j in range(8)] for h in range(2)] for q in range(2)], device=dev)      # [q, h, j]
     f2 = w2p.view(ct, 32, ht, 32)[:, :, :, unit]                               # [ct, m, ht, q, h, j]
     f2 = f2.permute(0, 2, 3, 4, 1, 5)                                          # [ct, ht, q, h, m, j]
-    wfrag = torch.cat([f1.reshape(-1), f2.reshape(-1)]).contiguous()
+    # hidden-tile-major: chunk ht = its KS1 W1 fragments, then its 2 CT W2 fragments (ct, q) -- what one step of the kernels' hidden loop reads (and what the
+    # large shapes stream through LDS one chunk at a time)
+    f1 = f1.reshape(ht, ks1 * 512)
+    f2 = f2.reshape(ct, ht, 2, 512).permute(1, 0, 2, 3).reshape(ht, ct * 2 * 512)
+    wfrag = torch.cat([f1, f2], dim=1).reshape(-1).contiguous()
     bias = torch.zeros(32 * (ht + ct), dtype=torch.float32, device=dev)
     if b1 is not None:
         bias[:h0] = b1.detach().float()

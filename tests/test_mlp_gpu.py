@@ -25,7 +25,8 @@ def _reference(z, x, w1, b1, w2, b2):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 128, 56, 56), (3, 128, 256, 28, 28), (2, 64, 120, 9, 11), (1, 48, 96, 56, 56), (2, 40, 80, 13, 7), (2, 56, 112, 28, 28),
-                                  (2, 96, 192, 28, 28), (1, 80, 160, 56, 56), (1, 80, 150, 5, 5), (1, 64, 128, 1, 1), (1, 128, 240, 3, 33)],
+                                  (2, 96, 192, 28, 28), (1, 80, 160, 56, 56), (1, 80, 150, 5, 5), (1, 64, 128, 1, 1), (1, 128, 240, 3, 33),
+                                  (3, 256, 512, 14, 14), (2, 256, 480, 14, 14), (1, 256, 512, 3, 5), (5, 256, 512, 16, 16)],
                          ids=lambda c: "x".join(map(str, c)))
 def test_fused_channel_mlp_against_float64_and_the_gemm_path(case):
     from recnext_amd import ops
@@ -36,9 +37,10 @@ def test_fused_channel_mlp_against_float64_and_the_gemm_path(case):
     x = rb(n, c, h, w).to(dev()).contiguous(memory_format=torch.channels_last)
     w1, b1 = rb(hid, c, sc=(2.0 / c) ** 0.5).to(dev()), rb(hid, sc=0.3).to(dev())
     w2, b2 = rb(c, hid, sc=(1.0 / hid) ** 0.5).to(dev()), rb(c, sc=0.3).to(dev())
-    assert ops.channel_mlp_supported(n * h * w, c, hid, torch.bfloat16)
-    wfrag, bias, hp = ops.pack_channel_mlp(w1, b1, w2, b2)
-    assert hp == -(-hid // 32) * 32
+    hp = ops.channel_mlp_hidden(n * h * w, c, hid, torch.bfloat16)
+    assert hp >= hid and hp % 32 == 0 and hp - hid < 64
+    wfrag, bias, hp2 = ops.pack_channel_mlp(w1, b1, w2, b2, hidden_to=hp)
+    assert hp2 == hp
     y = ops.channel_mlp(z, x, wfrag, bias, hp)
     assert y.shape == x.shape and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(y, ops.channel_mlp(z, x, wfrag, bias, hp)), "not deterministic"
@@ -59,14 +61,14 @@ def test_fused_channel_mlp_against_float64_and_the_gemm_path(case):
 
 def test_fused_channel_mlp_rejects_what_it_has_no_kernel_for():
     from recnext_amd import _lib, ops
-    assert not ops.channel_mlp_supported(1024, 256, 512, torch.bfloat16)          # the 14 x 14 stage: the GEMM library (products are compute-bound there)
+    assert not ops.channel_mlp_supported(1024, 512, 1024, torch.bfloat16)         # the 7 x 7 stage: the GEMM library
     assert not ops.channel_mlp_supported(1024, 64, 128, torch.float32) and not ops.channel_mlp_supported(1024, 64, 128, torch.float16)
     assert not ops.channel_mlp_supported(1024, 60, 128, torch.bfloat16)           # C % 8
-    z = torch.zeros(1, 256, 4, 4, device=dev(), dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    wfrag = torch.zeros(_lib.load().rcx_channel_mlp_pack_bytes(256, 512) // 2, device=dev(), dtype=torch.bfloat16)
-    bias = torch.zeros(32 * (16 + 8), device=dev())
+    z = torch.zeros(1, 512, 4, 4, device=dev(), dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wfrag = torch.zeros(_lib.load().rcx_channel_mlp_pack_bytes(512, 1024) // 2, device=dev(), dtype=torch.bfloat16)
+    bias = torch.zeros(32 * (32 + 16), device=dev())
     with pytest.raises(_lib.RcxError, match="no kernel"):
-        ops.channel_mlp(z, z.clone(), wfrag, bias, 512)
+        ops.channel_mlp(z, z.clone(), wfrag, bias, 1024)
 
 
 @pytest.mark.parametrize("name", ["recnext_m3", "recnext_a3", "recnext_m1"])

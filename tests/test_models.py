@@ -272,10 +272,10 @@ def test_channel_mlp_pack_layout_cpu():
     f = wfrag.float().view(-1, 64, 8)
     for (t, ks, lane, j) in [(0, 0, 0, 0), (1, 2, 37, 5), (2, 1, 63, 7), (2, 2, 31, 3)]:
         row, col = 32 * t + lane % 32, 16 * ks + 8 * (lane // 32) + j
-        assert f[t * ks1 + ks, lane, j] == (w1[row, col] if row < h0 and col < c else 0)
+        assert f[t * (ks1 + 2 * ct) + ks, lane, j] == (w1[row, col] if row < h0 and col < c else 0)
     for (tc, t, q, lane, j) in [(0, 0, 0, 0, 0), (1, 2, 1, 40, 6), (0, 1, 1, 33, 2), (1, 0, 0, 31, 7)]:
         row, col = 32 * tc + lane % 32, 32 * t + ops._mlp_acc_unit(8 * q + j, lane // 32)
-        assert f[ht * ks1 + tc * 2 * ht + 2 * t + q, lane, j] == (w2[row, col] if row < c and col < h0 else 0)
+        assert f[t * (ks1 + 2 * ct) + ks1 + 2 * tc + q, lane, j] == (w2[row, col] if row < c and col < h0 else 0)
     assert torch.equal(bias[:h0], b1) and bias[h0:96].abs().sum() == 0 and torch.equal(bias[96:96 + c], b2) and bias[96 + c:].abs().sum() == 0
 
 

@@ -11,7 +11,7 @@ from recnext_amd import ops
 
 dev = torch.device("cuda:0")
 REPS = int(os.environ.get("REPS", "30"))
-SHAPES = [(256, 64, 128, 56), (256, 128, 256, 28), (256, 48, 96, 56), (256, 96, 192, 28), (256, 80, 160, 56)]
+SHAPES = [(256, 64, 128, 56), (256, 128, 256, 28), (256, 256, 512, 14), (256, 48, 96, 56), (256, 96, 192, 28), (256, 80, 160, 56)]
 
 
 def timed(fn, n):
@@ -33,7 +33,7 @@ for b, c, hid, hw in SHAPES:
     xs = [torch.randn(b, c, hw, hw, device=dev).bfloat16().contiguous(memory_format=torch.channels_last) for _ in range(npool)]
     w1, b1 = (torch.randn(hid, c, device=dev) * 0.1).bfloat16(), torch.randn(hid, device=dev).bfloat16()
     w2, b2 = (torch.randn(c, hid, device=dev) * 0.1).bfloat16(), torch.randn(c, device=dev).bfloat16()
-    wfrag, bias, hp = ops.pack_channel_mlp(w1, b1, w2, b2)
+    wfrag, bias, hp = ops.pack_channel_mlp(w1, b1, w2, b2, hidden_to=ops.channel_mlp_hidden(b * hw * hw, c, hid, torch.bfloat16))
     m = b * hw * hw
 
     def lib(i):
