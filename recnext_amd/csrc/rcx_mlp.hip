@@ -16,6 +16,7 @@
 // in gelu -- a fiftieth of a bf16 ulp; the library's erff would be most of this kernel's vector work.
 #include "rcx_common.h"
 #include "rcx_launch.h"
+#include "rcx_opts.h"
 
 namespace rcx {
 namespace mlp {
@@ -304,41 +305,88 @@ k_channel_mlp_stream(const bf16_t* __restrict__ z, const bf16_t* __restrict__ xr
     deposit(cp[0], 0);
     request(cp[1], 1 % HT);
     __syncthreads();
+    // Global accesses: whole-wave contiguous kilobytes (as the small shapes' STAGED path).  A wave's 32 tokens are 32 RB = 1024 KS1 contiguous bytes: request i =
+    // bytes [1024 i + 16 lane, + 16) -> token t, byte bz of its row in the wave's bf16 z image.  The output leaves in halves of 64 channels (two output tiles): a
+    // float32 image of 32 x 64, read back as rows -- request j of half hf = the 128-byte pieces [128 hf, + 128) of 8 token rows.
+    static_assert(CT % 2 == 0, "output in halves of two tiles");
+    constexpr int RB = 32 * KS1, ZP = RB + 16, OP = 256 + 16, IMG = 32 * (ZP > OP ? ZP : OP), NH = CT / 2;
+    unsigned char* const Lt = lds_raw + (size_t)2 * NCH * 1024 + sizeof(float) * 32 * (HT + CT) + (size_t)wave * IMG;
+    unsigned zo[KS1], za[KS1];
+#pragma unroll
+    for (int i = 0; i < KS1; ++i) {
+        const unsigned o = 1024u * i + 16u * lane;
+        zo[i] = o;
+        za[i] = (o / RB) * ZP + o % RB;
+    }
+    // half hf, request j (4 per half): token t = 8 j + lane / 8, bytes 128 hf + 16 (lane % 8) of its row
+    const unsigned ht_tok = lane >> 3, ht_b = 16u * (lane & 7);
+    u32x4q zq[KS1];
+    auto load_z = [&](int blk) {
+        const unsigned base = (unsigned)(32 * (blk * NW + wave)) * (unsigned)RB;      // (tokens past M: past the buffer -- reads 0, stores dropped)
+#pragma unroll
+        for (int i = 0; i < KS1; ++i) zq[i] = __builtin_bit_cast(u32x4q, __builtin_amdgcn_raw_buffer_load_b128(zsrc, (int)(base + zo[i]), 0, 0));
+    };
+    if ((int)blockIdx.x < nblocks) load_z(blockIdx.x);
     for (int block = blockIdx.x; block < nblocks; block += gridDim.x) {
-        const unsigned row = (unsigned)(32 * (block * NW + wave) + r) * (unsigned)C * 2u;      // this lane's token (past M: past the buffer -- reads 0, stores dropped)
+        const unsigned base = (unsigned)(32 * (block * NW + wave)) * (unsigned)RB;
+#pragma unroll
+        for (int i = 0; i < KS1; ++i) *reinterpret_cast<u32x4q*>(Lt + za[i]) = zq[i];
+        wave_sync();
         bf16x8 zb[KS1];
 #pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) zb[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(zsrc, (int)(row + 2u * (16 * ks + 8 * h)), 0, 0));
+        for (int ks = 0; ks < KS1; ++ks) zb[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4q*>(Lt + r * ZP + 32 * ks + 16 * h));
+        wave_sync();
+        if (block + (int)gridDim.x < nblocks) load_z(block + gridDim.x);           // the next block's channels: in flight during this block
         f32x16 d2[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int i = 0; i < 16; ++i) d2[ct][i] = 0.f;
+        u32x4q xq[NH][4];                                                          // the residual: requested in the last step but one
 #pragma unroll 1
         for (int ht = 0; ht < HT; ht += 2) {
             request(cp[0], (ht + 2) % HT);
-            hidden_tile_ring<KS1, CT, 8>(Lring, Lb1 + 32 * ht, lane, h, zb, d2);                               // chunk ht: slot 0
+            if (ht == HT - 2) {
+#pragma unroll
+                for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        xq[hf][j] = __builtin_bit_cast(u32x4q, __builtin_amdgcn_raw_buffer_load_b128(xsrc, (int)(base + (8u * j + ht_tok) * RB + 128u * hf + ht_b), 0, 0));
+            }
+            hidden_tile_ring<KS1, CT, (NW > 4 ? 4 : 8)>(Lring, Lb1 + 32 * ht, lane, h, zb, d2);                               // chunk ht: slot 0
             deposit(cp[1], 1);                                                                                  // chunk ht + 1
             __syncthreads();                      // every wave is done with slot 0; slot 1 is complete
             request(cp[1], (ht + 3) % HT);
-            hidden_tile_ring<KS1, CT, 8>(Lring + NCH * 64, Lb1 + 32 * (ht + 1), lane, h, zb, d2);              // chunk ht + 1: slot 1
+            hidden_tile_ring<KS1, CT, (NW > 4 ? 4 : 8)>(Lring + NCH * 64, Lb1 + 32 * (ht + 1), lane, h, zb, d2);              // chunk ht + 1: slot 1
             deposit(cp[0], 0);                                                                                  // chunk ht + 2 (the next block's chunk 0 after the last)
             __syncthreads();
         }
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+        for (int hf = 0; hf < NH; ++hf) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const unsigned off = row + 2u * (32 * ct + 8 * g + 4 * h);
-                const u32x2q xv = __builtin_bit_cast(u32x2q, __builtin_amdgcn_raw_buffer_load_b64(xsrc, (int)off, 0, 0));
-                const f32x4q bb = *reinterpret_cast<const f32x4q*>(Lb2 + 32 * ct + 8 * g + 4 * h);
-                bf16x4 o;
-                o[0] = (__bf16)(d2[ct][4 * g + 0] + bb.x + __uint_as_float(xv.x << 16));
-                o[1] = (__bf16)(d2[ct][4 * g + 1] + bb.y + __uint_as_float(xv.x & 0xffff0000u));
-                o[2] = (__bf16)(d2[ct][4 * g + 2] + bb.z + __uint_as_float(xv.y << 16));
-                o[3] = (__bf16)(d2[ct][4 * g + 3] + bb.w + __uint_as_float(xv.y & 0xffff0000u));
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2q, o), ysrc, (int)off, 0, 0);
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ct = 2 * hf + c2;
+                    const f32x4q bb = *reinterpret_cast<const f32x4q*>(Lb2 + 32 * ct + 8 * g + 4 * h);
+                    *reinterpret_cast<f32x4q*>(Lt + r * OP + 4 * (32 * c2 + 8 * g + 4 * h)) =
+                        f32x4q{d2[ct][4 * g] + bb.x, d2[ct][4 * g + 1] + bb.y, d2[ct][4 * g + 2] + bb.z, d2[ct][4 * g + 3] + bb.w};
+                }
+            wave_sync();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned char* src = Lt + (8 * j + ht_tok) * OP + 2 * ht_b;
+                const f32x4q lo = *reinterpret_cast<const f32x4q*>(src), hi = *reinterpret_cast<const f32x4q*>(src + 16);
+                const u32x4q xv = xq[hf][j];
+                bf16x8 o;
+                o[0] = (__bf16)(lo.x + __uint_as_float(xv.x << 16)); o[1] = (__bf16)(lo.y + __uint_as_float(xv.x & 0xffff0000u));
+                o[2] = (__bf16)(lo.z + __uint_as_float(xv.y << 16)); o[3] = (__bf16)(lo.w + __uint_as_float(xv.y & 0xffff0000u));
+                o[4] = (__bf16)(hi.x + __uint_as_float(xv.z << 16)); o[5] = (__bf16)(hi.y + __uint_as_float(xv.z & 0xffff0000u));
+                o[6] = (__bf16)(hi.z + __uint_as_float(xv.w << 16)); o[7] = (__bf16)(hi.w + __uint_as_float(xv.w & 0xffff0000u));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4q, o), ysrc, (int)(base + (8u * j + ht_tok) * RB + 128u * hf + ht_b), 0, 0);
             }
+            wave_sync();
+        }
     }
 }
 
@@ -389,14 +437,14 @@ static hipError_t launch_mlp(const void* z, const void* x, void* y, const void* 
 }
 
 // C == 16 KS1 == 32 CT exactly (no padding lanes): the streamed form
-template <int KS1, int HT, int CT>
+template <int KS1, int HT, int CT, int NW>
 static hipError_t launch_mlp_stream(const void* z, const void* x, void* y, const void* wfrag, const float* bias, int M, int C, int ncu, hipStream_t s)
 {
-    constexpr int NW = 4, NCH = KS1 + 2 * CT;
-    constexpr size_t lds = (size_t)2 * NCH * 1024 + sizeof(float) * 32 * (HT + CT);
-    static_assert(lds <= 160 * 1024, "the ring must fit the LDS");
+    constexpr int NCH = KS1 + 2 * CT, ZP = 32 * KS1 + 16, OP = 256 + 16, IMG = 32 * (ZP > OP ? ZP : OP);
+    constexpr size_t lds = (size_t)2 * NCH * 1024 + sizeof(float) * 32 * (HT + CT) + (size_t)NW * IMG;
+    static_assert(lds <= 160 * 1024, "the ring and the waves' images must fit the LDS");
     if (C != 16 * KS1 || C != 32 * CT) return hipErrorInvalidConfiguration;
-    auto kfn = mlp::k_channel_mlp_stream<KS1, HT, CT, NW, 1>;
+    auto kfn = mlp::k_channel_mlp_stream<KS1, HT, CT, NW, NW / 4>;
     RCX_SET_LDS_ONCE(kfn, lds);
     const int nblocks = (M + 32 * NW - 1) / (32 * NW);
     const int grid = nblocks < ncu ? nblocks : ncu;
@@ -418,10 +466,14 @@ hipError_t channel_mlp(const void* z, const void* x, void* y, const void* wfrag,
             cus[dev].store(ncu, std::memory_order_relaxed);
         }
     }
-    if (C == 256 && ht == 16) return launch_mlp_stream<16, 16, 8>(z, x, y, wfrag, bias, M, C, ncu, s);              // M3 / A3 stage 2
+    if (C == 256 && ht == 16) return launch_mlp_stream<16, 16, 8, 4>(z, x, y, wfrag, bias, M, C, ncu, s);           // M3 / A3 stage 2
     if (ks1 == 4 && ht == 4) return C == 64 ? launch_mlp<4, 4, 2, true, true>(z, x, y, wfrag, bias, M, C, ncu, s)            // M3 / A3 stage 0 ...
                                             : launch_mlp<4, 4, 2, false, false>(z, x, y, wfrag, bias, M, C, ncu, s);         // ... M2 (56 channels)
-    if (ks1 == 8 && ht == 8) return C == 128 ? launch_mlp<8, 8, 4, true, true>(z, x, y, wfrag, bias, M, C, ncu, s) : hipErrorInvalidConfiguration;
+    if (ks1 == 8 && ht == 8) {
+        if (C != 128) return hipErrorInvalidConfiguration;
+        const char* v = rcx::opt::value(rcx::opt::MLP_STREAM);              // RCX_MLP_STREAM=0: the whole-weights-in-LDS kernel (A/B)
+        return v && *v == '0' ? launch_mlp<8, 8, 4, true, true>(z, x, y, wfrag, bias, M, C, ncu, s) : launch_mlp_stream<8, 8, 4, 8>(z, x, y, wfrag, bias, M, C, ncu, s);
+    }
     if (ks1 == 3 && ht == 3) return C == 48 ? launch_mlp<3, 3, 2, true, false>(z, x, y, wfrag, bias, M, C, ncu, s)            // M1 stage 0 ...
                                             : launch_mlp<3, 3, 2, false, false>(z, x, y, wfrag, bias, M, C, ncu, s);         // ... M0 (40 channels)
     if (ks1 == 6 && ht == 6) return C == 96 ? launch_mlp<6, 6, 3, true, true>(z, x, y, wfrag, bias, M, C, ncu, s) : hipErrorInvalidConfiguration;
