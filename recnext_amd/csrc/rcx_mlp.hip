@@ -406,6 +406,7 @@ bool channel_mlp_applicable(int M, int C, int H, int dtype)
     if (dtype != 1 || M <= 0 || !mlp_shape(C, H, &ks1, &ht, &ct)) return false;
     if ((unsigned long long)M * C * 2 >= (1ull << 31)) return false;
     if (C == 256 && ht == 16) return true;
+    if (C == 192 && ht == 12) return true;
     return (ks1 == 4 && ht == 4 && ct == 2) || (C == 128 && ht == 8) || (ks1 == 3 && ht == 3 && ct == 2) || (C == 96 && ht == 6) || (C == 80 && ht == 5);
 }
 
@@ -467,6 +468,7 @@ hipError_t channel_mlp(const void* z, const void* x, void* y, const void* wfrag,
         }
     }
     if (C == 256 && ht == 16) return launch_mlp_stream<16, 16, 8, 4>(z, x, y, wfrag, bias, M, C, ncu, s);           // M3 / A3 stage 2
+    if (C == 192 && ht == 12) return launch_mlp_stream<12, 12, 6, 4>(z, x, y, wfrag, bias, M, C, ncu, s);           // M1 stage 2
     if (ks1 == 4 && ht == 4) return C == 64 ? launch_mlp<4, 4, 2, true, true>(z, x, y, wfrag, bias, M, C, ncu, s)            // M3 / A3 stage 0 ...
                                             : launch_mlp<4, 4, 2, false, false>(z, x, y, wfrag, bias, M, C, ncu, s);         // ... M2 (56 channels)
     if (ks1 == 8 && ht == 8) {

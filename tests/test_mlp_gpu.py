@@ -26,7 +26,7 @@ def _reference(z, x, w1, b1, w2, b2):
 
 @pytest.mark.parametrize("case", [(2, 64, 128, 56, 56), (3, 128, 256, 28, 28), (2, 64, 120, 9, 11), (1, 48, 96, 56, 56), (2, 40, 80, 13, 7), (2, 56, 112, 28, 28),
                                   (2, 96, 192, 28, 28), (1, 80, 160, 56, 56), (1, 80, 150, 5, 5), (1, 64, 128, 1, 1), (1, 128, 240, 3, 33),
-                                  (3, 256, 512, 14, 14), (2, 256, 480, 14, 14), (1, 256, 512, 3, 5), (5, 256, 512, 16, 16)],
+                                  (3, 256, 512, 14, 14), (2, 256, 480, 14, 14), (1, 256, 512, 3, 5), (5, 256, 512, 16, 16), (3, 192, 384, 14, 14), (2, 128, 256, 64, 64)],
                          ids=lambda c: "x".join(map(str, c)))
 def test_fused_channel_mlp_against_float64_and_the_gemm_path(case):
     from recnext_amd import ops
