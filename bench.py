@@ -333,6 +333,28 @@ def maybe_spawn_ranks(argv):
     sys.exit(mod.spawn_ranks(n, os.path.abspath(__file__), argv))
 
 
+def count_fused_channel_mixers(net, x):
+    """(blocks whose x + channel_mixer(.) ran as rcx_channel_mlp_fwd in one forward of `net` on `x`, blocks in all)."""
+    import torch
+    from recnext_amd import models
+    hits, handles = [0, 0], []
+
+    def hook(mod, inputs, output):
+        fused = mod.__dict__.get("_fused_mlp")
+        hits[1] += 1
+        if fused is not None and not mod.training and fused.supported(output):
+            hits[0] += 1
+
+    for m in net.modules():
+        if isinstance(m, (models.MetaNeXtBlock, models.Downsample)):
+            handles.append(m.register_forward_hook(hook))
+    with torch.no_grad():
+        net(x)
+    for hnd in handles:
+        hnd.remove()
+    return hits[0], hits[1]
+
+
 def main():
     maybe_spawn_ranks(sys.argv[1:])
     args = parse_args()
@@ -360,6 +382,8 @@ def main():
 
     from recnext_amd.speed import tune_gemms
     gemm_tuned = tune_gemms(net, x)                       # before the warm-up steps, outside the timed region
+    # how many blocks run their channel mixer + residual as the fused HIP launch AT THIS INPUT (decided per call from the tensor's shape and dtype)
+    n_fused_mlp, n_blocks = count_fused_channel_mixers(net, x)
     copy_gbs = measure_copy_ceiling(torch, device) if rank == 0 else None
     plan_of = None
     with torch.no_grad():
@@ -419,6 +443,8 @@ def main():
             "rccl_ranks": world, "per_rank_images_per_s": [round(v, 1) for v in per_rank],
             "config": {"workload": f"{args.model} forward, BN-folded, channels_last, {args.resolution}x{args.resolution}, "
                                    f"batch {args.batch}/GPU, random-init weights, HIP token mixers"
+                                   + (f", HIP channel mixers on {n_fused_mlp} of {n_blocks} blocks (x + mlp in one launch where rcx_channel_mlp_fwd has a kernel "
+                                      "for the shape; the rest: GEMM library)" if n_fused_mlp else "")
                                    + (", GEMM solutions picked by TunableOp" if gemm_tuned else ""),
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world} (batch-sharded replicas, no collective in the timed region)"},
