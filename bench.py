@@ -283,7 +283,7 @@ def cpu_baseline(model_name, resolution, seconds, torch):
                       f"{share:.1f} s per thread count in {counts}, best = {best} threads; config 1 (M0, batch 1) timed beside it"}
 
 
-def load_traffic(kernel, fingerprint=None, profiles_dir=None):
+def load_traffic(kernel, fingerprint=None, profiles_dir=None, metric=None):
     """(HBM bytes per launch of `kernel`, source file, note) from the committed PMC profiles (profiles/*traffic*.json).  Not measured in this
     run -- PMC collection needs rocprofv3 around the process -- so a profile counts only if it was taken on THESE kernel sources: it records
     the sha256 of recnext_amd/csrc (recnext_amd/build.py::source_fingerprint) and a file without that field, or with another value, is stale:
@@ -306,6 +306,9 @@ def load_traffic(kernel, fingerprint=None, profiles_dir=None):
             continue
         for rec in doc.get("kernels", []):
             if rec.get("kernel") == kernel and rec.get("hbm_bytes_per_launch") is not None:
+                # a multi-launch unit's record is a mean over the units of ONE model's forward: it is that model's only (its name does not say which)
+                if rec.get("composite") and metric is not None and rec.get("bench_metric") != metric:
+                    continue
                 best = (rec["hbm_bytes_per_launch"], os.path.relpath(p, ROOT))
     if best[0] is None:
         return None, None, (f"no PMC profile of this kernel taken on the current kernel sources (sha256 {fingerprint[:12]}...; {stale} profile file(s) "
@@ -424,7 +427,7 @@ def main():
         dom = timed_kernels[0]                                # the kernel instantiation with the most time in the step, bracketed in the timed region
         per_shape, per_kernel = survey if survey else (timed_shapes, timed_kernels)
         table_steps = survey_steps if survey else args.steps
-        traffic, traffic_source, traffic_note = load_traffic(dom["kernel"])
+        traffic, traffic_source, traffic_note = load_traffic(dom["kernel"], metric=f"images/sec RecNeXt-{args.model.split('_')[1].upper()} {args.resolution}x{args.resolution} {args.dtype}")
         dom_shape = next(rr for rr in timed_shapes if kernel_name(rr["plan"], elem) == dom["kernel"])
         if dom_shape["level"] is None:                        # RecAttn2d (A family): a unit of several launches, no single-kernel flop count
             dom_flops = dom_tfs = None

@@ -79,7 +79,7 @@ if bench_line and "token_mixers" in bench_line:
         comp = [k for k in kernels if re.search(pat, k["kernel"]) and k.get("hbm_bytes_per_launch") is not None]
         units = ent["launches"] / float(survey) * passes
         if comp and units > 0:
-            kernels.append({"kernel": name, "composite": True, "units_in_run": units, "passes": passes,
+            kernels.append({"kernel": name, "composite": True, "bench_metric": bench_line.get("metric"), "units_in_run": units, "passes": passes,
                             "composed_of": [{"kernel": k["kernel"], "launches": k["launches_sampled"], "hbm_bytes_per_launch": k["hbm_bytes_per_launch"]} for k in comp],
                             "hbm_bytes_per_launch": sum(k["hbm_bytes_per_launch"] * k["launches_sampled"] for k in comp) / units,
                             "correction": "sum over the unit's device kernels of (2*FETCH_SIZE + WRITE_SIZE) x launches, divided by the units of the run"})
