@@ -270,14 +270,16 @@ k_channel_mlp(const bf16_t* __restrict__ z, const bf16_t* __restrict__ xres, bf1
 // C = 256) are STREAMED through a two-deep LDS ring while the products of the previous chunk run -- every workgroup walks the same chunks in the same order, so they
 // come from the L2.  NW waves per workgroup, 32 tokens each, hold their tokens' channels (B fragments, 4 KS1 registers) and the output accumulators (16 CT) for the
 // whole block; one barrier per hidden tile.  With NW = 4 (one wave per SIMD) a wave has 512 registers: the accumulators sit in the AGPRs.
-template <int KS1, int HT, int CT, int NW, int WPS>
+// CT: output tiles rounded up to even (the pack pads W2 / b2 with zero rows); ZH: the z image is staged in ZH column parts (2: 320 channels, whose whole rows would
+// not leave room for the ring); ZPF: request the next block's z during this block (off where its registers are needed)
+template <int KS1, int HT, int CT, int NW, int WPS, int ZH, bool ZPF>
 __global__ void __launch_bounds__(64 * NW, WPS)
 k_channel_mlp_stream(const bf16_t* __restrict__ z, const bf16_t* __restrict__ xres, bf16_t* __restrict__ y, const u32x4q* __restrict__ wfrag, const float* __restrict__ bias,
                      int M, int C, int nblocks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    constexpr int NCH = KS1 + 2 * CT, NT = 64 * NW, PER = NCH * 64 / NT;          // fragments per chunk; 16-byte pieces of a chunk per thread
-    static_assert(NCH * 64 % NT == 0, "a chunk is a whole number of 16-byte pieces per thread");
+    constexpr int NCH = KS1 + 2 * CT, NT = 64 * NW, PER = (NCH * 64 + NT - 1) / NT;          // fragments per chunk; 16-byte pieces of a chunk per thread (the last one ragged)
+    constexpr bool RAG = NCH * 64 % NT != 0;
     u32x4q* const Lring = reinterpret_cast<u32x4q*>(lds_raw);                        // [2][NCH * 64]
     float* const Lb1 = reinterpret_cast<float*>(lds_raw + (size_t)2 * NCH * 1024);
     float* const Lb2 = Lb1 + 32 * HT;
@@ -294,12 +296,14 @@ k_channel_mlp_stream(const bf16_t* __restrict__ z, const bf16_t* __restrict__ xr
     u32x4q cp[2][PER];
     auto request = [&](u32x4q (&dst)[PER], int chunk) {
 #pragma unroll
-        for (int i = 0; i < PER; ++i) dst[i] = wfrag[(size_t)chunk * NCH * 64 + threadIdx.x + i * NT];
+        for (int i = 0; i < PER; ++i)
+            if (!RAG || i + 1 < PER || threadIdx.x + i * NT < NCH * 64) dst[i] = wfrag[(size_t)chunk * NCH * 64 + threadIdx.x + i * NT];
     };
     auto deposit = [&](const u32x4q (&src)[PER], int slot) {
         u32x4q* const Ln = Lring + slot * NCH * 64;
 #pragma unroll
-        for (int i = 0; i < PER; ++i) Ln[threadIdx.x + i * NT] = src[i];
+        for (int i = 0; i < PER; ++i)
+            if (!RAG || i + 1 < PER || threadIdx.x + i * NT < NCH * 64) Ln[threadIdx.x + i * NT] = src[i];
     };
     request(cp[0], 0);
     deposit(cp[0], 0);
@@ -309,14 +313,15 @@ k_channel_mlp_stream(const bf16_t* __restrict__ z, const bf16_t* __restrict__ xr
     // bytes [1024 i + 16 lane, + 16) -> token t, byte bz of its row in the wave's bf16 z image.  The output leaves in halves of 64 channels (two output tiles): a
     // float32 image of 32 x 64, read back as rows -- request j of half hf = the 128-byte pieces [128 hf, + 128) of 8 token rows.
     static_assert(CT % 2 == 0, "output in halves of two tiles");
-    constexpr int RB = 32 * KS1, ZP = RB + 16, OP = 256 + 16, IMG = 32 * (ZP > OP ? ZP : OP), NH = CT / 2;
+    static_assert(KS1 % ZH == 0, "column parts of whole k-steps");
+    constexpr int RB = 32 * KS1, RBH = RB / ZH, KH = KS1 / ZH, ZP = RBH + 16, OP = 256 + 16, IMG = 32 * (ZP > OP ? ZP : OP), NH = CT / 2;
     unsigned char* const Lt = lds_raw + (size_t)2 * NCH * 1024 + sizeof(float) * 32 * (HT + CT) + (size_t)wave * IMG;
-    unsigned zo[KS1], za[KS1];
+    unsigned zo[KS1], za[KS1];                                                  // request i of column part q = i / KH: piece 1024 (i % KH) + 16 lane of that part
 #pragma unroll
     for (int i = 0; i < KS1; ++i) {
-        const unsigned o = 1024u * i + 16u * lane;
-        zo[i] = o;
-        za[i] = (o / RB) * ZP + o % RB;
+        const unsigned o = 1024u * (i % KH) + 16u * lane, t = o / RBH, bz = o % RBH;
+        zo[i] = t * RB + (i / KH) * RBH + bz;
+        za[i] = t * ZP + bz;
     }
     // half hf, request j (4 per half): token t = 8 j + lane / 8, bytes 128 hf + 16 (lane % 8) of its row
     const unsigned ht_tok = lane >> 3, ht_b = 16u * (lane & 7);
@@ -326,17 +331,21 @@ k_channel_mlp_stream(const bf16_t* __restrict__ z, const bf16_t* __restrict__ xr
 #pragma unroll
         for (int i = 0; i < KS1; ++i) zq[i] = __builtin_bit_cast(u32x4q, __builtin_amdgcn_raw_buffer_load_b128(zsrc, (int)(base + zo[i]), 0, 0));
     };
-    if ((int)blockIdx.x < nblocks) load_z(blockIdx.x);
+    if (ZPF && (int)blockIdx.x < nblocks) load_z(blockIdx.x);
     for (int block = blockIdx.x; block < nblocks; block += gridDim.x) {
         const unsigned base = (unsigned)(32 * (block * NW + wave)) * (unsigned)RB;
-#pragma unroll
-        for (int i = 0; i < KS1; ++i) *reinterpret_cast<u32x4q*>(Lt + za[i]) = zq[i];
-        wave_sync();
+        if constexpr (!ZPF) load_z(block);
         bf16x8 zb[KS1];
 #pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) zb[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4q*>(Lt + r * ZP + 32 * ks + 16 * h));
-        wave_sync();
-        if (block + (int)gridDim.x < nblocks) load_z(block + gridDim.x);           // the next block's channels: in flight during this block
+        for (int q = 0; q < ZH; ++q) {
+#pragma unroll
+            for (int i = 0; i < KH; ++i) *reinterpret_cast<u32x4q*>(Lt + za[q * KH + i]) = zq[q * KH + i];
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < KH; ++k) zb[q * KH + k] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4q*>(Lt + r * ZP + 32 * k + 16 * h));
+            wave_sync();
+        }
+        if (ZPF && block + (int)gridDim.x < nblocks) load_z(block + gridDim.x);    // the next block's channels: in flight during this block
         f32x16 d2[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -351,13 +360,13 @@ k_channel_mlp_stream(const bf16_t* __restrict__ z, const bf16_t* __restrict__ xr
                 for (int hf = 0; hf < NH; ++hf)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        xq[hf][j] = __builtin_bit_cast(u32x4q, __builtin_amdgcn_raw_buffer_load_b128(xsrc, (int)(base + (8u * j + ht_tok) * RB + 128u * hf + ht_b), 0, 0));
+                        xq[hf][j] = __builtin_bit_cast(u32x4q, __builtin_amdgcn_raw_buffer_load_b128(xsrc, (int)(128u * hf + ht_b < RB ? base + (8u * j + ht_tok) * RB + 128u * hf + ht_b : 0x80000000u), 0, 0));
             }
-            hidden_tile_ring<KS1, CT, (NW > 4 ? 4 : 8)>(Lring, Lb1 + 32 * ht, lane, h, zb, d2);                               // chunk ht: slot 0
+            hidden_tile_ring<KS1, CT, (NW > 4 || KS1 > 16 ? 4 : 8)>(Lring, Lb1 + 32 * ht, lane, h, zb, d2);                               // chunk ht: slot 0
             deposit(cp[1], 1);                                                                                  // chunk ht + 1
             __syncthreads();                      // every wave is done with slot 0; slot 1 is complete
             request(cp[1], (ht + 3) % HT);
-            hidden_tile_ring<KS1, CT, (NW > 4 ? 4 : 8)>(Lring + NCH * 64, Lb1 + 32 * (ht + 1), lane, h, zb, d2);              // chunk ht + 1: slot 1
+            hidden_tile_ring<KS1, CT, (NW > 4 || KS1 > 16 ? 4 : 8)>(Lring + NCH * 64, Lb1 + 32 * (ht + 1), lane, h, zb, d2);              // chunk ht + 1: slot 1
             deposit(cp[0], 0);                                                                                  // chunk ht + 2 (the next block's chunk 0 after the last)
             __syncthreads();
         }
@@ -383,7 +392,7 @@ k_channel_mlp_stream(const bf16_t* __restrict__ z, const bf16_t* __restrict__ xr
                 o[2] = (__bf16)(lo.z + __uint_as_float(xv.y << 16)); o[3] = (__bf16)(lo.w + __uint_as_float(xv.y & 0xffff0000u));
                 o[4] = (__bf16)(hi.x + __uint_as_float(xv.z << 16)); o[5] = (__bf16)(hi.y + __uint_as_float(xv.z & 0xffff0000u));
                 o[6] = (__bf16)(hi.z + __uint_as_float(xv.w << 16)); o[7] = (__bf16)(hi.w + __uint_as_float(xv.w & 0xffff0000u));
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4q, o), ysrc, (int)(base + (8u * j + ht_tok) * RB + 128u * hf + ht_b), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4q, o), ysrc, (int)(128u * hf + ht_b < RB ? base + (8u * j + ht_tok) * RB + 128u * hf + ht_b : 0x80000000u), 0, 0);   // (a half past the row's channels: dropped)
             }
             wave_sync();
         }
@@ -397,6 +406,7 @@ static bool mlp_shape(int C, int H, int* ks1, int* ht, int* ct)
 {
     if (C <= 0 || H <= 0 || C % 8 || H % 32) return false;
     *ks1 = (C + 15) / 16; *ht = H / 32; *ct = (C + 31) / 32;
+    if (C > 128 && (*ct & 1)) ++*ct;              // the streamed kernels write their output in halves of two tiles: W2 / b2 padded with zero rows (ops.pack_channel_mlp)
     return true;
 }
 
@@ -407,6 +417,7 @@ bool channel_mlp_applicable(int M, int C, int H, int dtype)
     if ((unsigned long long)M * C * 2 >= (1ull << 31)) return false;
     if (C == 256 && ht == 16) return true;
     if (C == 192 && ht == 12) return true;
+    if ((C == 160 && ht == 10) || (C == 320 && ht == 20)) return true;
     return (ks1 == 4 && ht == 4 && ct == 2) || (C == 128 && ht == 8) || (ks1 == 3 && ht == 3 && ct == 2) || (C == 96 && ht == 6) || (C == 80 && ht == 5);
 }
 
@@ -438,14 +449,15 @@ static hipError_t launch_mlp(const void* z, const void* x, void* y, const void* 
 }
 
 // C == 16 KS1 == 32 CT exactly (no padding lanes): the streamed form
-template <int KS1, int HT, int CT, int NW>
+template <int KS1, int HT, int CT, int NW, int ZH = 1, bool ZPF = true>
 static hipError_t launch_mlp_stream(const void* z, const void* x, void* y, const void* wfrag, const float* bias, int M, int C, int ncu, hipStream_t s)
 {
-    constexpr int NCH = KS1 + 2 * CT, ZP = 32 * KS1 + 16, OP = 256 + 16, IMG = 32 * (ZP > OP ? ZP : OP);
+    constexpr int NCH = KS1 + 2 * CT, ZP = 32 * KS1 / ZH + 16, OP = 256 + 16, IMG = 32 * (ZP > OP ? ZP : OP);
     constexpr size_t lds = (size_t)2 * NCH * 1024 + sizeof(float) * 32 * (HT + CT) + (size_t)NW * IMG;
     static_assert(lds <= 160 * 1024, "the ring and the waves' images must fit the LDS");
-    if (C != 16 * KS1 || C != 32 * CT) return hipErrorInvalidConfiguration;
-    auto kfn = mlp::k_channel_mlp_stream<KS1, HT, CT, NW, NW / 4>;
+    static_assert(CT % 2 == 0 && 32 * CT >= 16 * KS1 && 32 * (CT - 2) < 16 * KS1, "output tiles: the channel count rounded up to a multiple of 64");
+    if (C != 16 * KS1) return hipErrorInvalidConfiguration;
+    auto kfn = mlp::k_channel_mlp_stream<KS1, HT, CT, NW, NW / 4, ZH, ZPF>;
     RCX_SET_LDS_ONCE(kfn, lds);
     const int nblocks = (M + 32 * NW - 1) / (32 * NW);
     const int grid = nblocks < ncu ? nblocks : ncu;
@@ -469,6 +481,8 @@ hipError_t channel_mlp(const void* z, const void* x, void* y, const void* wfrag,
     }
     if (C == 256 && ht == 16) return launch_mlp_stream<16, 16, 8, 4>(z, x, y, wfrag, bias, M, C, ncu, s);           // M3 / A3 stage 2
     if (C == 192 && ht == 12) return launch_mlp_stream<12, 12, 6, 4>(z, x, y, wfrag, bias, M, C, ncu, s);           // M1 stage 2
+    if (C == 160 && ht == 10) return launch_mlp_stream<10, 10, 6, 4>(z, x, y, wfrag, bias, M, C, ncu, s);           // M5 / A5 stage 1
+    if (C == 320 && ht == 20) return launch_mlp_stream<20, 20, 10, 4, 2, false>(z, x, y, wfrag, bias, M, C, ncu, s); // M5 / A5 stage 2
     if (ks1 == 4 && ht == 4) return C == 64 ? launch_mlp<4, 4, 2, true, true>(z, x, y, wfrag, bias, M, C, ncu, s)            // M3 / A3 stage 0 ...
                                             : launch_mlp<4, 4, 2, false, false>(z, x, y, wfrag, bias, M, C, ncu, s);         // ... M2 (56 channels)
     if (ks1 == 8 && ht == 8) {

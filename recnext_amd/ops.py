@@ -488,6 +488,8 @@ def pack_channel_mlp(w1, b1, w2, b2, hidden_to=None):
     if hp % 32 or hp < h0:
         raise ValueError(f"hidden_to={hidden_to} must be a multiple of 32 and at least {h0}")
     ks1, ht, ct = -(-c // 16), hp // 32, -(-c // 32)
+    if c > 128 and ct % 2:                  # the streamed kernels write y in halves of two output tiles: one more tile of zero rows (rcx_mlp.hip mlp_shape)
+        ct += 1
     w1p = torch.zeros(32 * ht, 16 * ks1, dtype=torch.bfloat16, device=dev)
     w1p[:h0, :c] = w1.to(torch.bfloat16)
     f1 = w1p.view(ht, 32, ks1, 2, 8).permute(0, 2, 3, 1, 4)                    # [ht, ks, h, m, j]

@@ -26,7 +26,7 @@ def _reference(z, x, w1, b1, w2, b2):
 
 @pytest.mark.parametrize("case", [(2, 64, 128, 56, 56), (3, 128, 256, 28, 28), (2, 64, 120, 9, 11), (1, 48, 96, 56, 56), (2, 40, 80, 13, 7), (2, 56, 112, 28, 28),
                                   (2, 96, 192, 28, 28), (1, 80, 160, 56, 56), (1, 80, 150, 5, 5), (1, 64, 128, 1, 1), (1, 128, 240, 3, 33),
-                                  (3, 256, 512, 14, 14), (2, 256, 480, 14, 14), (1, 256, 512, 3, 5), (5, 256, 512, 16, 16), (3, 192, 384, 14, 14), (2, 128, 256, 64, 64)],
+                                  (3, 256, 512, 14, 14), (2, 256, 480, 14, 14), (1, 256, 512, 3, 5), (5, 256, 512, 16, 16), (3, 192, 384, 14, 14), (2, 128, 256, 64, 64), (2, 160, 320, 28, 28), (1, 160, 300, 9, 7), (3, 320, 640, 14, 14), (1, 320, 600, 5, 3), (9, 320, 640, 7, 9)],
                          ids=lambda c: "x".join(map(str, c)))
 def test_fused_channel_mlp_against_float64_and_the_gemm_path(case):
     from recnext_amd import ops
@@ -71,7 +71,7 @@ def test_fused_channel_mlp_rejects_what_it_has_no_kernel_for():
         ops.channel_mlp(z, z.clone(), wfrag, bias, 1024)
 
 
-@pytest.mark.parametrize("name", ["recnext_m3", "recnext_a3", "recnext_m1"])
+@pytest.mark.parametrize("name", ["recnext_m3", "recnext_a3", "recnext_m1", "recnext_m5"])
 def test_model_with_fused_mlp_matches_the_gemm_path(name):
     """build_inference_model(fused_mlp=True) against the same weights on the GEMM-library path: the logits agree within bf16 noise, the state_dict is the same,
     and the fused path is what ran (the stage-0 / stage-1 blocks)."""

@@ -11,7 +11,7 @@ from recnext_amd import ops
 
 dev = torch.device("cuda:0")
 REPS = int(os.environ.get("REPS", "30"))
-SHAPES = [(256, 64, 128, 56), (256, 128, 256, 28), (256, 256, 512, 14), (256, 192, 384, 14), (256, 48, 96, 56), (256, 96, 192, 28), (256, 80, 160, 56)]
+SHAPES = [(256, 64, 128, 56), (256, 128, 256, 28), (256, 256, 512, 14), (256, 192, 384, 14), (256, 160, 320, 28), (256, 320, 640, 14), (256, 48, 96, 56), (256, 96, 192, 28), (256, 80, 160, 56)]
 
 
 def timed(fn, n):
