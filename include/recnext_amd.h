@@ -243,7 +243,8 @@ int rcx_recattn2d_fwd(const void* x, void* y, const float* w_down_kkc, const flo
  *             reads (recnext_amd/ops.py::pack_channel_mlp builds it; layout in recnext_amd/csrc/rcx_mlp.hip); 16-byte aligned;
  *   bias    : 32 (H/32 + ceil(C/32)) floats: b1 (H), then b2 padded with zeros to a multiple of 32.
  * H % 32 == 0 (pad the hidden layer with zero units: gelu(0) = 0 meets zero weights), C % 8 == 0, M C 2 < 2^31, the weights must fit the LDS.
- * rcx_channel_mlp_supported() says whether there is a kernel for (C, H) (today: C = 64 / 56 with H = 128, 128 / 256, 48 / 40 with 96, 96 / 192, 80 / 160);
+ * rcx_channel_mlp_supported() says whether there is a kernel for (C, H): today C = 40 / 48 with H = 96, 56 / 64 with 128, 80 / 160, 96 / 192, 128 / 256 (weights resident in LDS) and
+ * C = 128 / 256, 160 / 320, 192 / 384, 256 / 512, 320 / 640 (weights streamed through LDS; W2 / b2 padded to an even number of 32-row output tiles when C > 128);
  * else RCX_ERR_UNSUPPORTED and the caller keeps the GEMM library.  The products run on the matrix cores with bf16 operands (the hidden activations are
  * rounded to bf16 once, after the GELU) and float32 accumulation.
  */

@@ -848,8 +848,8 @@ int rcx_channel_mlp_fwd(const void* z, const void* x, void* y, const void* wfrag
         return fail(RCX_ERR_BAD_ARG, "rcx_channel_mlp_fwd: z, wfrag and bias must be 16-byte aligned, x and y 8-byte aligned");
     if (y == z || y == x) return fail(RCX_ERR_BAD_ARG, "rcx_channel_mlp_fwd: y must not alias its inputs");
     if (!rcx::channel_mlp_applicable(M, C, H, dtype))
-        return fail(RCX_ERR_UNSUPPORTED, "rcx_channel_mlp_fwd: no kernel for M=%d C=%d H=%d dtype %d (bf16; C = 64 / 56 with H = 128, 128 / 256, 48 / 40 with 96, 96 / 192, 80 / 160; "
-                                         "M C 2 < 2^31)", M, C, H, dtype);
+        return fail(RCX_ERR_UNSUPPORTED, "rcx_channel_mlp_fwd: no kernel for M=%d C=%d H=%d dtype %d (bf16; (C, H) = (40 | 48, 96), (56 | 64, 128), (80, 160), (96, 192), (128, 256), (160, 320), "
+                                         "(192, 384), (256, 512), (320, 640); M C 2 < 2^31)", M, C, H, dtype);
     hipError_t e = rcx::channel_mlp(z, x, y, wfrag, bias, M, C, H, dtype, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_channel_mlp_fwd");
 }
