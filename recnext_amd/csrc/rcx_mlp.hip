@@ -3,7 +3,7 @@
 //                                               model/recattn.py:171, :184)
 // z = the token mixer's output (its BatchNorm already folded into the mixer's last conv), x = the block's input, W1 (H x C) / W2 (C x H) the two BN-folded 1x1
 // convs.  As four library launches (GEMM + bias, GELU, GEMM + bias, add) the hidden tensor -- 2 x the size of x -- is written and read twice and y once more:
-// 7 S of traffic where x, z in and y out are 3 S; at the 56 x 56 and 28 x 28 stages (C = 64 / 128) these GEMMs are memory-bound, so that is the whole cost.
+// 7 S of traffic where x, z in and y out are 3 S; at the 56 x 56 and 28 x 28 stages (C = 64 / 128) these GEMMs are memory-bound, so that is most of the cost.
 //
 // ONE WAVE = 32 tokens at a time, the hidden layer streamed through its registers 32 units at a time, never in memory:
 //   D1  (32 hidden units x 32 tokens) = W1[32 ht ..][:] z^T      v_mfma_f32_32x32x16_bf16: A = a W1 fragment (LDS), B = the tokens' channels (registers, loaded
@@ -11,7 +11,9 @@
 //   h   = gelu(D1 + b1) in float32, rounded to bf16              the accumulator layout (token on the lane, units in the registers) IS the B operand of ...
 //   D2 += W2[:][32 ht ..] h                                      ... the second product, with W2's columns stored in the order the registers imply
 //   y   = D2 + b2 + x                                            8-byte loads / stores of four channels per lane (token on the lane)
-// The weights live in LDS as ready-made fragments (one conflict-free 16-byte read per lane and product), packed once on the host (ops.pack_mlp).
+// The weights are ready-made fragments (one conflict-free 16-byte LDS read per lane and product), packed once on the host (ops.pack_channel_mlp), hidden tile by
+// hidden tile: resident in LDS for C <= 128 (k_channel_mlp), streamed through a two-slot LDS ring for C = 128 .. 320 (k_channel_mlp_stream, further down).  Global
+// accesses are whole-wave contiguous kilobytes, transposed to / from the token-on-lane layouts in per-wave LDS images (measurements: profiles/r05_channel_mlp.txt).
 // GELU is the exact form 0.5 v (1 + erf(v / sqrt 2)) with erf as an odd degree-15 polynomial of the argument clamped to +-2.8: |error| < 7.7e-5 in erf, i.e. 4e-5 |v|
 // in gelu -- a fiftieth of a bf16 ulp; the library's erff would be most of this kernel's vector work.
 #include "rcx_common.h"
@@ -36,7 +38,7 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ constexpr int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }      // row of accumulator register i in lane half h
+// (row of accumulator register i in lane half h of a 32 x 32 tile: (i & 3) + 8 (i >> 2) + 4 h -- ops.py::_mlp_acc_unit orders W2's columns by it)
 
 // erf(x) ~ xc Q(xc^2) with xc = x clamped to [-2.8, 2.8]: a weighted minimax fit constrained to reach 1 at the clamp (so the tails are +-1 to 1e-6 and
 // gelu(v) -> 0 / v), |error| < 7.7e-5; two values at a time on the packed pipe, one v_med3 each for the clamp
@@ -98,7 +100,6 @@ __device__ __forceinline__ void hidden_tile_ring(const u32x4q* Lc, const float* 
 }
 
 // LDS: per hidden tile ht its KS1 W1 fragments and 2 CT W2 fragments (1 KB each: 64 lanes x 16 bytes; ops.pack_channel_mlp), then b1 (32 HT floats), b2 (32 CT floats)
-static inline size_t lds_bytes(int KS1, int HT, int CT) { return (size_t)(HT * KS1 + CT * 2 * HT) * 1024 + sizeof(float) * 32 * (HT + CT); }
 
 // KS1 = ceil(C / 16) k-steps of the first product, HT = H / 32 hidden tiles, CT = ceil(C / 32) output tiles; C % 8 == 0 (a lane's 8 channels of a k-step are
 // all there or all padding).  NW waves per workgroup share the LDS weights; each takes every (grid x NW)-th 32-token tile.
@@ -214,7 +215,7 @@ k_channel_mlp(const bf16_t* __restrict__ z, const bf16_t* __restrict__ xres, bf1
         }
         return;
     }
-    // ---- more output tiles (C = 80 .. 128): the weights fill the LDS; a token per lane straight from / to memory
+    // ---- three output tiles or more (C = 80, 96; C = 128 with RCX_MLP_STREAM=0): the weights take the LDS the images would need; a token per lane straight from / to memory
     u32x4q zf[KS1];
     auto load_z = [&](int t) {
         const unsigned row = (unsigned)(32 * t + r) * (unsigned)C * 2u;       // (a token past M: past the buffer, reads 0)
@@ -228,13 +229,6 @@ k_channel_mlp(const bf16_t* __restrict__ z, const bf16_t* __restrict__ xres, bf1
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) zb[ks] = __builtin_bit_cast(bf16x8, zf[ks]);
         if (tile + stride < ntiles) load_z(tile + stride);                    // the next tile's channels: in flight during this tile's products
-        u32x2q xr[CT][4];                                                    // the residual: needed last, requested first (a memory round trip = about one tile's work)
-        if constexpr (false) {
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) xr[ct][g] = __builtin_bit_cast(u32x2q, __builtin_amdgcn_raw_buffer_load_b64(xsrc, (int)(row + oc[ct][g]), 0, 0));
-        }
         f32x16 d2[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -242,12 +236,11 @@ k_channel_mlp(const bf16_t* __restrict__ z, const bf16_t* __restrict__ xres, bf1
             for (int i = 0; i < 16; ++i) d2[ct][i] = 0.f;
 #pragma unroll 1
         for (int ht = 0; ht < HT; ++ht) hidden_tile(ht, zb, d2);
-        if constexpr (true) {                                             // (the large shapes: the registers are the accumulators' until here)
+        u32x2q xr[CT][4];                                                    // the residual (requested after the products: until here its registers are the accumulators')
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) xr[ct][g] = __builtin_bit_cast(u32x2q, __builtin_amdgcn_raw_buffer_load_b64(xsrc, (int)(row + oc[ct][g]), 0, 0));
-        }
+            for (int g = 0; g < 4; ++g) xr[ct][g] = __builtin_bit_cast(u32x2q, __builtin_amdgcn_raw_buffer_load_b64(xsrc, (int)(row + oc[ct][g]), 0, 0));
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
