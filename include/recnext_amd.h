@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RCX_ABI_VERSION 5
+#define RCX_ABI_VERSION 6
 
 enum { RCX_DTYPE_F32 = 0, RCX_DTYPE_BF16 = 1, RCX_DTYPE_F16 = 2 };   /* F16: the reference's autocast dtype (engine.py:48) */
 enum { RCX_MODE_BILINEAR = 0, RCX_MODE_NEAREST = 1 };   /* F.interpolate(mode=...), model/recnext.py:33 */
@@ -251,6 +251,20 @@ int rcx_recattn2d_fwd(const void* x, void* y, const float* w_down_kkc, const flo
 int rcx_channel_mlp_supported(int M, int C, int H, int dtype);
 size_t rcx_channel_mlp_pack_bytes(int C, int H);
 int rcx_channel_mlp_fwd(const void* z, const void* x, void* y, const void* wfrag, const float* bias, int M, int C, int H, int dtype, void* stream);
+
+/*
+ * RecNextStem, inference, ONE launch (model/recnext.py:134-146; both 3x3 stride-2 ConvNorms BN-folded, :75-97; nn.GELU between them):
+ *     y = conv3x3_s2_p1(gelu(conv3x3_s2_p1(x) + b1)) + b2
+ *   x  : N x H x W x 3 bf16 (NHWC);  y : N x ceil(ceil(H/2)/2) x ceil(ceil(W/2)/2) x CO bf16 (NHWC);
+ *   w1frag : 2 ceil(CM/32) KB, the first conv's (CM, 3, 3, 3) weight rounded to bf16 as matrix-core fragments (K = 27 taps padded to 32);  b1 : 32 ceil(CM/32) float32;
+ *   w2frag : rcx_stem_pack_bytes(CM, CO) bytes, the second conv's (CO, CM, 3, 3) weight likewise (recnext_amd/ops.py::pack_stem builds all four);
+ *   b2 : 32 ceil(CO/32) float32 (zero padded).  All four 16-byte aligned.  CM in {20, 24, 28, 32, 40} (the registered models' embed_dim[0] / 2), CO % 4 == 0, CO <= 96.
+ * The 112 x 112 x CM intermediate exists only as 17 x 17 tiles in LDS, rounded to bf16 once (as the library path does).  rcx_stem_supported() says whether the
+ * shape has a kernel; else RCX_ERR_UNSUPPORTED and the caller keeps the conv library.
+ */
+int rcx_stem_supported(int N, int H, int W, int CM, int CO, int dtype);
+size_t rcx_stem_pack_bytes(int CM, int CO);
+int rcx_stem_fwd(const void* x, void* y, const void* w1frag, const float* b1, const void* w2frag, const float* b2, int N, int H, int W, int CM, int CO, int dtype, void* stream);
 
 /*
  * Backward of rcx_linear_attention_fwd (the gradients engine.py:48-64 needs through RecAttn2d, model/recattn.py:16-28 / :39-51):

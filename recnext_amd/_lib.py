@@ -15,7 +15,7 @@ MODE_BILINEAR, MODE_NEAREST = 0, 1
 MODES = {"bilinear": MODE_BILINEAR, "nearest": MODE_NEAREST}
 MAX_LEVEL = 8
 ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE = -1, -2, -3     # include/recnext_amd.h (rcx_status); positive = hipError_t
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 
@@ -48,6 +48,9 @@ SIGNATURES = {
     "rcx_recattn_qkcore_fwd": (_i, [_vp] * 7 + [_sz] + [_i] * 5 + [_vp]),
     "rcx_recattn_down_qkcore_supported": (_i, [_i] * 6),
     "rcx_recattn_down_qkcore_fwd": (_i, [_vp] * 8 + [_i] * 6 + [_vp]),
+    "rcx_stem_supported": (_i, [_i] * 6),
+    "rcx_stem_pack_bytes": (_sz, [_i] * 2),
+    "rcx_stem_fwd": (_i, [_vp] * 6 + [_i] * 6 + [_vp]),
     "rcx_channel_mlp_supported": (_i, [_i] * 4),
     "rcx_channel_mlp_pack_bytes": (_sz, [_i] * 2),
     "rcx_channel_mlp_fwd": (_i, [_vp] * 5 + [_i] * 4 + [_vp]),

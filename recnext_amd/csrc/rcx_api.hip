@@ -835,6 +835,23 @@ int rcx_recattn2d_fwd(const void* x, void* y, const float* w_down_kkc, const flo
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_recattn2d_fwd");
 }
 
+int rcx_stem_supported(int N, int H, int W, int CM, int CO, int dtype) { return rcx::stem_applicable(N, H, W, CM, CO, dtype) ? 1 : 0; }
+
+size_t rcx_stem_pack_bytes(int CM, int CO) { return rcx::stem_pack_bytes(CM, CO); }
+
+int rcx_stem_fwd(const void* x, void* y, const void* w1frag, const float* b1, const void* w2frag, const float* b2, int N, int H, int W, int CM, int CO, int dtype, void* stream)
+{
+    if (!x || !y || !w1frag || !b1 || !w2frag || !b2) return fail(RCX_ERR_BAD_ARG, "rcx_stem_fwd: null pointer");
+    if (N <= 0 || H <= 0 || W <= 0 || CM <= 0 || CO <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive extent N=%d H=%d W=%d CM=%d CO=%d", N, H, W, CM, CO);
+    if (!known_dtype(dtype)) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d", dtype);
+    if (((size_t)x & 1) || ((size_t)y & 7) || ((size_t)w1frag & 15) || ((size_t)b1 & 15) || ((size_t)w2frag & 15) || ((size_t)b2 & 15))
+        return fail(RCX_ERR_BAD_ARG, "rcx_stem_fwd: w1frag, b1, w2frag and b2 must be 16-byte aligned, y 8-byte aligned");
+    if (!rcx::stem_applicable(N, H, W, CM, CO, dtype))
+        return fail(RCX_ERR_UNSUPPORTED, "rcx_stem_fwd: no kernel for CM=%d CO=%d dtype %d (bf16; CM in {20, 24, 28, 32, 40}, CO %% 4 == 0, CO <= 96; one image of x below 2^31 bytes)", CM, CO, dtype);
+    hipError_t e = rcx::stem_fwd(x, y, w1frag, b1, w2frag, b2, N, H, W, CM, CO, dtype, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(e, "rcx_stem_fwd");
+}
+
 int rcx_channel_mlp_supported(int M, int C, int H, int dtype) { return rcx::channel_mlp_applicable(M, C, H, dtype) ? 1 : 0; }
 
 size_t rcx_channel_mlp_pack_bytes(int C, int H) { return rcx::channel_mlp_pack_bytes(C, H); }

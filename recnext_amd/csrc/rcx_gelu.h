@@ -1,0 +1,29 @@
+// The exact (erf) GELU of the block's channel mixer and of the stem (model/recnext.py:125-146: nn.GELU()), two values at a time on the packed float32 pipe.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rcx {
+
+typedef float gelu_f32x2 __attribute__((ext_vector_type(2)));
+
+// erf(x) ~ xc Q(xc^2) with xc = x clamped to [-2.8, 2.8]: a weighted minimax fit constrained to reach 1 at the clamp (so the tails are +-1 to 1e-6 and
+// gelu(v) -> 0 / v), |error| < 7.7e-5; two values at a time on the packed pipe, one v_med3 each for the clamp
+__device__ __forceinline__ gelu_f32x2 gelu2(gelu_f32x2 v)
+{
+    constexpr float A = 2.8f;
+    const gelu_f32x2 x = v * 0.70710678f;
+    const gelu_f32x2 xc = {__builtin_amdgcn_fmed3f(x.x, -A, A), __builtin_amdgcn_fmed3f(x.y, -A, A)};
+    const gelu_f32x2 s = xc * xc;
+    gelu_f32x2 q = {-4.114877470e-07f, -4.114877470e-07f};
+    q = __builtin_elementwise_fma(q, s, gelu_f32x2{1.744569090e-05f, 1.744569090e-05f});
+    q = __builtin_elementwise_fma(q, s, gelu_f32x2{-3.191421274e-04f, -3.191421274e-04f});
+    q = __builtin_elementwise_fma(q, s, gelu_f32x2{3.352143336e-03f, 3.352143336e-03f});
+    q = __builtin_elementwise_fma(q, s, gelu_f32x2{-2.280939557e-02f, -2.280939557e-02f});
+    q = __builtin_elementwise_fma(q, s, gelu_f32x2{1.079412624e-01f, 1.079412624e-01f});
+    q = __builtin_elementwise_fma(q, s, gelu_f32x2{-3.734020293e-01f, -3.734020293e-01f});
+    q = __builtin_elementwise_fma(q, s, gelu_f32x2{1.127931833e+00f, 1.127931833e+00f});
+    const gelu_f32x2 e = xc * q, hv = v * 0.5f;
+    return __builtin_elementwise_fma(hv, e, hv);
+}
+
+}  // namespace rcx

@@ -153,6 +153,10 @@ bool recattn_down_qkcore_applicable(int B, int H, int W, int C, int heads, int x
 hipError_t recattn_down_qkcore(const void* x, const float* wdn, const float* bdn, const void* wqk_bf16, const float* bqk, const float* wpe, const float* bpe,
                                float* out, int B, int H, int C, int heads, int x_dt, hipStream_t s);
 // ... and RecAttn2d.forward whole (nearest resize): + the final conv(x + resize(a)), one launch from x to y
+// rcx_stem.hip: RecNextStem (conv3x3 s2 + GELU + conv3x3 s2) in one launch (bf16)
+bool stem_applicable(int N, int H, int W, int CM, int CO, int dtype);
+size_t stem_pack_bytes(int CM, int CO);
+hipError_t stem_fwd(const void* x, void* y, const void* w1frag, const float* b1, const void* w2frag, const float* b2, int N, int H, int W, int CM, int CO, int dtype, hipStream_t s);
 // rcx_mlp.hip: the channel mixer + residual of a block in one launch (bf16)
 bool channel_mlp_applicable(int M, int C, int H, int dtype);
 size_t channel_mlp_pack_bytes(int C, int H);

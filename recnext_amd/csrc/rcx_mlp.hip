@@ -19,6 +19,7 @@
 #include "rcx_common.h"
 #include "rcx_launch.h"
 #include "rcx_opts.h"
+#include "rcx_gelu.h"
 
 namespace rcx {
 namespace mlp {
@@ -39,26 +40,6 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 // (row of accumulator register i in lane half h of a 32 x 32 tile: (i & 3) + 8 (i >> 2) + 4 h -- ops.py::_mlp_acc_unit orders W2's columns by it)
-
-// erf(x) ~ xc Q(xc^2) with xc = x clamped to [-2.8, 2.8]: a weighted minimax fit constrained to reach 1 at the clamp (so the tails are +-1 to 1e-6 and
-// gelu(v) -> 0 / v), |error| < 7.7e-5; two values at a time on the packed pipe, one v_med3 each for the clamp
-__device__ __forceinline__ f32x2q gelu2(f32x2q v)
-{
-    constexpr float A = 2.8f;
-    const f32x2q x = v * 0.70710678f;
-    const f32x2q xc = {__builtin_amdgcn_fmed3f(x.x, -A, A), __builtin_amdgcn_fmed3f(x.y, -A, A)};
-    const f32x2q s = xc * xc;
-    f32x2q q = {-4.114877470e-07f, -4.114877470e-07f};
-    q = __builtin_elementwise_fma(q, s, f32x2q{1.744569090e-05f, 1.744569090e-05f});
-    q = __builtin_elementwise_fma(q, s, f32x2q{-3.191421274e-04f, -3.191421274e-04f});
-    q = __builtin_elementwise_fma(q, s, f32x2q{3.352143336e-03f, 3.352143336e-03f});
-    q = __builtin_elementwise_fma(q, s, f32x2q{-2.280939557e-02f, -2.280939557e-02f});
-    q = __builtin_elementwise_fma(q, s, f32x2q{1.079412624e-01f, 1.079412624e-01f});
-    q = __builtin_elementwise_fma(q, s, f32x2q{-3.734020293e-01f, -3.734020293e-01f});
-    q = __builtin_elementwise_fma(q, s, f32x2q{1.127931833e+00f, 1.127931833e+00f});
-    const f32x2q e = xc * q, hv = v * 0.5f;
-    return __builtin_elementwise_fma(hv, e, hv);
-}
 
 // One 32-unit tile of the hidden layer from its chunk of fragments in LDS (Lc: KS1 W1 fragments, then 2 CT W2 fragments in (ct, q) order):
 //   D1 = W1 tile x z^T, h = gelu(D1 + b1) -> bf16 (already the second product's B operand), D2 += W2 columns x h.

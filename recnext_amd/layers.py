@@ -154,3 +154,26 @@ class FusedChannelMlp:
         n, c, h, w = x.shape
         wfrag, bias, hidden = self._operands(ops.channel_mlp_hidden(n * h * w, c, self.fc1.out_channels, x.dtype))
         return ops.channel_mlp(z, x, wfrag, bias, hidden)
+
+
+class FusedStem:
+    """RecNextStem's [3x3 stride-2 conv, GELU, 3x3 stride-2 conv] (BatchNorms folded) as ONE HIP launch (ops.stem; inference, bf16, channels_last).  Not a Module: it
+    reads the two convs' own parameters (state_dict untouched) and rebuilds its packs when one changes."""
+
+    def __init__(self, conv1, conv2):
+        self.conv1, self.conv2 = conv1, conv2
+        self._key, self._pack = None, None
+
+    def supported(self, x):
+        from . import ops
+        n, c, h, w = x.shape
+        return x.is_cuda and x.dtype == torch.bfloat16 and c == 3 and ops.stem_supported(n, h, w, self.conv1.out_channels, self.conv2.out_channels, x.dtype)
+
+    def __call__(self, x):
+        from . import ops
+        ts = [self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias]
+        key = tuple(None if t is None else (t.data_ptr(), t._version, t.dtype, t.device) for t in ts)
+        if key != self._key:
+            self._pack = ops.pack_stem(*ts)
+            self._key = key
+        return ops.stem(x, *self._pack, self.conv1.out_channels, self.conv2.out_channels)

@@ -52,6 +52,9 @@ class RecNextStem(nn.Module):
                                   ConvNorm(out_channels // 2, out_channels, kernel_size=3, stride=2, padding=1))
 
     def forward(self, x):
+        fused = self.__dict__.get("_fused_stem")
+        if fused is not None and not self.training and fused.supported(x):
+            return fused(x)                             # one launch (use_fused_stem)
         return self.stem(x)
 
 
@@ -255,6 +258,23 @@ def use_linear_pointwise(net):
                 if isinstance(sub, nn.Conv2d) and sub.kernel_size == (1, 1) and sub.groups == 1 and sub.bias is not None:
                     seq[i] = PointwiseLinear(sub)
                     n += 1
+    return n
+
+
+def use_fused_stem(net):
+    """Inference-only, after ``replace_batchnorm``: evaluate RecNextStem ([3x3 stride-2 conv + bias, exact GELU, 3x3 stride-2 conv + bias]) as ONE HIP launch where
+    rcx_stem_fwd has a kernel (bf16 on a GPU; decided per call) -- the 112 x 112 intermediate never reaches memory.  The convs, their parameters and the state_dict
+    are untouched.  Returns the number of stems given the fused path (0 or 1)."""
+    from .layers import FusedStem
+    n = 0
+    for m in net.modules():
+        if isinstance(m, RecNextStem) and m.__dict__.get("_fused_stem") is None:
+            seq = m.stem
+            if len(seq) == 3 and all(isinstance(seq[i], nn.Conv2d) and seq[i].kernel_size == (3, 3) and seq[i].stride == (2, 2) and seq[i].padding == (1, 1)
+                                     and seq[i].groups == 1 and seq[i].dilation == (1, 1) for i in (0, 2)) \
+                    and isinstance(seq[1], nn.GELU) and getattr(seq[1], "approximate", "none") == "none" and seq[0].in_channels == 3:
+                object.__setattr__(m, "_fused_stem", FusedStem(seq[0], seq[2]))
+                n += 1
     return n
 
 

@@ -528,6 +528,53 @@ def channel_mlp(z, x, wfrag, bias, hidden):
     return y
 
 
+def stem_supported(n, h, w, cm, co, dtype):
+    """Whether rcx_stem_fwd has a kernel for a stem with CM intermediate and CO output channels on an N x 3 x H x W input (bf16 only)."""
+    return dtype == torch.bfloat16 and _lib.load().rcx_stem_supported(int(n), int(h), int(w), int(cm), int(co), _DT[dtype]) > 0
+
+
+def pack_stem(w1, b1, w2, b2):
+    """The stem's two BN-folded 3x3 stride-2 convs -> (w1p, b1p, w2frag, b2p) for stem(): w1 (CM, 3, 3, 3), b1 (CM), w2 (CO, CM, 3, 3), b2 (CO).
+
+    w1p: bf16 matrix-core fragments of the first conv (K = (dy, dx, c) padded to 32), b1p padded to a multiple of 32.  w2frag: bf16 matrix-core fragments, fragment (mt, ks) with ks = tap (KC / 16) + cg (KC = CM rounded up to 16):
+    lane (h, m), element j = w2[32 mt + m][16 cg + 8 h + j][tap] (zeros past CO / CM).  b2p: zero padded to a multiple of 32."""
+    cm, co = w1.shape[0], w2.shape[0]
+    if tuple(w1.shape) != (cm, 3, 3, 3) or tuple(w2.shape) != (co, cm, 3, 3):
+        raise ValueError(f"stem weights must be (CM, 3, 3, 3) and (CO, CM, 3, 3), got {tuple(w1.shape)} and {tuple(w2.shape)}")
+    dev = w1.device
+    kc, mt = -(-cm // 16) * 16, -(-co // 32)
+    m1 = -(-cm // 32)
+    # first conv: K = (dy, dx, c) = 27 padded to 32; fragment (m1, ks), lane (h, m), element j = w1[32 m1 + m][k = 16 ks + 8 h + j]
+    w1k = torch.zeros(32 * m1, 32, dtype=torch.bfloat16, device=dev)
+    w1k[:cm, :27] = w1.detach().permute(0, 2, 3, 1).reshape(cm, 27).to(torch.bfloat16)                # (CM, dy, dx, c)
+    w1p = w1k.view(m1, 32, 2, 2, 8).permute(0, 2, 3, 1, 4).reshape(-1).contiguous()                   # [m1, ks, h, m, j]
+    b1p = torch.zeros(32 * m1, dtype=torch.float32, device=dev)
+    if b1 is not None:
+        b1p[:cm] = b1.detach().float()
+    wp = torch.zeros(32 * mt, kc, 9, dtype=torch.bfloat16, device=dev)
+    wp[:co, :cm] = w2.detach().reshape(co, cm, 9).to(torch.bfloat16)
+    f = wp.view(mt, 32, kc // 16, 2, 8, 9).permute(0, 5, 2, 3, 1, 4)                         # [mt, tap, cg, h, m, j]
+    w2frag = f.reshape(-1).contiguous()
+    b2p = torch.zeros(32 * mt, dtype=torch.float32, device=dev)
+    if b2 is not None:
+        b2p[:co] = b2.detach().float()
+    return w1p, b1p, w2frag, b2p
+
+
+def stem(x, w1p, b1p, w2frag, b2p, cm, co):
+    """RecNextStem.forward in one launch (rcx_stem_fwd; model/recnext.py:134-146): x N x 3 x H x W channels_last bf16 -> N x CO x ceil(H/4) x ceil(W/4)."""
+    x = _nhwc(x, "x")
+    n, c, h, w = x.shape
+    if c != 3:
+        raise ValueError(f"the stem takes 3 input channels, got {c}")
+    h2, w2_ = -(-(-(-h // 2)) // 2), -(-(-(-w // 2)) // 2)
+    y = _empty_nhwc(n, co, h2, w2_, x.dtype, x.device)
+    with _on(x.device):
+        rc = _lib.load().rcx_stem_fwd(x.data_ptr(), y.data_ptr(), w1p.data_ptr(), b1p.data_ptr(), w2frag.data_ptr(), b2p.data_ptr(), n, h, w, cm, co, _dt(x), _stream(x.device))
+    _lib.check(rc, "rcx_stem_fwd")
+    return y
+
+
 def linear_attention_core_backward(qpre, kpre, v, gout, heads):
     """Gradients of linear_attention_core with respect to qpre, kpre (B, n, C) and v (N x C x h x w); dL/dpe = gout."""
     v = _nhwc(v, "v")

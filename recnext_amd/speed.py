@@ -25,7 +25,7 @@ DTYPES = {"fp32": torch.float32, "f32": torch.float32, "bf16": torch.bfloat16, "
 
 
 def build_inference_model(name, device, dtype=torch.bfloat16, token_mixer=None, seed=0, fold_mixer_norm=True,
-                          hip_downsample=True, linear_pointwise=True, pad_hidden=True, fused_mlp=True):
+                          hip_downsample=True, linear_pointwise=True, pad_hidden=True, fused_mlp=True, fused_stem=True):
     """create_model -> replace_batchnorm -> device/eval, as speed_gpu.py:47-50 (plus dtype + channels_last).
 
     ``fold_mixer_norm`` additionally absorbs the BatchNorm after each HIP token mixer into the mixer's last
@@ -33,6 +33,7 @@ def build_inference_model(name, device, dtype=torch.bfloat16, token_mixer=None, 
     runs the three strided depthwise Downsample convs (+ their BatchNorm) on the HIP kernels as well.  ``pad_hidden`` lets the
     channel mixers' GEMMs run at a zero-padded hidden width (``models.pad_mlp_hidden``: RecNeXt-A's 120 / 240 / 480 -> 128 / 256 / 512).
     ``fused_mlp`` (bf16): ``x + channel_mixer(.)`` of the blocks rcx_channel_mlp_fwd has a kernel for as one HIP launch (``models.use_fused_mlp``).
+    ``fused_stem`` (bf16): the stem's two convs and GELU as one HIP launch (``models.use_fused_stem``).
     """
     torch.manual_seed(seed)
     net = models.create_model(name, num_classes=1000, token_mixer=token_mixer)
@@ -51,6 +52,8 @@ def build_inference_model(name, device, dtype=torch.bfloat16, token_mixer=None, 
                 models.pad_mlp_hidden(net)
             if fused_mlp and dtype == torch.bfloat16:
                 models.use_fused_mlp(net)
+        if fused_stem and dtype == torch.bfloat16:
+            models.use_fused_stem(net)
     return net
 
 
