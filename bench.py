@@ -387,6 +387,9 @@ def main():
     gemm_tuned = tune_gemms(net, x)                       # before the warm-up steps, outside the timed region
     # how many blocks run their channel mixer + residual as the fused HIP launch AT THIS INPUT (decided per call from the tensor's shape and dtype)
     n_fused_mlp, n_blocks = count_fused_channel_mixers(net, x)
+    _fs = getattr(net, "stem", None)
+    _fs = _fs.__dict__.get("_fused_stem") if _fs is not None else None
+    fused_stem = _fs is not None and _fs.supported(x)
     copy_gbs = measure_copy_ceiling(torch, device) if rank == 0 else None
     plan_of = None
     with torch.no_grad():
@@ -448,6 +451,7 @@ def main():
                                    f"batch {args.batch}/GPU, random-init weights, HIP token mixers"
                                    + (f", HIP channel mixers on {n_fused_mlp} of {n_blocks} blocks (x + mlp in one launch where rcx_channel_mlp_fwd has a kernel "
                                       "for the shape; the rest: GEMM library)" if n_fused_mlp else "")
+                                   + (", HIP stem (one launch)" if fused_stem else "")
                                    + (", GEMM solutions picked by TunableOp" if gemm_tuned else ""),
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world} (batch-sharded replicas, no collective in the timed region)"},

@@ -33,11 +33,12 @@ k_stem(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const u32x4q* __res
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int KS = 9 * (KC / 16), NF = MT * KS, PIX = 2 * KC + 16, R = 17;      // k-steps, W2 fragments, bytes per pixel of the h1 tile (16 of padding: banks)
     constexpr int M1 = (CM + 31) / 32, XR = 35, XE = 105, XP = 216;                  // x tile: 35 rows of 35 pixels x 3 channels = 105 bf16 (210 bytes), pitch 216
+    constexpr int NPT = (R * R + 31) / 32;                                           // pixel tiles of the first product; the h1 tile holds 32 NPT pixels, the x tile 37 rows: no guarded LDS writes
     const u32x4q* const Lf = reinterpret_cast<const u32x4q*>(lds_raw);               // [NF] W2 fragments, then [2 M1] W1 fragments
     const u32x4q* const Lf1 = Lf + NF * 64;
     unsigned char* const Lh = lds_raw + (size_t)(NF + 2 * M1) * 1024;                // h1 tile [17 x 17][PIX]
-    unsigned char* const Lx = Lh + (size_t)R * R * PIX;                              // x tile [35][XP]
-    float* const Lb1 = reinterpret_cast<float*>(Lx + (size_t)XR * XP);              // [32 M1] then b2 [32 MT]
+    unsigned char* const Lx = Lh + (size_t)32 * NPT * PIX;                           // x tile [37][XP]
+    float* const Lb1 = reinterpret_cast<float*>(Lx + (size_t)(XR + 2) * XP);        // [32 M1] then b2 [32 MT]
     float* const Lb2 = Lb1 + 32 * M1;
     {                                                                                // the weights: once per workgroup (it walks tiles blockIdx.x, + gridDim.x, ...)
         u32x4q* Lw = reinterpret_cast<u32x4q*>(lds_raw);
@@ -51,17 +52,26 @@ k_stem(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const u32x4q* __res
     // the x tile of a tile: rows 32 ty - 3 + i, pixels 32 tx - 3 + j of the image (zeros outside it: the first conv's padding); consecutive lanes = consecutive
     // elements; a thread's XN elements are requested a tile ahead (during the previous tile's second product) and written to LDS at the top of the tile
     constexpr int XN = (XR * XE + 255) / 256;
+    static_assert(XN * 256 <= (XR + 2) * XE, "the two spare x-tile rows take the last round's overshoot");
+    unsigned xgo[XN], xlo[XN], xij[XN];               // element u of this thread: offset within the image relative to the tile's first element, LDS offset, (row, pixel) of the tile
+#pragma unroll
+    for (int u = 0; u < XN; ++u) {
+        const int e = threadIdx.x + 256 * u, i = e / XE, q = e - i * XE, px = q / 3;
+        xgo[u] = ((unsigned)(i * W + px) * 3u + (unsigned)(q - 3 * px)) * 2u;
+        xlo[u] = (unsigned)(i * XP + 2 * q);
+        xij[u] = (unsigned)i | ((unsigned)px << 8) | (e < XR * XE ? 0u : 0x10000u);
+    }
     bf16_t xq[XN];
     auto request_x = [&](int t) {
         const int nn = t / (tiles_x * tiles_y), trr = t - nn * tiles_x * tiles_y, tyy = trr / tiles_x, txx = trr - tyy * tiles_x;
         const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)nn * H * W * 3), 0, xbytes, 0x00020000);
         const int y0 = 32 * tyy - 3, x0 = 32 * txx - 3;
+        const unsigned base = (unsigned)((y0 * W + x0) * 6);                       // (may wrap below zero: only added to offsets of elements inside the image)
 #pragma unroll
         for (int u = 0; u < XN; ++u) {
-            const int e = threadIdx.x + 256 * u, i = e / XE, q = e - i * XE, px = q / 3, yy = y0 + i, xx = x0 + px;
-            const bool ok = e < XR * XE && yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const unsigned off = ok ? ((unsigned)(yy * W + xx) * 3u + (unsigned)(q - 3 * px)) * 2u : 0x80000000u;      // outside the image: past the buffer, reads 0
-            xq[u] = (bf16_t)__builtin_amdgcn_raw_buffer_load_b16(xsrc, (int)off, 0, 0);
+            const int yy = y0 + (int)(xij[u] & 0xff), xx = x0 + (int)((xij[u] >> 8) & 0xff);
+            const bool ok = xij[u] < 0x10000u && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            xq[u] = (bf16_t)__builtin_amdgcn_raw_buffer_load_b16(xsrc, (int)(ok ? base + xgo[u] : 0x80000000u), 0, 0);      // outside the image: past the buffer, reads 0
         }
     };
     const int ntiles = N * tiles_x * tiles_y;
@@ -69,10 +79,7 @@ k_stem(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const u32x4q* __res
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int n = tile / (tiles_x * tiles_y), tr = tile - n * tiles_x * tiles_y, ty = tr / tiles_x, tx = tr - ty * tiles_x;
 #pragma unroll
-    for (int u = 0; u < XN; ++u) {
-        const int e = threadIdx.x + 256 * u, i = e / XE, q = e - i * XE;
-        if (e < XR * XE) *reinterpret_cast<bf16_t*>(Lx + i * XP + 2 * q) = xq[u];
-    }
+    for (int u = 0; u < XN; ++u) *reinterpret_cast<bf16_t*>(Lx + xlo[u]) = xq[u];
     __syncthreads();                                   // the x tile (and, the first time, the weights) is in LDS; every wave has left the previous tile's second product
 
     // ---- A. the intermediate's 17 x 17 pixels (rows 16 ty - 1 + i, columns 16 tx - 1 + j) on the matrix cores: D (32 channels x 32 pixels) = W1 (channel x 27 taps,
@@ -83,9 +90,9 @@ k_stem(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const u32x4q* __res
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int kk = 16 * ks + 8 * h + jj, dy = (kk * 57) >> 9;
-            koff[ks][jj] = kk < 27 ? (unsigned)(dy * XP + 2 * (kk - 9 * dy)) : 0xffffffffu;
+            koff[ks][jj] = kk < 27 ? (unsigned)(dy * XP + 2 * (kk - 9 * dy)) : 0u;         // (k = 27 .. 31: zero weights; any input of the pixel's own window will do)
         }
-    for (int pt = wave; pt < (R * R + 31) / 32; pt += 4) {
+    for (int pt = wave; pt < NPT; pt += 4) {
         const int p = 32 * pt + r, pc = p < R * R ? p : R * R - 1, i = pc / R, j = pc - i * R;
         const int r1 = 16 * ty - 1 + i, c1 = 16 * tx - 1 + j;
         const bool inside = p < R * R && r1 >= 0 && r1 < H1 && c1 >= 0 && c1 < W1;
@@ -95,7 +102,7 @@ k_stem(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const u32x4q* __res
         for (int ks = 0; ks < 2; ++ks) {
             unsigned short v[8];
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) v[jj] = koff[ks][jj] != 0xffffffffu ? *reinterpret_cast<const unsigned short*>(xp + koff[ks][jj]) : (unsigned short)0;
+            for (int jj = 0; jj < 8; ++jj) v[jj] = *reinterpret_cast<const unsigned short*>(xp + koff[ks][jj]);
             const u32x4q pk = {(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16), (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
             bfr[ks] = __builtin_bit_cast(bf16x8, pk);
         }
@@ -110,12 +117,12 @@ k_stem(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const u32x4q* __res
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c0 = 32 * m1 + 8 * g + 4 * h;
-                if (c0 < KC) {
+                if (32 * m1 + 8 * g < KC) {
                     const f32x4q bb = *reinterpret_cast<const f32x4q*>(Lb1 + c0);
                     const gelu_f32x2 a = gelu2(gelu_f32x2{d[4 * g] + bb.x, d[4 * g + 1] + bb.y}), b = gelu2(gelu_f32x2{d[4 * g + 2] + bb.z, d[4 * g + 3] + bb.w});
                     bf16x4 o;
                     o[0] = (__bf16)(inside ? a.x : 0.f); o[1] = (__bf16)(inside ? a.y : 0.f); o[2] = (__bf16)(inside ? b.x : 0.f); o[3] = (__bf16)(inside ? b.y : 0.f);
-                    if (p < R * R) *reinterpret_cast<u32x2q*>(Lh + (size_t)p * PIX + 2 * c0) = __builtin_bit_cast(u32x2q, o);
+                    *reinterpret_cast<u32x2q*>(Lh + (size_t)p * PIX + 2 * c0) = __builtin_bit_cast(u32x2q, o);
                 }
             }
         }
@@ -189,7 +196,7 @@ static hipError_t launch_stem(const void* x, void* y, const void* w1, const floa
     const int H1 = (H + 1) / 2, W1 = (W + 1) / 2, H2 = (H1 + 1) / 2, W2 = (W1 + 1) / 2, tx = (W2 + 7) / 8, ty = (H2 + 7) / 8;
     constexpr int KS = 9 * (KC / 16), PIX = 2 * KC + 16;
     constexpr int M1 = (CM + 31) / 32;
-    const size_t lds = (size_t)(MT * KS + 2 * M1) * 1024 + (size_t)17 * 17 * PIX + (size_t)35 * 216 + sizeof(float) * 32 * (M1 + MT);
+    const size_t lds = (size_t)(MT * KS + 2 * M1) * 1024 + (size_t)320 * PIX + (size_t)37 * 216 + sizeof(float) * 32 * (M1 + MT);
     const long long ntiles = (long long)N * tx * ty;
     if (ntiles > 0x7fffffffLL || lds > 160 * 1024) return hipErrorInvalidConfiguration;
     const long long per_cu = (long long)(160 * 1024 / lds) > 0 ? (long long)(160 * 1024 / lds) : 1;
