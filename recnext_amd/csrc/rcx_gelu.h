@@ -26,4 +26,32 @@ __device__ __forceinline__ gelu_f32x2 gelu2(gelu_f32x2 v)
     return __builtin_elementwise_fma(hv, e, hv);
 }
 
+// The same on N pairs in lockstep: every step of the polynomial is issued for all N pairs before the next one, so that a wave alone on its SIMD (the streamed channel-mixer
+// kernels) does not wait out each dependent packed op's latency -- the compiler keeps the N chains of gelu2() calls one after the other.
+template <int N>
+__device__ __forceinline__ void gelu2_batch(gelu_f32x2 (&v)[N])
+{
+    constexpr float A = 2.8f;
+    gelu_f32x2 xc[N], s[N], q[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const gelu_f32x2 x = v[i] * 0.70710678f;
+        xc[i] = gelu_f32x2{__builtin_amdgcn_fmed3f(x.x, -A, A), __builtin_amdgcn_fmed3f(x.y, -A, A)};
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) s[i] = xc[i] * xc[i];
+    constexpr float C[8] = {1.127931833e+00f, -3.734020293e-01f, 1.079412624e-01f, -2.280939557e-02f, 3.352143336e-03f, -3.191421274e-04f, 1.744569090e-05f, -4.114877470e-07f};
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = __builtin_elementwise_fma(gelu_f32x2{C[7], C[7]}, s[i], gelu_f32x2{C[6], C[6]});
+#pragma unroll
+    for (int k = 5; k >= 0; --k)
+#pragma unroll
+        for (int i = 0; i < N; ++i) q[i] = __builtin_elementwise_fma(q[i], s[i], gelu_f32x2{C[k], C[k]});
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const gelu_f32x2 e = xc[i] * q[i], hv = v[i] * 0.5f;
+        v[i] = __builtin_elementwise_fma(hv, e, hv);
+    }
+}
+
 }  // namespace rcx

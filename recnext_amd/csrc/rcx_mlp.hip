@@ -65,12 +65,24 @@ __device__ __forceinline__ void hidden_tile_ring(const u32x4q* Lc, const float* 
 #pragma unroll
     for (int f = 0; f < R2; ++f) ring[f] = Lc[(KS1 + 2 * (f % CT) + f / CT) * 64 + lane];
     bf16x8 hb[2];
+    gelu_f32x2 gv[8];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const f32x4q bb = *reinterpret_cast<const f32x4q*>(b1t + 8 * g + 4 * h);
-        const f32x2q a = gelu2(f32x2q{d1[4 * g] + bb.x, d1[4 * g + 1] + bb.y}), b = gelu2(f32x2q{d1[4 * g + 2] + bb.z, d1[4 * g + 3] + bb.w});
-        hb[g >> 1][4 * (g & 1) + 0] = (__bf16)a.x; hb[g >> 1][4 * (g & 1) + 1] = (__bf16)a.y;
-        hb[g >> 1][4 * (g & 1) + 2] = (__bf16)b.x; hb[g >> 1][4 * (g & 1) + 3] = (__bf16)b.y;
+        gv[2 * g] = gelu_f32x2{d1[4 * g] + bb.x, d1[4 * g + 1] + bb.y};
+        gv[2 * g + 1] = gelu_f32x2{d1[4 * g + 2] + bb.z, d1[4 * g + 3] + bb.w};
+    }
+    {                                                 // the tile's 16 values, four pairs in lockstep at a time (eight: the kernels at their register limit spill)
+        gelu_f32x2 ga[4] = {gv[0], gv[1], gv[2], gv[3]}, gb[4] = {gv[4], gv[5], gv[6], gv[7]};
+        gelu2_batch<4>(ga);
+        gelu2_batch<4>(gb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { gv[i] = ga[i]; gv[4 + i] = gb[i]; }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        hb[g >> 1][4 * (g & 1) + 0] = (__bf16)gv[2 * g].x; hb[g >> 1][4 * (g & 1) + 1] = (__bf16)gv[2 * g].y;
+        hb[g >> 1][4 * (g & 1) + 2] = (__bf16)gv[2 * g + 1].x; hb[g >> 1][4 * (g & 1) + 3] = (__bf16)gv[2 * g + 1].y;
     }
 #pragma unroll
     for (int f = 0; f < N2; ++f) {
