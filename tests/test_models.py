@@ -259,6 +259,38 @@ def test_use_fused_mlp_marks_the_blocks_and_keeps_the_library_path_on_cpu():
         assert (net(x) - ref).abs().max() < 1e-5
 
 
+def test_use_fused_stem_marks_the_stem_and_keeps_the_library_path_on_cpu():
+    """use_fused_stem only attaches the fused path (bf16 on a GPU, decided per call); on the CPU the forward is unchanged; pack_stem's fragment layout."""
+    from recnext_amd import ops
+    torch.manual_seed(0)
+    net = models.create_model("recnext_m0", token_mixer=eager_token_mixer("m")).eval()
+    x = torch.randn(1, 3, 64, 64)
+    with torch.no_grad():
+        assert models.use_fused_stem(net) == 0                     # ConvNorm pairs: nothing to fuse before replace_batchnorm
+        models.replace_batchnorm(net)
+        ref = net(x)
+        keys = list(net.state_dict())
+        assert models.use_fused_stem(net) == 1 and models.use_fused_stem(net) == 0
+        assert list(net.state_dict()) == keys and not net.stem._fused_stem.supported(x)
+        assert (net(x) - ref).abs().max() < 1e-6
+    cm, co = 20, 40
+    w1 = torch.arange(cm * 27, dtype=torch.float32).reshape(cm, 3, 3, 3) % 127
+    w2 = (torch.arange(co * cm * 9, dtype=torch.float32).reshape(co, cm, 3, 3) * 3) % 113
+    w1p, b1p, w2f, b2p = ops.pack_stem(w1, torch.arange(cm, dtype=torch.float32), w2, -torch.arange(co, dtype=torch.float32))
+    assert w1p.numel() == 2 * 512 and b1p.numel() == 32 and w2f.numel() == 2 * 18 * 512 and b2p.numel() == 64
+    f1 = w1p.float().view(2, 64, 8)                                 # [ks][lane (h, m)][j] = w1[m][k = 16 ks + 8 h + j], k = (dy 3 + dx) 3 + c
+    for (ks, lane, j) in [(0, 0, 0), (1, 37, 2), (1, 45, 5), (0, 19, 7), (1, 63, 7)]:
+        m, k = lane % 32, 16 * ks + 8 * (lane // 32) + j
+        want = w1[m, k % 3, k // 9, (k // 3) % 3] if m < cm and k < 27 else 0
+        assert f1[ks, lane, j] == want
+    f2 = w2f.float().view(2, 18, 64, 8)                             # [mt][ks = tap 2 + cg][lane][j] = w2[32 mt + m][16 cg + 8 h + j][tap]
+    for (mt, ks, lane, j) in [(0, 0, 0, 0), (1, 17, 39, 3), (0, 9, 33, 4), (1, 4, 7, 7), (0, 5, 50, 6)]:
+        m, tap, ch = 32 * mt + lane % 32, ks // 2, 16 * (ks % 2) + 8 * (lane // 32) + j
+        want = w2[m, ch, tap // 3, tap % 3] if m < co and ch < cm else 0
+        assert f2[mt, ks, lane, j] == want
+    assert torch.equal(b2p[:co], -torch.arange(co, dtype=torch.float32)) and b2p[co:].abs().sum() == 0
+
+
 def test_channel_mlp_pack_layout_cpu():
     """pack_channel_mlp: every weight lands in the fragment slot the kernel's lane reads it from (rcx_mlp.hip), padding is zeros."""
     from recnext_amd import ops
