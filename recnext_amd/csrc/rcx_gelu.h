@@ -54,4 +54,26 @@ __device__ __forceinline__ void gelu2_batch(gelu_f32x2 (&v)[N])
     }
 }
 
+// TWICE the GELU, v (1 + erf(v / sqrt 2)), on N pairs in lockstep, with the 1 / sqrt 2 folded into the coefficients (erf(v / sqrt 2) ~ vc Q'(vc^2), vc = v clamped to
+// +-2.8 sqrt 2) and the final 0.5 left to the consumer (the channel mixer's W2 pack is stored halved, which is exact in bf16): 12 vector ops per pair instead of 15.
+template <int N>
+__device__ __forceinline__ void gelu2x_batch(gelu_f32x2 (&v)[N])
+{
+    constexpr float A = 3.9597979f;
+    gelu_f32x2 vc[N], s[N], q[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) vc[i] = gelu_f32x2{__builtin_amdgcn_fmed3f(v[i].x, -A, A), __builtin_amdgcn_fmed3f(v[i].y, -A, A)};
+#pragma unroll
+    for (int i = 0; i < N; ++i) s[i] = vc[i] * vc[i];
+    constexpr float C[8] = {7.975682616e-01f, -1.320175529e-01f, 1.908149943e-02f, -2.016084734e-03f, 1.481452055e-04f, -7.052111414e-06f, 1.927494679e-07f, -2.273170097e-09f};
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = __builtin_elementwise_fma(gelu_f32x2{C[7], C[7]}, s[i], gelu_f32x2{C[6], C[6]});
+#pragma unroll
+    for (int k = 5; k >= 0; --k)
+#pragma unroll
+        for (int i = 0; i < N; ++i) q[i] = __builtin_elementwise_fma(q[i], s[i], gelu_f32x2{C[k], C[k]});
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __builtin_elementwise_fma(v[i], vc[i] * q[i], v[i]);
+}
+
 }  // namespace rcx

@@ -8,7 +8,7 @@
 // ONE WAVE = 32 tokens at a time, the hidden layer streamed through its registers 32 units at a time, never in memory:
 //   D1  (32 hidden units x 32 tokens) = W1[32 ht ..][:] z^T      v_mfma_f32_32x32x16_bf16: A = a W1 fragment (LDS), B = the tokens' channels (registers, loaded
 //                                                               once per tile straight from memory: 16 bytes per lane and k-step)
-//   h   = gelu(D1 + b1) in float32, rounded to bf16              the accumulator layout (token on the lane, units in the registers) IS the B operand of ...
+//   h   = 2 gelu(D1 + b1) in float32, rounded to bf16 (W2 is packed halved: exact)   the accumulator layout (token on the lane, units in the registers) IS the B operand of ...
 //   D2 += W2[:][32 ht ..] h                                      ... the second product, with W2's columns stored in the order the registers imply
 //   y   = D2 + b2 + x                                            8-byte loads / stores of four channels per lane (token on the lane)
 // The weights are ready-made fragments (one conflict-free 16-byte LDS read per lane and product), packed once on the host (ops.pack_channel_mlp), hidden tile by
@@ -72,10 +72,11 @@ __device__ __forceinline__ void hidden_tile_ring(const u32x4q* Lc, const float* 
         gv[2 * g] = gelu_f32x2{d1[4 * g] + bb.x, d1[4 * g + 1] + bb.y};
         gv[2 * g + 1] = gelu_f32x2{d1[4 * g + 2] + bb.z, d1[4 * g + 3] + bb.w};
     }
-    {                                                 // the tile's 16 values, four pairs in lockstep at a time (eight: the kernels at their register limit spill)
+    {                                                 // the tile's 16 values, four pairs in lockstep at a time (eight: the kernels at their register limit spill); TWICE
+                                                      // the GELU -- W2 is stored halved (ops.pack_channel_mlp)
         gelu_f32x2 ga[4] = {gv[0], gv[1], gv[2], gv[3]}, gb[4] = {gv[4], gv[5], gv[6], gv[7]};
-        gelu2_batch<4>(ga);
-        gelu2_batch<4>(gb);
+        gelu2x_batch<4>(ga);
+        gelu2x_batch<4>(gb);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { gv[i] = ga[i]; gv[4 + i] = gb[i]; }
     }

@@ -475,7 +475,7 @@ def pack_channel_mlp(w1, b1, w2, b2, hidden_to=None):
     The hidden layer is padded with zero units to H = a multiple of 32, C to whole k-steps / output tiles with zero columns / rows; the weights are rounded to
     bf16 (they already are bf16 in a bf16 model) and laid out fragment by fragment in the order the kernel's lanes read them (rcx_mlp.hip):
       W1 fragment (ht, ks), lane (h, m), element j = W1[32 ht + m][16 ks + 8 h + j]
-      W2 fragment (ht, ct, q), lane (h, m), element j = W2[32 ct + m][32 ht + unit(8 q + j, h)]      unit = _mlp_acc_unit: the order the first product leaves in the registers
+      W2 fragment (ht, ct, q), lane (h, m), element j = 0.5 W2[32 ct + m][32 ht + unit(8 q + j, h)]      unit = _mlp_acc_unit: the order the first product leaves in the registers
     stored hidden tile by hidden tile: [W1 (ht, 0 .. KS1-1)] [W2 (ht, ct, q) for ct, q] for ht = 0 .. H/32 - 1, 1 KB (64 lanes x 8 bf16) per fragment.
     """
     w1 = w1.detach().reshape(w1.shape[0], -1)
@@ -494,7 +494,7 @@ def pack_channel_mlp(w1, b1, w2, b2, hidden_to=None):
     w1p[:h0, :c] = w1.to(torch.bfloat16)
     f1 = w1p.view(ht, 32, ks1, 2, 8).permute(0, 2, 3, 1, 4)                    # [ht, ks, h, m, j]
     w2p = torch.zeros(32 * ct, 32 * ht, dtype=torch.bfloat16, device=dev)
-    w2p[:c, :h0] = w2.to(torch.bfloat16)
+    w2p[:c, :h0] = (0.5 * w2.float()).to(torch.bfloat16)           # the kernel's hidden activations are 2 gelu(.) (rcx_gelu.h gelu2x_batch); halving a bf16 is exact
     unit = torch.tensor([[[_mlp_acc_unit(8 * q + j, h) for j in range(8)] for h in range(2)] for q in range(2)], device=dev)      # [q, h, j]
     f2 = w2p.view(ct, 32, ht, 32)[:, :, :, unit]                               # [ct, m, ht, q, h, j]
     f2 = f2.permute(0, 2, 3, 4, 1, 5)                                          # [ct, ht, q, h, m, j]

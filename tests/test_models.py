@@ -307,7 +307,7 @@ def test_channel_mlp_pack_layout_cpu():
         assert f[t * (ks1 + 2 * ct) + ks, lane, j] == (w1[row, col] if row < h0 and col < c else 0)
     for (tc, t, q, lane, j) in [(0, 0, 0, 0, 0), (1, 2, 1, 40, 6), (0, 1, 1, 33, 2), (1, 0, 0, 31, 7)]:
         row, col = 32 * tc + lane % 32, 32 * t + ops._mlp_acc_unit(8 * q + j, lane // 32)
-        assert f[t * (ks1 + 2 * ct) + ks1 + 2 * tc + q, lane, j] == (w2[row, col] if row < c and col < h0 else 0)
+        assert f[t * (ks1 + 2 * ct) + ks1 + 2 * tc + q, lane, j] == (0.5 * w2[row, col] if row < c and col < h0 else 0)      # stored halved: the kernel's hidden layer is 2 gelu(.)
     assert torch.equal(bias[:h0], b1) and bias[h0:96].abs().sum() == 0 and torch.equal(bias[96:96 + c], b2) and bias[96 + c:].abs().sum() == 0
 
 
