@@ -3,7 +3,8 @@
 
   rcx_recattn_qkcore_fwd        any plane h x w <= 48 x 48, heads in {1, 2, 4, 8, 16} (where rcx_recattn_qkcore_launches says 1 or 2)
   rcx_recattn_down_qkcore_fwd   14 x 14 / 7 x 7 planes
-  rcx_recattn2d_fwd             14 x 14 / 7 x 7 planes, up to 8 heads, nearest
+  rcx_recattn2d_fwd             14 x 14 (up to 8 heads) / 7 x 7 (up to 16) planes, nearest
+Head dimension 32, or (half of the cases with more than one head) 4 .. 28.
 Prints the worst err / tol (tol = 1e-2 + 1e-2 |ref|) per entry point and fails on the first case over 1.
 """
 import os
@@ -43,7 +44,8 @@ def check(name, got, ref, what):
 
 for i in range(CASES):
     heads = int(rng.choice([1, 2, 4, 8, 16]))
-    c = 32 * heads
+    d_head = 32 if heads == 1 or rng.random() < 0.5 else int(rng.choice([4, 8, 12, 16, 20, 24, 28]))      # round 5: heads padded to 32 inside the kernels
+    c = d_head * heads
     h, w = (int(v) for v in rng.integers(1, 49, 2))
     if rng.random() < 0.3:
         h, w = (int(v) for v in rng.integers(1, 10, 2))            # short planes more often
@@ -69,7 +71,8 @@ for i in range(CASES):
 for i in range(CASES // 3):
     hw = int(rng.choice([14, 7]))
     heads = int(rng.choice([1, 2, 4, 8] + ([16] if hw == 7 else [])))
-    c = 32 * heads
+    d_head = 32 if heads == 1 or rng.random() < 0.5 else int(rng.choice([8, 16, 20, 24, 28]))
+    c = d_head * heads
     b = int(rng.integers(1, 5))
     xdt = torch.bfloat16 if rng.random() < 0.6 else torch.float16
     rnd = bf if xdt == torch.bfloat16 else (lambda a: a.astype(np.float16).astype(np.float32))
@@ -94,6 +97,6 @@ for i in range(CASES // 3):
         check("unit", got, ref, (b, c, heads, hw, str(xdt)))
         counts["unit"] += 1
     else:
-        assert heads == 16
+        raise SystemExit(f"no one-launch unit for {(b, c, heads, hw)}")          # round 5: 16 heads too (two per wave)
 print("cases", counts)
 print("worst err/tol", {k: round(v, 3) for k, v in worst.items()})
