@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RCX_ABI_VERSION 6
+#define RCX_ABI_VERSION 7
 
 enum { RCX_DTYPE_F32 = 0, RCX_DTYPE_BF16 = 1, RCX_DTYPE_F16 = 2 };   /* F16: the reference's autocast dtype (engine.py:48) */
 enum { RCX_MODE_BILINEAR = 0, RCX_MODE_NEAREST = 1 };   /* F.interpolate(mode=...), model/recnext.py:33 */
@@ -103,18 +103,29 @@ int rcx_launch_events_pending(void);
  *   rcx_recconv2d_fwd_train   same contract as rcx_recconv2d_fwd (the blocks of RecNeXt at 224x224 run their inference launch, which then also
  *                             writes the pyramid; other shapes the per-level schedule); `saved` must hold
  *                             rcx_recconv2d_train_saved_bytes() and stay untouched until rcx_recconv2d_bwd has run.
- *   rcx_recconv2d_bwd         gy: N x H x W x C float32 (dL/dy);  gx: N x H x W x C of `dtype` (dL/dx);
+ *   rcx_recconv2d_bwd         gy: N x H x W x C of `gy_dtype` (dL/dy): float32 always works; the block's own 16-bit `dtype` -- dL/dy exactly as
+ *                             autograd hands it over under autocast, no float32 copy -- where rcx_recconv2d_bwd_gy_dtype() returns it (the
+ *                             tiled 56x56 / level 4 and 28x28 / level 3 backward);  gx: N x H x W x C of `dtype` (dL/dx);
  *                             wpack_flipped: wpack with every k x k tap block rotated by 180 degrees (transpose convs);
  *                             gwpack: (level+2, k, k, C) float32 = dL/d[down, convs[0..level]] in the packed layout, the
  *                             shared down weight accumulated over all levels (model/recnext.py:21,28);
- *                             gbpack: (level+2, C) float32 or NULL.  Needs C % 4 == 0.  Deterministic (no atomics).
+ *                             gbpack: (level+2, C) float32 or NULL.
+ *                             gw_out / gb_out (HOST arrays of level+2 DEVICE pointers, or NULL): if gw_out is given the gradients leave in the
+ *                             PARAMETERS' own layout and type instead -- gw_out[i] (C,1,k,k) contiguous, gb_out[i] (C) (gb_out may be NULL when
+ *                             the block has no bias), elements of `grad_dtype` -- written by the final reduction itself (no unpack launch, no
+ *                             dtype copy); gwpack / gbpack are then not written and may be NULL.
+ *                             Needs C % 4 == 0.  Deterministic (no atomics).
+ *   rcx_recconv2d_bwd_gy_dtype  the element type rcx_recconv2d_bwd wants gy in for this problem: `dtype` where a 16-bit gy is read as it is,
+ *                             else RCX_DTYPE_F32.
  */
 size_t rcx_recconv2d_train_saved_bytes(int N, int C, int H, int W, int level, int k);
 size_t rcx_recconv2d_bwd_workspace_bytes(int N, int C, int H, int W, int level, int k);
 int rcx_recconv2d_fwd_train(const void* x, void* y, const float* wpack, const float* bpack, void* saved, size_t saved_bytes,
                             int N, int C, int H, int W, int level, int k, int mode, int dtype, void* stream);
-int rcx_recconv2d_bwd(const void* x, const float* gy, const float* wpack, const float* wpack_flipped, const void* saved,
-                      void* gx, float* gwpack, float* gbpack, void* workspace, size_t workspace_bytes,
+int rcx_recconv2d_bwd_gy_dtype(int N, int C, int H, int W, int level, int k, int dtype);
+int rcx_recconv2d_bwd(const void* x, const void* gy, int gy_dtype, const float* wpack, const float* wpack_flipped, const void* saved,
+                      void* gx, float* gwpack, float* gbpack, void* const* gw_out, void* const* gb_out, int grad_dtype,
+                      void* workspace, size_t workspace_bytes,
                       int N, int C, int H, int W, int level, int k, int mode, int dtype, void* stream);
 
 /*

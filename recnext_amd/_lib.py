@@ -15,7 +15,7 @@ MODE_BILINEAR, MODE_NEAREST = 0, 1
 MODES = {"bilinear": MODE_BILINEAR, "nearest": MODE_NEAREST}
 MAX_LEVEL = 8
 ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE = -1, -2, -3     # include/recnext_amd.h (rcx_status); positive = hipError_t
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 
@@ -37,7 +37,8 @@ SIGNATURES = {
     "rcx_recconv2d_train_saved_bytes": (_sz, [_i] * 6),
     "rcx_recconv2d_bwd_workspace_bytes": (_sz, [_i] * 6),
     "rcx_recconv2d_fwd_train": (_i, [_vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 8 + [_vp]),
-    "rcx_recconv2d_bwd": (_i, [_vp] * 9 + [_sz] + [_i] * 8 + [_vp]),
+    "rcx_recconv2d_bwd_gy_dtype": (_i, [_i] * 7),
+    "rcx_recconv2d_bwd": (_i, [_vp, _vp, _i] + [_vp] * 8 + [_i, _vp, _sz] + [_i] * 8 + [_vp]),
     "rcx_dwconv2d_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "rcx_dwconv2d_mult2_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
     "rcx_upadd_dwconv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),

@@ -521,12 +521,36 @@ int rcx_recconv2d_fwd_train(const void* x, void* y, const float* wpack, const fl
     return e == hipSuccess ? 0 : hip_fail(e, "train fwd: final conv");
 }
 
-int rcx_recconv2d_bwd(const void* x, const float* gy, const float* wpack, const float* wpack_flipped, const void* saved,
-                      void* gx, float* gwpack, float* gbpack, void* workspace, size_t workspace_bytes,
+// the fine levels above a 14 x 14 / level 2 tail run on the tiled adjoint kernels (rcx_cptbwd.hip) when every one of their planes is 56 x 56 or 28 x 28:
+// the number of such levels (2: the 56 x 56 / level 4 block, 1: 28 x 28 / level 3), 0 = the per-step schedule
+static int bwd_cpt_levels(const TrainLadder& L, int N, int C, int level, int k, int dtype)
+{
+    if (level < 3 || lanes_off() || rcx::opt::is_zero(rcx::opt::BWD_FUSED) || rcx::opt::is_zero(rcx::opt::BWD_NESTED)) return 0;
+    const int m = level - 2;
+    if (L.h[m] != 14 || L.w[m] != 14 || !rcx::cplbwd_applicable(N, C, 14, 14, 2, k, RCX_DTYPE_F32)) return 0;
+    for (int l = 0; l < m; ++l)
+        if (!rcx::bwd_cpt_applicable(N, C, L.h[l], L.w[l], k) || L.h[l + 1] * 2 != L.h[l] || L.w[l + 1] * 2 != L.w[l] ||
+            !rcx::wgrad_cpl_applicable(N, C, L.h[l], L.w[l], L.h[l + 1], L.w[l + 1], k, 1, true) ||
+            !rcx::wgrad2_cpl_applicable(N, C, L.h[l], L.w[l], L.h[l + 1], L.w[l + 1], k, 2, false)) return 0;
+    (void)dtype;
+    return m;
+}
+
+int rcx_recconv2d_bwd_gy_dtype(int N, int C, int H, int W, int level, int k, int dtype)
+{
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0 || !known_dtype(dtype)) return RCX_DTYPE_F32;
+    if (dtype == RCX_DTYPE_F32 || C % 4) return RCX_DTYPE_F32;
+    return bwd_cpt_levels(make_train_ladder(N, C, H, W, level, k), N, C, level, k, dtype) > 0 ? dtype : RCX_DTYPE_F32;
+}
+
+int rcx_recconv2d_bwd(const void* x, const void* gy, int gy_dtype, const float* wpack, const float* wpack_flipped, const void* saved,
+                      void* gx, float* gwpack, float* gbpack, void* const* gw_out, void* const* gb_out, int grad_dtype,
+                      void* workspace, size_t workspace_bytes,
                       int N, int C, int H, int W, int level, int k, int mode, int dtype, void* stream)
 {
     if (int rc = check_common(x, gx, N, C, H, W, k, dtype)) return rc;
-    if (!gy || !wpack || !wpack_flipped || !gwpack) return fail(RCX_ERR_BAD_ARG, "null gradient / weight pointer");
+    if (!gy || !wpack || !wpack_flipped || (!gwpack && !gw_out)) return fail(RCX_ERR_BAD_ARG, "null gradient / weight pointer");
+    if (!known_dtype(gy_dtype) || (gw_out && !known_dtype(grad_dtype))) return fail(RCX_ERR_BAD_ARG, "unknown gy / gradient dtype");
     if (level < 0 || level > RCX_MAX_LEVEL) return fail(RCX_ERR_BAD_ARG, "level %d outside [0,%d]", level, RCX_MAX_LEVEL);
     if (mode != RCX_MODE_BILINEAR && mode != RCX_MODE_NEAREST) return fail(RCX_ERR_BAD_ARG, "unknown mode %d", mode);
     if (C % 4) return fail(RCX_ERR_UNSUPPORTED, "the backward kernels need C %% 4 == 0, got C=%d", C);
@@ -534,12 +558,19 @@ int rcx_recconv2d_bwd(const void* x, const float* gy, const float* wpack, const 
     if (level >= 1 && !saved) return fail(RCX_ERR_BAD_ARG, "null saved-activation buffer");
     if (!workspace || workspace_bytes < L.bwd_total)
         return fail(RCX_ERR_WORKSPACE, "backward workspace too small: need %zu bytes, got %zu", L.bwd_total, workspace_bytes);
+    const int mcpt = bwd_cpt_levels(L, N, C, level, k, dtype);
+    if (gy_dtype != RCX_DTYPE_F32 && !(mcpt > 0 && gy_dtype == dtype))
+        return fail(RCX_ERR_UNSUPPORTED, "gy of dtype %d: this problem takes float32 (rcx_recconv2d_bwd_gy_dtype)", gy_dtype);
+    if (gw_out)
+        for (int i = 0; i < level + 2; ++i)
+            if (!gw_out[i]) return fail(RCX_ERR_BAD_ARG, "null gw_out[%d]", i);
     hipStream_t s = (hipStream_t)stream;
     const size_t wsz = (size_t)k * k * C;
     auto W_ = [&](int i) { return wpack + (size_t)i * wsz; };
     auto Wf = [&](int i) { return wpack_flipped + (size_t)i * wsz; };
-    auto GW = [&](int i) { return gwpack + (size_t)i * wsz; };
-    auto GB = [&](int i) { return gbpack ? gbpack + (size_t)i * C : nullptr; };
+    // where the final reduction leaves conv i's gradients: the packed float32 rows, or the parameters' own tensors
+    auto GW = [&](int i) { return gw_out ? (float*)gw_out[i] : gwpack + (size_t)i * wsz; };
+    auto GB = [&](int i) { return gw_out ? (gb_out ? (float*)gb_out[i] : nullptr) : (gbpack ? gbpack + (size_t)i * C : nullptr); };
     const char* sv = (const char*)saved;
     auto F_ = [&](int l) { return (const float*)(sv + L.f_off[l]); };
     auto C_ = [&](int l) { return (const float*)(sv + L.c_off[l]); };
@@ -550,6 +581,8 @@ int rcx_recconv2d_bwd(const void* x, const float* gy, const float* wpack, const 
     auto PART = [&](int i) { return (float*)(ws + L.part_off + (size_t)i * L.part_bytes); };
     rcx::WgradJobs J{};
     J.kk = k * k; J.C = C;
+    J.param_layout = gw_out ? 1 : 0;
+    J.param_dt = grad_dtype;
     // job 0 = the shared down conv (its partial buffers are appended as the ladder is walked), job 1 + j = convs[j]
     J.njobs = level + 2;
     J.gw[0] = GW(0); J.gb[0] = GB(0); J.nslots[0] = 0;
@@ -562,15 +595,53 @@ int rcx_recconv2d_bwd(const void* x, const float* gy, const float* wpack, const 
     if (level >= 1 && !lanes_off() && rcx::cplbwd_applicable(N, C, H, W, level, k, dtype)) {
         float* parts[RCX_MAX_LEVEL + 2];
         for (int j = 0; j < level + 2; ++j) { parts[j] = PART(j); add_slot(j, PART(j), N); }
-        RCX_TRY(rcx::cplbwd_recconv(x, gy, wpack, wpack_flipped, saved, L.f_off, L.c_off, gx, parts, N, C, H, level,
+        RCX_TRY(rcx::cplbwd_recconv(x, (const float*)gy, wpack, wpack_flipped, saved, L.f_off, L.c_off, gx, parts, N, C, H, level,
                                     mode == RCX_MODE_NEAREST ? 1 : 0, dtype, s), "bwd: fused block");
         RCX_TRY(rcx::bwd_wgrad_reduce_jobs(J, s), "bwd: weight-gradient reduction");
         return 0;
     }
+    // The 56x56 / level 4 and 28x28 / level 3 blocks (RecNeXt at 224x224): the fine levels on the tiled adjoint kernels, the 14x14 / level 2 tail as
+    // its one launch.  Top-down: gW_j from (a_l, C_{l+1}, g_l) and gC_{l+1} = R^T K^ g_l; the tail returns G_m; bottom-up: gW_d from (a_l, G_{l+1})
+    // and G_l = K^ g_l + D^T G_{l+1} (G_0 = gx).  g_0 = gy in its own type, g_l = gC_l float32 (parked in the full-resolution slot G_(0) the per-step
+    // schedule keeps gT_0 in: no gT plane exists here).
+    if (mcpt > 0) {
+        const int m = mcpt, md = mode == RCX_MODE_NEAREST ? 1 : 0;
+        float* gcl[RCX_MAX_LEVEL + 1] = {};
+        {
+            size_t off = 0;
+            for (int l = 1; l <= m; ++l) { gcl[l] = (float*)(ws + L.g_off[0] + off); off += align256(sizeof(float) * (size_t)N * C * L.h[l] * L.w[l]); }
+        }
+        auto g_of = [&](int l) { return l == 0 ? gy : (const void*)gcl[l]; };
+        auto gdt_of = [&](int l) { return l == 0 ? gy_dtype : RCX_DTYPE_F32; };
+        auto a_of = [&](int l) { return l == 0 ? x : (const void*)F_(l); };
+        auto adt_of = [&](int l) { return l == 0 ? dtype : RCX_DTYPE_F32; };
+        for (int l = 0; l < m; ++l) {
+            const int j = level - l;                              // convs[j] is level l's conv
+            RCX_TRY(rcx::wgrad_cpl(a_of(l), adt_of(l), C_(l + 1), g_of(l), gdt_of(l), PART(slot), N, C, L.h[l], md, s, &rows), "bwd: conv weight grad");
+            add_slot(1 + j, PART(slot++), rows);
+            RCX_TRY(rcx::bwd_gc_cpt(g_of(l), gdt_of(l), gcl[l + 1], Wf(1 + j), N, C, L.h[l], md, s), "bwd: gradient handed down");
+        }
+        {
+            float* parts[4];
+            for (int q = 0; q < 4; ++q) parts[q] = PART(slot++);
+            RCX_TRY(rcx::cplbwd_recconv(F_(m), gcl[m], wpack, wpack_flipped, saved, L.f_off + m, L.c_off + m, G_(m), parts, N, C, 14, 2, md,
+                                        RCX_DTYPE_F32, s), "bwd: fused nested block");
+            for (int q = 0; q < 4; ++q) add_slot(q, parts[q], N);
+        }
+        for (int l = m - 1; l >= 0; --l) {
+            RCX_TRY(rcx::wgrad2_cpl(a_of(l), adt_of(l), G_(l + 1), PART(slot), N, C, L.h[l], s, &rows), "bwd: down weight grad");
+            add_slot(0, PART(slot++), rows);
+            RCX_TRY(rcx::bwd_gx_cpt(g_of(l), gdt_of(l), G_(l + 1), l == 0 ? gx : (void*)G_(l), l == 0 ? dtype : RCX_DTYPE_F32, Wf(1 + level - l), W_(0),
+                                    N, C, L.h[l], s), "bwd: gradient handed up");
+        }
+        RCX_TRY(rcx::bwd_wgrad_reduce_jobs(J, s), "bwd: weight-gradient reduction");
+        return 0;
+    }
+    const float* gyf = (const float*)gy;                          // the per-step schedule reads float32
     // final conv (model/recnext.py:34): gT_0 = K_L^T gy ; gW_L = <x + R(C_1), gy>
-    if (level == 0) RCX_TRY(step_dwconv(gy, gx, Wf(1), nullptr, N, C, H, W, k, 1, RCX_DTYPE_F32, dtype, s), "bwd: final conv input grad");
-    else RCX_TRY(step_dwconv(gy, G_(0), Wf(1 + level), nullptr, N, C, H, W, k, 1, RCX_DTYPE_F32, RCX_DTYPE_F32, s), "bwd: final conv input grad");
-    RCX_TRY(rcx::bwd_wgrad(x, dtype, level >= 1 ? C_(1) : nullptr, gy, PART(slot), GW(1 + level), GB(1 + level), N, C, H, W,
+    if (level == 0) RCX_TRY(step_dwconv(gyf, gx, Wf(1), nullptr, N, C, H, W, k, 1, RCX_DTYPE_F32, dtype, s), "bwd: final conv input grad");
+    else RCX_TRY(step_dwconv(gyf, G_(0), Wf(1 + level), nullptr, N, C, H, W, k, 1, RCX_DTYPE_F32, RCX_DTYPE_F32, s), "bwd: final conv input grad");
+    RCX_TRY(rcx::bwd_wgrad(x, dtype, level >= 1 ? C_(1) : nullptr, gyf, PART(slot), GW(1 + level), GB(1 + level), N, C, H, W,
                            level >= 1 ? L.h[1] : 0, level >= 1 ? L.w[1] : 0, H, W, k, 1, mode, 0, s, &rows), "bwd: final conv weight grad");
     add_slot(1 + level, PART(slot++), rows);
     // A deeper block whose level (level - 2) plane is 14x14 -- the 28x28 / level 3 and 56x56 / level 4 blocks of RecNeXt at 224x224 --
@@ -613,8 +684,11 @@ int rcx_recconv2d_bwd(const void* x, const float* gy, const float* wpack, const 
     RCX_TRY(rcx::bwd_wgrad_reduce_jobs(J, s), "bwd: weight-gradient reduction");
 #undef RCX_TRY
     if (level == 0) {   // no ladder: the shared down weight is unused, its gradient is zero
-        e = hipMemsetAsync(GW(0), 0, sizeof(float) * wsz, s);
-        if (e == hipSuccess && gbpack) e = hipMemsetAsync(GB(0), 0, sizeof(float) * C, s);
+        const size_t esz = gw_out ? (grad_dtype == RCX_DTYPE_F32 ? 4 : 2) : 4;
+        float* gw0 = gw_out ? (float*)gw_out[0] : gwpack;
+        float* gb0 = gw_out ? (gb_out ? (float*)gb_out[0] : nullptr) : gbpack;
+        e = hipMemsetAsync(gw0, 0, esz * wsz, s);
+        if (e == hipSuccess && gb0) e = hipMemsetAsync(gb0, 0, esz * C, s);
         if (e != hipSuccess) return hip_fail(e, "bwd: zero down grad");
     }
     return 0;

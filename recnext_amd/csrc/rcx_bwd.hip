@@ -541,8 +541,19 @@ k_wgrad_reduce_jobs(WgradJobs J)
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) t += red[r][threadIdx.x];
-        if (i < J.kk * J.C) J.gw[job][i] = t;
-        else if (J.gb[job]) J.gb[job][i - J.kk * J.C] = t;
+        if (!J.param_layout) {
+            if (i < J.kk * J.C) J.gw[job][i] = t;
+            else if (J.gb[job]) J.gb[job][i - J.kk * J.C] = t;
+        } else {
+            // straight into the parameter's gradient: i = tap * C + c  ->  (C, 1, k, k) element c * kk + tap, in the parameter's own type
+            void* dst = i < J.kk * J.C ? (void*)J.gw[job] : (void*)J.gb[job];
+            const int e = i < J.kk * J.C ? (i % J.C) * J.kk + i / J.C : i - J.kk * J.C;
+            if (dst) {
+                if (J.param_dt == 0) reinterpret_cast<float*>(dst)[e] = t;
+                else if (J.param_dt == 1) reinterpret_cast<bf16_t*>(dst)[e] = f32_to_bf16(t);
+                else reinterpret_cast<f16_t*>(dst)[e] = (f16_t)t;
+            }
+        }
     }
 }
 
@@ -629,7 +640,7 @@ hipError_t bwd_wgrad(const void* a, int a_dt, const float* coarse, const float* 
         const bool t2 = !t1 && wgrad2_cpl_applicable(N, C, H, W, Ho, Wo, k, stride, coarse != nullptr);
         if (t1 || t2) {
             int rows = 0;
-            hipError_t e = t1 ? wgrad_cpl(a, a_dt, coarse, g, partial, N, C, H, mode, s, &rows) : wgrad2_cpl(a, a_dt, g, partial, N, C, H, s, &rows);
+            hipError_t e = t1 ? wgrad_cpl(a, a_dt, coarse, g, 0, partial, N, C, H, mode, s, &rows) : wgrad2_cpl(a, a_dt, g, partial, N, C, H, s, &rows);
             if (e != hipSuccess) return e;
             if (rows_out) { *rows_out = rows; return hipSuccess; }        // the caller reduces all its partial buffers in one launch
             const int kk = k * k, n5 = (kk + 1) * C;

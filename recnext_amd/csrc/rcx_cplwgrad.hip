@@ -19,9 +19,10 @@ namespace cplwgrad {
 using namespace cplbwd;
 
 // MODE 0 / 1: T = a + bilinear / nearest resize of `coarse`; MODE 2: T = a (a plain depthwise conv, e.g. RecAttn2d's: model/recattn.py:163-171)
-template <int MODE, typename TA, int H>
+// TG: the gradient's element type (float32; or the block's own 16-bit type at level 0, where g is the incoming gy as autograd hands it over)
+template <int MODE, typename TA, int H, typename TG = float>
 __global__ __launch_bounds__(64 * (H / 14))
-void k_wgrad_cpl(const TA* __restrict__ a, const float* __restrict__ coarse, const float* __restrict__ g, float* __restrict__ partial,
+void k_wgrad_cpl(const TA* __restrict__ a, const float* __restrict__ coarse, const TG* __restrict__ g, float* __restrict__ partial,
                  int N, int C)
 {
     constexpr int W = H, NT = W / 14, NB = H / 14, Hc = H / 2, Wc = W / 2, TP = 9;      // TP: pairs of a T row (18 columns)
@@ -34,10 +35,10 @@ void k_wgrad_cpl(const TA* __restrict__ a, const float* __restrict__ coarse, con
     const bool live = c < C;
     const unsigned cl = (unsigned)(live ? c : C - 1);                      // ragged last block: the spare lanes shadow the last channel
     const int r0 = 14 * band, c0 = 14 * tile;
-    const unsigned voa = cl * (unsigned)sizeof(TA), vof = cl * 4u;
-    const size_t pixa = (size_t)C * sizeof(TA), pixf = (size_t)C * 4;
+    const unsigned voa = cl * (unsigned)sizeof(TA), vof = cl * 4u, vog = cl * (unsigned)sizeof(TG);
+    const size_t pixa = (size_t)C * sizeof(TA), pixf = (size_t)C * 4, pixg = (size_t)C * sizeof(TG);
     const gcptr ab = (gcptr)a + (size_t)n * H * W * pixa;
-    const gcptr gb = (gcptr)g + (size_t)n * H * W * pixf;
+    const gcptr gb = (gcptr)g + (size_t)n * H * W * pixg;
     const gcptr cbp = (gcptr)coarse + (size_t)n * Hc * Wc * pixf;
 
     // ---- loads (ordered, compiler-counted: SafeLd) ----
@@ -61,9 +62,9 @@ void k_wgrad_cpl(const TA* __restrict__ a, const float* __restrict__ coarse, con
     };
     auto ld_g = [&](auto tc) {
         constexpr int t = decltype(tc)::value;
-        const gcptr rowp = gb + ((size_t)(r0 + t) * W + c0) * pixf;
+        const gcptr rowp = gb + ((size_t)(r0 + t) * W + c0) * pixg;
 #pragma unroll
-        for (int q = 0; q < 14; ++q) rg[t][q] = SafeLd<float>::ld(rowp + (size_t)q * pixf + vof);
+        for (int q = 0; q < 14; ++q) rg[t][q] = SafeLd<TG>::ld(rowp + (size_t)q * pixg + vog);
     };
     auto ld_c = [&](auto ic) {                                             // coarse local row il = coarse row 7 band - 2 + il (clamped), 11 columns
         constexpr int il = decltype(ic)::value;
@@ -148,7 +149,7 @@ void k_wgrad_cpl(const TA* __restrict__ a, const float* __restrict__ coarse, con
         pin_raw(rg[t]);
         f32x2 gp[7];
 #pragma unroll
-        for (int j = 0; j < 7; ++j) gp[j] = f32x2{__uint_as_float(rg[t][2 * j]), __uint_as_float(rg[t][2 * j + 1])};
+        for (int j = 0; j < 7; ++j) gp[j] = f32x2{SafeLd<TG>::cvt(rg[t][2 * j]), SafeLd<TG>::cvt(rg[t][2 * j + 1])};
         // gradient column cc (local) meets T local columns cc .. cc + 4, i.e. pairs cc/2 + k (even) / (cc - 1)/2 + k (odd, set O)
 #pragma unroll
         for (int cc = 0; cc < 14; ++cc) {
@@ -190,18 +191,22 @@ void k_wgrad_cpl(const TA* __restrict__ a, const float* __restrict__ coarse, con
     }
 }
 
-template <int MODE, typename TA, int H>
-static hipError_t launch(const void* a, const float* coarse, const float* g, float* partial, int N, int C, hipStream_t s)
+template <int MODE, typename TA, int H, typename TG>
+static hipError_t launch(const void* a, const float* coarse, const void* g, float* partial, int N, int C, hipStream_t s)
 {
     const unsigned grid = (unsigned)(N * (H / 14) * ((C + 63) / 64));
-    hipLaunchKernelGGL((k_wgrad_cpl<MODE, TA, H>), dim3(grid), dim3(64 * (H / 14)), 0, s, (const TA*)a, coarse, g, partial, N, C);
+    hipLaunchKernelGGL((k_wgrad_cpl<MODE, TA, H, TG>), dim3(grid), dim3(64 * (H / 14)), 0, s, (const TA*)a, coarse, (const TG*)g, partial, N, C);
     return hipGetLastError();
 }
 
+// g_same: the gradient has a's (16-bit) element type instead of float32
 template <int MODE, typename TA>
-static hipError_t launch_h(const void* a, const float* coarse, const float* g, float* partial, int N, int C, int H, hipStream_t s)
+static hipError_t launch_h(const void* a, const float* coarse, const void* g, bool g_same, float* partial, int N, int C, int H, hipStream_t s)
 {
-    return H == 56 ? launch<MODE, TA, 56>(a, coarse, g, partial, N, C, s) : launch<MODE, TA, 28>(a, coarse, g, partial, N, C, s);
+    if constexpr (sizeof(TA) == 2) {
+        if (g_same) return H == 56 ? launch<MODE, TA, 56, TA>(a, coarse, g, partial, N, C, s) : launch<MODE, TA, 28, TA>(a, coarse, g, partial, N, C, s);
+    }
+    return H == 56 ? launch<MODE, TA, 56, float>(a, coarse, g, partial, N, C, s) : launch<MODE, TA, 28, float>(a, coarse, g, partial, N, C, s);
 }
 
 // ---- stride-2 convs: gW[u][v] += sum_{o,i} G[o][i] * a[2o+u-P][2i+v-P] ----
@@ -398,11 +403,13 @@ hipError_t wgrad2m_cpl(const void* a, int a_dt, const float* g, float* partial, 
                                                                                                      : cplwgrad::launch2_h<float, 7, 2>(a, g, partial, N, Cout, H, s);
 }
 
-hipError_t wgrad_cpl(const void* a, int a_dt, const float* coarse, const float* g, float* partial, int N, int C, int H, int mode,
+hipError_t wgrad_cpl(const void* a, int a_dt, const float* coarse, const void* g, int g_dt, float* partial, int N, int C, int H, int mode,
                      hipStream_t s, int* rows_out)
 {
     if (rows_out) *rows_out = N * (H / 14);
-#define RCX_WC(MD_) (a_dt == 1 ? cplwgrad::launch_h<MD_, bf16_t>(a, coarse, g, partial, N, C, H, s) : a_dt == 2 ? cplwgrad::launch_h<MD_, f16_t>(a, coarse, g, partial, N, C, H, s) : cplwgrad::launch_h<MD_, float>(a, coarse, g, partial, N, C, H, s))
+    if (g_dt != 0 && g_dt != a_dt) return hipErrorInvalidValue;             // float32, or the same 16-bit type as a
+    const bool gs = g_dt != 0;
+#define RCX_WC(MD_) (a_dt == 1 ? cplwgrad::launch_h<MD_, bf16_t>(a, coarse, g, gs, partial, N, C, H, s) : a_dt == 2 ? cplwgrad::launch_h<MD_, f16_t>(a, coarse, g, gs, partial, N, C, H, s) : cplwgrad::launch_h<MD_, float>(a, coarse, g, gs, partial, N, C, H, s))
     if (!coarse) return RCX_WC(2);
     return mode == 1 ? RCX_WC(1) : RCX_WC(0);
 #undef RCX_WC

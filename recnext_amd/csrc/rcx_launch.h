@@ -110,8 +110,8 @@ hipError_t cplbwd_recconv(const void* x, const float* gy, const float* wpack, co
 // tiled channel-per-lane weight gradient of a stride-1 5x5 conv over T = a + R(coarse) on the 56x56 / 28x28 planes (rcx_cplwgrad.hip):
 // one partial row of (25 + 1) * C sums per (image, 14-row band)
 bool wgrad_cpl_applicable(int N, int C, int H, int W, int Hc, int Wc, int k, int stride, bool has_coarse);
-hipError_t wgrad_cpl(const void* a, int a_dt, const float* coarse, const float* g, float* partial, int N, int C, int H, int mode,
-                     hipStream_t s, int* rows_out);
+hipError_t wgrad_cpl(const void* a, int a_dt, const float* coarse, const void* g, int g_dt, float* partial, int N, int C, int H, int mode,
+                     hipStream_t s, int* rows_out);            // g_dt: 0 = float32, or a_dt (a 16-bit gradient of a's own type)
 
 // ... and of the shared stride-2 5x5 conv (a: H x W, g: H/2 x W/2): one partial row per (image, 14-row band of g)
 bool wgrad2_cpl_applicable(int N, int C, int H, int W, int Ho, int Wo, int k, int stride, bool has_coarse);
@@ -119,6 +119,12 @@ hipError_t wgrad2_cpl(const void* a, int a_dt, const float* g, float* partial, i
 // ... and of the Downsample conv (7x7, stride 2, channel multiplier 2; Cout = 2 Cin channels of g and of the weight)
 bool wgrad2m_cpl_applicable(int N, int Cout, int H, int W, int k);
 hipError_t wgrad2m_cpl(const void* a, int a_dt, const float* g, float* partial, int N, int Cout, int H, hipStream_t s, int* rows_out);
+
+// tiled channel-per-lane adjoints of the fine levels on the 56x56 / 28x28 planes (rcx_cptbwd.hip): gC = R^T (K^ g) at half resolution, and
+// out = K^ g + D^T G (G = nullptr: the conv adjoint alone); g_dt / out_dt: dtype ids, G and gC float32
+bool bwd_cpt_applicable(int N, int C, int H, int W, int k);
+hipError_t bwd_gc_cpt(const void* g, int g_dt, float* gC, const float* wf, int N, int C, int H, int mode, hipStream_t s);
+hipError_t bwd_gx_cpt(const void* g, int g_dt, const float* G, void* out, int out_dt, const float* wf, const float* wd, int N, int C, int H, hipStream_t s);
 
 // channel-per-lane, tiled kernel of the 56x56 / level 4 and 28x28 / level 3 blocks (rcx_cpt.hip): any channel count
 bool cpt_applicable(int N, int C, int H, int W, int level, int k, int dtype);
@@ -183,6 +189,9 @@ struct WgradJobs {
     const float* part[10][8];
     float* gw[10];
     float* gb[10];
+    // param_layout 0: gw[j] is a row of the packed (k*k, C) float32 gradient, gb[j] (C) float32.  1: gw[j] / gb[j] are the PARAMETERS' gradients
+    // themselves, (C, 1, k, k) contiguous / (C), elements of dtype id param_dt (rcx_recconv2d_bwd's gw_out / gb_out)
+    int param_layout, param_dt;
 };
 hipError_t bwd_wgrad_reduce_jobs(const WgradJobs& J, hipStream_t s);
 hipError_t bwd_mult2(const void* x, int x_dt, const float* g, const float* w, void* gx, float* partial, float* gw, float* gb,

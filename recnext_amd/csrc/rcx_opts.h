@@ -12,7 +12,7 @@ namespace opt {
 
 enum Id {
     FORCE_SPLIT, FORCE_GENERIC, LANES, LANES_WAVES, LANES_NI, WGRAD_CPL, CPT, CPT_GRID, CPL, CPL14, CPL14_LDS, CPL14_RL, UPADD_CPL, UPADD_CPT, NESTED,
-    ATTN_MFMA, ATTN_SCALAR, ATTN_FUSED, TRAIN_FUSED, BWD_SPLIT, BWD_NESTED, BWD_FUSED, PLANE_LPP, PLANE_B2, PLANE_NT, PLANE_ABLATE, LANES_ABLATE, CPT_CB, CPT_STG, CPT16, MLP_STREAM, COUNT
+    ATTN_MFMA, ATTN_SCALAR, ATTN_FUSED, TRAIN_FUSED, BWD_SPLIT, BWD_NESTED, BWD_FUSED, PLANE_LPP, PLANE_B2, PLANE_NT, PLANE_ABLATE, LANES_ABLATE, CPT_CB, CPT_STG, CPT16, MLP_STREAM, BWD_CPT, COUNT
 };
 
 namespace detail {
@@ -22,7 +22,7 @@ inline const char* name_of(int i)
         "RCX_FORCE_SPLIT", "RCX_FORCE_GENERIC", "RCX_LANES", "RCX_LANES_WAVES", "RCX_LANES_NI", "RCX_WGRAD_CPL", "RCX_CPT", "RCX_CPT_GRID",
         "RCX_CPL", "RCX_CPL14", "RCX_CPL14_LDS", "RCX_CPL14_RL", "RCX_UPADD_CPL", "RCX_UPADD_CPT", "RCX_NESTED", "RCX_ATTN_MFMA", "RCX_ATTN_SCALAR", "RCX_ATTN_FUSED", "RCX_TRAIN_FUSED",
         "RCX_BWD_SPLIT", "RCX_BWD_NESTED", "RCX_BWD_FUSED", "RCX_PLANE_LPP", "RCX_PLANE_B2", "RCX_PLANE_NT", "RCX_PLANE_ABLATE", "RCX_LANES_ABLATE",
-        "RCX_CPT_CB", "RCX_CPT_STG", "RCX_CPT16", "RCX_MLP_STREAM"};
+        "RCX_CPT_CB", "RCX_CPT_STG", "RCX_CPT16", "RCX_MLP_STREAM", "RCX_BWD_CPT"};
     return k[i];
 }
 struct Table {

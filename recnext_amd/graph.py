@@ -52,6 +52,11 @@ class GraphedInference:
             static_y = self.module(static_x)
         # the derived packs whose addresses the graph has baked in: kept alive with it
         packs = [getattr(m, a) for m in self.module.modules() for a in ("_pack", "_pad_w", "_pad_b") if getattr(m, a, None) is not None]
+        for m in self.module.modules():                       # the fused channel mixer / stem helpers are not Modules: ask them
+            for a in ("_fused_mlp", "_fused_stem"):
+                helper = m.__dict__.get(a)
+                if helper is not None:
+                    packs.extend(helper.packs())
         return graph, static_x, static_y, packs
 
     def __call__(self, x):

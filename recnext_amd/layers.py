@@ -127,6 +127,14 @@ class PointwiseLinear(nn.Module):
         return y2.view(n, h, w, self.out_padded).permute(0, 3, 1, 2)
 
 
+def _is_exact_gelu(m):
+    return type(m) is nn.GELU and getattr(m, "approximate", "none") == "none"
+
+
+def _needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
 class FusedChannelMlp:
     """The channel mixer [PointwiseLinear, GELU, PointwiseLinear] of a block and the residual add around it as ONE HIP launch (ops.channel_mlp; inference,
     bf16, channels_last).  Not a Module: it reads the two layers' own parameters (state_dict untouched) and rebuilds its fragment pack when one changes."""
@@ -139,6 +147,22 @@ class FusedChannelMlp:
         from . import ops
         n, c, h, w = x.shape
         return x.is_cuda and x.dtype == torch.bfloat16 and ops.channel_mlp_hidden(n * h * w, c, self.fc1.out_channels, x.dtype) > 0
+
+    def usable(self, seq, t, x):
+        """May this call take the fused launch?  Only if it still describes the mixer ``seq`` as it is NOW (a layer or the activation replaced after
+        use_fused_mlp -- a fusion / quantisation pass, nn.DataParallel's replicas, ``seq[1] = nn.ReLU()`` -- is followed, not ignored), the operands
+        agree in dtype and device with the weights, and nothing on the way needs a gradient: ops.channel_mlp is a raw launch with no grad_fn, so
+        an eval-mode forward with grad enabled (input gradients, a frozen-BN fine-tune) must keep the autograd path."""
+        if len(seq) != 3 or seq[0] is not self.fc1 or seq[2] is not self.fc2 or not _is_exact_gelu(seq[1]):
+            return False
+        if t.dtype != x.dtype or t.device != x.device or self.fc1.weight.device != x.device or self.fc2.weight.device != x.device:
+            return False
+        if _needs_grad(t, x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias):
+            return False
+        return self.supported(x)
+
+    def packs(self):
+        return [] if self._pack is None else [p for p in self._pack if torch.is_tensor(p)]
 
     def _operands(self, hidden_to):
         from . import ops
@@ -168,6 +192,19 @@ class FusedStem:
         from . import ops
         n, c, h, w = x.shape
         return x.is_cuda and x.dtype == torch.bfloat16 and c == 3 and ops.stem_supported(n, h, w, self.conv1.out_channels, self.conv2.out_channels, x.dtype)
+
+    def usable(self, seq, x):
+        """As FusedChannelMlp.usable: the stem must still be [conv1, exact GELU, conv2] with these very layers, on x's device, with no gradient wanted."""
+        if len(seq) != 3 or seq[0] is not self.conv1 or seq[2] is not self.conv2 or not _is_exact_gelu(seq[1]):
+            return False
+        if self.conv1.weight.device != x.device or self.conv2.weight.device != x.device:
+            return False
+        if _needs_grad(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias):
+            return False
+        return self.supported(x)
+
+    def packs(self):
+        return [] if self._pack is None else [p for p in self._pack if torch.is_tensor(p)]
 
     def __call__(self, x):
         from . import ops

@@ -53,7 +53,7 @@ class RecNextStem(nn.Module):
 
     def forward(self, x):
         fused = self.__dict__.get("_fused_stem")
-        if fused is not None and not self.training and fused.supported(x):
+        if fused is not None and not self.training and fused.usable(self.stem, x):
             return fused(x)                             # one launch (use_fused_stem)
         return self.stem(x)
 
@@ -75,7 +75,7 @@ class MetaNeXtBlock(nn.Module):
         if self._has_norm:
             t = self.norm(t)
         fused = self.__dict__.get("_fused_mlp")
-        if fused is not None and not self.training and fused.supported(x):
+        if fused is not None and not self.training and fused.usable(self.channel_mixer, t, x):
             return fused(t, x)                          # x + channel_mixer(t) in one launch (use_fused_mlp)
         return x + self.drop_path(self.channel_mixer(t))
 
@@ -109,7 +109,7 @@ class Downsample(nn.Module):
         hip = self._hip_path()
         x = hip(x) if hip is not None else self.norm(self.token_mixer(x))
         fused = self.__dict__.get("_fused_mlp")
-        if fused is not None and not self.training and fused.supported(x):
+        if fused is not None and not self.training and fused.usable(self.channel_mixer, x, x):
             return fused(x, x)
         return x + self.channel_mixer(x)
 

@@ -511,6 +511,13 @@ def pack_channel_mlp(w1, b1, w2, b2, hidden_to=None):
     return wfrag, bias, 32 * ht
 
 
+def _check_pack(t, dtype, numel, device, name):
+    """A derived pack handed to a raw launch: the kernels read its whole extent, so a wrong size / dtype / device is refused here, not found by the GPU."""
+    if not torch.is_tensor(t) or t.dtype != dtype or t.numel() != numel or not t.is_contiguous() or t.device != device:
+        got = f"{tuple(t.shape)} {t.dtype} on {t.device}" if torch.is_tensor(t) else type(t).__name__
+        raise ValueError(f"{name} must be a contiguous {dtype} tensor of {numel} elements on {device}, got {got}")
+
+
 def channel_mlp(z, x, wfrag, bias, hidden):
     """y = x + W2 gelu(W1 z + b1) + b2 in one launch (rcx_channel_mlp_fwd; model/recnext.py:157-158): z, x N x C x H x W channels_last bf16 -> y like x."""
     z = _nhwc(z, "z")
@@ -521,6 +528,12 @@ def channel_mlp(z, x, wfrag, bias, hidden):
     lib = _lib.load()
     if wfrag.dtype != torch.bfloat16 or wfrag.numel() * 2 != lib.rcx_channel_mlp_pack_bytes(c, hidden) or not wfrag.is_contiguous():
         raise ValueError("wfrag is not the pack of pack_channel_mlp for this (C, H)")
+    ct = -(-c // 32)
+    ct += 1 if c > 128 and ct % 2 else 0
+    _check_pack(bias, torch.float32, hidden + 32 * ct, x.device, "bias")     # the kernel copies 32 (H/32 + CT) floats into LDS unconditionally
+    _check_pack(wfrag, torch.bfloat16, wfrag.numel(), x.device, "wfrag")
+    if z.device != x.device:
+        raise ValueError("z and x must be on the same device")
     y = _empty_nhwc(n, c, h, w, x.dtype, x.device)
     with _on(x.device):
         rc = lib.rcx_channel_mlp_fwd(z.data_ptr(), x.data_ptr(), y.data_ptr(), wfrag.data_ptr(), bias.data_ptr(), n * h * w, c, hidden, _dt(x), _stream(x.device))
@@ -568,6 +581,11 @@ def stem(x, w1p, b1p, w2frag, b2p, cm, co):
     if c != 3:
         raise ValueError(f"the stem takes 3 input channels, got {c}")
     h2, w2_ = -(-(-(-h // 2)) // 2), -(-(-(-w // 2)) // 2)
+    m1, mt = -(-cm // 32), -(-co // 32)
+    _check_pack(w1p, torch.bfloat16, m1 * 2 * 512, x.device, "w1p")           # 2 KB per 32 intermediate channels (K = 27 padded to 32)
+    _check_pack(b1p, torch.float32, 32 * m1, x.device, "b1p")
+    _check_pack(w2frag, torch.bfloat16, _lib.load().rcx_stem_pack_bytes(cm, co) // 2, x.device, "w2frag")
+    _check_pack(b2p, torch.float32, 32 * mt, x.device, "b2p")
     y = _empty_nhwc(n, co, h2, w2_, x.dtype, x.device)
     with _on(x.device):
         rc = _lib.load().rcx_stem_fwd(x.data_ptr(), y.data_ptr(), w1p.data_ptr(), b1p.data_ptr(), w2frag.data_ptr(), b2p.data_ptr(), n, h, w, cm, co, _dt(x), _stream(x.device))
@@ -627,23 +645,42 @@ def recconv2d_forward_train(x, wpack, bpack, level, k, mode="bilinear"):
     return y, saved
 
 
-def recconv2d_backward(x, gy, wpack, saved, level, k, mode="bilinear", need_bias=False, wflip=None):
+def recconv2d_backward(x, gy, wpack, saved, level, k, mode="bilinear", need_bias=False, wflip=None, param_grads=None):
     """-> (gx like x, gwpack (level+2, k*k*C) f32, gbpack (level+2, C) f32 | None). Deterministic.
-    wflip: the flipped pack from pack_recconv_params(with_flipped=True), if the caller has it (else it is made here)."""
+    wflip: the flipped pack from pack_recconv_params(with_flipped=True), if the caller has it (else it is made here).
+    param_grads=(gws, gbs | None): level+2 preallocated contiguous (C,1,k,k) / (C) tensors of ONE dtype; the final reduction writes the parameters'
+    gradients straight into them (no packed gradient, no unpack launch, no dtype copy) and (gx, None, None) is returned.
+    gy may be float32 or, where the library reads it as it is (rcx_recconv2d_bwd_gy_dtype: the 56x56 / level 4 and 28x28 / level 3 blocks), x's own
+    16-bit dtype; anything else is converted to float32 here."""
     x = _nhwc(x)
     n, c, h, w = x.shape
-    gy = _nhwc(gy.to(torch.float32), "grad_output")
     lib = _lib.load()
+    want = lib.rcx_recconv2d_bwd_gy_dtype(n, c, h, w, level, k, _dt(x))
+    gy = _nhwc(gy if (gy.dtype == torch.float32 or (_DT.get(gy.dtype) == want and gy.dtype == x.dtype)) else gy.to(torch.float32), "grad_output")
     if wflip is None:
         wflip = wpack.view(level + 2, k, k, c).flip(1, 2).contiguous()
     gx = _empty_nhwc(n, c, h, w, x.dtype, x.device)
-    gw = torch.empty_like(wpack)
-    gb = torch.empty((level + 2, c), dtype=torch.float32, device=x.device) if need_bias else None
+    gw = gb = None
+    gw_ptrs = gb_ptrs = None
+    grad_dt = 0
+    if param_grads is not None:
+        gws, gbs = param_grads
+        ts = list(gws) + (list(gbs) if gbs is not None else [])
+        if len(gws) != level + 2 or (gbs is not None and len(gbs) != level + 2) or any(t.dtype != ts[0].dtype or not t.is_contiguous() or t.device != x.device for t in ts) \
+                or any(t.numel() != c * k * k for t in gws) or (gbs is not None and any(t.numel() != c for t in gbs)):
+            raise ValueError("param_grads: level+2 contiguous (C,1,k,k) [and (C)] tensors of one dtype on x's device")
+        grad_dt = _DT[ts[0].dtype]
+        gw_ptrs = _ptr_array(list(gws))
+        gb_ptrs = _ptr_array(list(gbs)) if gbs is not None else None
+    else:
+        gw = torch.empty_like(wpack)
+        gb = torch.empty((level + 2, c), dtype=torch.float32, device=x.device) if need_bias else None
     nbytes = lib.rcx_recconv2d_bwd_workspace_bytes(n, c, h, w, level, k)
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
     with _on(x.device):
-        rc = lib.rcx_recconv2d_bwd(x.data_ptr(), gy.data_ptr(), wpack.data_ptr(), wflip.data_ptr(), saved.data_ptr(),
-                                   gx.data_ptr(), gw.data_ptr(), gb.data_ptr() if gb is not None else None,
+        rc = lib.rcx_recconv2d_bwd(x.data_ptr(), gy.data_ptr(), _DT[gy.dtype], wpack.data_ptr(), wflip.data_ptr(), saved.data_ptr(),
+                                   gx.data_ptr(), gw.data_ptr() if gw is not None else None, gb.data_ptr() if gb is not None else None,
+                                   gw_ptrs, gb_ptrs, grad_dt,
                                    ws.data_ptr(), nbytes, n, c, h, w, level, k, _lib.MODES[mode], _dt(x), _stream(x.device))
     _lib.check(rc, "rcx_recconv2d_bwd")
     return gx, gw, gb

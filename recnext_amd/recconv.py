@@ -165,15 +165,25 @@ class _RecConv2dFn(torch.autograd.Function):
         x, wpack, saved, wflip = ctx.saved_tensors
         m = ctx.module
         k, c, L = m.kernel_size, m.in_channels, m.level
-        gx, gw, gb = ops.recconv2d_backward(x, grad_out, wpack, saved, L, k, m.mode, need_bias=ctx.has_bias, wflip=wflip)
-        gw = ops.unpack_recconv_grads(gw, L + 2, c, k)                       # (L+2, C, 1, k, k), each [i] contiguous
+        # the parameters' gradients are written by the backward's final reduction itself, in the parameters' layout and dtype (one dtype per module)
+        dts = set(ctx.param_dtypes)
+        if len(dts) == 1:
+            dt = ctx.param_dtypes[0]
+            gws = torch.empty((L + 2, c, 1, k, k), dtype=dt, device=x.device)
+            gbs = torch.empty((L + 2, c), dtype=dt, device=x.device) if ctx.has_bias else None
+            gx, _, _ = ops.recconv2d_backward(x, grad_out, wpack, saved, L, k, m.mode, wflip=wflip,
+                                              param_grads=([gws[i] for i in range(L + 2)], [gbs[i] for i in range(L + 2)] if ctx.has_bias else None))
+            gw, gb = gws, gbs
+        else:                                                        # mixed parameter dtypes: packed float32 gradients, then a copy each
+            gx, gw, gb = ops.recconv2d_backward(x, grad_out, wpack, saved, L, k, m.mode, need_bias=ctx.has_bias, wflip=wflip)
+            gw = ops.unpack_recconv_grads(gw, L + 2, c, k)                       # (L+2, C, 1, k, k), each [i] contiguous
         grads = []
         # parameter order of nn.Module.parameters(): down.weight, [down.bias], convs.0.weight, [convs.0.bias], ...
         for i in range(L + 2):
             grads.append(gw[i])
             if ctx.has_bias:
                 grads.append(gb[i])
-        grads = [g.to(dt) for g, dt in zip(grads, ctx.param_dtypes)]
+        grads = [g if g.dtype == dt_ else g.to(dt_) for g, dt_ in zip(grads, ctx.param_dtypes)]
         # a (C, 1, k, k) parameter of a channels_last model has strides (k*k, 1, k, 1), the same memory as the contiguous (k*k, k*k, k, 1): hand the
         # gradient back with the parameter's own strides, so that DDP's bucket views take it without a copy (its "grad strides do not match bucket
         # view strides" warning, GPUTEST_r04).  Only size-1 dimensions may differ: no data moves.

@@ -21,6 +21,6 @@ total = sum(tot.values())
 with open(out, "w", newline="") as fh:
     w = csv.writer(fh)
     w.writerow(["Name", "Calls", "TotalNs", "AverageNs", "Percentage"])
-    for k, v in tot.most_common(40):
+    for k, v in tot.most_common(60):
         w.writerow([k, cnt[k], v, round(v / cnt[k], 1), round(100.0 * v / total, 2)])
 print(f"{len(last)} dispatches, {total / 1e6:.2f} ms of kernels, wall span {(int(last[-1]['End_Timestamp']) - int(last[0]['Start_Timestamp'])) / 1e6:.2f} ms -> {out}")
