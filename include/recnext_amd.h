@@ -173,6 +173,21 @@ int rcx_dwconv2d_bwd(const void* x, const float* gy, const float* w_kkc, const f
                      int N, int C, int H, int W, int k, int stride, int x_dtype, void* stream);
 
 /*
+ * Backward of rcx_upadd_dwconv_fwd with a coarse plane: what autograd derives for the last line of RecAttn2d.forward,
+ * `conv(x + F.interpolate(a, size=x.shape[2:], mode))` (model/recattn.py:67; also model/recnext.py:33-34), in a training step (engine.py:48-64).
+ *   x: N x H x W x C (`dtype`); coarse: N x Hc x Wc x C float32 (the forward's `a`); gy: N x H x W x C of `gy_dtype` -- float32 always works, the
+ *   16-bit `dtype` itself where rcx_upadd_dwconv_bwd_gy_dtype() returns it (56x56 / 28x28 planes with an exact 2x coarse plane: the tiled adjoint
+ *   kernels of rcx_recconv2d_bwd); w_kkc / w_flipped_kkc as for rcx_dwconv2d_bwd.
+ *   gx: like x (= K^T gy) or NULL; gcoarse: N x Hc x Wc x C float32 (= R^T K^T gy) or NULL; gw: (k,k,C) float32 (= <x + R(coarse), gy>), gb: (C) float32
+ *   or NULL -- all overwritten.  workspace: rcx_upadd_dwconv_bwd_workspace_bytes() bytes.  Deterministic.  C must be a multiple of 4.
+ */
+size_t rcx_upadd_dwconv_bwd_workspace_bytes(int N, int C, int H, int W, int Hc, int Wc, int k);
+int rcx_upadd_dwconv_bwd_gy_dtype(int N, int C, int H, int W, int Hc, int Wc, int k, int dtype);
+int rcx_upadd_dwconv_bwd(const void* x, const float* coarse, const void* gy, int gy_dtype, const float* w_kkc, const float* w_flipped_kkc,
+                         void* gx, float* gcoarse, float* gw, float* gb, void* workspace, size_t workspace_bytes,
+                         int N, int C, int H, int W, int Hc, int Wc, int k, int mode, int dtype, void* stream);
+
+/*
  * Backward of rcx_dwconv2d_mult2_fwd with stride 2 (Downsample.token_mixer, model/recnext.py:165, in a training step).
  *   x: N x H x W x Cin (dtype); gy: N x Ho x Wo x 2*Cin float32; w_kkc: (k,k,2*Cin) float32; gx: like x or NULL;
  *   gw: (k,k,2*Cin) float32, gb: (2*Cin) float32 or NULL; workspace: rcx_dwconv2d_bwd_workspace_bytes(2*Cin, k) bytes.

@@ -38,6 +38,9 @@ SIGNATURES = {
     "rcx_recconv2d_bwd_workspace_bytes": (_sz, [_i] * 6),
     "rcx_recconv2d_fwd_train": (_i, [_vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 8 + [_vp]),
     "rcx_recconv2d_bwd_gy_dtype": (_i, [_i] * 7),
+    "rcx_upadd_dwconv_bwd_workspace_bytes": (_sz, [_i] * 7),
+    "rcx_upadd_dwconv_bwd_gy_dtype": (_i, [_i] * 8),
+    "rcx_upadd_dwconv_bwd": (_i, [_vp, _vp, _vp, _i] + [_vp] * 7 + [_sz] + [_i] * 9 + [_vp]),
     "rcx_recconv2d_bwd": (_i, [_vp, _vp, _i] + [_vp] * 8 + [_i, _vp, _sz] + [_i] * 8 + [_vp]),
     "rcx_dwconv2d_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "rcx_dwconv2d_mult2_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),

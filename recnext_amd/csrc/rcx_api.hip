@@ -629,7 +629,7 @@ int rcx_recconv2d_bwd(const void* x, const void* gy, int gy_dtype, const float* 
             for (int q = 0; q < 4; ++q) add_slot(q, parts[q], N);
         }
         for (int l = m - 1; l >= 0; --l) {
-            RCX_TRY(rcx::wgrad2_cpl(a_of(l), adt_of(l), G_(l + 1), PART(slot), N, C, L.h[l], s, &rows), "bwd: down weight grad");
+            RCX_TRY(rcx::bwd_wgrad_d_cpt(a_of(l), adt_of(l), G_(l + 1), PART(slot), N, C, L.h[l], s, &rows), "bwd: down weight grad");
             add_slot(0, PART(slot++), rows);
             RCX_TRY(rcx::bwd_gx_cpt(g_of(l), gdt_of(l), G_(l + 1), l == 0 ? gx : (void*)G_(l), l == 0 ? dtype : RCX_DTYPE_F32, Wf(1 + level - l), W_(0),
                                     N, C, L.h[l], s), "bwd: gradient handed up");
@@ -785,6 +785,72 @@ int rcx_dwconv2d_bwd(const void* x, const float* gy, const float* w_kkc, const f
     }
     e = rcx::bwd_wgrad(x, x_dtype, nullptr, gy, (float*)workspace, gw, gb, N, C, H, W, 0, 0, Ho, Wo, k, stride, 0, 0, s);
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_dwconv2d_bwd: weight gradient");
+}
+
+// ---- backward of conv(x + resize(coarse)) (RecAttn2d's last line in a training step) ----
+static bool upadd_bwd_tiled(int N, int C, int H, int W, int Hc, int Wc, int k)
+{
+    return !lanes_off() && rcx::bwd_cpt_applicable(N, C, H, W, k) && Hc * 2 == H && Wc * 2 == W && rcx::wgrad_cpl_applicable(N, C, H, W, Hc, Wc, k, 1, true);
+}
+
+size_t rcx_upadd_dwconv_bwd_workspace_bytes(int N, int C, int H, int W, int Hc, int Wc, int k)
+{
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || (k & 1) == 0) return 0;
+    const size_t part = align256(rcx::wgrad_partial_bytes(C, k));
+    return upadd_bwd_tiled(N, C, H, W, Hc, Wc, k) ? part : part + align256(sizeof(float) * (size_t)N * C * H * W);      // + the float32 gT the resize adjoint reads
+}
+
+int rcx_upadd_dwconv_bwd_gy_dtype(int N, int C, int H, int W, int Hc, int Wc, int k, int dtype)
+{
+    if (!known_dtype(dtype) || dtype == RCX_DTYPE_F32 || N <= 0 || C <= 0 || C % 4 || k <= 0 || (k & 1) == 0) return RCX_DTYPE_F32;
+    return upadd_bwd_tiled(N, C, H, W, Hc, Wc, k) ? dtype : RCX_DTYPE_F32;
+}
+
+int rcx_upadd_dwconv_bwd(const void* x, const float* coarse, const void* gy, int gy_dtype, const float* w_kkc, const float* w_flipped_kkc,
+                         void* gx, float* gcoarse, float* gw, float* gb, void* workspace, size_t workspace_bytes,
+                         int N, int C, int H, int W, int Hc, int Wc, int k, int mode, int dtype, void* stream)
+{
+    if (!x || !coarse || !gy || !gw || !w_flipped_kkc) return fail(RCX_ERR_BAD_ARG, "rcx_upadd_dwconv_bwd: null pointer");
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || Hc <= 0 || Wc <= 0) return fail(RCX_ERR_BAD_ARG, "non-positive extent N=%d C=%d H=%d W=%d Hc=%d Wc=%d", N, C, H, W, Hc, Wc);
+    if (k <= 0 || (k & 1) == 0) return fail(RCX_ERR_BAD_ARG, "kernel_size must be odd and positive, got %d", k);
+    if (!known_dtype(dtype) || !known_dtype(gy_dtype)) return fail(RCX_ERR_BAD_ARG, "unknown dtype %d / %d", dtype, gy_dtype);
+    if (mode != RCX_MODE_BILINEAR && mode != RCX_MODE_NEAREST) return fail(RCX_ERR_BAD_ARG, "unknown mode %d", mode);
+    if (C % 4) return fail(RCX_ERR_UNSUPPORTED, "the backward kernels need C %% 4 == 0, got C=%d", C);
+    const size_t need = rcx_upadd_dwconv_bwd_workspace_bytes(N, C, H, W, Hc, Wc, k);
+    if (!workspace || workspace_bytes < need) return fail(RCX_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    const bool tiled = upadd_bwd_tiled(N, C, H, W, Hc, Wc, k);
+    if (gy_dtype != RCX_DTYPE_F32 && !(tiled && gy_dtype == dtype))
+        return fail(RCX_ERR_UNSUPPORTED, "gy of dtype %d: this problem takes float32 (rcx_upadd_dwconv_bwd_gy_dtype)", gy_dtype);
+    hipStream_t s = (hipStream_t)stream;
+    float* part = (float*)workspace;
+    hipError_t e;
+    if (tiled) {
+        const int md = mode == RCX_MODE_NEAREST ? 1 : 0;
+        if (gcoarse) {
+            e = rcx::bwd_gc_cpt(gy, gy_dtype, gcoarse, w_flipped_kkc, N, C, H, md, s);
+            if (e != hipSuccess) return hip_fail(e, "rcx_upadd_dwconv_bwd: coarse gradient");
+        }
+        if (gx) {
+            e = rcx::bwd_gx_cpt(gy, gy_dtype, nullptr, gx, dtype, w_flipped_kkc, nullptr, N, C, H, s);
+            if (e != hipSuccess) return hip_fail(e, "rcx_upadd_dwconv_bwd: input gradient");
+        }
+        e = rcx::bwd_wgrad(x, dtype, coarse, (const float*)gy, part, gw, gb, N, C, H, W, Hc, Wc, H, W, k, 1, mode, 0, s, nullptr, gy_dtype);
+        return e == hipSuccess ? 0 : hip_fail(e, "rcx_upadd_dwconv_bwd: weight gradient");
+    }
+    const float* gyf = (const float*)gy;
+    float* gT = (float*)((char*)workspace + align256(rcx::wgrad_partial_bytes(C, k)));
+    if (gcoarse) {
+        e = step_dwconv(gyf, gT, w_flipped_kkc, nullptr, N, C, H, W, k, 1, RCX_DTYPE_F32, RCX_DTYPE_F32, s);
+        if (e == hipSuccess) e = rcx::bwd_resize(gT, gcoarse, N, C, H, W, Hc, Wc, mode, s);
+        if (e != hipSuccess) return hip_fail(e, "rcx_upadd_dwconv_bwd: coarse gradient");
+    }
+    if (gx) {
+        if (gcoarse && dtype == RCX_DTYPE_F32) e = hipMemcpyAsync(gx, gT, sizeof(float) * (size_t)N * C * H * W, hipMemcpyDeviceToDevice, s);
+        else e = step_dwconv(gyf, gx, w_flipped_kkc, nullptr, N, C, H, W, k, 1, RCX_DTYPE_F32, dtype, s);
+        if (e != hipSuccess) return hip_fail(e, "rcx_upadd_dwconv_bwd: input gradient");
+    }
+    e = rcx::bwd_wgrad(x, dtype, coarse, gyf, part, gw, gb, N, C, H, W, Hc, Wc, H, W, k, 1, mode, 0, s);
+    return e == hipSuccess ? 0 : hip_fail(e, "rcx_upadd_dwconv_bwd: weight gradient");
 }
 
 int rcx_dwconv2d_mult2_bwd(const void* x, const float* gy, const float* w_kkc, void* gx, float* gw, float* gb,

@@ -632,15 +632,16 @@ static hipError_t wgrad_launch(const void* a, const float* coarse, const float* 
 
 hipError_t bwd_wgrad(const void* a, int a_dt, const float* coarse, const float* g, float* partial, float* gw, float* gb,
                      int N, int C, int H, int W, int Hc, int Wc, int Ho, int Wo, int k, int stride, int mode, int accumulate, hipStream_t s,
-                     int* rows_out)
+                     int* rows_out, int g_dt)
 {
     // the 56x56 / 28x28 convs over T = a + R(coarse): tiled channel-per-lane kernel (rcx_cplwgrad.hip), when the caller reduces itself
     {
         const bool t1 = Ho == H && Wo == W && wgrad_cpl_applicable(N, C, H, W, Hc, Wc, k, stride, coarse != nullptr);
         const bool t2 = !t1 && wgrad2_cpl_applicable(N, C, H, W, Ho, Wo, k, stride, coarse != nullptr);
+        if (g_dt != 0 && !t1) return hipErrorInvalidValue;
         if (t1 || t2) {
             int rows = 0;
-            hipError_t e = t1 ? wgrad_cpl(a, a_dt, coarse, g, 0, partial, N, C, H, mode, s, &rows) : wgrad2_cpl(a, a_dt, g, partial, N, C, H, s, &rows);
+            hipError_t e = t1 ? wgrad_cpl(a, a_dt, coarse, g, g_dt, partial, N, C, H, mode, s, &rows) : wgrad2_cpl(a, a_dt, g, partial, N, C, H, s, &rows);
             if (e != hipSuccess) return e;
             if (rows_out) { *rows_out = rows; return hipSuccess; }        // the caller reduces all its partial buffers in one launch
             const int kk = k * k, n5 = (kk + 1) * C;

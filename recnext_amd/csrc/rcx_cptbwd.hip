@@ -71,13 +71,16 @@ __device__ __forceinline__ bool decode_unit(Unit& u, int N, int C)
 // ---------------------------------------------------------------------------------------------------------------------------------
 // k_bwd_gx: out = K^ g + D^T G on a 14 x 14 tile.  g: N x H x H x C (TG), G: N x H/2 x H/2 x C float32 (HAS_D), out: TO.
 // wf: this conv's 25 x C flipped taps; wd: the shared down conv's 25 x C taps (as the forward applies them).
-template <typename TG, typename TO, int H, bool HAS_D>
-__global__ __launch_bounds__(256, 2)
+// AH = g rows requested ahead of use, OCC = workgroups per CU the register budget is set for: <1, 2> (at most 256 registers: two waves per SIMD) where a
+// launch fills the chip; <3, 1> where it has at most one wave per SIMD anyway (the float32 level-1 plane of the 56 x 56 block at batch 128: 512 waves) and
+// only requests in flight hide the memory latency
+template <typename TG, typename TO, int H, bool HAS_D, int AH = RCX_GX_AHEAD, int OCC = 2>
+__global__ __launch_bounds__(256, OCC)
 void k_bwd_gx(const TG* __restrict__ g, const float* __restrict__ Gc, TO* __restrict__ out, const float* __restrict__ wf,
               const float* __restrict__ wd, int N, int C)
 {
     using GE = Geo<H>;
-    constexpr int W = GE::W, Hc = GE::Hc, Wc = GE::Wc, AHEAD = RCX_GX_AHEAD, NS = 18;
+    constexpr int W = GE::W, Hc = GE::Hc, Wc = GE::Wc, AHEAD = AH, NS = 18;
     Unit U;
     if (!decode_unit<H>(U, N, C)) return;
     const int r0 = 14 * U.tr, c0 = 14 * U.tc;
@@ -218,12 +221,12 @@ void k_bwd_gx(const TG* __restrict__ g, const float* __restrict__ Gc, TO* __rest
 // k_bwd_gc: gC = R^T (K^ g) on the 7 x 7 coarse pixels of a 14 x 14 tile.  g: N x H x H x C (TG); gC: N x H/2 x H/2 x C float32.
 // Local frames: g row s = image row r0 - 3 + s, column q = image column c0 - 3 + q (20 x 20); gT row o = image row r0 - 1 + o,
 // column p = image column c0 - 1 + p (16 x 16: pairs start at an ODD image column); gT(o, p) = sum_{u,v} K^[u][v] g(o + u, p + v).
-template <int MODE, typename TG, int H>
-__global__ __launch_bounds__(256, 2)
+template <int MODE, typename TG, int H, int AH = RCX_GC_AHEAD, int OCC = 2>
+__global__ __launch_bounds__(256, OCC)
 void k_bwd_gc(const TG* __restrict__ g, float* __restrict__ gC, const float* __restrict__ wf, int N, int C)
 {
     using GE = Geo<H>;
-    constexpr int W = GE::W, Hc = GE::Hc, Wc = GE::Wc, AHEAD = RCX_GC_AHEAD, NS = 20;
+    constexpr int W = GE::W, Hc = GE::Hc, Wc = GE::Wc, AHEAD = AH, NS = 20;
     constexpr float WQ = MODE == 1 ? 0.f : 0.25f, WT = MODE == 1 ? 1.f : 0.75f;
     Unit U;
     if (!decode_unit<H>(U, N, C)) return;
@@ -352,14 +355,128 @@ void k_bwd_gc(const TG* __restrict__ g, float* __restrict__ gC, const float* __r
     });
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_wgrad_d: the shared stride-2 conv's weight gradient from one level, gW_d[u][v] += sum_{o,i} G[o][i] a[2o + u - 2][2i + v - 2]
+// (model/recnext.py:21, :28), on the same tiles: a wave = 64 channels of a 14 x 14 tile of a = the 7 x 7 pixels of G it produced.
+// rcx_cplwgrad.hip's k_wgrad2_cpl gives a wave a 14 x 14 tile of G (28 x 28 of a): 512 waves at 128 x 64 x 56 x 56, 330 registers, one
+// wave on every second SIMD -- 50 us for 0.1 GB.  Here: four times the waves, G's 49 values resident, a-row stationary with the taps paired
+// against a's aligned pairs (rcx_cplbwd_pieces.h), rows requested AHEAD before use.  The NT column tiles of a band share a workgroup and add
+// their 26 sums per channel through LDS in a fixed order: one partial row per (image, 14-row band), reduced over the batch by k_wgrad_reduce_jobs.
+template <typename TA, int H>
+__global__ __launch_bounds__(64 * (H / 14))
+void k_wgrad_d(const TA* __restrict__ a, const float* __restrict__ Gc, float* __restrict__ partial, int N, int C)
+{
+    using GE = Geo<H>;
+    constexpr int W = GE::W, NT = GE::NT, NB = GE::NB, Hc = GE::Hc, Wc = GE::Wc, AHEAD = 2, NS = 17;
+    __shared__ float red[NT][26][64];
+    const int tile = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int nb = (C + 63) / 64;
+    const unsigned unit = blockIdx.x;
+    const int cb = (int)(unit % (unsigned)nb), band = (int)((unit / (unsigned)nb) % (unsigned)NB), n = (int)(unit / (unsigned)(nb * NB));
+    const int c = cb * 64 + lane;
+    const bool live = c < C;
+    const unsigned cl = (unsigned)(live ? c : C - 1);
+    const int r0 = 14 * band, c0 = 14 * tile;
+    const size_t pixa = (size_t)C * sizeof(TA), pixf = (size_t)C * 4;
+    const unsigned voa = cl * (unsigned)sizeof(TA), vof = cl * 4u;
+    const gcptr ab = (gcptr)a + (size_t)n * H * W * pixa;
+    const gcptr Gb = (gcptr)Gc + ((size_t)n * Hc * Wc + (size_t)(7 * band) * Wc + 7 * tile) * pixf;
+
+    uint32_t ra[NS][18], rG[7][7];
+    auto ld_a = [&](auto sc) {                                // local row s = image row r0 - 2 + s, local column q = image column c0 - 2 + q (clamped; zeroed when taken)
+        constexpr int s = decltype(sc)::value;
+        int r = r0 - 2 + s;
+        r = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
+        const gcptr rowp = ab + (size_t)r * W * pixa;
+#pragma unroll
+        for (int q = 0; q < 18; ++q) {
+            int col = c0 + q - 2;
+            if (q < 2) col = col < 0 ? 0 : col;
+            if (q >= 16) col = col > W - 1 ? W - 1 : col;
+            ra[s][q] = SafeLd<TA>::ld(rowp + (size_t)col * pixa + voa);
+        }
+    };
+    sfor<7>([&](auto oc) {
+        constexpr int o = decltype(oc)::value;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) rG[o][i] = SafeLd<float>::ld(Gb + ((size_t)o * Wc + i) * pixf + vof);
+    });
+    sfor<AHEAD>([&](auto sc) { ld_a(sc); });
+    const f32x2 keep_lo = splat(c0 == 0 ? 0.f : 1.f), keep_hi = splat(c0 + 14 == W ? 0.f : 1.f);
+    DAcc acc;
+    acc.zero();
+    float G[7][7];
+    sfor<7>([&](auto oc) {
+        constexpr int o = decltype(oc)::value;
+        pin_raw(rG[o]);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { G[o][i] = __uint_as_float(rG[o][i]); if (i & 1) acc.bs.y += G[o][i]; else acc.bs.x += G[o][i]; }
+    });
+    sfor<NS>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (s + AHEAD < NS) ld_a(IC<s + AHEAD>{});
+        pin_raw(ra[s]);
+        f32x2 ar[9];
+        {
+            const int r = r0 - 2 + s;
+            const f32x2 keep = splat((s >= 2 && s < 16) || (r >= 0 && r < H) ? 1.f : 0.f);
+#pragma unroll
+            for (int m = 0; m < 9; ++m) {
+                ar[m] = f32x2{SafeLd<TA>::cvt(ra[s][2 * m]), SafeLd<TA>::cvt(ra[s][2 * m + 1])};
+                if constexpr (s < 2 || s >= 16) ar[m] = ar[m] * keep;
+            }
+            ar[0] = ar[0] * keep_lo;
+            ar[8] = ar[8] * keep_hi;
+        }
+        // a row s = 2o + u: the G rows o whose window covers it, tap row u; G column i against the pairs ar[i + k] = a columns 2i + 2k, 2i + 2k + 1
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+#pragma unroll
+            for (int o = 0; o < 7; ++o) {
+                const int u = s - 2 * o;
+                if (u < 0 || u > 4) continue;
+                const f32x2 gv = splat(G[o][i]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc.a[u][k] = pfma(gv, ar[i + k], acc.a[u][k]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) pin(acc.a[u]);
+        RCX_FENCE;
+    });
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+#pragma unroll
+        for (int v = 0; v < 5; ++v) red[tile][u * 5 + v][lane] = acc.tap(u, v);
+    red[tile][25][lane] = acc.bias();
+    __syncthreads();
+    if (tile == 0 && live) {
+        float* q = partial + ((size_t)(n * NB + band) * 26) * C + c;
+#pragma unroll
+        for (int t = 0; t < 26; ++t) {
+            float sum = red[0][t][lane];
+#pragma unroll
+            for (int w = 1; w < NT; ++w) sum += red[w][t][lane];
+            q[(size_t)t * C] = sum;
+        }
+    }
+}
+
 #ifndef RCX_CPTBWD_KERNELS_ONLY            // (a tuning harness instantiates single kernels)
+// tile-waves up to which a launch leaves at most one wave per SIMD (256 CUs x 4): the deep-prefetch instantiations (RCX_BWD_CPT=shallow: never)
+static long long few_units()
+{
+    const char* v = rcx::opt::value(rcx::opt::BWD_CPT);
+    return (v && *v == 's') ? 0 : 1024;
+}
 template <typename TG, typename TO, int H>
 static hipError_t launch_gx(const void* g, const float* G, void* out, const float* wf, const float* wd, int N, int C, hipStream_t s)
 {
     const long long units = (long long)N * ((C + 63) / 64) * (H / 14) * (H / 14);
     const dim3 grid((unsigned)((units + 3) / 4)), block(256);
-    if (G) hipLaunchKernelGGL((k_bwd_gx<TG, TO, H, true>), grid, block, 0, s, (const TG*)g, G, (TO*)out, wf, wd, N, C);
-    else hipLaunchKernelGGL((k_bwd_gx<TG, TO, H, false>), grid, block, 0, s, (const TG*)g, G, (TO*)out, wf, wd, N, C);
+    if (!G) hipLaunchKernelGGL((k_bwd_gx<TG, TO, H, false>), grid, block, 0, s, (const TG*)g, G, (TO*)out, wf, wd, N, C);
+    else if (units <= few_units()) hipLaunchKernelGGL((k_bwd_gx<TG, TO, H, true, 3, 1>), grid, block, 0, s, (const TG*)g, G, (TO*)out, wf, wd, N, C);
+    else hipLaunchKernelGGL((k_bwd_gx<TG, TO, H, true>), grid, block, 0, s, (const TG*)g, G, (TO*)out, wf, wd, N, C);
     return hipGetLastError();
 }
 
@@ -368,15 +485,38 @@ static hipError_t launch_gc(const void* g, float* gC, const float* wf, int N, in
 {
     const long long units = (long long)N * ((C + 63) / 64) * (H / 14) * (H / 14);
     const dim3 grid((unsigned)((units + 3) / 4)), block(256);
-    if (mode == 1) hipLaunchKernelGGL((k_bwd_gc<1, TG, H>), grid, block, 0, s, (const TG*)g, gC, wf, N, C);
-    else hipLaunchKernelGGL((k_bwd_gc<0, TG, H>), grid, block, 0, s, (const TG*)g, gC, wf, N, C);
+    if (units <= few_units()) {
+        if (mode == 1) hipLaunchKernelGGL((k_bwd_gc<1, TG, H, 3, 1>), grid, block, 0, s, (const TG*)g, gC, wf, N, C);
+        else hipLaunchKernelGGL((k_bwd_gc<0, TG, H, 3, 1>), grid, block, 0, s, (const TG*)g, gC, wf, N, C);
+    } else {
+        if (mode == 1) hipLaunchKernelGGL((k_bwd_gc<1, TG, H>), grid, block, 0, s, (const TG*)g, gC, wf, N, C);
+        else hipLaunchKernelGGL((k_bwd_gc<0, TG, H>), grid, block, 0, s, (const TG*)g, gC, wf, N, C);
+    }
     return hipGetLastError();
 }
 
+template <typename TA, int H>
+static hipError_t launch_wd(const void* a, const float* G, float* partial, int N, int C, hipStream_t s)
+{
+    const unsigned grid = (unsigned)(N * (H / 14) * ((C + 63) / 64));
+    hipLaunchKernelGGL((k_wgrad_d<TA, H>), dim3(grid), dim3(64 * (H / 14)), 0, s, (const TA*)a, G, partial, N, C);
+    return hipGetLastError();
+}
 #endif
 }  // namespace cptbwd
 
 #ifndef RCX_CPTBWD_KERNELS_ONLY
+// the shared down conv's weight gradient from (a: H x H of a_dt, G: H/2 x H/2 float32): one partial row of 26 C sums per (image, 14-row band of a)
+hipError_t bwd_wgrad_d_cpt(const void* a, int a_dt, const float* G, float* partial, int N, int C, int H, hipStream_t s, int* rows_out)
+{
+    if (rows_out) *rows_out = N * (H / 14);
+#define RCX_WD(TA_) (H == 56 ? cptbwd::launch_wd<TA_, 56>(a, G, partial, N, C, s) : cptbwd::launch_wd<TA_, 28>(a, G, partial, N, C, s))
+    if (a_dt == 1) return RCX_WD(bf16_t);
+    if (a_dt == 2) return RCX_WD(f16_t);
+    return RCX_WD(float);
+#undef RCX_WD
+}
+
 bool bwd_cpt_applicable(int N, int C, int H, int W, int k)
 {
     if (rcx::opt::is_zero(rcx::opt::BWD_CPT)) return false;

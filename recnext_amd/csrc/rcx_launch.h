@@ -124,6 +124,7 @@ hipError_t wgrad2m_cpl(const void* a, int a_dt, const float* g, float* partial, 
 // out = K^ g + D^T G (G = nullptr: the conv adjoint alone); g_dt / out_dt: dtype ids, G and gC float32
 bool bwd_cpt_applicable(int N, int C, int H, int W, int k);
 hipError_t bwd_gc_cpt(const void* g, int g_dt, float* gC, const float* wf, int N, int C, int H, int mode, hipStream_t s);
+hipError_t bwd_wgrad_d_cpt(const void* a, int a_dt, const float* G, float* partial, int N, int C, int H, hipStream_t s, int* rows_out);
 hipError_t bwd_gx_cpt(const void* g, int g_dt, const float* G, void* out, int out_dt, const float* wf, const float* wd, int N, int C, int H, hipStream_t s);
 
 // channel-per-lane, tiled kernel of the 56x56 / level 4 and 28x28 / level 3 blocks (rcx_cpt.hip): any channel count
@@ -180,7 +181,8 @@ hipError_t linattn_core_bwd(const void* qpre, const void* kpre, const void* v, c
 size_t wgrad_partial_bytes(int C, int k);
 hipError_t bwd_wgrad(const void* a, int a_dt, const float* coarse, const float* g, float* partial, float* gw, float* gb,
                      int N, int C, int H, int W, int Hc, int Wc, int Ho, int Wo, int k, int stride, int mode, int accumulate, hipStream_t s,
-                     int* rows_out = nullptr);   // rows_out: leave the partial sums in `partial` (that many rows) for bwd_wgrad_reduce_jobs
+                     int* rows_out = nullptr,    // rows_out: leave the partial sums in `partial` (that many rows) for bwd_wgrad_reduce_jobs
+                     int g_dt = 0);              // g of a's own 16-bit type: only where the tiled kernel runs (wgrad_cpl_applicable), else an error
 // every weight gradient of one block's backward reduced in one launch: job j sums nslots[j] partial buffers (rows[j][.] rows each) into gw[j] / gb[j]
 struct WgradJobs {
     int njobs, kk, C;

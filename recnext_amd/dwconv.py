@@ -33,6 +33,33 @@ class DwConvFn(torch.autograd.Function):
         return gx, gw, (gb.to(ctx.wdtype) if gb is not None else None), None
 
 
+class UpAddDwConvFn(torch.autograd.Function):
+    """conv_k(x + interpolate(a, size=x.shape[2:], mode)) -- the last line of RecAttn2d.forward (model/recattn.py:67) -- as ONE HIP launch each way for the
+    resize, the add and the conv: rcx_upadd_dwconv_fwd / rcx_upadd_dwconv_bwd (no ATen resize or add in the training step).  The coarse plane is taken
+    in float32 (a quarter of x's pixels), as the inference path keeps it."""
+
+    @staticmethod
+    def forward(ctx, x, a, weight, bias, mode):
+        k = weight.shape[-1]
+        wp = ops.pack_dw_weight(weight.float())
+        bp = ops.pack_bias(bias.float()) if bias is not None else None
+        a32 = a if a.dtype == torch.float32 else a.float()
+        ctx.save_for_backward(x, a32, wp)
+        ctx.k, ctx.mode, ctx.has_bias, ctx.wdtype, ctx.adtype = k, mode, bias is not None, weight.dtype, a.dtype
+        return ops.upadd_dwconv(x, a32, wp, bp, k=k, mode=mode)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, a32, wp = ctx.saved_tensors
+        k, c = ctx.k, x.shape[1]
+        gx, ga, gw, gb = ops.upadd_dwconv_backward(x, a32, gy, wp, k, ctx.mode, need_input_grad=ctx.needs_input_grad[0],
+                                                   need_coarse_grad=ctx.needs_input_grad[1], need_bias=ctx.has_bias)
+        gw = gw.view(k, k, c).permute(2, 0, 1).unsqueeze(1).to(ctx.wdtype)
+        if ga is not None and ga.dtype != ctx.adtype:
+            ga = ga.to(ctx.adtype)
+        return gx, ga, gw, (gb.to(ctx.wdtype) if gb is not None else None), None
+
+
 class DwConvMult2Fn(torch.autograd.Function):
     """nn.Conv2d(C, 2C, k, stride=2, padding=k//2, groups=C): rcx_dwconv2d_mult2_fwd / rcx_dwconv2d_mult2_bwd."""
 

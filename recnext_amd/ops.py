@@ -295,6 +295,34 @@ def dwconv2d_backward(x, gy, w_kkc, k, stride, need_input_grad=True, need_bias=F
     return gx, gw, gb
 
 
+def upadd_dwconv_backward(x, coarse, gy, w_kkc, k=5, mode="nearest", need_input_grad=True, need_coarse_grad=True, need_bias=False):
+    """Backward of upadd_dwconv with a coarse plane (rcx_upadd_dwconv_bwd; model/recattn.py:67): -> (gx like x | None, gcoarse float32 like coarse | None,
+    gw (k,k,C) float32, gb (C) float32 | None).  coarse must be float32; gy float32 or (where the library takes it) x's own 16-bit dtype.  Deterministic."""
+    x = _nhwc(x)
+    coarse = _nhwc(coarse, "coarse")
+    if coarse.dtype != torch.float32:
+        raise TypeError("upadd_dwconv_backward takes the coarse plane in float32")
+    n, c, h, w = x.shape
+    hc, wc = coarse.shape[2:]
+    lib = _lib.load()
+    want = lib.rcx_upadd_dwconv_bwd_gy_dtype(n, c, h, w, hc, wc, k, _dt(x))
+    gy = _nhwc(gy if (gy.dtype == torch.float32 or (_DT.get(gy.dtype) == want and gy.dtype == x.dtype)) else gy.to(torch.float32), "grad_output")
+    wflip = w_kkc.view(k, k, c).flip(0, 1).contiguous()
+    gx = _empty_nhwc(n, c, h, w, x.dtype, x.device) if need_input_grad else None
+    gc = _empty_nhwc(n, c, hc, wc, torch.float32, x.device) if need_coarse_grad else None
+    gw = torch.empty(k * k * c, dtype=torch.float32, device=x.device)
+    gb = torch.empty(c, dtype=torch.float32, device=x.device) if need_bias else None
+    nbytes = lib.rcx_upadd_dwconv_bwd_workspace_bytes(n, c, h, w, hc, wc, k)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
+    with _on(x.device):
+        rc = lib.rcx_upadd_dwconv_bwd(x.data_ptr(), coarse.data_ptr(), gy.data_ptr(), _DT[gy.dtype], w_kkc.data_ptr(), wflip.data_ptr(),
+                                      gx.data_ptr() if gx is not None else None, gc.data_ptr() if gc is not None else None, gw.data_ptr(),
+                                      gb.data_ptr() if gb is not None else None, ws.data_ptr(), nbytes, n, c, h, w, hc, wc, k, _lib.MODES[mode], _dt(x),
+                                      _stream(x.device))
+    _lib.check(rc, "rcx_upadd_dwconv_bwd")
+    return gx, gc, gw, gb
+
+
 def dwconv2d_mult2_backward(x, gy, w_kkc, k, need_input_grad=True, need_bias=False):
     """Backward of dwconv2d_mult2 (stride 2): -> (gx like x | None, gw (k,k,2C) float32, gb (2C) float32 | None)."""
     x = _nhwc(x)

@@ -19,6 +19,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .dwconv import DwConvFn as _DwConvFn
+from .dwconv import UpAddDwConvFn as _UpAddDwConvFn
 from .layers import ConvNorm
 
 
@@ -81,6 +82,14 @@ def _conv_norm_train(m, x, stride):
     if isinstance(m, nn.Conv2d):
         return _DwConvFn.apply(x, m.weight, m.bias, stride)
     return m.norm(_DwConvFn.apply(x, m.conv.weight, m.conv.bias, stride))
+
+
+def _upadd_conv_norm_train(m, x, a, mode):
+    """ConvNorm(x + interpolate(a, size(x), mode)) in a training step: resize, add and conv in one HIP launch with a HIP backward (rcx_upadd_dwconv_fwd / _bwd),
+    then the module's own BatchNorm (batch statistics)."""
+    if isinstance(m, nn.Conv2d):
+        return _UpAddDwConvFn.apply(x, a, m.weight, m.bias, mode)
+    return m.norm(_UpAddDwConvFn.apply(x, a, m.conv.weight, m.conv.bias, mode))
 
 
 def _folded(m):
@@ -162,7 +171,7 @@ class RecAttn2d(nn.Module):
                 raise NotImplementedError("the HIP depthwise backward needs a channel count that is a multiple of 4")
             d = _conv_norm_train(self.down[0], x, 2)
             a = self.down[1](d)
-            return _conv_norm_train(self.conv, x + F.interpolate(a, size=x.shape[2:], mode=self.mode), 1)
+            return _upadd_conv_norm_train(self.conv, x, a, self.mode)           # conv(x + resize(a)), :67: one HIP launch each way
         wd, bd, wc, bc, wq, bq, wk, bk, wpe, bpe, wqk16, bqk = self.packed_params()
         k = self.kernel_size
         la = self.down[1]

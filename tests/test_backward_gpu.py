@@ -223,6 +223,40 @@ def test_recattn2d_training_step_matches_aten(stage, dim, hw):
         assert torch.allclose(br.float(), bo.float(), atol=1e-5, rtol=1e-4), name
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["nearest", "bilinear"])
+@pytest.mark.parametrize("case", [(2, 64, 56, 56, 28, 28), (3, 128, 28, 28, 14, 14), (2, 40, 56, 56, 28, 28), (2, 16, 14, 14, 7, 7), (3, 32, 7, 7, 4, 4),
+                                  (1, 8, 25, 13, 13, 7)], ids=lambda c: "x".join(map(str, c)))
+def test_upadd_dwconv_backward_matches_aten_autograd(case, mode, dtype):
+    """conv5(x + interpolate(a, size(x), mode)) -- RecAttn2d's last line (model/recattn.py:67) -- as recnext_amd.dwconv.UpAddDwConvFn (one HIP launch each
+    way for resize + add + conv) against autograd through the ATen operators in float32: gx, ga, gw, gb.  56x56 / 28x28 with an exact 2x coarse plane
+    take the tiled adjoint kernels (and a 16-bit gy as it is); the others the per-step kernels."""
+    from recnext_amd.dwconv import UpAddDwConvFn
+    n, c, h, w, hc, wc = case
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(c, c, 5, padding=2, groups=c, bias=True).to(dev)
+    x = torch.randn(n, c, h, w, device=dev).to(dtype)
+    a = torch.randn(n, c, hc, wc, device=dev).to(dtype)
+    gy = torch.randn(n, c, h, w, device=dev).to(dtype)
+    xr, ar = x.float().clone().requires_grad_(True), a.float().clone().requires_grad_(True)
+    yr = conv(xr + torch.nn.functional.interpolate(ar, size=(h, w), mode=mode))
+    yr.backward(gy.float())
+    gwr, gbr = conv.weight.grad.clone(), conv.bias.grad.clone()
+    conv.weight.grad = conv.bias.grad = None
+    xo = x.detach().clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ao = a.detach().clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yo = UpAddDwConvFn.apply(xo, ao, conv.weight, conv.bias, mode)
+    assert yo.dtype == dtype
+    yo.backward(gy.contiguous(memory_format=torch.channels_last))
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    assert _rel(yo.float(), yr) < tol
+    assert xo.grad.dtype == dtype and ao.grad.dtype == dtype
+    assert _rel(xo.grad.float(), xr.grad) < tol
+    assert _rel(ao.grad.float(), ar.grad) < tol
+    assert _rel(conv.weight.grad, gwr) < 2e-4 and _rel(conv.bias.grad, gbr) < 2e-4      # float32 sums either way (inputs are the same rounded values)
+
+
 @pytest.mark.parametrize("case", [(2, 16, 14, 14, 7), (1, 64, 56, 56, 7), (3, 6, 9, 12, 7), (2, 8, 10, 10, 5), (2, 8, 7, 7, 3),
                                   (2, 32, 28, 28, 7), (1, 24, 56, 56, 7), (2, 72, 28, 28, 7)],    # the tiled weight-gradient kernel: both plane sizes, ragged 64-channel blocks
                          ids=lambda c: "x".join(map(str, c)))
