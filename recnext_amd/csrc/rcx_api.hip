@@ -617,7 +617,7 @@ int rcx_recconv2d_bwd(const void* x, const void* gy, int gy_dtype, const float* 
         auto adt_of = [&](int l) { return l == 0 ? dtype : RCX_DTYPE_F32; };
         for (int l = 0; l < m; ++l) {
             const int j = level - l;                              // convs[j] is level l's conv
-            RCX_TRY(rcx::wgrad_cpl(a_of(l), adt_of(l), C_(l + 1), g_of(l), gdt_of(l), PART(slot), N, C, L.h[l], md, s, &rows), "bwd: conv weight grad");
+            RCX_TRY(rcx::bwd_wgrad_k_cpt(a_of(l), adt_of(l), C_(l + 1), g_of(l), gdt_of(l), PART(slot), N, C, L.h[l], md, s, &rows), "bwd: conv weight grad");
             add_slot(1 + j, PART(slot++), rows);
             RCX_TRY(rcx::bwd_gc_cpt(g_of(l), gdt_of(l), gcl[l + 1], Wf(1 + j), N, C, L.h[l], md, s), "bwd: gradient handed down");
         }

@@ -514,10 +514,11 @@ k_wgrad_reduce8(const float* __restrict__ partial, float* __restrict__ gw, float
 
 // stage 2 for a whole block's backward in ONE launch (blockIdx.y = job): every conv of the block has its own partial buffer(s); the
 // shared down conv sums the buffers of all its levels (coarsest first).  Fixed order throughout: deterministic.
-__global__ void __launch_bounds__(256)
+constexpr int RJ = 32;             // threads that share one output (rows r = j mod RJ each): the tiled weight-gradient kernels leave up to 512 rows per buffer
+__global__ void __launch_bounds__(32 * RJ)
 k_wgrad_reduce_jobs(WgradJobs J)
 {
-    __shared__ float red[8][32];
+    __shared__ float red[RJ][32];
     const int job = blockIdx.y;
     const int i = blockIdx.x * 32 + threadIdx.x, j = threadIdx.y, total = (J.kk + 1) * J.C;
     float s = 0.f;
@@ -527,20 +528,20 @@ k_wgrad_reduce_jobs(WgradJobs J)
             const int rows = J.rows[job][sl];
             int r = j;
             // four rows in flight at a time (the loads are independent, the sum keeps its fixed order): a row per iteration is one
-            // exposed memory latency per row -- 15 us for the 128 rows the fused backward leaves, where the traffic is worth 3
-            for (; r + 24 < rows; r += 32) {
-                const float a0 = part[(size_t)r * total + i], a1 = part[(size_t)(r + 8) * total + i];
-                const float a2 = part[(size_t)(r + 16) * total + i], a3 = part[(size_t)(r + 24) * total + i];
+            // exposed memory latency per row
+            for (; r + 3 * RJ < rows; r += 4 * RJ) {
+                const float a0 = part[(size_t)r * total + i], a1 = part[(size_t)(r + RJ) * total + i];
+                const float a2 = part[(size_t)(r + 2 * RJ) * total + i], a3 = part[(size_t)(r + 3 * RJ) * total + i];
                 s += a0; s += a1; s += a2; s += a3;
             }
-            for (; r < rows; r += 8) s += part[(size_t)r * total + i];
+            for (; r < rows; r += RJ) s += part[(size_t)r * total + i];
         }
     red[j][threadIdx.x] = s;
     __syncthreads();
     if (j == 0 && i < total) {
         float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) t += red[r][threadIdx.x];
+        for (int r = 0; r < RJ; ++r) t += red[r][threadIdx.x];
         if (!J.param_layout) {
             if (i < J.kk * J.C) J.gw[job][i] = t;
             else if (J.gb[job]) J.gb[job][i - J.kk * J.C] = t;
@@ -661,7 +662,7 @@ hipError_t bwd_wgrad(const void* a, int a_dt, const float* coarse, const float* 
 hipError_t bwd_wgrad_reduce_jobs(const WgradJobs& J, hipStream_t s)
 {
     const int n5 = (J.kk + 1) * J.C;
-    hipLaunchKernelGGL(k_wgrad_reduce_jobs, dim3((n5 + 31) / 32, J.njobs), dim3(32, 8), 0, s, J);
+    hipLaunchKernelGGL(k_wgrad_reduce_jobs, dim3((n5 + 31) / 32, J.njobs), dim3(32, RJ), 0, s, J);
     return hipGetLastError();
 }
 

@@ -20,13 +20,14 @@
 // forward clamps its source index, so the fine pixel that would lie outside gives its weight to the edge pixel (1/4 + 3/4 = 1):
 // resolved per tile with wave-uniform weights, no branch.  Nearest: weights 0, 1, 1, 0.
 // Arithmetic: float32 throughout, packed pairs of horizontally adjacent pixels (v_pk_fma_f32), input-row stationary with five
-// accumulator rows in flight, exactly as the forward's pass 2; loads are ordered loads the compiler counts itself (SafeLd), requested
-// AHEAD rows before they are used.
-#include "rcx_cplbwd_pieces.h"
+// accumulator rows in flight, exactly as the forward's pass 2.  Rows are hand-issued buffer loads through per-row descriptors (rcx_upcpt.hip): a 16-bit
+// element lands in float32 position (D16-hi), everything outside the plane is out of range and reads 0 -- no conversion, mask or address instructions;
+// every wave issues the same sequence, so the s_waitcnt counts are compile-time numbers (SchedGX / SchedGC / SchedWD).
+#include "rcx_cpt_kernel.h"
 #include "rcx_opts.h"
 
 #ifndef RCX_GX_AHEAD
-#define RCX_GX_AHEAD 1
+#define RCX_GX_AHEAD 1              /* g rows in flight in front of the row being used (k_bwd_gx / k_bwd_gc) */
 #endif
 #ifndef RCX_GC_AHEAD
 #define RCX_GC_AHEAD 1
@@ -35,7 +36,7 @@
 namespace rcx {
 namespace cptbwd {
 
-using namespace cplbwd;
+using namespace cpt;
 
 template <int H> struct Geo {
     static constexpr int W = H, NT = W / 14, NB = H / 14, Hc = H / 2, Wc = W / 2;
@@ -45,7 +46,7 @@ template <int H> struct Geo {
 struct Unit {
     int n, cb, tr, tc, c;
     bool live;
-    unsigned cl;
+    int cl;
 };
 template <int H>
 __device__ __forceinline__ bool decode_unit(Unit& u, int N, int C)
@@ -64,92 +65,189 @@ __device__ __forceinline__ bool decode_unit(Unit& u, int N, int C)
     u.n = (int)(q / (unsigned)nb);
     u.c = u.cb * 64 + lane;
     u.live = u.c < C;
-    u.cl = (unsigned)(u.live ? u.c : C - 1);          // ragged last block: the spare lanes shadow the last channel and store nothing
+    u.cl = u.live ? u.c : C - 1;                      // ragged last block: the spare lanes shadow the last channel and store out of range
     return true;
 }
+
+// A row of a plane as a buffer of its own (base = the row, num_records = its bytes): everything left and right of it -- and, with zero records, a row
+// outside the plane -- is out of range: loads return 0 (the zero padding of the convs, the absent terms of the adjoint sums), stores are dropped.
+// Scalar arithmetic on uniform values only (see rcx_upcpt.hip::row_desc for the hazard a v_readfirstlane here would open).
+__device__ __forceinline__ i32x4 row_desc(unsigned long long base, int row, int rows, int rowbytes)
+{
+    const bool ok = row >= 0 && row < rows;
+    const unsigned long long a = base + (unsigned long long)(ok ? row : 0) * (unsigned long long)rowbytes;
+    i32x4 d;
+    d.x = (int)(unsigned)a;
+    d.y = (int)(unsigned)(a >> 32) & 0xffff;
+    d.z = ok ? rowbytes : 0;
+    d.w = 0x00020000;
+    return d;
+}
+
+// ---- row statements of this file (the 18-column row of 2 + 14 + 2 is rcx_cpt_kernel.h's row_load) ----
+// nine float32 columns of a coarse row: -1 (vl), 0 .. 6 (vm), 7 (vr); run-time pitch
+#define BW_LD9                                                                                                                        \
+    "s_add_i32 %[t], %[rb], 0\n\t"                                                                                                   \
+    "buffer_load_dword %0, %[vl], %[rs], %[t] offen\n\tbuffer_load_dword %8, %[vr], %[rs], %[t] offen\n\t"                           \
+    "buffer_load_dword %1, %[vm], %[rs], %[t] offen\n\t"                                                                             \
+    "s_add_i32 %[t], %[t], %[pix]\n\tbuffer_load_dword %2, %[vm], %[rs], %[t] offen\n\t"                                             \
+    "s_add_i32 %[t], %[t], %[pix]\n\tbuffer_load_dword %3, %[vm], %[rs], %[t] offen\n\t"                                             \
+    "s_add_i32 %[t], %[t], %[pix]\n\tbuffer_load_dword %4, %[vm], %[rs], %[t] offen\n\t"                                             \
+    "s_add_i32 %[t], %[t], %[pix]\n\tbuffer_load_dword %5, %[vm], %[rs], %[t] offen\n\t"                                             \
+    "s_add_i32 %[t], %[t], %[pix]\n\tbuffer_load_dword %6, %[vm], %[rs], %[t] offen\n\t"                                             \
+    "s_add_i32 %[t], %[t], %[pix]\n\tbuffer_load_dword %7, %[vm], %[rs], %[t] offen\n\t"
+__device__ __forceinline__ void row_load9(uint32_t (&v)[9], unsigned vl, unsigned vm, unsigned vr, i32x4 rs, int rb, int pix)
+{
+    int t;
+    asm volatile(BW_LD9 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]), [t] "=&s"(t)
+                 : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+}
+template <int PENDING> __device__ __forceinline__ void pin_row9(uint32_t (&v)[9])
+{
+    asm volatile("s_waitcnt vmcnt(%9)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]) : "n"(PENDING));
+}
+// twenty columns as 3 + 14 + 3: -3, -2, -1 (vl), 0 .. 13 (vm), 14, 15, 16 (vr) -- the three columns either side share the fate of their voffset (all out of
+// range at a plane edge).  Immediate pitch where 13 pitches fit the 12-bit offset field, else the scalar offset walks along the row.
+#define BW_L20_IMM(OP)                                                                                                               \
+    "s_add_i32 %[t], %[rb], 0\n\t"                                                                                                   \
+    CPT_LI(OP, 0, "vl", "t", 0) CPT_LI(OP, 1, "vl", "t", 1) CPT_LI(OP, 2, "vl", "t", 2)                                               \
+    CPT_LI(OP, 3, "vm", "t", 0) CPT_LI(OP, 4, "vm", "t", 1) CPT_LI(OP, 5, "vm", "t", 2) CPT_LI(OP, 6, "vm", "t", 3)                   \
+    CPT_LI(OP, 7, "vm", "t", 4) CPT_LI(OP, 8, "vm", "t", 5) CPT_LI(OP, 9, "vm", "t", 6) CPT_LI(OP, 10, "vm", "t", 7)                  \
+    CPT_LI(OP, 11, "vm", "t", 8) CPT_LI(OP, 12, "vm", "t", 9) CPT_LI(OP, 13, "vm", "t", 10) CPT_LI(OP, 14, "vm", "t", 11)             \
+    CPT_LI(OP, 15, "vm", "t", 12) CPT_LI(OP, 16, "vm", "t", 13)                                                                       \
+    CPT_LI(OP, 17, "vr", "t", 0) CPT_LI(OP, 18, "vr", "t", 1) CPT_LI(OP, 19, "vr", "t", 2)
+#define BW_N(OP, d, V) "s_add_i32 %[t2], %[t2], %[pix]\n\t" CPT_LG(OP, d, V, "t2")
+#define BW_L20_GEN(OP)                                                                                                               \
+    "s_add_i32 %[t2], %[rb], 0\n\t" CPT_LG(OP, 0, "vl", "t2") BW_N(OP, 1, "vl") BW_N(OP, 2, "vl")                                      \
+    "s_add_i32 %[t2], %[rb], 0\n\t" CPT_LG(OP, 17, "vr", "t2") BW_N(OP, 18, "vr") BW_N(OP, 19, "vr")                                   \
+    "s_add_i32 %[t2], %[rb], 0\n\t" CPT_LG(OP, 3, "vm", "t2") BW_N(OP, 4, "vm") BW_N(OP, 5, "vm") BW_N(OP, 6, "vm") BW_N(OP, 7, "vm")   \
+    BW_N(OP, 8, "vm") BW_N(OP, 9, "vm") BW_N(OP, 10, "vm") BW_N(OP, 11, "vm") BW_N(OP, 12, "vm") BW_N(OP, 13, "vm") BW_N(OP, 14, "vm")  \
+    BW_N(OP, 15, "vm") BW_N(OP, 16, "vm")
+template <typename TIO, int PIXB>
+__device__ __forceinline__ void row_load20w(uint32_t (&v)[20], unsigned vl, unsigned vm, unsigned vr, i32x4 rs, int rb, int pix)
+{
+    int t, t2;
+    if constexpr (PIXB > 0 && PIXB * 13 <= 4095) {
+        (void)pix; (void)t2;
+        if constexpr (std::is_same<TIO, f16_t>::value)
+            asm volatile(BW_L20_IMM(CPT_LDH) : CPT_OUT20(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+        else if constexpr (sizeof(TIO) == 2)
+            asm volatile(BW_L20_IMM(CPT_LD16) : CPT_OUT20(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+        else
+            asm volatile(BW_L20_IMM(CPT_LD32) : CPT_OUT20(v), [t] "=&s"(t) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pb] "n"(PIXB) : "scc");
+    } else {
+        (void)t;
+        if constexpr (std::is_same<TIO, f16_t>::value)
+            asm volatile(BW_L20_GEN(CPT_LDH) : CPT_OUT20(v), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+        else if constexpr (sizeof(TIO) == 2)
+            asm volatile(BW_L20_GEN(CPT_LD16) : CPT_OUT20(v), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+        else
+            asm volatile(BW_L20_GEN(CPT_LD32) : CPT_OUT20(v), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+    }
+}
+// seven float32 values, run-time pitch
+__device__ __forceinline__ void row_store7(const float (&p)[7], unsigned vo, i32x4 rs, int rb, int pix)
+{
+    int t2;
+    asm volatile("s_add_i32 %[t2], %[rb], 0\n\t"
+                 CPT_SG("buffer_store_dword", 0, "t2") CPT_SGN("buffer_store_dword", 1) CPT_SGN("buffer_store_dword", 2) CPT_SGN("buffer_store_dword", 3)
+                 CPT_SGN("buffer_store_dword", 4) CPT_SGN("buffer_store_dword", 5) CPT_SGN("buffer_store_dword", 6)
+                 : [t2] "=&s"(t2)
+                 : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [p4] "v"(p[4]), [p5] "v"(p[5]), [p6] "v"(p[6]),
+                   [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc", "memory");
+}
+
+// The order in which a wave issues its vector-memory instructions -- identical for every wave: rows outside the plane still load (and return 0), the stores
+// of the spare lanes are issued and dropped -- replayed at compile time: the s_waitcnt counts are exact numbers (rcx_upcpt.hip::Sched).
+template <int AHEAD, bool HAS_D> struct SchedGX {
+    static constexpr int NS = 18;
+    // kind 0: g row `target`, 1: G row `target`.  Result: memory instructions issued after the awaited ones and before the wait.
+    static constexpr int pending(int kind, int target)
+    {
+        int seq = 0, gend[NS + 8] = {}, Gend[12] = {};
+        if (HAS_D) { seq += 9; Gend[0] = seq; }
+        for (int r = 0; r < AHEAD; ++r) { seq += 18; gend[r] = seq; }
+        for (int s = 0; s < NS; ++s) {
+            if (s + AHEAD < NS) { seq += 18; gend[s + AHEAD] = seq; }
+            if (HAS_D && (s & 1) == 0 && s / 2 + 1 <= 8) { seq += 9; Gend[s / 2 + 1] = seq; }
+            if (kind == 0 && s == target) return seq - gend[s];
+            if (HAS_D && (s & 1) == 0 && kind == 1 && s / 2 == target) return seq - Gend[s / 2];
+            if (s >= 4) seq += 14;
+        }
+        return 0;
+    }
+    static constexpr int cap(int v) { return v > 63 ? 63 : v; }
+};
+template <int AHEAD> struct SchedGC {
+    static constexpr int NS = 20;
+    static constexpr int pending(int target)
+    {
+        int seq = 0, gend[NS + 8] = {};
+        for (int r = 0; r < AHEAD; ++r) { seq += 20; gend[r] = seq; }
+        for (int s = 0; s < NS; ++s) {
+            if (s + AHEAD < NS) { seq += 20; gend[s + AHEAD] = seq; }
+            if (s == target) return seq - gend[s];
+            if (s >= 7 && ((s - 4) & 1) == 1) seq += 7;          // gT row o = s - 4 (odd, >= 3) closes coarse row (o - 3) / 2: seven stores
+        }
+        return 0;
+    }
+    static constexpr int cap(int v) { return v > 63 ? 63 : v; }
+};
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // k_bwd_gx: out = K^ g + D^T G on a 14 x 14 tile.  g: N x H x H x C (TG), G: N x H/2 x H/2 x C float32 (HAS_D), out: TO.
 // wf: this conv's 25 x C flipped taps; wd: the shared down conv's 25 x C taps (as the forward applies them).
-// AH = g rows requested ahead of use, OCC = workgroups per CU the register budget is set for: <1, 2> (at most 256 registers: two waves per SIMD) where a
-// launch fills the chip; <3, 1> where it has at most one wave per SIMD anyway (the float32 level-1 plane of the 56 x 56 block at batch 128: 512 waves) and
-// only requests in flight hide the memory latency
-template <typename TG, typename TO, int H, bool HAS_D, int AH = RCX_GX_AHEAD, int OCC = 2>
+// PG / PO: bytes per pixel of g / out when known at compile time (0 = run time).  AH = g rows requested ahead of use, OCC = workgroups per CU the
+// register budget is set for.
+template <typename TG, typename TO, int H, bool HAS_D, int PG, int PO, int AH = RCX_GX_AHEAD, int OCC = 2>
 __global__ __launch_bounds__(256, OCC)
 void k_bwd_gx(const TG* __restrict__ g, const float* __restrict__ Gc, TO* __restrict__ out, const float* __restrict__ wf,
               const float* __restrict__ wd, int N, int C)
 {
     using GE = Geo<H>;
-    constexpr int W = GE::W, Hc = GE::Hc, Wc = GE::Wc, AHEAD = AH, NS = 18;
+    constexpr int W = GE::W, Hc = GE::Hc, Wc = GE::Wc, AHEAD = AH, NS = 18, GSZ = (int)sizeof(TG), OSZ = (int)sizeof(TO);
+    using S = SchedGX<AHEAD, HAS_D>;
     Unit U;
     if (!decode_unit<H>(U, N, C)) return;
-    const int r0 = 14 * U.tr, c0 = 14 * U.tc;
-    const size_t pixg = (size_t)C * sizeof(TG), pixf = (size_t)C * 4, pixo = (size_t)C * sizeof(TO);
-    const unsigned vog = U.cl * (unsigned)sizeof(TG), vof = U.cl * 4u, voo = U.cl * (unsigned)sizeof(TO);
-    const gcptr gb = (gcptr)g + (size_t)U.n * H * W * pixg;
-    const gcptr Gb = (gcptr)Gc + (size_t)U.n * Hc * Wc * pixf;
-    const gcptr ob = (gcptr)out + (size_t)U.n * H * W * pixo;
+    const int pixg = PG ? PG : C * GSZ, pixo = PO ? PO : C * OSZ, pixf = C * 4;
+    const unsigned long long gbase = (unsigned long long)(reinterpret_cast<const char*>(g) + (size_t)U.n * H * W * pixg);
+    const unsigned long long Gbase = (unsigned long long)(reinterpret_cast<const char*>(Gc) + (size_t)U.n * Hc * Wc * pixf);
+    const unsigned long long obase = (unsigned long long)(reinterpret_cast<char*>(out) + (size_t)U.n * H * W * pixo);
+    // g columns: tile column 0 of the left-most tile has its two halo columns at a negative offset = out of range = 0; the right-most likewise
+    const unsigned voffM = (unsigned)((14 * U.tc) * pixg + U.cl * GSZ);
+    const unsigned voffL = voffM - 2u * (unsigned)pixg, voffR = voffM + 14u * (unsigned)pixg;
+    const unsigned GvM = (unsigned)((7 * U.tc) * pixf + U.cl * 4), GvL = GvM - (unsigned)pixf, GvR = GvM + 7u * (unsigned)pixf;
+    auto load_row = [&](uint32_t (&raw)[18], int s) { row_load<TG, PG>(raw, voffL, voffM, voffR, row_desc(gbase, 14 * U.tr - 2 + s, H, W * pixg), 0, pixg); };
+    auto load_G = [&](uint32_t (&raw)[9], int m) { row_load9(raw, GvL, GvM, GvR, row_desc(Gbase, 7 * U.tr - 1 + m, Hc, Wc * pixf), 0, pixf); };
 
-    uint32_t rg[NS][18];                                   // g rows as loaded: local row s = image row r0 - 2 + s, local column q = image column c0 - 2 + q
-    uint32_t rG[9][9];                                     // G rows: local row m = coarse row 7 tr - 1 + m, local column q = coarse column 7 tc - 1 + q
-    auto ld_g = [&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        int r = r0 - 2 + s;
-        r = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);          // rows and columns outside the plane: a valid address, zeroed when the row is taken
-        const gcptr rowp = gb + (size_t)r * W * pixg;
-#pragma unroll
-        for (int q = 0; q < 18; ++q) {
-            int col = c0 + q - 2;
-            if (q < 2) col = col < 0 ? 0 : col;
-            if (q >= 16) col = col > W - 1 ? W - 1 : col;
-            rg[s][q] = SafeLd<TG>::ld(rowp + (size_t)col * pixg + vog);
-        }
-    };
-    auto ld_G = [&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        int r = 7 * U.tr - 1 + m;
-        r = r < 0 ? 0 : (r > Hc - 1 ? Hc - 1 : r);
-        const gcptr rowp = Gb + (size_t)r * Wc * pixf;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            int col = 7 * U.tc - 1 + q;
-            if (q == 0) col = col < 0 ? 0 : col;
-            if (q == 8) col = col > Wc - 1 ? Wc - 1 : col;
-            rG[m][q] = SafeLd<float>::ld(rowp + (size_t)col * pixf + vof);
-        }
-    };
-    // prologue: the first rows, then the taps (ordinary loads the compiler places)
-    if constexpr (HAS_D) ld_G(IC<0>{});
-    sfor<AHEAD>([&](auto sc) { ld_g(sc); });
+    uint32_t rg[NS][18];
+    uint32_t rG[2][9];
+    if constexpr (HAS_D) load_G(rG[0], 0);
+    sfor<AHEAD>([&](auto sc) { load_row(rg[decltype(sc)::value], decltype(sc)::value); });
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, 25 * C * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t zsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, 0, 0x00020000);            // no bias: zero records
     Taps tf, td;
-    load_taps<0>(tf, wf, nullptr, 0, C, vof, 0);
-    if constexpr (HAS_D) load_taps<0>(td, wd, nullptr, 0, C, vof, 0);
+    load_taps(tf, wsrc, zsrc, 0, C, U.cl);
+    if constexpr (HAS_D) load_taps(td, __builtin_amdgcn_make_buffer_rsrc((void*)wd, 0, 25 * C * 4, 0x00020000), zsrc, 0, C, U.cl);
+    // the taps land HERE, on every path (rcx_upcpt.hip: left to the compiler their waits sink into the loop and drain the row prefetch)
 #pragma unroll
-    for (int u = 0; u < 5; ++u) { pin(tf.p[u]); if constexpr (HAS_D) pin(td.p[u]); }
-
-    const f32x2 keep_lo = splat(c0 == 0 ? 0.f : 1.f), keep_hi = splat(c0 + 14 == W ? 0.f : 1.f);
-    const float Gkeep_lo = U.tc == 0 ? 0.f : 1.f, Gkeep_hi = 7 * U.tc + 7 == Wc ? 0.f : 1.f;
+    for (int u = 0; u < 5; ++u) {
+        pin(tf.p[u][0]); pin(tf.p[u][1]); pin(tf.p[u][2]);
+        if constexpr (HAS_D) { pin(td.p[u][0]); pin(td.p[u][1]); pin(td.p[u][2]); }
+    }
+    const unsigned yoff = U.live ? (unsigned)((14 * U.tc) * pixo + U.c * OSZ) : 0x80000000u;
     f32x2 acc[5][7];
 
     sfor<NS>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        if constexpr (s + AHEAD < NS) ld_g(IC<s + AHEAD>{});
+        if constexpr (s + AHEAD < NS) load_row(rg[s + AHEAD], s + AHEAD);
         // D^T is input-row stationary too: coarse row i (local m = i + 1) feeds the fine rows o = 2i - 2 .. 2i + 2 (tap row u = o + 2 - 2i), exactly
         // the accumulator rows in flight in iteration s = 2i + 2 = 2m: G row m is taken there, and requested one even iteration earlier
-        if constexpr (HAS_D && (s & 1) == 0 && s / 2 + 1 <= 8) ld_G(IC<(s / 2 + 1 <= 8 ? s / 2 + 1 : 8)>{});
-        pin_raw(rg[s]);
+        if constexpr (HAS_D && (s & 1) == 0 && s / 2 + 1 <= 8) load_G(rG[(s / 2 + 1) & 1], s / 2 + 1);
+        pin_row<S::cap(S::pending(0, s))>(rg[s]);
         f32x2 row[9], odd[8];
-        {
-            const int r = r0 - 2 + s;
-            const f32x2 keep = splat((s >= 2 && s < 16) || (r >= 0 && r < H) ? 1.f : 0.f);
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                row[k] = f32x2{SafeLd<TG>::cvt(rg[s][2 * k]), SafeLd<TG>::cvt(rg[s][2 * k + 1])};
-                if constexpr (s < 2 || s >= 16) row[k] = row[k] * keep;
-            }
-            row[0] = row[0] * keep_lo;
-            row[8] = row[8] * keep_hi;
-        }
+        for (int k = 0; k < 9; ++k) row[k] = f32x2{raw_f32<TG>(rg[s][2 * k]), raw_f32<TG>(rg[s][2 * k + 1])};
 #pragma unroll
         for (int j = 0; j < 8; ++j) odd[j] = shift1(row[j], row[j + 1]);
 #pragma unroll
@@ -174,17 +272,11 @@ void k_bwd_gx(const TG* __restrict__ g, const float* __restrict__ Gc, TO* __rest
             for (int j = 0; j < 7; ++j) a[j] = pfma(row[j + 2], splat(tf.at(u, 4)), a[j]);
         }
         if constexpr (HAS_D && (s & 1) == 0 && s / 2 <= 8) {
-            constexpr int m = s / 2 <= 8 ? s / 2 : 8;
-            pin_raw(rG[m]);
-            float Gm[9];                                    // zero outside the plane: the adjoint sums over existing coarse pixels only
-            {
-                const int r = 7 * U.tr - 1 + m;
-                const float keep = (r >= 0 && r < Hc) ? 1.f : 0.f;
+            constexpr int m = s / 2;
+            pin_row9<S::cap(S::pending(1, m))>(rG[m & 1]);
+            float Gm[9];                                    // zero outside the plane (the descriptors): the adjoint sums over existing coarse pixels only
 #pragma unroll
-                for (int q = 0; q < 9; ++q) Gm[q] = (m == 0 || m == 8) ? __uint_as_float(rG[m][q]) * keep : __uint_as_float(rG[m][q]);
-                Gm[0] *= Gkeep_lo;
-                Gm[8] *= Gkeep_hi;
-            }
+            for (int q = 0; q < 9; ++q) Gm[q] = __uint_as_float(rG[m & 1][q]);
             // out(2j, 2j+1) += G[i][j+1] (w0, w1) + G[i][j] (w2, w3) + (G[i][j-1] w4, 0); coarse column j of the tile = local q = j + 1
 #pragma unroll
             for (int u = 0; u < 5; ++u) {
@@ -201,19 +293,11 @@ void k_bwd_gx(const TG* __restrict__ g, const float* __restrict__ Gc, TO* __rest
         }
         if constexpr (s >= 4) {
             constexpr int o = s - 4;
-            if (U.live) {
-                const gcptr rowp = ob + ((size_t)(r0 + o) * W + c0) * pixo + voo;
-#pragma unroll
-                for (int j = 0; j < 7; ++j) {
-                    const typename PixSt<TO>::packed pk = PixSt<TO>::prep(acc[o % 5][j]);
-                    PixSt<TO>::st(rowp + (size_t)(2 * j) * pixo, pk, 0);
-                    PixSt<TO>::st(rowp + (size_t)(2 * j + 1) * pixo, pk, 1);
-                }
-            }
+            RowSt<TO, PO>::st(acc[o % 5], yoff, row_desc(obase, 14 * U.tr + o, H, W * pixo), 0, pixo);
         }
 #pragma unroll
         for (int o = 0; o < 14; ++o) if (o > s - 4 && o <= s) pin(acc[o % 5]);
-        RCX_FENCE;
+        CPT_FENCE;
     });
 }
 
@@ -221,69 +305,49 @@ void k_bwd_gx(const TG* __restrict__ g, const float* __restrict__ Gc, TO* __rest
 // k_bwd_gc: gC = R^T (K^ g) on the 7 x 7 coarse pixels of a 14 x 14 tile.  g: N x H x H x C (TG); gC: N x H/2 x H/2 x C float32.
 // Local frames: g row s = image row r0 - 3 + s, column q = image column c0 - 3 + q (20 x 20); gT row o = image row r0 - 1 + o,
 // column p = image column c0 - 1 + p (16 x 16: pairs start at an ODD image column); gT(o, p) = sum_{u,v} K^[u][v] g(o + u, p + v).
-template <int MODE, typename TG, int H, int AH = RCX_GC_AHEAD, int OCC = 2>
+template <int MODE, typename TG, int H, int PG, int AH = RCX_GC_AHEAD, int OCC = 2>
 __global__ __launch_bounds__(256, OCC)
 void k_bwd_gc(const TG* __restrict__ g, float* __restrict__ gC, const float* __restrict__ wf, int N, int C)
 {
     using GE = Geo<H>;
-    constexpr int W = GE::W, Hc = GE::Hc, Wc = GE::Wc, AHEAD = AH, NS = 20;
+    constexpr int W = GE::W, Hc = GE::Hc, Wc = GE::Wc, AHEAD = AH, NS = 20, GSZ = (int)sizeof(TG);
     constexpr float WQ = MODE == 1 ? 0.f : 0.25f, WT = MODE == 1 ? 1.f : 0.75f;
+    using S = SchedGC<AHEAD>;
     Unit U;
     if (!decode_unit<H>(U, N, C)) return;
     const int r0 = 14 * U.tr, c0 = 14 * U.tc;
-    const size_t pixg = (size_t)C * sizeof(TG), pixf = (size_t)C * 4;
-    const unsigned vog = U.cl * (unsigned)sizeof(TG), vof = U.cl * 4u;
-    const gcptr gb = (gcptr)g + (size_t)U.n * H * W * pixg;
-    const gcptr cb = (gcptr)gC + (size_t)U.n * Hc * Wc * pixf;
+    const int pixg = PG ? PG : C * GSZ, pixf = C * 4;
+    const unsigned long long gbase = (unsigned long long)(reinterpret_cast<const char*>(g) + (size_t)U.n * H * W * pixg);
+    const unsigned long long cbase = (unsigned long long)(reinterpret_cast<char*>(gC) + (size_t)U.n * Hc * Wc * pixf);
+    const unsigned voffM = (unsigned)(c0 * pixg + U.cl * GSZ);
+    const unsigned voffL = voffM - 3u * (unsigned)pixg, voffR = voffM + 14u * (unsigned)pixg;
+    auto load_row = [&](uint32_t (&raw)[20], int s) { row_load20w<TG, PG>(raw, voffL, voffM, voffR, row_desc(gbase, r0 - 3 + s, H, W * pixg), 0, pixg); };
 
     uint32_t rg[NS][20];
-    auto ld_g = [&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        int r = r0 - 3 + s;
-        r = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
-        const gcptr rowp = gb + (size_t)r * W * pixg;
-#pragma unroll
-        for (int q = 0; q < 20; ++q) {
-            int col = c0 + q - 3;
-            if (q < 3) col = col < 0 ? 0 : col;
-            if (q >= 17) col = col > W - 1 ? W - 1 : col;
-            rg[s][q] = SafeLd<TG>::ld(rowp + (size_t)col * pixg + vog);
-        }
-    };
-    sfor<AHEAD>([&](auto sc) { ld_g(sc); });
+    sfor<AHEAD>([&](auto sc) { load_row(rg[decltype(sc)::value], decltype(sc)::value); });
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, 25 * C * 4, 0x00020000);
     Taps tf;
-    load_taps<0>(tf, wf, nullptr, 0, C, vof, 0);
+    load_taps(tf, wsrc, __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, 0, 0x00020000), 0, C, U.cl);
 #pragma unroll
-    for (int u = 0; u < 5; ++u) pin(tf.p[u]);
+    for (int u = 0; u < 5; ++u) { pin(tf.p[u][0]); pin(tf.p[u][1]); pin(tf.p[u][2]); }
 
-    // columns of g outside the plane are zero padding of K^'s input: local q = 0, 1, 2 at the left edge, 17, 18, 19 at the right one
     const bool left = c0 == 0, right = c0 + 14 == W, top = r0 == 0, bottom = r0 + 14 == H;
-    const f32x2 m0 = splat(left ? 0.f : 1.f), m1 = f32x2{left ? 0.f : 1.f, 1.f};                  // pairs (0,1), (2,3)
-    const f32x2 m8 = f32x2{1.f, right ? 0.f : 1.f}, m9 = splat(right ? 0.f : 1.f);                // pairs (16,17), (18,19)
     // R^T, vertical: gT row o feeds coarse rows (o even) o/2 with WQ' and o/2 - 1 with WT', (o odd) (o-1)/2 with WT' and (o-3)/2 with WQ';
     // the clamped borders move the outside row's weight to the edge row: rows 0 / 15 get 0, rows 1 / 14 get WT + WQ there
     const float wv_o0 = top ? 0.f : WQ, wv_o1 = top ? WT + WQ : WT, wv_o14 = bottom ? WT + WQ : WT, wv_o15 = bottom ? 0.f : WQ;
     // horizontal: coarse column j = dot(A[j], (WQ, WT)) + dot(A[j+1], (WT, WQ)) over the pairs A[k] = (p = 2k, 2k + 1); same border rule
     const f32x2 hA0 = f32x2{left ? 0.f : WQ, left ? WT + WQ : WT}, hB6 = f32x2{right ? WT + WQ : WT, right ? 0.f : WQ};
+    const unsigned yoff = U.live ? (unsigned)((7 * U.tc) * pixf + U.c * 4) : 0x80000000u;
 
     f32x2 acc[5][8];
     float V[2][7];
-    const unsigned live = U.live ? 1u : 0u;
     sfor<NS>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        if constexpr (s + AHEAD < NS) ld_g(IC<s + AHEAD>{});
-        pin_raw(rg[s]);
+        if constexpr (s + AHEAD < NS) load_row(rg[s + AHEAD], s + AHEAD);
+        pin_row20<S::cap(S::pending(s))>(rg[s]);
         f32x2 row[10], odd[9];
-        {
-            const int r = r0 - 3 + s;
-            const f32x2 keep = splat((s >= 3 && s < 17) || (r >= 0 && r < H) ? 1.f : 0.f);
 #pragma unroll
-            for (int k = 0; k < 10; ++k) {
-                row[k] = f32x2{SafeLd<TG>::cvt(rg[s][2 * k]), SafeLd<TG>::cvt(rg[s][2 * k + 1])};
-                if constexpr (s < 3 || s >= 17) row[k] = row[k] * keep;
-            }
-            row[0] = row[0] * m0; row[1] = row[1] * m1; row[8] = row[8] * m8; row[9] = row[9] * m9;
-        }
+        for (int k = 0; k < 10; ++k) row[k] = f32x2{raw_f32<TG>(rg[s][2 * k]), raw_f32<TG>(rg[s][2 * k + 1])};
 #pragma unroll
         for (int j = 0; j < 9; ++j) odd[j] = shift1(row[j], row[j + 1]);
         // g row s meets gT rows o = s - u
@@ -339,11 +403,10 @@ void k_bwd_gc(const TG* __restrict__ g, float* __restrict__ gC, const float* __r
                 if constexpr (o >= 3) {
                     constexpr int i = (o - 3) / 2;          // closes coarse row i
                     const float w = o == 15 ? wv_o15 : WQ;
-                    if (live) {
-                        const gcptr rowp = cb + ((size_t)(7 * U.tr + i) * Wc + 7 * U.tc) * pixf + vof;
+                    float outv[7];
 #pragma unroll
-                        for (int j = 0; j < 7; ++j) gstore<float>(rowp + (size_t)j * pixf, fmaf(h[j], w, V[i & 1][j]));
-                    }
+                    for (int j = 0; j < 7; ++j) outv[j] = fmaf(h[j], w, V[i & 1][j]);
+                    row_store7(outv, yoff, row_desc(cbase, 7 * U.tr + i, Hc, Wc * pixf), 0, pixf);
                 }
             }
         }
@@ -351,7 +414,7 @@ void k_bwd_gc(const TG* __restrict__ g, float* __restrict__ gC, const float* __r
         for (int o = 0; o < 16; ++o) if (o > s - 4 && o <= s) pin(acc[o % 5]);
 #pragma unroll
         for (int j = 0; j < 7; ++j) { pin(V[0][j]); pin(V[1][j]); }
-        RCX_FENCE;
+        CPT_FENCE;
     });
 }
 
@@ -362,72 +425,97 @@ void k_bwd_gc(const TG* __restrict__ g, float* __restrict__ gC, const float* __r
 // wave on every second SIMD -- 50 us for 0.1 GB.  Here: four times the waves, G's 49 values resident, a-row stationary with the taps paired
 // against a's aligned pairs (rcx_cplbwd_pieces.h), rows requested AHEAD before use.  The NT column tiles of a band share a workgroup and add
 // their 26 sums per channel through LDS in a fixed order: one partial row per (image, 14-row band), reduced over the batch by k_wgrad_reduce_jobs.
-template <typename TA, int H>
-__global__ __launch_bounds__(64 * (H / 14))
+// seven float32 columns, run-time pitch
+#define BW_LD7                                                                                                                        \
+    "s_add_i32 %[t], %[rb], 0\n\tbuffer_load_dword %0, %[vo], %[rs], %[t] offen\n\t"                                                 \
+    "s_add_i32 %[t], %[t], %[pix]\n\tbuffer_load_dword %1, %[vo], %[rs], %[t] offen\n\t"                                             \
+    "s_add_i32 %[t], %[t], %[pix]\n\tbuffer_load_dword %2, %[vo], %[rs], %[t] offen\n\t"                                             \
+    "s_add_i32 %[t], %[t], %[pix]\n\tbuffer_load_dword %3, %[vo], %[rs], %[t] offen\n\t"                                             \
+    "s_add_i32 %[t], %[t], %[pix]\n\tbuffer_load_dword %4, %[vo], %[rs], %[t] offen\n\t"                                             \
+    "s_add_i32 %[t], %[t], %[pix]\n\tbuffer_load_dword %5, %[vo], %[rs], %[t] offen\n\t"                                             \
+    "s_add_i32 %[t], %[t], %[pix]\n\tbuffer_load_dword %6, %[vo], %[rs], %[t] offen\n\t"
+__device__ __forceinline__ void row_load7(uint32_t (&v)[7], unsigned vo, i32x4 rs, int rb, int pix)
+{
+    int t;
+    asm volatile(BW_LD7 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), [t] "=&s"(t)
+                 : [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+}
+template <int PENDING> __device__ __forceinline__ void pin_row7(uint32_t (&v)[7])
+{
+    asm volatile("s_waitcnt vmcnt(%7)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]) : "n"(PENDING));
+}
+// the shared stride-2 conv's 25 tap sums: tap pairs (0,1) (2,3) (4,-)
+struct DAcc {
+    f32x2 a[5][3];
+    f32x2 bs;
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a[u][k] = f32x2{0.f, 0.f};
+        bs = f32x2{0.f, 0.f};
+    }
+    __device__ __forceinline__ float tap(int u, int v) const { return (v & 1) ? a[u][v >> 1].y : a[u][v >> 1].x; }
+    __device__ __forceinline__ float bias() const { return bs.x + bs.y; }
+};
+template <int AHEAD> struct SchedWD {
+    static constexpr int NS = 17;
+    static constexpr int pending(int target)
+    {
+        int seq = 0, aend[NS + 8] = {};
+        for (int r = 0; r < AHEAD; ++r) { seq += 18; aend[r] = seq; }
+        for (int s = 0; s < NS; ++s) {
+            if (s + AHEAD < NS) { seq += 18; aend[s + AHEAD] = seq; }
+            if (s == target) return seq - aend[s];
+        }
+        return 0;
+    }
+    static constexpr int cap(int v) { return v > 63 ? 63 : v; }
+};
+
+template <typename TA, int H, int PA>
+__global__ __launch_bounds__(64 * (H / 14), 2)
 void k_wgrad_d(const TA* __restrict__ a, const float* __restrict__ Gc, float* __restrict__ partial, int N, int C)
 {
     using GE = Geo<H>;
-    constexpr int W = GE::W, NT = GE::NT, NB = GE::NB, Hc = GE::Hc, Wc = GE::Wc, AHEAD = 2, NS = 17;
+    constexpr int W = GE::W, NT = GE::NT, NB = GE::NB, Hc = GE::Hc, Wc = GE::Wc, AHEAD = 2, NS = 17, ASZ = (int)sizeof(TA);
+    using S = SchedWD<AHEAD>;
     __shared__ float red[NT][26][64];
-    const int tile = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int tile = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
     const int nb = (C + 63) / 64;
     const unsigned unit = blockIdx.x;
     const int cb = (int)(unit % (unsigned)nb), band = (int)((unit / (unsigned)nb) % (unsigned)NB), n = (int)(unit / (unsigned)(nb * NB));
     const int c = cb * 64 + lane;
     const bool live = c < C;
-    const unsigned cl = (unsigned)(live ? c : C - 1);
-    const int r0 = 14 * band, c0 = 14 * tile;
-    const size_t pixa = (size_t)C * sizeof(TA), pixf = (size_t)C * 4;
-    const unsigned voa = cl * (unsigned)sizeof(TA), vof = cl * 4u;
-    const gcptr ab = (gcptr)a + (size_t)n * H * W * pixa;
-    const gcptr Gb = (gcptr)Gc + ((size_t)n * Hc * Wc + (size_t)(7 * band) * Wc + 7 * tile) * pixf;
+    const int cl = live ? c : C - 1;
+    const int pixa = PA ? PA : C * ASZ, pixf = C * 4;
+    const unsigned long long abase = (unsigned long long)(reinterpret_cast<const char*>(a) + (size_t)n * H * W * pixa);
+    const unsigned long long Gbase = (unsigned long long)(reinterpret_cast<const char*>(Gc) + (size_t)n * Hc * Wc * pixf);
+    const unsigned voffM = (unsigned)((14 * tile) * pixa + cl * ASZ);
+    const unsigned voffL = voffM - 2u * (unsigned)pixa, voffR = voffM + 14u * (unsigned)pixa;
+    const unsigned Gvo = (unsigned)((7 * tile) * pixf + cl * 4);
+    auto load_row = [&](uint32_t (&raw)[18], int s) { row_load<TA, PA>(raw, voffL, voffM, voffR, row_desc(abase, 14 * band - 2 + s, H, W * pixa), 0, pixa); };
 
     uint32_t ra[NS][18], rG[7][7];
-    auto ld_a = [&](auto sc) {                                // local row s = image row r0 - 2 + s, local column q = image column c0 - 2 + q (clamped; zeroed when taken)
-        constexpr int s = decltype(sc)::value;
-        int r = r0 - 2 + s;
-        r = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
-        const gcptr rowp = ab + (size_t)r * W * pixa;
-#pragma unroll
-        for (int q = 0; q < 18; ++q) {
-            int col = c0 + q - 2;
-            if (q < 2) col = col < 0 ? 0 : col;
-            if (q >= 16) col = col > W - 1 ? W - 1 : col;
-            ra[s][q] = SafeLd<TA>::ld(rowp + (size_t)col * pixa + voa);
-        }
-    };
-    sfor<7>([&](auto oc) {
-        constexpr int o = decltype(oc)::value;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) rG[o][i] = SafeLd<float>::ld(Gb + ((size_t)o * Wc + i) * pixf + vof);
-    });
-    sfor<AHEAD>([&](auto sc) { ld_a(sc); });
-    const f32x2 keep_lo = splat(c0 == 0 ? 0.f : 1.f), keep_hi = splat(c0 + 14 == W ? 0.f : 1.f);
+    sfor<7>([&](auto oc) { row_load7(rG[decltype(oc)::value], Gvo, row_desc(Gbase, 7 * band + decltype(oc)::value, Hc, Wc * pixf), 0, pixf); });
+    sfor<AHEAD>([&](auto sc) { load_row(ra[decltype(sc)::value], decltype(sc)::value); });
     DAcc acc;
     acc.zero();
     float G[7][7];
     sfor<7>([&](auto oc) {
         constexpr int o = decltype(oc)::value;
-        pin_raw(rG[o]);
+        pin_row7<AHEAD * 18>(rG[o]);                             // every G row is older than the first a rows
 #pragma unroll
         for (int i = 0; i < 7; ++i) { G[o][i] = __uint_as_float(rG[o][i]); if (i & 1) acc.bs.y += G[o][i]; else acc.bs.x += G[o][i]; }
     });
     sfor<NS>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        if constexpr (s + AHEAD < NS) ld_a(IC<s + AHEAD>{});
-        pin_raw(ra[s]);
+        if constexpr (s + AHEAD < NS) load_row(ra[s + AHEAD], s + AHEAD);
+        pin_row<S::cap(S::pending(s))>(ra[s]);
         f32x2 ar[9];
-        {
-            const int r = r0 - 2 + s;
-            const f32x2 keep = splat((s >= 2 && s < 16) || (r >= 0 && r < H) ? 1.f : 0.f);
 #pragma unroll
-            for (int m = 0; m < 9; ++m) {
-                ar[m] = f32x2{SafeLd<TA>::cvt(ra[s][2 * m]), SafeLd<TA>::cvt(ra[s][2 * m + 1])};
-                if constexpr (s < 2 || s >= 16) ar[m] = ar[m] * keep;
-            }
-            ar[0] = ar[0] * keep_lo;
-            ar[8] = ar[8] * keep_hi;
-        }
+        for (int m = 0; m < 9; ++m) ar[m] = f32x2{raw_f32<TA>(ra[s][2 * m]), raw_f32<TA>(ra[s][2 * m + 1])};
         // a row s = 2o + u: the G rows o whose window covers it, tap row u; G column i against the pairs ar[i + k] = a columns 2i + 2k, 2i + 2k + 1
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
@@ -441,8 +529,8 @@ void k_wgrad_d(const TA* __restrict__ a, const float* __restrict__ Gc, float* __
             }
         }
 #pragma unroll
-        for (int u = 0; u < 5; ++u) pin(acc.a[u]);
-        RCX_FENCE;
+        for (int u = 0; u < 5; ++u) { pin(acc.a[u][0]); pin(acc.a[u][1]); pin(acc.a[u][2]); }
+        CPT_FENCE;
     });
 #pragma unroll
     for (int u = 0; u < 5; ++u)
@@ -462,45 +550,306 @@ void k_wgrad_d(const TA* __restrict__ a, const float* __restrict__ Gc, float* __
     }
 }
 
-#ifndef RCX_CPTBWD_KERNELS_ONLY            // (a tuning harness instantiates single kernels)
-// tile-waves up to which a launch leaves at most one wave per SIMD (256 CUs x 4): the deep-prefetch instantiations (RCX_BWD_CPT=shallow: never)
-static long long few_units()
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_wgrad_k: weight gradient of a stride-1 5x5 conv whose input is T = a + R(coarse) (the final conv and the level convs, model/recnext.py:33-34; MODE 2:
+// T = a, a plain depthwise conv), gW[u][v] = sum_{t,c} g[t][c] T[t+u-2][c+v-2], on the same tiles.  rcx_cplwgrad.hip's k_wgrad_cpl keeps a five-row ring
+// of T and two accumulator sets (358 registers: one wave per SIMD, 60 us at 128 x 64 x 56 x 56); here T rows are built once and used at once -- T-row
+// stationary against a five-row ring of g (7 pairs a row instead of 9) -- and the odd gradient columns read T's pairs shifted by one pixel (eight
+// v_pk_mov per row); and the packed FMAs pair PIXELS, not taps: acc[u][v] += (g[t][c], g[t][c+1]) * (T[t+u][c+v], T[t+u][c+v+1]), both halves of an
+// accumulator belong to the same tap -- no broadcast operand (a broadcast of an odd column costs a move and an aligned register pair each), 175 packed FMAs
+// per (T row, g row) instead of 210.  T local column q = image column c0 - 2 + q; hand-issued rows; two waves per SIMD.
+// eleven float32 columns of the coarse plane at per-column scalar offsets (clamped into the plane by the caller: ATen's border rule)
+#define BW_C(d) "s_add_i32 %[t], %[rb], %[c" #d "]\n\tbuffer_load_dword %" #d ", %[vo], %[rs], %[t] offen\n\t"
+__device__ __forceinline__ void coarse_load11(uint32_t (&v)[11], unsigned vo, i32x4 rs, int rb, const int (&ck)[11])
 {
-    const char* v = rcx::opt::value(rcx::opt::BWD_CPT);
-    return (v && *v == 's') ? 0 : 1024;
+    int t;
+    asm volatile(BW_C(0) BW_C(1) BW_C(2) BW_C(3) BW_C(4) BW_C(5) BW_C(6) BW_C(7) BW_C(8) BW_C(9) BW_C(10)
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), [t] "=&s"(t)
+                 : [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [c0] "s"(ck[0]), [c1] "s"(ck[1]), [c2] "s"(ck[2]), [c3] "s"(ck[3]), [c4] "s"(ck[4]), [c5] "s"(ck[5]),
+                   [c6] "s"(ck[6]), [c7] "s"(ck[7]), [c8] "s"(ck[8]), [c9] "s"(ck[9]), [c10] "s"(ck[10]) : "scc");
+}
+template <int PENDING> __device__ __forceinline__ void pin_row11(uint32_t (&v)[11])
+{
+    asm volatile("s_waitcnt vmcnt(%11)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                 "+v"(v[9]), "+v"(v[10]) : "n"(PENDING));
+}
+// fourteen columns of a row (the tile's own: always inside the plane), run-time pitch
+#define BW_L14(OP)                                                                                                                   \
+    "s_add_i32 %[t2], %[rb], 0\n\t" CPT_LG(OP, 0, "vm", "t2") BW_N(OP, 1, "vm") BW_N(OP, 2, "vm") BW_N(OP, 3, "vm") BW_N(OP, 4, "vm")   \
+    BW_N(OP, 5, "vm") BW_N(OP, 6, "vm") BW_N(OP, 7, "vm") BW_N(OP, 8, "vm") BW_N(OP, 9, "vm") BW_N(OP, 10, "vm") BW_N(OP, 11, "vm")     \
+    BW_N(OP, 12, "vm") BW_N(OP, 13, "vm")
+#define BW_OUT14(v) "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]), "=&v"(v[9]), \
+                    "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13])
+template <typename TIO>
+__device__ __forceinline__ void row_load14(uint32_t (&v)[14], unsigned vm, i32x4 rs, int rb, int pix)
+{
+    int t2;
+    if constexpr (std::is_same<TIO, f16_t>::value) asm volatile(BW_L14(CPT_LDH) : BW_OUT14(v), [t2] "=&s"(t2) : [vm] "v"(vm), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+    else if constexpr (sizeof(TIO) == 2) asm volatile(BW_L14(CPT_LD16) : BW_OUT14(v), [t2] "=&s"(t2) : [vm] "v"(vm), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+    else asm volatile(BW_L14(CPT_LD32) : BW_OUT14(v), [t2] "=&s"(t2) : [vm] "v"(vm), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+}
+template <int PENDING> __device__ __forceinline__ void pin_row14(uint32_t (&v)[14])
+{
+    asm volatile("s_waitcnt vmcnt(%14)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                 "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]) : "n"(PENDING));
+}
+
+// which coarse rows T row s reads (local il = coarse row 7 band - 2 + il, clamped): the exact 2x step -- even image row -> (s/2, s/2 + 1) with (1/4, 3/4),
+// odd -> ((s+1)/2, (s+1)/2 + 1) with (3/4, 1/4); nearest: (s + 2) >> 1
+template <int MODE> struct CoarseRows {
+    static constexpr int hi(int s) { return MODE == 1 ? (s + 2) >> 1 : ((s & 1) ? (s + 1) / 2 : s / 2) + 1; }       // the highest local coarse row T row s reads
+    static constexpr int first_new(int s) { return s == 0 ? (MODE == 1 ? hi(0) : 0) : (hi(s) > hi(s - 1) ? hi(s) : -1); }   // s = 0 (bilinear): rows 0 and 1
+    static constexpr int count_new(int s) { return MODE == 2 ? 0 : (s == 0 ? (MODE == 1 ? 1 : 2) : (hi(s) > hi(s - 1) ? 1 : 0)); }
+};
+// issue order of one tile: prologue = coarse rows of T row 0, a rows 0 .. AHEAD-1, g row 0; iteration s = [a row s + AHEAD] [coarse rows new to T row s + 1]
+// [g row s + 1]; waits in the order a row s, coarse rows of T row s, g row s
+template <int MODE, int AHEAD> struct SchedWK {
+    static constexpr int NS = 18;
+    // kind 0: a row, 1: the coarse rows T row `target` is the first to read, 2: g row
+    static constexpr int pending(int kind, int target)
+    {
+        using CR = CoarseRows<MODE>;
+        int seq = 0, aend[NS + 8] = {}, cend[NS + 2] = {}, gend[16] = {};
+        seq += 11 * CR::count_new(0); cend[0] = seq;
+        for (int r = 0; r < AHEAD; ++r) { seq += 18; aend[r] = seq; }
+        seq += 14; gend[0] = seq;
+        for (int s = 0; s < NS; ++s) {
+            if (s + AHEAD < NS) { seq += 18; aend[s + AHEAD] = seq; }
+            if (s + 1 < NS) { seq += 11 * CR::count_new(s + 1); cend[s + 1] = seq; }
+            if (s + 1 < 14) { seq += 14; gend[s + 1] = seq; }
+            if (kind == 0 && s == target) return seq - aend[s];
+            if (kind == 1 && s == target) return seq - cend[s];
+            if (kind == 2 && s == target) return seq - gend[s];
+        }
+        return 0;
+    }
+    static constexpr int cap(int v) { return v > 63 ? 63 : v; }
+};
+
+template <int MODE, typename TA, typename TG, int H, int PA>
+__global__ __launch_bounds__(64 * (H / 14), 2)
+void k_wgrad_k(const TA* __restrict__ a, const float* __restrict__ coarse, const TG* __restrict__ g, float* __restrict__ partial, int N, int C)
+{
+    using GE = Geo<H>;
+    using CR = CoarseRows<MODE>;
+    constexpr int W = GE::W, NT = GE::NT, NB = GE::NB, Hc = GE::Hc, Wc = GE::Wc, AHEAD = 1, NS = 18, ASZ = (int)sizeof(TA), GSZ = (int)sizeof(TG);
+    using S = SchedWK<MODE, AHEAD>;
+    __shared__ float red[NT][26][64];
+    const int tile = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+    const int nb = (C + 63) / 64;
+    const unsigned unit = blockIdx.x;
+    const int cb = __builtin_amdgcn_readfirstlane((int)(unit % (unsigned)nb)), band = __builtin_amdgcn_readfirstlane((int)((unit / (unsigned)nb) % (unsigned)NB)),
+              n = __builtin_amdgcn_readfirstlane((int)(unit / (unsigned)(nb * NB)));
+    const int c = cb * 64 + lane;
+    const bool live = c < C;
+    const int cl = live ? c : C - 1;
+    const int r0 = 14 * band, c0 = 14 * tile;
+    const int pixa = PA ? PA : C * ASZ, pixg = C * GSZ, pixf = C * 4;
+    const unsigned long long abase = (unsigned long long)(reinterpret_cast<const char*>(a) + (size_t)n * H * W * pixa);
+    const unsigned long long gbase = (unsigned long long)(reinterpret_cast<const char*>(g) + (size_t)n * H * W * pixg);
+    const unsigned voffM = (unsigned)(c0 * pixa + cl * ASZ);
+    const unsigned voffL = voffM - 2u * (unsigned)pixa, voffR = voffM + 14u * (unsigned)pixa;
+    const unsigned gvo = (unsigned)(c0 * pixg + cl * GSZ);
+    auto load_a = [&](uint32_t (&raw)[18], int s) { row_load<TA, PA>(raw, voffL, voffM, voffR, row_desc(abase, r0 - 2 + s, H, W * pixa), 0, pixa); };
+    auto load_g = [&](uint32_t (&raw)[14], int t) { row_load14<TG>(raw, gvo, row_desc(gbase, r0 + t, H, W * pixg), 0, pixg); };
+    // the coarse plane of this image as one buffer: its row and column indices are clamped, never out of range
+    i32x4 csrc;
+    int ck[11];
+    if constexpr (MODE != 2) {
+        const unsigned long long ca = (unsigned long long)(reinterpret_cast<const char*>(coarse) + (size_t)n * Hc * Wc * pixf);
+        csrc.x = (int)(unsigned)ca;
+        csrc.y = (int)(unsigned)(ca >> 32) & 0xffff;
+        csrc.z = Hc * Wc * pixf;
+        csrc.w = 0x00020000;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            int col = 7 * tile - 2 + k;
+            col = col < 0 ? 0 : (col > Wc - 1 ? Wc - 1 : col);
+            ck[k] = __builtin_amdgcn_readfirstlane(col * pixf);
+        }
+    }
+    const unsigned cvo = (unsigned)(cl * 4);
+    auto load_c = [&](uint32_t (&raw)[11], int il) {
+        int i = 7 * band - 2 + il;
+        i = i < 0 ? 0 : (i > Hc - 1 ? Hc - 1 : i);
+        coarse_load11(raw, cvo, csrc, __builtin_amdgcn_readfirstlane(i * Wc * pixf), ck);
+    };
+
+    uint32_t ra[NS][18], rg[14][14], rc[11][11];
+    f32x2 Hr[2][9];
+    // the resized coarse row is zero outside the plane (the conv pads T with zeros): column masks of the two halo pairs, row mask per T row
+    const f32x2 keep_lo = splat(c0 == 0 ? 0.f : 1.f), keep_hi = splat(c0 + 14 == W ? 0.f : 1.f);
+    auto build_h = [&](auto ic) {
+        constexpr int il = decltype(ic)::value;
+        float cv[11];
+#pragma unroll
+        for (int jl = 0; jl < 11; ++jl) cv[jl] = __uint_as_float(rc[il][jl]);
+#pragma unroll
+        for (int m = 0; m < 9; ++m) {                            // T columns q = 2m (even image column), 2m + 1 (odd)
+            if (MODE == 1) Hr[il & 1][m] = f32x2{cv[m + 1], cv[m + 1]};
+            else Hr[il & 1][m] = f32x2{fmaf(0.25f, cv[m], 0.75f * cv[m + 1]), fmaf(0.75f, cv[m + 1], 0.25f * cv[m + 2])};
+        }
+        Hr[il & 1][0] = Hr[il & 1][0] * keep_lo;
+        Hr[il & 1][8] = Hr[il & 1][8] * keep_hi;
+    };
+
+    // prologue, in the order SchedWK replays
+    if constexpr (MODE == 0) { load_c(rc[0], 0); load_c(rc[1], 1); }
+    if constexpr (MODE == 1) load_c(rc[1], 1);
+    sfor<AHEAD>([&](auto sc) { load_a(ra[decltype(sc)::value], decltype(sc)::value); });
+    load_g(rg[0], 0);
+
+    f32x2 acc[5][5], bs = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+#pragma unroll
+        for (int v = 0; v < 5; ++v) acc[u][v] = f32x2{0.f, 0.f};
+    f32x2 Gr[5][7];
+
+    sfor<NS>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (s + AHEAD < NS) load_a(ra[s + AHEAD], s + AHEAD);
+        if constexpr (s + 1 < NS && CR::count_new(s + 1) > 0) load_c(rc[CR::hi(s + 1)], CR::hi(s + 1));
+        if constexpr (s + 1 < 14) load_g(rg[s + 1], s + 1);
+        pin_row<S::cap(S::pending(0, s))>(ra[s]);
+        f32x2 T[9], To[8];
+#pragma unroll
+        for (int m = 0; m < 9; ++m) T[m] = f32x2{raw_f32<TA>(ra[s][2 * m]), raw_f32<TA>(ra[s][2 * m + 1])};
+        if constexpr (MODE != 2) {
+            if constexpr (CR::count_new(s) > 0) {
+                pin_row11<S::cap(S::pending(1, s))>(rc[CR::hi(s)]);     // the youngest of the rows T row s is the first to read
+                if constexpr (s == 0 && MODE == 0) {                   // ... and the older one: landed before it, but its registers must be tied to a wait as well
+                    pin_row11<S::cap(S::pending(1, s))>(rc[0]);
+                    build_h(IC<0>{});
+                }
+                build_h(IC<CR::hi(s)>{});
+            }
+            // rows outside the plane are zero padding of T: a read 0 there (descriptor), the resized coarse row is masked
+            const int r = r0 - 2 + s;
+            const f32x2 keep = splat((s >= 2 && s < 16) || (r >= 0 && r < H) ? 1.f : 0.f);
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int m = 0; m < 9; ++m) T[m] = (s < 2 || s >= 16) ? pfma(Hr[CR::hi(s) & 1][m], keep, T[m]) : T[m] + Hr[CR::hi(s) & 1][m];
+            } else {
+                constexpr int i0 = CR::hi(s) - 1;
+                constexpr float w0 = (s & 1) ? 0.75f : 0.25f, w1 = 1.f - w0;
+#pragma unroll
+                for (int m = 0; m < 9; ++m) {
+                    if (s < 2 || s >= 16) T[m] = pfma(pfma(splat(w1), Hr[(i0 + 1) & 1][m], splat(w0) * Hr[i0 & 1][m]), keep, T[m]);
+                    else T[m] = pfma(splat(w1), Hr[(i0 + 1) & 1][m], pfma(splat(w0), Hr[i0 & 1][m], T[m]));
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) To[p] = shift1(T[p], T[p + 1]);
+        if constexpr (s < 14) {                                  // g row s enters the ring (slot s % 5: row s - 5 met its last T row in iteration s - 1)
+            pin_row14<S::cap(S::pending(2, s))>(rg[s]);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                Gr[s % 5][j] = f32x2{raw_f32<TG>(rg[s][2 * j]), raw_f32<TG>(rg[s][2 * j + 1])};
+                bs = bs + Gr[s % 5][j];
+            }
+        }
+        // pixel pairs, no broadcast: acc[u][v] (both halves belong to tap (u, v); added at the end) += (g[t][2j], g[t][2j+1]) * (T[2j + v], T[2j + v + 1]):
+        // T's aligned pairs for even v, the pairs shifted by one pixel for odd v
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int t = s - u;
+                if (t < 0 || t > 13) continue;
+#pragma unroll
+                for (int v = 0; v < 5; ++v) acc[u][v] = pfma(Gr[t % 5][j], (v & 1) ? To[j + (v - 1) / 2] : T[j + v / 2], acc[u][v]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) { pin(acc[u][0]); pin(acc[u][1]); pin(acc[u][2]); pin(acc[u][3]); pin(acc[u][4]); }
+        pin(bs);                                                 // (unpinned, the bias sums sink to the end of the kernel and every g row stays live until then)
+        pin(Hr[0]);
+        pin(Hr[1]);
+        CPT_FENCE;
+    });
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+#pragma unroll
+        for (int v = 0; v < 5; ++v) red[tile][u * 5 + v][lane] = acc[u][v].x + acc[u][v].y;
+    red[tile][25][lane] = bs.x + bs.y;
+    __syncthreads();
+    if (tile == 0 && live) {
+        float* q = partial + ((size_t)(n * NB + band) * 26) * C + c;
+#pragma unroll
+        for (int t = 0; t < 26; ++t) {
+            float sum = red[0][t][lane];
+#pragma unroll
+            for (int w = 1; w < NT; ++w) sum += red[w][t][lane];
+            q[(size_t)t * C] = sum;
+        }
+    }
+}
+
+#ifndef RCX_CPTBWD_KERNELS_ONLY            // (a tuning harness instantiates single kernels)
+// bytes per pixel as a template argument where the row statements have an immediate form for it (64 / 128 channels of a 16-bit type, 64 of float32)
+template <typename TG, typename TO, int H, int PG, int PO>
+static hipError_t launch_gx2(const void* g, const float* G, void* out, const float* wf, const float* wd, int N, int C, hipStream_t s)
+{
+    const long long units = (long long)N * ((C + 63) / 64) * (H / 14) * (H / 14);
+    const dim3 grid((unsigned)((units + 3) / 4)), block(256);
+    if (!G) hipLaunchKernelGGL((k_bwd_gx<TG, TO, H, false, PG, PO>), grid, block, 0, s, (const TG*)g, G, (TO*)out, wf, wd, N, C);
+    else hipLaunchKernelGGL((k_bwd_gx<TG, TO, H, true, PG, PO>), grid, block, 0, s, (const TG*)g, G, (TO*)out, wf, wd, N, C);
+    return hipGetLastError();
 }
 template <typename TG, typename TO, int H>
 static hipError_t launch_gx(const void* g, const float* G, void* out, const float* wf, const float* wd, int N, int C, hipStream_t s)
 {
-    const long long units = (long long)N * ((C + 63) / 64) * (H / 14) * (H / 14);
-    const dim3 grid((unsigned)((units + 3) / 4)), block(256);
-    if (!G) hipLaunchKernelGGL((k_bwd_gx<TG, TO, H, false>), grid, block, 0, s, (const TG*)g, G, (TO*)out, wf, wd, N, C);
-    else if (units <= few_units()) hipLaunchKernelGGL((k_bwd_gx<TG, TO, H, true, 3, 1>), grid, block, 0, s, (const TG*)g, G, (TO*)out, wf, wd, N, C);
-    else hipLaunchKernelGGL((k_bwd_gx<TG, TO, H, true>), grid, block, 0, s, (const TG*)g, G, (TO*)out, wf, wd, N, C);
-    return hipGetLastError();
+    const int pg = C * (int)sizeof(TG), po = C * (int)sizeof(TO);
+    if (pg == 128 && po == 128) return launch_gx2<TG, TO, H, 128, 128>(g, G, out, wf, wd, N, C, s);
+    if (pg == 256 && po == 256) return launch_gx2<TG, TO, H, 256, 256>(g, G, out, wf, wd, N, C, s);
+    return launch_gx2<TG, TO, H, 0, 0>(g, G, out, wf, wd, N, C, s);
 }
 
-template <typename TG, int H>
-static hipError_t launch_gc(const void* g, float* gC, const float* wf, int N, int C, int mode, hipStream_t s)
+template <typename TG, int H, int PG>
+static hipError_t launch_gc2(const void* g, float* gC, const float* wf, int N, int C, int mode, hipStream_t s)
 {
     const long long units = (long long)N * ((C + 63) / 64) * (H / 14) * (H / 14);
     const dim3 grid((unsigned)((units + 3) / 4)), block(256);
-    if (units <= few_units()) {
-        if (mode == 1) hipLaunchKernelGGL((k_bwd_gc<1, TG, H, 3, 1>), grid, block, 0, s, (const TG*)g, gC, wf, N, C);
-        else hipLaunchKernelGGL((k_bwd_gc<0, TG, H, 3, 1>), grid, block, 0, s, (const TG*)g, gC, wf, N, C);
-    } else {
-        if (mode == 1) hipLaunchKernelGGL((k_bwd_gc<1, TG, H>), grid, block, 0, s, (const TG*)g, gC, wf, N, C);
-        else hipLaunchKernelGGL((k_bwd_gc<0, TG, H>), grid, block, 0, s, (const TG*)g, gC, wf, N, C);
-    }
+    if (mode == 1) hipLaunchKernelGGL((k_bwd_gc<1, TG, H, PG>), grid, block, 0, s, (const TG*)g, gC, wf, N, C);
+    else hipLaunchKernelGGL((k_bwd_gc<0, TG, H, PG>), grid, block, 0, s, (const TG*)g, gC, wf, N, C);
     return hipGetLastError();
+}
+template <typename TG, int H>
+static hipError_t launch_gc(const void* g, float* gC, const float* wf, int N, int C, int mode, hipStream_t s)
+{
+    const int pg = C * (int)sizeof(TG);
+    if (pg == 128) return launch_gc2<TG, H, 128>(g, gC, wf, N, C, mode, s);
+    if (pg == 256) return launch_gc2<TG, H, 256>(g, gC, wf, N, C, mode, s);
+    return launch_gc2<TG, H, 0>(g, gC, wf, N, C, mode, s);
 }
 
 template <typename TA, int H>
 static hipError_t launch_wd(const void* a, const float* G, float* partial, int N, int C, hipStream_t s)
 {
     const unsigned grid = (unsigned)(N * (H / 14) * ((C + 63) / 64));
-    hipLaunchKernelGGL((k_wgrad_d<TA, H>), dim3(grid), dim3(64 * (H / 14)), 0, s, (const TA*)a, G, partial, N, C);
+    const int pa = C * (int)sizeof(TA);
+    if (pa == 128) hipLaunchKernelGGL((k_wgrad_d<TA, H, 128>), dim3(grid), dim3(64 * (H / 14)), 0, s, (const TA*)a, G, partial, N, C);
+    else if (pa == 256) hipLaunchKernelGGL((k_wgrad_d<TA, H, 256>), dim3(grid), dim3(64 * (H / 14)), 0, s, (const TA*)a, G, partial, N, C);
+    else hipLaunchKernelGGL((k_wgrad_d<TA, H, 0>), dim3(grid), dim3(64 * (H / 14)), 0, s, (const TA*)a, G, partial, N, C);
     return hipGetLastError();
+}
+
+template <int MODE, typename TA, typename TG, int H>
+static hipError_t launch_wk(const void* a, const float* coarse, const void* g, float* partial, int N, int C, hipStream_t s)
+{
+    const unsigned grid = (unsigned)(N * (H / 14) * ((C + 63) / 64));
+    const int pa = C * (int)sizeof(TA);
+    if (pa == 128) hipLaunchKernelGGL((k_wgrad_k<MODE, TA, TG, H, 128>), dim3(grid), dim3(64 * (H / 14)), 0, s, (const TA*)a, coarse, (const TG*)g, partial, N, C);
+    else if (pa == 256) hipLaunchKernelGGL((k_wgrad_k<MODE, TA, TG, H, 256>), dim3(grid), dim3(64 * (H / 14)), 0, s, (const TA*)a, coarse, (const TG*)g, partial, N, C);
+    else hipLaunchKernelGGL((k_wgrad_k<MODE, TA, TG, H, 0>), dim3(grid), dim3(64 * (H / 14)), 0, s, (const TA*)a, coarse, (const TG*)g, partial, N, C);
+    return hipGetLastError();
+}
+template <int MODE, typename TA, typename TG>
+static hipError_t launch_wk_h(const void* a, const float* coarse, const void* g, float* partial, int N, int C, int H, hipStream_t s)
+{
+    return H == 56 ? launch_wk<MODE, TA, TG, 56>(a, coarse, g, partial, N, C, s) : launch_wk<MODE, TA, TG, 28>(a, coarse, g, partial, N, C, s);
 }
 #endif
 }  // namespace cptbwd
@@ -515,6 +864,24 @@ hipError_t bwd_wgrad_d_cpt(const void* a, int a_dt, const float* G, float* parti
     if (a_dt == 2) return RCX_WD(f16_t);
     return RCX_WD(float);
 #undef RCX_WD
+}
+
+// weight gradient of a stride-1 conv over T = a + R(coarse) (coarse == nullptr: T = a) from the gradient g of its output (float32, or a's own 16-bit type):
+// one partial row of 26 C sums per (image, 14-row band)
+hipError_t bwd_wgrad_k_cpt(const void* a, int a_dt, const float* coarse, const void* g, int g_dt, float* partial, int N, int C, int H, int mode, hipStream_t s,
+                           int* rows_out)
+{
+    if (rows_out) *rows_out = N * (H / 14);
+    if (g_dt != 0 && g_dt != a_dt) return hipErrorInvalidValue;
+    // float16 a AND g: both rows take a conversion register per element and the kernel no longer fits 256 registers (the compiler then spills row registers
+    // whose loads are still in flight: tools/check_asm_hazards.py) -- that combination keeps rcx_cplwgrad.hip's kernel (same partial rows)
+    if (a_dt == 2 && g_dt == 2) return wgrad_cpl(a, a_dt, coarse, g, g_dt, partial, N, C, H, mode, s, rows_out);
+#define RCX_WK2(MD_, TA_) (g_dt == 0 ? cptbwd::launch_wk_h<MD_, TA_, float>(a, coarse, g, partial, N, C, H, s) : cptbwd::launch_wk_h<MD_, TA_, TA_>(a, coarse, g, partial, N, C, H, s))
+#define RCX_WK(MD_) (a_dt == 1 ? RCX_WK2(MD_, bf16_t) : a_dt == 2 ? cptbwd::launch_wk_h<MD_, f16_t, float>(a, coarse, g, partial, N, C, H, s) : cptbwd::launch_wk_h<MD_, float, float>(a, coarse, g, partial, N, C, H, s))
+    if (!coarse) return RCX_WK(2);
+    return mode == 1 ? RCX_WK(1) : RCX_WK(0);
+#undef RCX_WK
+#undef RCX_WK2
 }
 
 bool bwd_cpt_applicable(int N, int C, int H, int W, int k)
