@@ -446,6 +446,26 @@ __device__ __forceinline__ void fetch_row(uint32_t (&raw)[18], unsigned addr)
         }
 }
 
+// XCD-aware workgroup order of the tile kernels (rcx_upcpt.hip, rcx_cptbwd_kernels.h).  Workgroups are dealt round-robin over the 8 XCDs, each with its own
+// L2: with the natural order the tiles of one (image, channel block) plane -- which read each other's halo rows and columns -- land on eight different L2s
+// and every halo row comes from HBM once per tile row (k_upadd_cpt at 32 x 64 x 128 x 128: 1.44 x its bytes).  Remapped, XCD x walks planes x, x + 8, ...
+// tile by tile: neighbours in space are neighbours in time on one L2.  b = blockIdx.x, G = workgroups per plane, NP = planes; planes past the last multiple
+// of 8 keep the natural order.  (RCX_UPCPT_XCD=0 at build time: natural order, for A/B runs.)
+#ifndef RCX_UPCPT_XCD
+#define RCX_UPCPT_XCD 1
+#endif
+__device__ __forceinline__ unsigned xcd_workgroup(unsigned b, unsigned G, unsigned NP)
+{
+#if RCX_UPCPT_XCD
+    const unsigned npf = NP & ~7u;
+    if (b >= npf * G) return b;
+    const unsigned x = b & 7u, slot = b >> 3;
+    return (x + 8u * (slot / G)) * G + slot % G;
+#else
+    return b;
+#endif
+}
+
 // the 25 taps of one conv for this lane's channel as three register pairs per tap row: (w0,w1) (w2,w3) (w4,0)
 struct Taps {
     f32x2 p[5][3];

@@ -23,8 +23,10 @@
 // accumulator rows in flight, exactly as the forward's pass 2.  Rows are hand-issued buffer loads through per-row descriptors (rcx_upcpt.hip): a 16-bit
 // element lands in float32 position (D16-hi), everything outside the plane is out of range and reads 0 -- no conversion, mask or address instructions;
 // every wave issues the same sequence, so the s_waitcnt counts are compile-time numbers (SchedGX / SchedGC / SchedWD).
+#pragma once
 #include "rcx_cpt_kernel.h"
 #include "rcx_opts.h"
+// Compiled as four translation units (rcx_cptbwd_gx.hip, _gc.hip, _wk.hip, _wd.hip: RCX_CPTBWD_PART = 1 .. 4), each instantiating one kernel family.
 
 #ifndef RCX_GX_AHEAD
 #define RCX_GX_AHEAD 1              /* g rows in flight in front of the row being used (k_bwd_gx / k_bwd_gc) */
@@ -55,7 +57,8 @@ __device__ __forceinline__ bool decode_unit(Unit& u, int N, int C)
     const int lane = (int)(threadIdx.x & 63);
     const int nb = (C + 63) / 64;
     const unsigned total = (unsigned)N * nb * G::NB * G::NT;
-    const unsigned unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    constexpr unsigned upp = (unsigned)(G::NB * G::NT);          // tile-waves per (image, channel block) plane: 16 or 4
+    const unsigned unit = __builtin_amdgcn_readfirstlane(xcd_workgroup(blockIdx.x, upp >> 2, total / upp) * 4 + (threadIdx.x >> 6));
     if (unit >= total) return false;
     u.tc = (int)(unit % (unsigned)G::NT);
     unsigned q = unit / (unsigned)G::NT;
@@ -787,7 +790,7 @@ void k_wgrad_k(const TA* __restrict__ a, const float* __restrict__ coarse, const
     }
 }
 
-#ifndef RCX_CPTBWD_KERNELS_ONLY            // (a tuning harness instantiates single kernels)
+#if RCX_CPTBWD_PART == 1
 // bytes per pixel as a template argument where the row statements have an immediate form for it (64 / 128 channels of a 16-bit type, 64 of float32)
 template <typename TG, typename TO, int H, int PG, int PO>
 static hipError_t launch_gx2(const void* g, const float* G, void* out, const float* wf, const float* wd, int N, int C, hipStream_t s)
@@ -807,6 +810,8 @@ static hipError_t launch_gx(const void* g, const float* G, void* out, const floa
     return launch_gx2<TG, TO, H, 0, 0>(g, G, out, wf, wd, N, C, s);
 }
 
+#endif
+#if RCX_CPTBWD_PART == 2
 template <typename TG, int H, int PG>
 static hipError_t launch_gc2(const void* g, float* gC, const float* wf, int N, int C, int mode, hipStream_t s)
 {
@@ -825,6 +830,8 @@ static hipError_t launch_gc(const void* g, float* gC, const float* wf, int N, in
     return launch_gc2<TG, H, 0>(g, gC, wf, N, C, mode, s);
 }
 
+#endif
+#if RCX_CPTBWD_PART == 4
 template <typename TA, int H>
 static hipError_t launch_wd(const void* a, const float* G, float* partial, int N, int C, hipStream_t s)
 {
@@ -836,6 +843,8 @@ static hipError_t launch_wd(const void* a, const float* G, float* partial, int N
     return hipGetLastError();
 }
 
+#endif
+#if RCX_CPTBWD_PART == 3
 template <int MODE, typename TA, typename TG, int H>
 static hipError_t launch_wk(const void* a, const float* coarse, const void* g, float* partial, int N, int C, hipStream_t s)
 {
@@ -854,7 +863,7 @@ static hipError_t launch_wk_h(const void* a, const float* coarse, const void* g,
 #endif
 }  // namespace cptbwd
 
-#ifndef RCX_CPTBWD_KERNELS_ONLY
+#if RCX_CPTBWD_PART == 4
 // the shared down conv's weight gradient from (a: H x H of a_dt, G: H/2 x H/2 float32): one partial row of 26 C sums per (image, 14-row band of a)
 hipError_t bwd_wgrad_d_cpt(const void* a, int a_dt, const float* G, float* partial, int N, int C, int H, hipStream_t s, int* rows_out)
 {
@@ -866,6 +875,8 @@ hipError_t bwd_wgrad_d_cpt(const void* a, int a_dt, const float* G, float* parti
 #undef RCX_WD
 }
 
+#endif
+#if RCX_CPTBWD_PART == 3
 // weight gradient of a stride-1 conv over T = a + R(coarse) (coarse == nullptr: T = a) from the gradient g of its output (float32, or a's own 16-bit type):
 // one partial row of 26 C sums per (image, 14-row band)
 hipError_t bwd_wgrad_k_cpt(const void* a, int a_dt, const float* coarse, const void* g, int g_dt, float* partial, int N, int C, int H, int mode, hipStream_t s,
@@ -884,6 +895,8 @@ hipError_t bwd_wgrad_k_cpt(const void* a, int a_dt, const float* coarse, const v
 #undef RCX_WK2
 }
 
+#endif
+#if RCX_CPTBWD_PART == 1
 bool bwd_cpt_applicable(int N, int C, int H, int W, int k)
 {
     if (rcx::opt::is_zero(rcx::opt::BWD_CPT)) return false;
@@ -903,6 +916,8 @@ hipError_t bwd_gx_cpt(const void* g, int g_dt, const float* G, void* out, int ou
     return hipErrorInvalidValue;
 }
 
+#endif
+#if RCX_CPTBWD_PART == 2
 // gC (float32, H/2 x H/2) = R^T (K^ g)
 hipError_t bwd_gc_cpt(const void* g, int g_dt, float* gC, const float* wf, int N, int C, int H, int mode, hipStream_t s)
 {

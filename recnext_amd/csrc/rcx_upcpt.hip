@@ -209,7 +209,9 @@ __global__ __launch_bounds__(256, 2) void k_upadd_cpt(const TIO* __restrict__ x,
     const int pix = PIXB ? PIXB : C * ESZ, pixc = C * CSZ;
     const unsigned total = (unsigned)N * nb * TR * TCn;
     const int lane = (int)(threadIdx.x & 63);
-    const unsigned unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const unsigned upp = (unsigned)(TR * TCn);                    // tile-waves per (image, channel block) plane
+    const unsigned wg = (upp & 3u) == 0 ? xcd_workgroup(blockIdx.x, upp >> 2, total / upp) : blockIdx.x;
+    const unsigned unit = __builtin_amdgcn_readfirstlane(wg * 4 + (threadIdx.x >> 6));
     if (unit >= total) return;
     // tile column fastest: the four waves of a workgroup are horizontal neighbours (their halo columns are each other's interiors)
     const int tc = (int)(unit % (unsigned)TCn);
@@ -453,7 +455,9 @@ __global__ __launch_bounds__(256, 2) void k_down5_cpt(const TIO* __restrict__ x,
     const int pix = PIXB ? PIXB : C * ESZ, pixo = C * OSZ;
     const unsigned total = (unsigned)N * nb * TR * TCn;
     const int lane = (int)(threadIdx.x & 63);
-    const unsigned unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const unsigned upp = (unsigned)(TR * TCn);                    // tile-waves per (image, channel block) plane
+    const unsigned wg = (upp & 3u) == 0 ? xcd_workgroup(blockIdx.x, upp >> 2, total / upp) : blockIdx.x;
+    const unsigned unit = __builtin_amdgcn_readfirstlane(wg * 4 + (threadIdx.x >> 6));
     if (unit >= total) return;
     const int tc = (int)(unit % (unsigned)TCn);
     unsigned q = unit / (unsigned)TCn;
@@ -623,7 +627,9 @@ __global__ __launch_bounds__(256, 2) void k_down7m2_cpt(const TIO* __restrict__ 
     const int pix = PIXB ? PIXB : Cin * ESZ, pixo = Co * ESZ;
     const unsigned total = (unsigned)N * nb * TR * TCn;
     const int lane = (int)(threadIdx.x & 63);
-    const unsigned unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const unsigned upp = (unsigned)(TR * TCn);                    // tile-waves per (image, channel block) plane
+    const unsigned wg = (upp & 3u) == 0 ? xcd_workgroup(blockIdx.x, upp >> 2, total / upp) : blockIdx.x;
+    const unsigned unit = __builtin_amdgcn_readfirstlane(wg * 4 + (threadIdx.x >> 6));
     if (unit >= total) return;
     const int tc = (int)(unit % (unsigned)TCn);
     unsigned q = unit / (unsigned)TCn;

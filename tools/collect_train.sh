@@ -27,11 +27,11 @@ PY
 for s in "64 56 4" "128 28 3"; do
   set -- $s
   rocprofv3 --kernel-trace --output-format csv -d "$OUT/kt$2" -- python3 "$OUT/bwd_one.py" $1 $2 $3 > "$OUT/kt$2.log" 2>&1 || exit 1
-  python3 tools/step_kernels.py "$OUT/kt$2" 12 "$OUT/bwd$2_kernels.csv" > "$OUT/bwd$2_kernels.txt"
+  python3 tools/step_kernels.py "$OUT/kt$2" 12 "$OUT/bwd$2_kernels.csv" k_recconv_cpt 1 > "$OUT/bwd$2_kernels.txt"
   rm -rf "$OUT/kt$2"
 done
 rocprofv3 --kernel-trace --output-format csv -d "$OUT/ktm3" -- python3 tools/bench_train.py --which hip --batch 128 --steps 5 > "$OUT/m3_train_step.jsonl" 2> "$OUT/ktm3.log" || exit 1
-python3 tools/step_kernels.py "$OUT/ktm3" 8 "$OUT/m3_train_step_kernels.csv" > "$OUT/m3_train_step_kernels.txt"
+python3 tools/step_kernels.py "$OUT/ktm3" 8 "$OUT/m3_train_step_kernels.csv" "k_recconv_cpt<4" 3 > "$OUT/m3_train_step_kernels.txt"
 rm -rf "$OUT/ktm3"
 python3 tools/bench_train.py --which hip --batch 128 --steps 8 >> "$OUT/m3_train_step.jsonl" 2>> "$OUT/ktm3.log"
 tail -n 5 "$OUT/blocks_fwd_bwd.jsonl" "$OUT/bwd56_kernels.txt" "$OUT/m3_train_step.jsonl"
