@@ -449,6 +449,11 @@ TrainLadder make_train_ladder(int N, int C, int H, int W, int level, int k)
     for (int l = 0; l <= level; ++l) { L.g_off[l] = off; off += align256(sizeof(float) * (size_t)N * C * L.h[l] * L.w[l]); }
     L.gc_off = off; off += level >= 1 ? align256(sizeof(float) * (size_t)N * C * L.h[1] * L.w[1]) : 0;
     L.part_bytes = align256(rcx::wgrad_partial_bytes(C, k));
+    // the tiled weight-gradient kernels (rcx_cptbwd_kernels.h) leave one row of (k*k + 1) * C sums per (image, 14-row band): N * H / 14 rows
+    if (rcx::bwd_cpt_applicable(N, C, H, W, k)) {
+        const size_t tiled = align256(sizeof(float) * (size_t)N * ((H + 13) / 14) * (size_t)(k * k + 1) * C);
+        if (tiled > L.part_bytes) L.part_bytes = tiled;
+    }
     L.part_off = off; off += L.part_bytes * (size_t)(2 * level + 1);     // one partial buffer per weight-gradient call: reduced together
     L.bwd_total = off;
     return L;
@@ -529,9 +534,7 @@ static int bwd_cpt_levels(const TrainLadder& L, int N, int C, int level, int k, 
     const int m = level - 2;
     if (L.h[m] != 14 || L.w[m] != 14 || !rcx::cplbwd_applicable(N, C, 14, 14, 2, k, RCX_DTYPE_F32)) return 0;
     for (int l = 0; l < m; ++l)
-        if (!rcx::bwd_cpt_applicable(N, C, L.h[l], L.w[l], k) || L.h[l + 1] * 2 != L.h[l] || L.w[l + 1] * 2 != L.w[l] ||
-            !rcx::wgrad_cpl_applicable(N, C, L.h[l], L.w[l], L.h[l + 1], L.w[l + 1], k, 1, true) ||
-            !rcx::wgrad2_cpl_applicable(N, C, L.h[l], L.w[l], L.h[l + 1], L.w[l + 1], k, 2, false)) return 0;
+        if (!rcx::bwd_cpt_applicable(N, C, L.h[l], L.w[l], k) || L.h[l + 1] * 2 != L.h[l] || L.w[l + 1] * 2 != L.w[l]) return 0;
     (void)dtype;
     return m;
 }
@@ -539,7 +542,8 @@ static int bwd_cpt_levels(const TrainLadder& L, int N, int C, int level, int k, 
 int rcx_recconv2d_bwd_gy_dtype(int N, int C, int H, int W, int level, int k, int dtype)
 {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0 || !known_dtype(dtype)) return RCX_DTYPE_F32;
-    if (dtype == RCX_DTYPE_F32 || C % 4) return RCX_DTYPE_F32;
+    // bfloat16 only: with float16 rows on both sides the tiled weight-gradient kernel does not fit its register budget (rcx_cptbwd_kernels.h)
+    if (dtype != RCX_DTYPE_BF16 || C % 4) return RCX_DTYPE_F32;
     return bwd_cpt_levels(make_train_ladder(N, C, H, W, level, k), N, C, level, k, dtype) > 0 ? dtype : RCX_DTYPE_F32;
 }
 
@@ -559,7 +563,7 @@ int rcx_recconv2d_bwd(const void* x, const void* gy, int gy_dtype, const float* 
     if (!workspace || workspace_bytes < L.bwd_total)
         return fail(RCX_ERR_WORKSPACE, "backward workspace too small: need %zu bytes, got %zu", L.bwd_total, workspace_bytes);
     const int mcpt = bwd_cpt_levels(L, N, C, level, k, dtype);
-    if (gy_dtype != RCX_DTYPE_F32 && !(mcpt > 0 && gy_dtype == dtype))
+    if (gy_dtype != RCX_DTYPE_F32 && !(mcpt > 0 && gy_dtype == dtype && dtype == RCX_DTYPE_BF16))
         return fail(RCX_ERR_UNSUPPORTED, "gy of dtype %d: this problem takes float32 (rcx_recconv2d_bwd_gy_dtype)", gy_dtype);
     if (gw_out)
         for (int i = 0; i < level + 2; ++i)
@@ -615,6 +619,9 @@ int rcx_recconv2d_bwd(const void* x, const void* gy, int gy_dtype, const float* 
         auto gdt_of = [&](int l) { return l == 0 ? gy_dtype : RCX_DTYPE_F32; };
         auto a_of = [&](int l) { return l == 0 ? x : (const void*)F_(l); };
         auto adt_of = [&](int l) { return l == 0 ? dtype : RCX_DTYPE_F32; };
+        // (Round 6 measured the four weight-gradient kernels on a second stream, forked and joined by events inside the call -- nothing but the final
+        // reduction waits for them, and the chain's middle runs on a fraction of the chip: the event hand-offs cost more than the overlap returns,
+        // 342 vs 301 us at 128 x 64 x 56 x 56, 301 vs 220 us at 256 x 128 x 28 x 28, equal at 256 x 64 x 56 x 56; profiles/r06_backward_side_stream.txt.)
         for (int l = 0; l < m; ++l) {
             const int j = level - l;                              // convs[j] is level l's conv
             RCX_TRY(rcx::bwd_wgrad_k_cpt(a_of(l), adt_of(l), C_(l + 1), g_of(l), gdt_of(l), PART(slot), N, C, L.h[l], md, s, &rows), "bwd: conv weight grad");
@@ -790,19 +797,20 @@ int rcx_dwconv2d_bwd(const void* x, const float* gy, const float* w_kkc, const f
 // ---- backward of conv(x + resize(coarse)) (RecAttn2d's last line in a training step) ----
 static bool upadd_bwd_tiled(int N, int C, int H, int W, int Hc, int Wc, int k)
 {
-    return !lanes_off() && rcx::bwd_cpt_applicable(N, C, H, W, k) && Hc * 2 == H && Wc * 2 == W && rcx::wgrad_cpl_applicable(N, C, H, W, Hc, Wc, k, 1, true);
+    return !lanes_off() && rcx::bwd_cpt_applicable(N, C, H, W, k) && Hc * 2 == H && Wc * 2 == W;
 }
 
 size_t rcx_upadd_dwconv_bwd_workspace_bytes(int N, int C, int H, int W, int Hc, int Wc, int k)
 {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || (k & 1) == 0) return 0;
     const size_t part = align256(rcx::wgrad_partial_bytes(C, k));
-    return upadd_bwd_tiled(N, C, H, W, Hc, Wc, k) ? part : part + align256(sizeof(float) * (size_t)N * C * H * W);      // + the float32 gT the resize adjoint reads
+    if (upadd_bwd_tiled(N, C, H, W, Hc, Wc, k)) return align256(sizeof(float) * (size_t)N * ((H + 13) / 14) * (size_t)(k * k + 1) * C);      // one partial row per (image, band)
+    return part + align256(sizeof(float) * (size_t)N * C * H * W);      // + the float32 gT the resize adjoint reads
 }
 
 int rcx_upadd_dwconv_bwd_gy_dtype(int N, int C, int H, int W, int Hc, int Wc, int k, int dtype)
 {
-    if (!known_dtype(dtype) || dtype == RCX_DTYPE_F32 || N <= 0 || C <= 0 || C % 4 || k <= 0 || (k & 1) == 0) return RCX_DTYPE_F32;
+    if (dtype != RCX_DTYPE_BF16 || N <= 0 || C <= 0 || C % 4 || k <= 0 || (k & 1) == 0) return RCX_DTYPE_F32;
     return upadd_bwd_tiled(N, C, H, W, Hc, Wc, k) ? dtype : RCX_DTYPE_F32;
 }
 
@@ -819,7 +827,7 @@ int rcx_upadd_dwconv_bwd(const void* x, const float* coarse, const void* gy, int
     const size_t need = rcx_upadd_dwconv_bwd_workspace_bytes(N, C, H, W, Hc, Wc, k);
     if (!workspace || workspace_bytes < need) return fail(RCX_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     const bool tiled = upadd_bwd_tiled(N, C, H, W, Hc, Wc, k);
-    if (gy_dtype != RCX_DTYPE_F32 && !(tiled && gy_dtype == dtype))
+    if (gy_dtype != RCX_DTYPE_F32 && !(tiled && gy_dtype == dtype && dtype == RCX_DTYPE_BF16))
         return fail(RCX_ERR_UNSUPPORTED, "gy of dtype %d: this problem takes float32 (rcx_upadd_dwconv_bwd_gy_dtype)", gy_dtype);
     hipStream_t s = (hipStream_t)stream;
     float* part = (float*)workspace;
@@ -834,7 +842,14 @@ int rcx_upadd_dwconv_bwd(const void* x, const float* coarse, const void* gy, int
             e = rcx::bwd_gx_cpt(gy, gy_dtype, nullptr, gx, dtype, w_flipped_kkc, nullptr, N, C, H, s);
             if (e != hipSuccess) return hip_fail(e, "rcx_upadd_dwconv_bwd: input gradient");
         }
-        e = rcx::bwd_wgrad(x, dtype, coarse, (const float*)gy, part, gw, gb, N, C, H, W, Hc, Wc, H, W, k, 1, mode, 0, s, nullptr, gy_dtype);
+        int rows = 0;
+        e = rcx::bwd_wgrad_k_cpt(x, dtype, coarse, gy, gy_dtype, part, N, C, H, md, s, &rows);
+        if (e == hipSuccess) {
+            rcx::WgradJobs J{};
+            J.njobs = 1; J.kk = k * k; J.C = C;
+            J.nslots[0] = 1; J.part[0][0] = part; J.rows[0][0] = rows; J.gw[0] = gw; J.gb[0] = gb;
+            e = rcx::bwd_wgrad_reduce_jobs(J, s);
+        }
         return e == hipSuccess ? 0 : hip_fail(e, "rcx_upadd_dwconv_bwd: weight gradient");
     }
     const float* gyf = (const float*)gy;
