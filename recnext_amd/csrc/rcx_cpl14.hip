@@ -690,7 +690,7 @@ static hipError_t launch(const void* x, void* y, const float* wpack, const float
 }
 
 // x through LDS: 16-bit I/O and whole 64-channel blocks.  OFF by default (RCX_CPL14_LDS=1 switches it on for A/B runs): measured
-// 19.96 us against 19.27 us for the register / AGPR-stash form at 256 x 256 x 14 x 14 bf16 (profiles/r02c_cpl14_lds_variant.txt) --
+// 19.96 us against 19.27 us for the register / AGPR-stash form at 256 x 256 x 14 x 14 bf16 (profiles/archive/r02c_cpl14_lds_variant.txt) --
 // the kernel is bound by its ~5.3 k instructions at one wave per SIMD, not by the latency of its x loads.
 // It is an A/B variant: only the diagnostic library (make diag: -DRCX_AB_VARIANTS) carries it (round 3: the shipped library has the one
 // form that is used, and its asm-hazard scan -- part of `make all` -- reported this variant's f16 / nearest instantiation).
@@ -773,7 +773,7 @@ hipError_t cpl14_short_recconv(const void* x, void* y, const float* wpack, const
     return mode == 1 ? cpl14::launch_short<1, float>(x, y, wpack, bpack, N, C, s) : cpl14::launch_short<0, float>(x, y, wpack, bpack, N, C, s);
 }
 
-// the 7x7 / level 1 block on the pieces of this file (round 1's first version, rcx_cpl.hip, left the tree in round 3: profiles/r01*, r02a_*)
+// the 7x7 / level 1 block on the pieces of this file (round 1's first version, rcx_cpl.hip, left the tree in round 3: profiles/archive/r01*, r02a_*)
 bool cpl7b_applicable(int N, int C, int H, int W, int level, int k, int dtype)
 {
     (void)N;

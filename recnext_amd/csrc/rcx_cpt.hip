@@ -12,7 +12,7 @@ hipError_t launch_ts16(const void* x, void* y, const float* wpack, const float* 
 
 // RCX_CPT=0 gives both blocks back to the banded lanes kernels.  The 28x28 block with a channel count that is not a multiple of 64
 // (RecNeXt-M0/M1/M2/M5) stays on the banded kernel by default; RCX_CPT=32 puts it on 32-channel workgroups (k_recconv_cpt<2, 2, ...>, four
-// per CU).  Measured (profiles/r03_cpt_28_ragged.txt, bf16, us, 32-channel workgroups / banded): 256 x 112 (1 024 units) 51.9 / 57.4,
+// per CU).  Measured (profiles/archive/r03_cpt_28_ragged.txt, bf16, us, 32-channel workgroups / banded): 256 x 112 (1 024 units) 51.9 / 57.4,
 // 256 x 96 (768) 45.3 / 46.9 (inside RecNeXt-M1: 46.7 / 47.0), 256 x 80 46.8 / 46.9, 128 x 160 (640) 41.7 / 42.6 -- but with fewer units a
 // unit's own ~37 us of phases is the floor (128 x 96: 37.8 / 28.9, 64 x 160: 37.3 / 27.8) and with more the second round runs on a fraction
 // of the chip (256 x 160: 63.0 / 67.3 alone, 75.6 / 68.7 inside RecNeXt-M5; 512 x 96: 84.0 / 79.3).  A rule on the unit count would pick a

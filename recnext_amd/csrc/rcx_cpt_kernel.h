@@ -392,7 +392,7 @@ template <typename TIO> __device__ __forceinline__ uint32_t pk16(float lo, float
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // ---- staged x rows (STG, round 4).  What bounds the passes is the NUMBER of vector-memory wave-instructions: a load costs the CU ~7.3 cycles
-// (8.7 at 8 waves per CU) whatever its width up to 4 bytes per lane, 15.8 at 16 bytes (tools/ubench/vmem_rate.hip, profiles/r04_vmem_rate.txt);
+// (8.7 at 8 waves per CU) whatever its width up to 4 bytes per lane, 15.8 at 16 bytes (tools/ubench/vmem_rate.hip, profiles/archive/r04_vmem_rate.txt);
 // eighteen 2-byte loads per row and lane are 157 cycles of the CU's one texture-address path, three 16-byte LDS-DMA pieces are ~48, and the
 // row no longer waits in registers.  A row = the wave's 2 x 18 x 64-byte image (Geo::SLOTB) in LDS order = piece order: piece j, lane i =
 // 16-byte chunk 64 j + i; the source address is per lane (an out-of-range offset writes zeros: the padding left and right of the image;
@@ -646,7 +646,7 @@ struct Geo {
 
 // T = 2, HALVES = 2 (round 3): a wave = 32 channels x the two tiles of one tile row, a workgroup = two waves = 32 channels of an image with
 // 35.7 KB of LDS, four per CU -- for the channel counts that are not multiples of 64 (RecNeXt-M1: 96, M5: 160); it replaces round 2's
-// image-pair variant (two half-waves = two images; slower than the banded kernel, profiles/r02c_cpt_img2_variant.txt).
+// image-pair variant (two half-waves = two images; slower than the banded kernel, profiles/archive/r02c_cpt_img2_variant.txt).
 // TRAIN: the training-forward instantiation (saves the pyramid); the inference instantiations carry none of that code.
 // HALVES = 4 (T = 4; round 3): a wave = 16 channels x the four tiles of one tile row (the quarters of the wave are the tile columns), a
 // workgroup = four waves = 16 channels of an image with 69 KB of LDS -- TWO workgroups per CU, which run different units and so are
@@ -1330,7 +1330,7 @@ static inline bool enabled()
 // x rows by LDS-DMA + transposing reads (STG) where the kernel has the form and the data allow it: 16-bit activations, whole 16-byte chunks of
 // eight channels (C % 8 == 0: every RecNeXt width) at 16-byte-aligned addresses, inference.  Parity-green (the 820 bf16 / float16 / golden cases of
 // tests/test_recconv_gpu.py) and NOT faster inside a model -- 56x56 x 64: 123.3 us either way (a loop over one input: 112.2 against 113.8), 28x28 x 128:
-// 55.6 against 53.6 (loop: 49.2 against 53.7), profiles/r04_staged_rows.txt: with two waves per SIMD these kernels are bound by their vector-ALU
+// 55.6 against 53.6 (loop: 49.2 against 53.7), profiles/archive/r04_staged_rows.txt: with two waves per SIMD these kernels are bound by their vector-ALU
 // issue, not by the 976 -> 451 vector-memory instructions per wave this removes.  So the instantiations exist in the diagnostic build only
 // (make diag, RCX_AB_VARIANTS; RCX_CPT_STG=0 there: element loads).
 template <int T, int HALVES, typename TIO, bool TRAIN> constexpr int stg_slots()
@@ -1398,7 +1398,7 @@ static hipError_t launch_c(const void* x, void* y, const float* wpack, const flo
 }
 
 // The 56x56 block with 16-channel workgroups, two per CU (HALVES = 4), or with 32-channel workgroups (HALVES = 2).  Measured INSIDE the
-// models (bench.py per-kernel event times, batch 256, bf16; profiles/r03_cpt_cb16.txt): 64 channels 108.1 us with 32-channel blocks, 117.5
+// models (bench.py per-kernel event times, batch 256, bf16; profiles/archive/r03_cpt_cb16.txt): 64 channels 108.1 us with 32-channel blocks, 117.5
 // with 16 (32-byte runs per cache-line access); 48 channels (RecNeXt-M1) 111.6 -> 92.5 us and 80 channels (M5) 175.6 -> 157.2 us with
 // 16 (no half-empty last block); few units (3 images x 48 channels) 53.7 -> 37.2 us.  So: 16 where the channel count is not a multiple
 // of 32 or where 32-channel units would not fill the chip; RCX_CPT_CB=16 / 32 pins either (A/B).

@@ -806,7 +806,7 @@ static int band_stage_items(const PlaneArgs& a, int lpp, int cpl)
 
 static int pick_threads(const PlaneArgs& a, int lpp, int cpl)
 {
-    // Measured (profiles/r01b_plane_knob_sweep_*): these kernels are latency-bound, so about two threads per
+    // Measured (profiles/archive/r01b_plane_knob_sweep_*): these kernels are latency-bound, so about two threads per
     // strip item of the widest conv (every item then has a partner wave to hide its LDS round trips), and in
     // banded mode enough threads that one band's staging fits PL_IPB 16-byte items per thread.
     const int stage_items = band_stage_items(a, lpp, cpl);
@@ -851,7 +851,7 @@ PlanePlan plan_plane(int N, int C, int H, int W, int level, int k, int dtype)
         return true;
     };
 
-    // Measured on MI355X (tools/sweep_plane.py, profiles/r01b_plane_knob_sweep_*): planes up to 16x16 run best
+    // Measured on MI355X (tools/sweep_plane.py, profiles/archive/r01b_plane_knob_sweep_*): planes up to 16x16 run best
     // whole (x read once, no band loop) with the widest channel block that still lets two workgroups share a
     // CU; larger planes run banded with the widest block that fits and the tallest band that fits with it.
     PlanePlan p{};

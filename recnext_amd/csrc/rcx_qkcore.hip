@@ -17,7 +17,7 @@
 //   + pe        the depthwise 3x3 of d (float32, from the LDS image) where it is added; a is stored as float32.
 // Numerics: the MFMA operands are bf16 (d, the weights, k, v, q, kv), every accumulation, the activation, the normaliser and pe are float32.
 // That form holds north_star's flat 1e-2 for 16-bit activations (tests/test_recconv_gpu.py: the recattn goldens and A3 stages 2 / 3 run it;
-// profiles/r04_recattn_qk_gemm_operands.txt measured the projection with bf16 operands alone); float32 activations keep the float32 GEMMs and
+// profiles/archive/r04_recattn_qk_gemm_operands.txt measured the projection with bf16 operands alone); float32 activations keep the float32 GEMMs and
 // rcx_linear_attention_pe_fwd (their bar is 1e-3).
 #include "rcx_common.h"
 #include "rcx_launch.h"
@@ -33,7 +33,7 @@ typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
 typedef float f32x4q __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // eight float32 (two 16-byte LDS reads kept WHOLE: converted element by element, the compiler re-splits the reads into 12 + 4 + 4-byte pieces whose
-// row-strided 4-byte parts hit the same bank four ways: SQ_LDS_BANK_CONFLICT 0.40 of the LDS cycles, profiles/r04_sq_wave_states.txt) -> a bf16 operand
+// row-strided 4-byte parts hit the same bank four ways: SQ_LDS_BANK_CONFLICT 0.40 of the LDS cycles, profiles/archive/r04_sq_wave_states.txt) -> a bf16 operand
 __device__ __forceinline__ bf16x8 to_bf16x8(f32x4q lo, f32x4q hi)
 {
     const bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
@@ -220,7 +220,7 @@ __device__ __forceinline__ void out_epilogue(const f32x16& aq, bf16x8 kv0, bf16x
 //      stand, B = v gathered from the LDS image in the token order those registers imply);
 //   2. q^T = Wq d^T (lane = token), then the shared tile epilogue (out_epilogue: normaliser, out^T = kv^T q^T, pe, 16-byte stores).
 // The first version kept q in the lane = channel form and took it through a wave-private LDS image for the second product, computed pe with 9
-// bounds-checked 4-byte LDS reads per output and divided per output: 26-28 us at 256 x 49 x 256, of which pe 8.5 (profiles/r04_recattn_one_launch.txt).
+// bounds-checked 4-byte LDS reads per output and divided per output: 26-28 us at 256 x 49 x 256, of which pe 8.5 (profiles/archive/r04_recattn_one_launch.txt).
 // Weight fragments come from global memory (L2) through a ring PF k-steps deep; NT = 32-token tiles, KS = C / 32 = heads.
 // XW > 0: d is not read from memory but computed here, d = conv5 stride 2 (x) + bias of RecAttn2d.forward (model/recattn.py:61), from the image's XW x XW
 // plane of 16-bit activations (XW = 14 / 7: Hp = Wp = 7 / 4): two lanes per channel, each the upper / lower output rows, every x row loaded once and

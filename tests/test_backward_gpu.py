@@ -39,7 +39,8 @@ def _pair(c, level, mode, bias, dev):
 
 # the shapes at which rcx_recconv2d_bwd switches kernels: the one-launch backward with its two-wave split (< 512 planes per
 # wave set: batch 128 x 256 channels), the nested launch inside the deeper blocks, the tiled weight gradients at batch 128 x 256 channels
-DISPATCH_CASES = [(128, 256, 14, 2), (128, 512, 7, 1), (128, 128, 28, 3), (64, 64, 56, 4)]
+# ... and (round 6) the tiled backward of the fine levels past 512 partial rows per weight-gradient launch (N * H / 14: its buffers are sized per launch)
+DISPATCH_CASES = [(128, 256, 14, 2), (128, 512, 7, 1), (128, 128, 28, 3), (64, 64, 56, 4), (160, 64, 56, 4), (288, 128, 28, 3)]
 
 
 @pytest.mark.parametrize("case", DISPATCH_CASES, ids=lambda c: "x".join(map(str, c)))

@@ -291,6 +291,76 @@ def test_use_fused_stem_marks_the_stem_and_keeps_the_library_path_on_cpu():
     assert torch.equal(b2p[:co], -torch.arange(co, dtype=torch.float32)) and b2p[co:].abs().sum() == 0
 
 
+def test_fused_paths_follow_replaced_layers_and_gradients_cpu(monkeypatch):
+    """The fused channel-mixer / stem launch is taken only while it still describes the module (a layer or the activation replaced after use_fused_*
+    is followed, not ignored), the operands agree in dtype, and nothing on the way wants a gradient: FusedChannelMlp.usable / FusedStem.usable."""
+    from recnext_amd.layers import FusedChannelMlp, FusedStem
+    torch.manual_seed(0)
+    net = models.create_model("recnext_m0", token_mixer=eager_token_mixer("m")).eval()
+    models.replace_batchnorm(net)
+    models.use_linear_pointwise(net)
+    models.use_fused_mlp(net)
+    models.use_fused_stem(net)
+    monkeypatch.setattr(FusedChannelMlp, "supported", lambda self, x: True)          # isolate the checks from "is there a kernel on this device"
+    monkeypatch.setattr(FusedStem, "supported", lambda self, x: True)
+    blk = net.stages[0].blocks[0]
+    fused, seq = blk._fused_mlp, blk.channel_mixer
+    x = torch.randn(1, 40, 8, 8)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    with torch.no_grad():
+        assert fused.usable(seq, x, x)
+    assert fused.usable(seq, x, x)                                  # grad mode on, but nothing requires grad
+    assert not fused.usable(seq, x, x.clone().requires_grad_(True))   # an input gradient is wanted: the autograd path
+    seq[0].weight.requires_grad_(True)
+    assert not fused.usable(seq, x, x)                              # a parameter gradient is wanted
+    with torch.no_grad():
+        assert fused.usable(seq, x, x)
+        assert not fused.usable(seq, x.double(), x)                 # t and x disagree in dtype
+        act = seq[1]
+        seq[1] = torch.nn.ReLU()
+        assert not fused.usable(seq, x, x)                          # the activation was replaced
+        seq[1] = torch.nn.GELU(approximate="tanh")
+        assert not fused.usable(seq, x, x)
+        seq[1] = act
+        assert fused.usable(seq, x, x)
+        old = seq[2]
+        seq[2] = type(old)(torch.nn.Conv2d(old.in_channels, old.out_channels, 1))
+        assert not fused.usable(seq, x, x)                          # a layer was replaced
+        seq[2] = old
+        stem = net.stem
+        img = torch.randn(1, 3, 32, 32)
+        assert stem._fused_stem.usable(stem.stem, img)
+        stem.stem[1] = torch.nn.ReLU()
+        assert not stem._fused_stem.usable(stem.stem, img)
+    assert not stem._fused_stem.usable(stem.stem, img.clone().requires_grad_(True))
+
+
+@pytest.mark.gpu
+def test_eval_mode_input_gradients_pass_through_the_fused_blocks_gpu():
+    """eval() outside no_grad is legal: with the fused channel mixers and stem attached, an input gradient must be the one the unfused model gives
+    (the fused launches have no grad_fn: they may only run when no gradient is wanted)."""
+    from recnext_amd.speed import build_inference_model, synthetic_batch
+    dev = torch.device("cuda:0")
+    nets = [build_inference_model("recnext_m0", dev, torch.bfloat16, seed=3, fold_mixer_norm=False, fused_mlp=f, fused_stem=f) for f in (True, False)]
+    for n_ in nets:
+        for p in n_.parameters():
+            p.requires_grad_(False)
+    x = synthetic_batch(2, 64, dev, torch.bfloat16, seed=1)
+    grads, outs = [], []
+    for n_ in nets:
+        xi = x.clone().requires_grad_(True)
+        y = n_(xi)
+        y.float().square().sum().backward()
+        assert xi.grad is not None and torch.isfinite(xi.grad.float()).all() and float(xi.grad.float().abs().max()) > 0
+        grads.append(xi.grad.float())
+        outs.append(y.float())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(grads[0], grads[1])       # the same operators ran: the fused launches stood aside
+    with torch.no_grad():
+        y_fused = nets[0](x).float()                                 # ... and without a gradient in sight the fused launches run (close, not equal)
+    assert float((y_fused - outs[1]).abs().max()) <= 2e-2 * max(1.0, float(outs[1].abs().max()))
+
+
 def test_channel_mlp_pack_layout_cpu():
     """pack_channel_mlp: every weight lands in the fragment slot the kernel's lane reads it from (rcx_mlp.hip), padding is zeros."""
     from recnext_amd import ops

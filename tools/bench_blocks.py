@@ -54,7 +54,7 @@ def time_fn(fn, iters, rounds=3):
 def time_fresh(fn, x, iters):
     """As inside a model: x is WRITTEN by another kernel right before every launch (dirty lines in the producer's L2, nothing of it clean
     in the consumer's), and only the launch itself is bracketed.  Stand-alone loops over a read-only x rank some variants the other way
-    round (profiles/r03_cpt_cb16.txt, r03_cpt_28_ragged.txt)."""
+    round (profiles/archive/r03_cpt_cb16.txt, r03_cpt_28_ragged.txt)."""
     x0 = x.clone()
     other = torch.empty(256 * 1024 * 1024 // 4, device=x.device)             # 256 MB: what a model's other kernels leave in the caches
     ts = []

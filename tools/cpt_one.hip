@@ -1,6 +1,6 @@
 // One instantiation of k_recconv_cpt, timed the way a model runs it (development tool; no torch, no library): x is rewritten by a copy
 // kernel and 256 MB of other data are touched before EVERY launch, and each launch is bracketed by its own pair of events.  A loop over a
-// read-only x (tools/cpt_bench.hip) ranks some variants the other way round (profiles/r03_cpt_cb16.txt, r03_cpt_fresh_sweep.txt).
+// read-only x (tools/cpt_bench.hip) ranks some variants the other way round (profiles/archive/r03_cpt_cb16.txt, r03_cpt_fresh_sweep.txt).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -DVARIANT=0 [-DRCX_CPT_AHEAD1=4 ...] tools/cpt_one.hip -o tools/cpt_one_v0
 //   tools/cpt_one_v0 [N=256] [iters=40] [fresh=1]
 // VARIANT 0: <4, 2, 0, 128, bf16> (56x56x64), 1: <4, 4, 0, 128, bf16>, 2: <2, 1, 0, 256, bf16> (28x28x128), 3: <2, 2, 0, 0, bf16> (28x28x96),
