@@ -29,7 +29,7 @@
 // Compiled as four translation units (rcx_cptbwd_gx.hip, _gc.hip, _wk.hip, _wd.hip: RCX_CPTBWD_PART = 1 .. 4), each instantiating one kernel family.
 
 #ifndef RCX_GX_AHEAD
-#define RCX_GX_AHEAD 1              /* g rows in flight in front of the row being used (k_bwd_gx / k_bwd_gc) */
+#define RCX_GX_AHEAD 1              /* g rows in flight in front of the row being used (k_bwd_gx: two measured 31.1 vs 30.0 us at 128 x 64 x 56 x 56 -- these kernels move 3 - 4.3 TB/s, not latency-bound) */
 #endif
 #ifndef RCX_GC_AHEAD
 #define RCX_GC_AHEAD 1

@@ -6,11 +6,14 @@ namespace rcx {
 
 typedef float gelu_f32x2 __attribute__((ext_vector_type(2)));
 
-// erf(x) ~ xc Q(xc^2) with xc = x clamped to [-2.8, 2.8]: a weighted minimax fit constrained to reach 1 at the clamp (so the tails are +-1 to 1e-6 and
-// gelu(v) -> 0 / v), |error| < 7.7e-5; two values at a time on the packed pipe, one v_med3 each for the clamp
+// erf(x) ~ xc Q(xc^2) with xc = x clamped to [-A, A], A = 2.799997: a weighted minimax fit constrained to reach 1 at the clamp, |error| < 7.7e-5; two values
+// at a time on the packed pipe, one v_med3 each for the clamp.  A is not 2.8 but the float32 twelve ulps below it at which the float32 evaluation of xc Q(xc^2)
+// below (this multiply, these seven FMAs) returns EXACTLY +-1 (round 6): past the clamp 1 + erf is exactly 2 or 0, so gelu(v) is exactly v or 0 for
+// large |v| -- at 2.8 the fit returned +-0.9999983 there and a large negative pre-activation left -1.7e-6 |v| instead of 0, an error growing with |v|.
+// (Just inside the clamp the fit overshoots 1 by at most 1.9e-6: bounded by 8e-6 in gelu, inside the fit's own error.)
 __device__ __forceinline__ gelu_f32x2 gelu2(gelu_f32x2 v)
 {
-    constexpr float A = 2.8f;
+    constexpr float A = 2.799997f;
     const gelu_f32x2 x = v * 0.70710678f;
     const gelu_f32x2 xc = {__builtin_amdgcn_fmed3f(x.x, -A, A), __builtin_amdgcn_fmed3f(x.y, -A, A)};
     const gelu_f32x2 s = xc * xc;
@@ -31,7 +34,7 @@ __device__ __forceinline__ gelu_f32x2 gelu2(gelu_f32x2 v)
 template <int N>
 __device__ __forceinline__ void gelu2_batch(gelu_f32x2 (&v)[N])
 {
-    constexpr float A = 2.8f;
+    constexpr float A = 2.799997f;
     gelu_f32x2 xc[N], s[N], q[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -55,11 +58,11 @@ __device__ __forceinline__ void gelu2_batch(gelu_f32x2 (&v)[N])
 }
 
 // TWICE the GELU, v (1 + erf(v / sqrt 2)), on N pairs in lockstep, with the 1 / sqrt 2 folded into the coefficients (erf(v / sqrt 2) ~ vc Q'(vc^2), vc = v clamped to
-// +-2.8 sqrt 2) and the final 0.5 left to the consumer (the channel mixer's W2 pack is stored halved, which is exact in bf16): 12 vector ops per pair instead of 15.
+// +-3.95979 = the float32 33 ulps below 2.8 sqrt 2 at which this evaluation returns exactly +-1: see gelu2) and the final 0.5 left to the consumer (the channel mixer's W2 pack is stored halved, which is exact in bf16): 12 vector ops per pair instead of 15.
 template <int N>
 __device__ __forceinline__ void gelu2x_batch(gelu_f32x2 (&v)[N])
 {
-    constexpr float A = 3.9597979f;
+    constexpr float A = 3.95979f;
     gelu_f32x2 vc[N], s[N], q[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) vc[i] = gelu_f32x2{__builtin_amdgcn_fmed3f(v[i].x, -A, A), __builtin_amdgcn_fmed3f(v[i].y, -A, A)};

@@ -59,6 +59,32 @@ def test_fused_channel_mlp_against_float64_and_the_gemm_path(case):
     assert float(err.mean()) <= 1.05 * float(lib_err.mean()) + 1e-5 and float(err.max()) <= 1.25 * float(lib_err.max()) + 1e-3
 
 
+@pytest.mark.parametrize("case", [(2, 64, 128, 28, 28), (2, 256, 512, 14, 14)], ids=lambda c: "x".join(map(str, c)))
+def test_fused_channel_mlp_gelu_tails_are_exact(case):
+    """Hidden pre-activations of magnitude 1e2 .. 1e3: past its clamp the kernel's erf is exactly +-1 (rcx_gelu.h), so gelu(v) is exactly v or 0 and
+    the error does not grow with |v|.  W2 picks out single hidden units, so the output shows gelu of one pre-activation each."""
+    from recnext_amd import ops
+    n, c, hid, h, w = case
+    g = torch.Generator(device="cpu").manual_seed(7)
+    z = (torch.randn(n, c, h, w, generator=g)).to(torch.bfloat16).to(dev()).contiguous(memory_format=torch.channels_last)
+    x = torch.zeros_like(z)
+    w1 = (torch.randn(hid, c, generator=g) * 40.0).to(torch.bfloat16).to(dev())          # pre-activations ~ N(0, (40 sqrt(c))^2): |v| up to ~1e3
+    b1 = torch.zeros(hid).to(torch.bfloat16).to(dev())
+    w2 = torch.zeros(c, hid)
+    w2[torch.arange(c), torch.arange(c)] = 1.0                                            # y[:, j] = gelu(hidden unit j)
+    w2, b2 = w2.to(torch.bfloat16).to(dev()), torch.zeros(c).to(torch.bfloat16).to(dev())
+    hp = ops.channel_mlp_hidden(n * h * w, c, hid, torch.bfloat16)
+    wfrag, bias, _ = ops.pack_channel_mlp(w1, b1, w2, b2, hidden_to=hp)
+    y = ops.channel_mlp(z, x, wfrag, bias, hp).float()
+    pre = (z.float().permute(0, 2, 3, 1).reshape(-1, c) @ w1.float().t())[:, :c].reshape(n, h, w, c).permute(0, 3, 1, 2)
+    assert float(pre.abs().max()) > 300.0
+    neg = pre < -6.0
+    assert bool(neg.any()) and float(y[neg].abs().max()) == 0.0, float(y[neg].abs().max())        # exactly zero, not -1.7e-6 |v|
+    pos = pre > 6.0
+    ref = pre.double().cpu()
+    assert bool(((y.double().cpu() - ref)[pos.cpu()].abs() <= 8e-3 * ref[pos.cpu()].abs() + 1e-6).all())          # gelu(v) = v there: only the bf16 roundings (hidden layer, output) remain
+
+
 def test_fused_channel_mlp_rejects_what_it_has_no_kernel_for():
     from recnext_amd import _lib, ops
     assert not ops.channel_mlp_supported(1024, 512, 1024, torch.bfloat16)         # the 7 x 7 stage: the GEMM library
