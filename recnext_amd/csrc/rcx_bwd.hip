@@ -676,6 +676,10 @@ hipError_t bwd_mult2(const void* x, int x_dt, const float* g, const float* w, vo
     q.N = N; q.C = Cin; q.H = H; q.W = W; q.Hc = Ho; q.Wc = Wo; q.k = k;
     if (gx) {
         const unsigned grid = grid_for((long long)N * H * W * (Cin / 2));
+        if (bwd_down7m2_cpt_applicable(N, Cin, H, W, k)) {          // RecNeXt's three Downsample convs at 224 x 224: tile kernel (rcx_cptbwd_kernels.h)
+            hipError_t et = bwd_down7m2_cpt(g, gx, x_dt, w, N, Cin, H, s);
+            if (et != hipSuccess) return et;
+        } else
         if (k == 7) {
             if (x_dt == 1) hipLaunchKernelGGL((k_down_bwd_input_k<bf16_t, 7, 2>), dim3(grid), dim3(256), 0, s, (const float*)nullptr, g, (bf16_t*)gx, w, q);
             else if (x_dt == 2) hipLaunchKernelGGL((k_down_bwd_input_k<f16_t, 7, 2>), dim3(grid), dim3(256), 0, s, (const float*)nullptr, g, (f16_t*)gx, w, q);

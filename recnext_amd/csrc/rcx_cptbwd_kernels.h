@@ -26,7 +26,7 @@
 #pragma once
 #include "rcx_cpt_kernel.h"
 #include "rcx_opts.h"
-// Compiled as four translation units (rcx_cptbwd_gx.hip, _gc.hip, _wk.hip, _wd.hip: RCX_CPTBWD_PART = 1 .. 4), each instantiating one kernel family.
+// Compiled as five translation units (rcx_cptbwd_gx.hip, _gc.hip, _wk.hip, _wd.hip, _dn.hip: RCX_CPTBWD_PART = 1 .. 5), each instantiating one kernel family.
 
 #ifndef RCX_GX_AHEAD
 #define RCX_GX_AHEAD 1              /* g rows in flight in front of the row being used (k_bwd_gx: two measured 31.1 vs 30.0 us at 128 x 64 x 56 x 56 -- these kernels move 3 - 4.3 TB/s, not latency-bound) */
@@ -58,7 +58,8 @@ __device__ __forceinline__ bool decode_unit(Unit& u, int N, int C)
     const int nb = (C + 63) / 64;
     const unsigned total = (unsigned)N * nb * G::NB * G::NT;
     constexpr unsigned upp = (unsigned)(G::NB * G::NT);          // tile-waves per (image, channel block) plane: 16 or 4
-    const unsigned unit = __builtin_amdgcn_readfirstlane(xcd_workgroup(blockIdx.x, upp >> 2, total / upp) * 4 + (threadIdx.x >> 6));
+    const unsigned wg = (upp & 3u) == 0 ? xcd_workgroup(blockIdx.x, (upp >> 2) ? (upp >> 2) : 1u, total / upp) : blockIdx.x;      // (a 14 x 14 plane is one tile: natural order)
+    const unsigned unit = __builtin_amdgcn_readfirstlane(wg * 4 + (threadIdx.x >> 6));
     if (unit >= total) return false;
     u.tc = (int)(unit % (unsigned)G::NT);
     unsigned q = unit / (unsigned)G::NT;
@@ -790,6 +791,166 @@ void k_wgrad_k(const TA* __restrict__ a, const float* __restrict__ coarse, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_bwd_down7m2: the input gradient of Downsample's depthwise conv (nn.Conv2d(C, 2C, 7, stride 2, padding 3, groups = C), model/recnext.py:165) on the same
+// tiles: gx[c][y][x] = sum over the two output channels o = 2c, 2c + 1 and the taps (u, v) with 2 oy + u - 3 = y, 2 ox + v - 3 = x of W[o][u][v] g[o][oy][ox].
+// rcx_bwd.hip's k_down_bwd_input_k<7, 2> is a gather of one thread per two channels of a pixel (105 us average over the three convs of RecNeXt-M3 at batch 128:
+// the largest kernel of this library in a training step).  Here a lane is an OUTPUT channel o, as in the forward's k_down7m2_cpt (a wave reads 256 contiguous
+// bytes of g per pixel): it forms its own channel's share of the 14 x 14 input tile, coarse-row stationary -- coarse row m feeds the fine rows 2m - 5 .. 2m + 1
+// of the tile (tap row u = y + 5 - 2m), seven accumulator rows of seven pixel pairs in flight -- with the taps paired against the pixel pair's parities:
+//   (out(2j), out(2j+1)) += g[j+3] (0, w0) + g[j+2] (w1, w2) + g[j+1] (w3, w4) + g[j] (w5, w6)          (coarse column j of the tile = local q = j + 1 ...)
+// and a finished row's two shares are added across the lane pair by one DPP add (quad_perm 1,0,3,2); the even lane then stores the even pixels of the row, the
+// odd lane the odd ones (7 stores each, every lane busy).  g rows are hand-issued through per-row descriptors like everything else in this file.
+template <int AHEAD> struct SchedDN {
+    static constexpr int NM = 10;
+    static constexpr int rows_done(int m) { return m < 2 ? 0 : (m == 2 ? 1 : (m == 9 ? 1 : 2)); }        // fine rows completed by coarse row m: 2m - 5, 2m - 4 inside [0, 13]
+    static constexpr int pending(int target)
+    {
+        int seq = 0, gend[NM + 8] = {};
+        for (int r = 0; r < AHEAD; ++r) { seq += 10; gend[r] = seq; }
+        for (int m = 0; m < NM; ++m) {
+            if (m + AHEAD < NM) { seq += 10; gend[m + AHEAD] = seq; }
+            if (m == target) return seq - gend[m];
+            seq += 7 * rows_done(m);
+        }
+        return 0;
+    }
+    static constexpr int cap(int v) { return v > 63 ? 63 : v; }
+};
+// ten columns of a coarse row as 1 + 7 + 2: -1 (vl), 0 .. 6 (vm), 7, 8 (vr); run-time pitch
+#define BW_L10(OP)                                                                                                                   \
+    "s_add_i32 %[t2], %[rb], 0\n\t" CPT_LG(OP, 0, "vl", "t2") CPT_LG(OP, 8, "vr", "t2") CPT_LG(OP, 1, "vm", "t2")                       \
+    "s_add_i32 %[t2], %[t2], %[pix]\n\t" CPT_LG(OP, 9, "vr", "t2") CPT_LG(OP, 2, "vm", "t2")                                          \
+    BW_N(OP, 3, "vm") BW_N(OP, 4, "vm") BW_N(OP, 5, "vm") BW_N(OP, 6, "vm") BW_N(OP, 7, "vm")
+#define BW_OUT10(v) "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]), "=&v"(v[9])
+template <typename TIO>
+__device__ __forceinline__ void row_load10(uint32_t (&v)[10], unsigned vl, unsigned vm, unsigned vr, i32x4 rs, int rb, int pix)
+{
+    int t2;
+    if constexpr (std::is_same<TIO, f16_t>::value) asm volatile(BW_L10(CPT_LDH) : BW_OUT10(v), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+    else if constexpr (sizeof(TIO) == 2) asm volatile(BW_L10(CPT_LD16) : BW_OUT10(v), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+    else asm volatile(BW_L10(CPT_LD32) : BW_OUT10(v), [t2] "=&s"(t2) : [vl] "v"(vl), [vm] "v"(vm), [vr] "v"(vr), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pix) : "scc");
+}
+template <int PENDING> __device__ __forceinline__ void pin_row10(uint32_t (&v)[10])
+{
+    asm volatile("s_waitcnt vmcnt(%10)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]) : "n"(PENDING));
+}
+// seven elements of one row at every second pixel (pitch2 = two pixels), low 16 bits of each register for the 16-bit types
+template <typename TO>
+__device__ __forceinline__ void row_store7_stride2(const uint32_t (&p)[7], unsigned vo, i32x4 rs, int rb, int pitch2)
+{
+    int t2;
+    if constexpr (sizeof(TO) == 2)
+        asm volatile("s_add_i32 %[t2], %[rb], 0\n\t"
+                     CPT_SG("buffer_store_short", 0, "t2") "s_add_i32 %[t2], %[t2], %[pix]\n\t" CPT_SG("buffer_store_short", 1, "t2") "s_add_i32 %[t2], %[t2], %[pix]\n\t"
+                     CPT_SG("buffer_store_short", 2, "t2") "s_add_i32 %[t2], %[t2], %[pix]\n\t" CPT_SG("buffer_store_short", 3, "t2") "s_add_i32 %[t2], %[t2], %[pix]\n\t"
+                     CPT_SG("buffer_store_short", 4, "t2") "s_add_i32 %[t2], %[t2], %[pix]\n\t" CPT_SG("buffer_store_short", 5, "t2") "s_add_i32 %[t2], %[t2], %[pix]\n\t"
+                     CPT_SG("buffer_store_short", 6, "t2")
+                     : [t2] "=&s"(t2)
+                     : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [p4] "v"(p[4]), [p5] "v"(p[5]), [p6] "v"(p[6]),
+                       [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pitch2) : "scc", "memory");
+    else
+        asm volatile("s_add_i32 %[t2], %[rb], 0\n\t"
+                     CPT_SG("buffer_store_dword", 0, "t2") "s_add_i32 %[t2], %[t2], %[pix]\n\t" CPT_SG("buffer_store_dword", 1, "t2") "s_add_i32 %[t2], %[t2], %[pix]\n\t"
+                     CPT_SG("buffer_store_dword", 2, "t2") "s_add_i32 %[t2], %[t2], %[pix]\n\t" CPT_SG("buffer_store_dword", 3, "t2") "s_add_i32 %[t2], %[t2], %[pix]\n\t"
+                     CPT_SG("buffer_store_dword", 4, "t2") "s_add_i32 %[t2], %[t2], %[pix]\n\t" CPT_SG("buffer_store_dword", 5, "t2") "s_add_i32 %[t2], %[t2], %[pix]\n\t"
+                     CPT_SG("buffer_store_dword", 6, "t2")
+                     : [t2] "=&s"(t2)
+                     : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [p4] "v"(p[4]), [p5] "v"(p[5]), [p6] "v"(p[6]),
+                       [vo] "v"(vo), [rs] "s"(rs), [rb] "s"(rb), [pix] "s"(pitch2) : "scc", "memory");
+}
+
+// g: N x H/2 x H/2 x 2 Cin float32 (the gradient of the conv's output), w: the (7, 7, 2 Cin) pack the forward applies, gx: N x H x H x Cin of TO
+template <typename TO, int H>
+__global__ __launch_bounds__(256, 2)
+void k_bwd_down7m2(const float* __restrict__ g, TO* __restrict__ gx, const float* __restrict__ w, int N, int Cin)
+{
+    using GE = Geo<H>;
+    constexpr int W = GE::W, Hc = GE::Hc, Wc = GE::Wc, AHEAD = 2, NM = 10, OSZ = (int)sizeof(TO);
+    using S = SchedDN<AHEAD>;
+    const int Co = 2 * Cin;
+    Unit U;
+    if (!decode_unit<H>(U, N, Co)) return;                       // a wave = 64 OUTPUT channels of one tile
+    const int pixg = Co * 4, pixo = Cin * OSZ;
+    const unsigned long long gbase = (unsigned long long)(reinterpret_cast<const char*>(g) + (size_t)U.n * Hc * Wc * pixg);
+    const unsigned long long obase = (unsigned long long)(reinterpret_cast<char*>(gx) + (size_t)U.n * H * W * pixo);
+    const unsigned gvM = (unsigned)((7 * U.tc) * pixg + U.cl * 4), gvL = gvM - (unsigned)pixg, gvR = gvM + 7u * (unsigned)pixg;
+    auto load_g = [&](uint32_t (&raw)[10], int m) { row_load10<float>(raw, gvL, gvM, gvR, row_desc(gbase, 7 * U.tr - 1 + m, Hc, Wc * pixg), 0, pixg); };
+
+    uint32_t rg[NM][10];
+    sfor<AHEAD>([&](auto mc) { load_g(rg[decltype(mc)::value], decltype(mc)::value); });
+    // the 49 taps of this lane's output channel as pairs against a pixel pair's parities: (0, w0) (w1, w2) (w3, w4) (w5, w6) per tap row
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 49 * Co * 4, 0x00020000);
+    f32x2 P[7][4];
+    {
+        int Cc = Co;
+        asm volatile("" : "+s"(Cc));
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            float t[7];
+#pragma unroll
+            for (int v = 0; v < 7; ++v) t[v] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wsrc, U.cl * 4, (u * 7 + v) * Cc * 4, 0));
+            P[u][0] = f32x2{0.f, t[0]}; P[u][1] = f32x2{t[1], t[2]}; P[u][2] = f32x2{t[3], t[4]}; P[u][3] = f32x2{t[5], t[6]};
+        }
+#pragma unroll
+        for (int u = 0; u < 7; ++u) { pin(P[u][0]); pin(P[u][1]); pin(P[u][2]); pin(P[u][3]); }
+    }
+    const int odd = U.c & 1;                                     // this lane stores the odd pixels of a row (its partner the even ones)
+    const unsigned yoff = U.live ? (unsigned)((14 * U.tc + odd) * pixo + (U.c >> 1) * OSZ) : 0x80000000u;
+    f32x2 acc[7][7];
+
+    sfor<NM>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        if constexpr (m + AHEAD < NM) load_g(rg[m + AHEAD], m + AHEAD);
+        pin_row10<S::cap(S::pending(m))>(rg[m]);
+        f32x2 gs[10];                                            // each value in the low half of an aligned pair: the packed FMAs broadcast it for free
+#pragma unroll
+        for (int q = 0; q < 10; ++q) gs[q] = f32x2{__uint_as_float(rg[m][q]), 0.f};
+        // coarse row m (coarse row 7 tr - 1 + m) feeds fine row y = 2m + u - 5 with tap row u; rows opened here (first touched): u = 6 -> y = 2m + 1, u = 5 -> y = 2m
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int y = 2 * m + u - 5;
+            if (y < 0 || y > 13) continue;
+            f32x2(&a)[7] = acc[y % 7];
+            const bool opens = (m == 0) || (u >= 5);             // the first coarse row opens every row it touches; later ones the two newest
+            if (opens) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) a[j] = splat(gs[j + 3].x) * P[u][0];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) a[j] = pfma(splat(gs[j + 3].x), P[u][0], a[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 7; ++j) a[j] = pfma(splat(gs[j + 2].x), P[u][1], a[j]);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) a[j] = pfma(splat(gs[j + 1].x), P[u][2], a[j]);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) a[j] = pfma(splat(gs[j].x), P[u][3], a[j]);
+        }
+        // fine rows 2m - 5 (tap row 0 was its last) and 2m - 4 (tap row 1) are complete: add the lane pair's shares, store this lane's parity of the pixels
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int y = 2 * m - 5 + d;
+            if (y < 0 || y > 13) continue;
+            uint32_t pk[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const f32x2 v = acc[y % 7][j];
+                const float mine = odd ? v.y : v.x, other = odd ? v.x : v.y;         // what this lane stores / what its partner stores
+                // partner's share of MY pixel: the partner holds it in its `other` slot
+                const float theirs = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, other), 0xB1, 0xf, 0xf, true));
+                const float sum = mine + theirs;
+                if constexpr (std::is_same<TO, float>::value) pk[j] = __float_as_uint(sum);
+                else pk[j] = pk16<TO>(sum, sum);
+            }
+            row_store7_stride2<TO>(pk, yoff, row_desc(obase, 14 * U.tr + y, H, W * pixo), 0, 2 * pixo);
+        }
+#pragma unroll
+        for (int y = 0; y < 14; ++y) if (y >= 2 * m - 3 && y <= 2 * m + 1) pin(acc[y % 7]);
+        CPT_FENCE;
+    });
+}
+
 #if RCX_CPTBWD_PART == 1
 // bytes per pixel as a template argument where the row statements have an immediate form for it (64 / 128 channels of a 16-bit type, 64 of float32)
 template <typename TG, typename TO, int H, int PG, int PO>
@@ -861,6 +1022,15 @@ static hipError_t launch_wk_h(const void* a, const float* coarse, const void* g,
     return H == 56 ? launch_wk<MODE, TA, TG, 56>(a, coarse, g, partial, N, C, s) : launch_wk<MODE, TA, TG, 28>(a, coarse, g, partial, N, C, s);
 }
 #endif
+#if RCX_CPTBWD_PART == 5
+template <typename TO, int H>
+static hipError_t launch_dn(const float* g, void* gx, const float* w, int N, int Cin, hipStream_t s)
+{
+    const long long units = (long long)N * ((2 * Cin + 63) / 64) * (H / 14) * (H / 14);
+    hipLaunchKernelGGL((k_bwd_down7m2<TO, H>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, g, (TO*)gx, w, N, Cin);
+    return hipGetLastError();
+}
+#endif
 }  // namespace cptbwd
 
 #if RCX_CPTBWD_PART == 4
@@ -916,6 +1086,22 @@ hipError_t bwd_gx_cpt(const void* g, int g_dt, const float* G, void* out, int ou
     return hipErrorInvalidValue;
 }
 
+#endif
+#if RCX_CPTBWD_PART == 5
+// input gradient of the 7 x 7 stride-2 multiplier-2 conv (Downsample) on the 56 x 56 / 28 x 28 / 14 x 14 input planes
+bool bwd_down7m2_cpt_applicable(int N, int Cin, int H, int W, int k)
+{
+    if (rcx::opt::is_zero(rcx::opt::BWD_CPT)) return false;
+    return k == 7 && H == W && (H == 56 || H == 28 || H == 14) && N >= 1 && Cin >= 1 && (long long)N * ((2 * Cin + 63) / 64) * (H / 14) * (H / 14) < (1LL << 31);
+}
+hipError_t bwd_down7m2_cpt(const float* g, void* gx, int x_dt, const float* w, int N, int Cin, int H, hipStream_t s)
+{
+#define RCX_DN(TO_) (H == 56 ? cptbwd::launch_dn<TO_, 56>(g, gx, w, N, Cin, s) : H == 28 ? cptbwd::launch_dn<TO_, 28>(g, gx, w, N, Cin, s) : cptbwd::launch_dn<TO_, 14>(g, gx, w, N, Cin, s))
+    if (x_dt == 1) return RCX_DN(bf16_t);
+    if (x_dt == 2) return RCX_DN(f16_t);
+    return RCX_DN(float);
+#undef RCX_DN
+}
 #endif
 #if RCX_CPTBWD_PART == 2
 // gC (float32, H/2 x H/2) = R^T (K^ g)

@@ -285,6 +285,28 @@ def test_downsample_conv_backward_matches_aten_autograd(case):
     assert _rel(ours.norm.weight.grad, bn.weight.grad) < 1e-3
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32], ids=["bf16", "f16", "f32"])
+@pytest.mark.parametrize("case", [(3, 64, 56), (2, 128, 28), (5, 256, 14), (2, 40, 56), (1, 104, 28)], ids=lambda c: "x".join(map(str, c)))
+def test_downsample_input_gradient_tile_kernel(case, dtype):
+    """The input gradient of nn.Conv2d(C, 2C, 7, stride 2, groups = C) on the 56 / 28 / 14 planes (k_bwd_down7m2: a lane per output channel, the lane pair's
+    shares added by DPP) against ATen autograd in float32 on the same (rounded) x, for every I/O type and ragged 64-channel blocks."""
+    from recnext_amd import ops
+    n, c, h = case
+    dev = torch.device("cuda:0")
+    torch.manual_seed(c + h)
+    conv = torch.nn.Conv2d(c, 2 * c, 7, stride=2, padding=3, groups=c, bias=False).to(dev)
+    x = torch.randn(n, c, h, h, device=dev).to(dtype)
+    gy = torch.randn(n, 2 * c, h // 2, h // 2, device=dev)
+    xr = x.float().clone().requires_grad_(True)
+    conv(xr).backward(gy)
+    wp = ops.pack_dw_weight(conv.weight.detach().float())
+    gx, gw, _ = ops.dwconv2d_mult2_backward(x.contiguous(memory_format=torch.channels_last), gy.contiguous(memory_format=torch.channels_last), wp, 7)
+    assert gx.dtype == dtype and gx.shape == x.shape
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    assert _rel(gx.float(), xr.grad) < tol
+    assert _rel(gw.view(7, 7, 2 * c).permute(2, 0, 1), conv.weight.grad[:, 0]) < 2e-4
+
+
 def _la_reference(qpre, kpre, v, pe, heads):
     """model/recattn.py:21-27 on token-major (B, n, C) tensors in float32 (LinearAttention1; LinearAttention2 is the same function)."""
     b, n, c = qpre.shape
