@@ -692,6 +692,14 @@ hipError_t bwd_mult2(const void* x, int x_dt, const float* g, const float* w, vo
         if (e != hipSuccess) return e;
     }
     q.C = 2 * Cin;                                     // the weight-gradient kernel counts output channels
+    if (bwd_wgrad_dm_cpt_applicable(N, q.C, H, W, k)) {  // RecNeXt's three Downsample convs at 224 x 224: tile kernel (rcx_cptbwd_kernels.h)
+        int rows = 0;
+        hipError_t e3 = bwd_wgrad_dm_cpt(x, x_dt, g, partial, N, q.C, H, s, &rows);
+        if (e3 != hipSuccess) return e3;
+        const int kk3 = k * k, n53 = (kk3 + 1) * q.C;
+        hipLaunchKernelGGL(k_wgrad_reduce8, dim3((n53 + 31) / 32), dim3(32, 8), 0, s, partial, gw, gb, rows, kk3, q.C, 0);
+        return hipGetLastError();
+    }
     if (wgrad2m_cpl_applicable(N, q.C, H, W, k)) {      // the first two Downsample convs of RecNeXt at 224x224: tiled kernel (rcx_cplwgrad.hip)
         int rows = 0;
         hipError_t e2 = wgrad2m_cpl(x, x_dt, g, partial, N, q.C, H, s, &rows);

@@ -448,104 +448,118 @@ template <int PENDING> __device__ __forceinline__ void pin_row7(uint32_t (&v)[7]
 {
     asm volatile("s_waitcnt vmcnt(%7)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]) : "n"(PENDING));
 }
-// the shared stride-2 conv's 25 tap sums: tap pairs (0,1) (2,3) (4,-)
-struct DAcc {
-    f32x2 a[5][3];
+// the K x K tap sums of a stride-2 conv: tap pairs (0,1) (2,3) .. ((K-1), -)
+template <int K> struct DAccK {
+    static constexpr int KP = (K + 1) / 2;
+    f32x2 a[K][KP];
     f32x2 bs;
     __device__ __forceinline__ void zero()
     {
 #pragma unroll
-        for (int u = 0; u < 5; ++u)
+        for (int u = 0; u < K; ++u)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) a[u][k] = f32x2{0.f, 0.f};
+            for (int k = 0; k < KP; ++k) a[u][k] = f32x2{0.f, 0.f};
         bs = f32x2{0.f, 0.f};
     }
     __device__ __forceinline__ float tap(int u, int v) const { return (v & 1) ? a[u][v >> 1].y : a[u][v >> 1].x; }
     __device__ __forceinline__ float bias() const { return bs.x + bs.y; }
 };
-template <int AHEAD> struct SchedWD {
-    static constexpr int NS = 17;
+template <int AHEAD, int K> struct SchedWD {
+    static constexpr int NS = 14 + K - 2, NC = K == 5 ? 18 : 20;
     static constexpr int pending(int target)
     {
         int seq = 0, aend[NS + 8] = {};
-        for (int r = 0; r < AHEAD; ++r) { seq += 18; aend[r] = seq; }
+        for (int r = 0; r < AHEAD; ++r) { seq += NC; aend[r] = seq; }
         for (int s = 0; s < NS; ++s) {
-            if (s + AHEAD < NS) { seq += 18; aend[s + AHEAD] = seq; }
+            if (s + AHEAD < NS) { seq += NC; aend[s + AHEAD] = seq; }
             if (s == target) return seq - aend[s];
         }
         return 0;
     }
     static constexpr int cap(int v) { return v > 63 ? 63 : v; }
 };
+template <typename TA, int PA> __device__ __forceinline__ void wd_row_load(uint32_t (&v)[18], unsigned vl, unsigned vm, unsigned vr, i32x4 rs, int pix) { row_load<TA, PA>(v, vl, vm, vr, rs, 0, pix); }
+template <typename TA, int PA> __device__ __forceinline__ void wd_row_load(uint32_t (&v)[20], unsigned vl, unsigned vm, unsigned vr, i32x4 rs, int pix) { row_load20w<TA, PA>(v, vl, vm, vr, rs, 0, pix); }
+template <int PENDING> __device__ __forceinline__ void wd_row_pin(uint32_t (&v)[18]) { pin_row<PENDING>(v); }
+template <int PENDING> __device__ __forceinline__ void wd_row_pin(uint32_t (&v)[20]) { pin_row20<PENDING>(v); }
 
-template <typename TA, int H, int PA>
+// K = 5, MULT = 1: the block's shared down conv.  K = 7, MULT = 2: Downsample's conv (nn.Conv2d(C/2, C, 7, stride 2, groups = C/2): a lane is an OUTPUT channel and
+// reads input channel c / 2; C counts g's channels), on the 56 / 28 / 14 planes -- rcx_cplwgrad.hip's k_wgrad2_cpl<7, 2> and the generic k_wgrad_rows took
+// 70 + 44 + 83 us for RecNeXt-M3's three at batch 128.
+template <typename TA, int H, int PA, int K = 5, int MULT = 1>
 __global__ __launch_bounds__(64 * (H / 14), 2)
 void k_wgrad_d(const TA* __restrict__ a, const float* __restrict__ Gc, float* __restrict__ partial, int N, int C)
 {
     using GE = Geo<H>;
-    constexpr int W = GE::W, NT = GE::NT, NB = GE::NB, Hc = GE::Hc, Wc = GE::Wc, AHEAD = 2, NS = 17, ASZ = (int)sizeof(TA);
-    using S = SchedWD<AHEAD>;
-    __shared__ float red[NT][26][64];
+    constexpr int W = GE::W, NT = GE::NT, NB = GE::NB, Hc = GE::Hc, Wc = GE::Wc, AHEAD = 2, P = K / 2, NS = 14 + K - 2, NC = K == 5 ? 18 : 20, KP = (K + 1) / 2, KK1 = K * K + 1;
+    constexpr int ASZ = (int)sizeof(TA);
+    static_assert(K == 5 || K == 7, "tap rows of 18 (2 + 14 + 2) or 20 (3 + 14 + 3) columns");
+    using S = SchedWD<AHEAD, K>;
+    __shared__ float red[NT][KK1][64];
     const int tile = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
     const int nb = (C + 63) / 64;
     const unsigned unit = blockIdx.x;
-    const int cb = (int)(unit % (unsigned)nb), band = (int)((unit / (unsigned)nb) % (unsigned)NB), n = (int)(unit / (unsigned)(nb * NB));
+    const int cb = __builtin_amdgcn_readfirstlane((int)(unit % (unsigned)nb)), band = __builtin_amdgcn_readfirstlane((int)((unit / (unsigned)nb) % (unsigned)NB)),
+              n = __builtin_amdgcn_readfirstlane((int)(unit / (unsigned)(nb * NB)));
     const int c = cb * 64 + lane;
     const bool live = c < C;
     const int cl = live ? c : C - 1;
-    const int pixa = PA ? PA : C * ASZ, pixf = C * 4;
+    const int Ca = C / MULT;
+    const int pixa = PA ? PA : Ca * ASZ, pixf = C * 4;
     const unsigned long long abase = (unsigned long long)(reinterpret_cast<const char*>(a) + (size_t)n * H * W * pixa);
     const unsigned long long Gbase = (unsigned long long)(reinterpret_cast<const char*>(Gc) + (size_t)n * Hc * Wc * pixf);
-    const unsigned voffM = (unsigned)((14 * tile) * pixa + cl * ASZ);
-    const unsigned voffL = voffM - 2u * (unsigned)pixa, voffR = voffM + 14u * (unsigned)pixa;
+    const unsigned voffM = (unsigned)((14 * tile) * pixa + (cl / MULT) * ASZ);
+    const unsigned voffL = voffM - (unsigned)P * (unsigned)pixa, voffR = voffM + 14u * (unsigned)pixa;
     const unsigned Gvo = (unsigned)((7 * tile) * pixf + cl * 4);
-    auto load_row = [&](uint32_t (&raw)[18], int s) { row_load<TA, PA>(raw, voffL, voffM, voffR, row_desc(abase, 14 * band - 2 + s, H, W * pixa), 0, pixa); };
+    auto load_row = [&](uint32_t (&raw)[NC], int s) { wd_row_load<TA, PA>(raw, voffL, voffM, voffR, row_desc(abase, 14 * band - P + s, H, W * pixa), pixa); };
 
-    uint32_t ra[NS][18], rG[7][7];
+    uint32_t ra[NS][NC], rG[7][7];
     sfor<7>([&](auto oc) { row_load7(rG[decltype(oc)::value], Gvo, row_desc(Gbase, 7 * band + decltype(oc)::value, Hc, Wc * pixf), 0, pixf); });
     sfor<AHEAD>([&](auto sc) { load_row(ra[decltype(sc)::value], decltype(sc)::value); });
-    DAcc acc;
+    DAccK<K> acc;
     acc.zero();
     float G[7][7];
     sfor<7>([&](auto oc) {
         constexpr int o = decltype(oc)::value;
-        pin_row7<AHEAD * 18>(rG[o]);                             // every G row is older than the first a rows
+        pin_row7<AHEAD * NC>(rG[o]);                             // every G row is older than the first a rows
 #pragma unroll
         for (int i = 0; i < 7; ++i) { G[o][i] = __uint_as_float(rG[o][i]); if (i & 1) acc.bs.y += G[o][i]; else acc.bs.x += G[o][i]; }
     });
     sfor<NS>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         if constexpr (s + AHEAD < NS) load_row(ra[s + AHEAD], s + AHEAD);
-        pin_row<S::cap(S::pending(s))>(ra[s]);
-        f32x2 ar[9];
+        wd_row_pin<S::cap(S::pending(s))>(ra[s]);
+        f32x2 ar[NC / 2];
 #pragma unroll
-        for (int m = 0; m < 9; ++m) ar[m] = f32x2{raw_f32<TA>(ra[s][2 * m]), raw_f32<TA>(ra[s][2 * m + 1])};
-        // a row s = 2o + u: the G rows o whose window covers it, tap row u; G column i against the pairs ar[i + k] = a columns 2i + 2k, 2i + 2k + 1
+        for (int m = 0; m < NC / 2; ++m) ar[m] = f32x2{raw_f32<TA>(ra[s][2 * m]), raw_f32<TA>(ra[s][2 * m + 1])};
+        // a row s = 2o + u: the G rows o whose window covers it, tap row u; G column i against the pairs ar[i + k] = a columns 2i + 2k, 2i + 2k + 1 (local column q = image column c0 - P + q)
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
 #pragma unroll
             for (int o = 0; o < 7; ++o) {
                 const int u = s - 2 * o;
-                if (u < 0 || u > 4) continue;
+                if (u < 0 || u > K - 1) continue;
                 const f32x2 gv = splat(G[o][i]);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) acc.a[u][k] = pfma(gv, ar[i + k], acc.a[u][k]);
+                for (int k = 0; k < KP; ++k) acc.a[u][k] = pfma(gv, ar[i + k], acc.a[u][k]);
             }
         }
 #pragma unroll
-        for (int u = 0; u < 5; ++u) { pin(acc.a[u][0]); pin(acc.a[u][1]); pin(acc.a[u][2]); }
+        for (int u = 0; u < K; ++u)
+#pragma unroll
+            for (int k = 0; k < KP; ++k) pin(acc.a[u][k]);
         CPT_FENCE;
     });
 #pragma unroll
-    for (int u = 0; u < 5; ++u)
+    for (int u = 0; u < K; ++u)
 #pragma unroll
-        for (int v = 0; v < 5; ++v) red[tile][u * 5 + v][lane] = acc.tap(u, v);
-    red[tile][25][lane] = acc.bias();
+        for (int v = 0; v < K; ++v) red[tile][u * K + v][lane] = acc.tap(u, v);
+    red[tile][K * K][lane] = acc.bias();
     __syncthreads();
     if (tile == 0 && live) {
-        float* q = partial + ((size_t)(n * NB + band) * 26) * C + c;
+        float* q = partial + ((size_t)(n * NB + band) * KK1) * C + c;
 #pragma unroll
-        for (int t = 0; t < 26; ++t) {
+        for (int t = 0; t < KK1; ++t) {
             float sum = red[0][t][lane];
 #pragma unroll
             for (int w = 1; w < NT; ++w) sum += red[w][t][lane];
@@ -993,17 +1007,16 @@ static hipError_t launch_gc(const void* g, float* gC, const float* wf, int N, in
 
 #endif
 #if RCX_CPTBWD_PART == 4
-template <typename TA, int H>
+template <typename TA, int H, int K, int MULT>
 static hipError_t launch_wd(const void* a, const float* G, float* partial, int N, int C, hipStream_t s)
 {
     const unsigned grid = (unsigned)(N * (H / 14) * ((C + 63) / 64));
-    const int pa = C * (int)sizeof(TA);
-    if (pa == 128) hipLaunchKernelGGL((k_wgrad_d<TA, H, 128>), dim3(grid), dim3(64 * (H / 14)), 0, s, (const TA*)a, G, partial, N, C);
-    else if (pa == 256) hipLaunchKernelGGL((k_wgrad_d<TA, H, 256>), dim3(grid), dim3(64 * (H / 14)), 0, s, (const TA*)a, G, partial, N, C);
-    else hipLaunchKernelGGL((k_wgrad_d<TA, H, 0>), dim3(grid), dim3(64 * (H / 14)), 0, s, (const TA*)a, G, partial, N, C);
+    const int pa = (C / MULT) * (int)sizeof(TA);
+    if (pa == 128) hipLaunchKernelGGL((k_wgrad_d<TA, H, 128, K, MULT>), dim3(grid), dim3(64 * (H / 14)), 0, s, (const TA*)a, G, partial, N, C);
+    else if (pa == 256) hipLaunchKernelGGL((k_wgrad_d<TA, H, 256, K, MULT>), dim3(grid), dim3(64 * (H / 14)), 0, s, (const TA*)a, G, partial, N, C);
+    else hipLaunchKernelGGL((k_wgrad_d<TA, H, 0, K, MULT>), dim3(grid), dim3(64 * (H / 14)), 0, s, (const TA*)a, G, partial, N, C);
     return hipGetLastError();
 }
-
 #endif
 #if RCX_CPTBWD_PART == 3
 template <int MODE, typename TA, typename TG, int H>
@@ -1038,13 +1051,30 @@ static hipError_t launch_dn(const float* g, void* gx, const float* w, int N, int
 hipError_t bwd_wgrad_d_cpt(const void* a, int a_dt, const float* G, float* partial, int N, int C, int H, hipStream_t s, int* rows_out)
 {
     if (rows_out) *rows_out = N * (H / 14);
-#define RCX_WD(TA_) (H == 56 ? cptbwd::launch_wd<TA_, 56>(a, G, partial, N, C, s) : cptbwd::launch_wd<TA_, 28>(a, G, partial, N, C, s))
+#define RCX_WD(TA_) (H == 56 ? cptbwd::launch_wd<TA_, 56, 5, 1>(a, G, partial, N, C, s) : cptbwd::launch_wd<TA_, 28, 5, 1>(a, G, partial, N, C, s))
     if (a_dt == 1) return RCX_WD(bf16_t);
     if (a_dt == 2) return RCX_WD(f16_t);
     return RCX_WD(float);
 #undef RCX_WD
 }
 
+#endif
+#if RCX_CPTBWD_PART == 4
+// ... and of Downsample's 7 x 7 stride-2 multiplier-2 conv (a: H x H with Cout / 2 channels, G: H/2 x H/2 with Cout): one partial row of 50 Cout sums per (image, band)
+bool bwd_wgrad_dm_cpt_applicable(int N, int Cout, int H, int W, int k)
+{
+    if (rcx::opt::is_zero(rcx::opt::BWD_CPT)) return false;
+    return k == 7 && H == W && (H == 56 || H == 28 || H == 14) && Cout >= 2 && Cout % 2 == 0 && N * (H / 14) <= 512;      // 512 partial rows: rcx_dwconv2d_bwd_workspace_bytes
+}
+hipError_t bwd_wgrad_dm_cpt(const void* a, int a_dt, const float* G, float* partial, int N, int Cout, int H, hipStream_t s, int* rows_out)
+{
+    if (rows_out) *rows_out = N * (H / 14);
+#define RCX_WDM(TA_) (H == 56 ? cptbwd::launch_wd<TA_, 56, 7, 2>(a, G, partial, N, Cout, s) : H == 28 ? cptbwd::launch_wd<TA_, 28, 7, 2>(a, G, partial, N, Cout, s) : cptbwd::launch_wd<TA_, 14, 7, 2>(a, G, partial, N, Cout, s))
+    if (a_dt == 1) return RCX_WDM(bf16_t);
+    if (a_dt == 2) return RCX_WDM(f16_t);
+    return RCX_WDM(float);
+#undef RCX_WDM
+}
 #endif
 #if RCX_CPTBWD_PART == 3
 // weight gradient of a stride-1 conv over T = a + R(coarse) (coarse == nullptr: T = a) from the gradient g of its output (float32, or a's own 16-bit type):

@@ -124,6 +124,8 @@ hipError_t wgrad2m_cpl(const void* a, int a_dt, const float* g, float* partial, 
 // out = K^ g + D^T G (G = nullptr: the conv adjoint alone); g_dt / out_dt: dtype ids, G and gC float32
 bool bwd_cpt_applicable(int N, int C, int H, int W, int k);
 hipError_t bwd_gc_cpt(const void* g, int g_dt, float* gC, const float* wf, int N, int C, int H, int mode, hipStream_t s);
+bool bwd_wgrad_dm_cpt_applicable(int N, int Cout, int H, int W, int k);
+hipError_t bwd_wgrad_dm_cpt(const void* a, int a_dt, const float* G, float* partial, int N, int Cout, int H, hipStream_t s, int* rows_out);
 bool bwd_down7m2_cpt_applicable(int N, int Cin, int H, int W, int k);
 hipError_t bwd_down7m2_cpt(const float* g, void* gx, int x_dt, const float* w, int N, int Cin, int H, hipStream_t s);
 hipError_t bwd_wgrad_k_cpt(const void* a, int a_dt, const float* coarse, const void* g, int g_dt, float* partial, int N, int C, int H, int mode, hipStream_t s,
