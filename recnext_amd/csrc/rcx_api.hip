@@ -544,6 +544,7 @@ int rcx_recconv2d_bwd_gy_dtype(int N, int C, int H, int W, int level, int k, int
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level > RCX_MAX_LEVEL || k <= 0 || (k & 1) == 0 || !known_dtype(dtype)) return RCX_DTYPE_F32;
     // bfloat16 only: with float16 rows on both sides the tiled weight-gradient kernel does not fit its register budget (rcx_cptbwd_kernels.h)
     if (dtype != RCX_DTYPE_BF16 || C % 4) return RCX_DTYPE_F32;
+    if (level >= 1 && !lanes_off() && rcx::cplbwd_applicable(N, C, H, W, level, k, dtype)) return dtype;      // the one-launch 14 x 14 / 7 x 7 backward
     return bwd_cpt_levels(make_train_ladder(N, C, H, W, level, k), N, C, level, k, dtype) > 0 ? dtype : RCX_DTYPE_F32;
 }
 
@@ -563,7 +564,8 @@ int rcx_recconv2d_bwd(const void* x, const void* gy, int gy_dtype, const float* 
     if (!workspace || workspace_bytes < L.bwd_total)
         return fail(RCX_ERR_WORKSPACE, "backward workspace too small: need %zu bytes, got %zu", L.bwd_total, workspace_bytes);
     const int mcpt = bwd_cpt_levels(L, N, C, level, k, dtype);
-    if (gy_dtype != RCX_DTYPE_F32 && !(mcpt > 0 && gy_dtype == dtype && dtype == RCX_DTYPE_BF16))
+    const bool whole = level >= 1 && !lanes_off() && rcx::cplbwd_applicable(N, C, H, W, level, k, dtype);
+    if (gy_dtype != RCX_DTYPE_F32 && !((mcpt > 0 || whole) && gy_dtype == dtype && dtype == RCX_DTYPE_BF16))
         return fail(RCX_ERR_UNSUPPORTED, "gy of dtype %d: this problem takes float32 (rcx_recconv2d_bwd_gy_dtype)", gy_dtype);
     if (gw_out)
         for (int i = 0; i < level + 2; ++i)
@@ -596,11 +598,11 @@ int rcx_recconv2d_bwd(const void* x, const void* gy, int gy_dtype, const float* 
     hipError_t e;
 #define RCX_TRY(call, what) do { e = (call); if (e != hipSuccess) return hip_fail(e, what); } while (0)
     // the blocks whose planes fit one lane: the whole backward in one launch + the batch reduction (RCX_BWD_FUSED=0: per-step schedule)
-    if (level >= 1 && !lanes_off() && rcx::cplbwd_applicable(N, C, H, W, level, k, dtype)) {
+    if (whole) {
         float* parts[RCX_MAX_LEVEL + 2];
         for (int j = 0; j < level + 2; ++j) { parts[j] = PART(j); add_slot(j, PART(j), N); }
-        RCX_TRY(rcx::cplbwd_recconv(x, (const float*)gy, wpack, wpack_flipped, saved, L.f_off, L.c_off, gx, parts, N, C, H, level,
-                                    mode == RCX_MODE_NEAREST ? 1 : 0, dtype, s), "bwd: fused block");
+        RCX_TRY(rcx::cplbwd_recconv(x, gy, wpack, wpack_flipped, saved, L.f_off, L.c_off, gx, parts, N, C, H, level,
+                                    mode == RCX_MODE_NEAREST ? 1 : 0, dtype, s, gy_dtype), "bwd: fused block");
         RCX_TRY(rcx::bwd_wgrad_reduce_jobs(J, s), "bwd: weight-gradient reduction");
         return 0;
     }

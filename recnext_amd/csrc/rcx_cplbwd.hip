@@ -26,7 +26,7 @@ namespace cplbwd {
 
 struct BwdArgs {
     const void* x;                 // N x W x W x C, the block's input (TIO)
-    const float* gy;               // N x W x W x C float32
+    const void* gy;                // N x W x W x C of TGY: float32, or (round 6) the block's own bf16 -- dL/dy as autograd hands it over under autocast
     const float* wpack;            // (level+2, 25, C): the down conv's taps are read from here
     const float* wflip;            // the same pack with every 5x5 flipped: conv^T = conv with these
     const char* saved;             // the training forward's pyramid
@@ -129,7 +129,7 @@ __device__ __forceinline__ void level1_bwd(f32x2 (&X)[NW][(NW + 1) / 2], const f
 }
 
 // ---- 7x7 / level 1 ----
-template <int MODE, int CT, typename TIO>
+template <int MODE, int CT, typename TIO, typename TGY = float>
 __global__ __launch_bounds__(64)
 void k_recconv_bwd_cpl7(BwdArgs A)
 {
@@ -146,10 +146,10 @@ void k_recconv_bwd_cpl7(BwdArgs A)
     const size_t pix = (size_t)C * sizeof(TIO);
     const gcptr xb = (gcptr)A.x + (size_t)n * W * W * pix;
     const gcptr gxb = (gcptr)A.gx + (size_t)n * W * W * pix;
-    const gcptr gyb = (gcptr)A.gy + (size_t)n * W * W * (size_t)C * 4;
+    const gcptr gyb = (gcptr)A.gy + (size_t)n * W * W * (size_t)C * sizeof(TGY);
     const unsigned vo = (unsigned)c * (unsigned)sizeof(TIO), vow = (unsigned)c * 4u;
     const RowAddr<W, CT, TIO> ra(vo, pix);
-    const RowAddr<W, CT, float> rg(vow, (size_t)C * 4);
+    const RowAddr<W, CT, TGY> rg((unsigned)c * (unsigned)sizeof(TGY), (size_t)C * sizeof(TGY));
 
     uint32_t raw[W][W], rawg[W][W];
     sfor<W>([&](auto rc) {
@@ -161,7 +161,7 @@ void k_recconv_bwd_cpl7(BwdArgs A)
     sfor<W>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         rg.row(gyb, r, [&](auto qc, gcptr base, unsigned voff, auto immc) {
-            rawg[r][decltype(qc)::value] = SafeLd<float>::ld(base + decltype(immc)::value + voff);
+            rawg[r][decltype(qc)::value] = SafeLd<TGY>::ld(base + decltype(immc)::value + voff);
         });
     });
     RCX_FENCE;
@@ -176,7 +176,7 @@ void k_recconv_bwd_cpl7(BwdArgs A)
     for (int r = 0; r < W; ++r) {
         pin_raw(rawg[r]);
 #pragma unroll
-        for (int j = 0; j < P; ++j) GY[r][j] = f32x2{__uint_as_float(rawg[r][2 * j]), 2 * j + 1 < W ? __uint_as_float(rawg[r][2 * j + 1]) : 0.f};
+        for (int j = 0; j < P; ++j) GY[r][j] = f32x2{SafeLd<TGY>::cvt(rawg[r][2 * j]), 2 * j + 1 < W ? SafeLd<TGY>::cvt(rawg[r][2 * j + 1]) : 0.f};
     }
     RCX_FENCE;
     DAcc wd;
@@ -204,7 +204,7 @@ void k_recconv_bwd_cpl7(BwdArgs A)
 // gx = gT0 + down^T(gF1) leaves row by row.
 // A.split: sweep (1) is independent of the rest, and a batch of 128 x 256 channels is 512 planes on 1024 SIMDs -- two waves per plane
 // then (workgroups b and b + 8, the same XCD: both read the plane's gy), one doing sweep (1), the other sweeps (2)-(4).
-template <int MODE, int CT, typename TIO>
+template <int MODE, int CT, typename TIO, typename TGY = float>
 __global__ __launch_bounds__(64)
 void k_recconv_bwd_cpl14(BwdArgs A)
 {
@@ -228,10 +228,10 @@ void k_recconv_bwd_cpl14(BwdArgs A)
     const size_t pix = (size_t)C * sizeof(TIO);
     const gcptr xb = (gcptr)A.x + (size_t)n * W * W * pix;
     const gcptr gxb = (gcptr)A.gx + (size_t)n * W * W * pix;
-    const gcptr gyb = (gcptr)A.gy + (size_t)n * W * W * (size_t)C * 4;
+    const gcptr gyb = (gcptr)A.gy + (size_t)n * W * W * (size_t)C * sizeof(TGY);
     const unsigned vo = (unsigned)c * (unsigned)sizeof(TIO), vow = (unsigned)c * 4u;
     const RowAddr<W, CT, TIO> ra(vo, pix);
-    const RowAddr<W, CT, float> rg(vow, (size_t)C * 4);
+    const RowAddr<W, CT, TGY> rg((unsigned)c * (unsigned)sizeof(TGY), (size_t)C * sizeof(TGY));
     uint32_t rx[W][W], rgy[W][W];                           // rows as loaded; only the rows in flight are live
     auto ld_x = [&](auto rc) {
         constexpr int r = decltype(rc)::value;
@@ -242,7 +242,7 @@ void k_recconv_bwd_cpl14(BwdArgs A)
     auto ld_g = [&](auto rc) {
         constexpr int r = decltype(rc)::value;
         rg.row(gyb, r, [&](auto qc, gcptr base, unsigned voff, auto immc) {
-            rgy[r][decltype(qc)::value] = SafeLd<float>::ld(base + decltype(immc)::value + voff);
+            rgy[r][decltype(qc)::value] = SafeLd<TGY>::ld(base + decltype(immc)::value + voff);
         });
     };
 
@@ -278,7 +278,7 @@ void k_recconv_bwd_cpl14(BwdArgs A)
             pin_raw(rgy[t]);
             f32x2 g[P];
 #pragma unroll
-            for (int j = 0; j < P; ++j) g[j] = f32x2{__uint_as_float(rgy[t][2 * j]), __uint_as_float(rgy[t][2 * j + 1])};
+            for (int j = 0; j < P; ++j) g[j] = f32x2{SafeLd<TGY>::cvt(rgy[t][2 * j]), SafeLd<TGY>::cvt(rgy[t][2 * j + 1])};
             wgrad_row<W>(g, t, [&](int r) -> const f32x2(&)[P] { return T0[r % 5]; }, w2);
 #pragma unroll
             for (int u = 0; u < 5; ++u) { pin(w2.E[u]); pin(w2.O[u]); }
@@ -316,7 +316,7 @@ void k_recconv_bwd_cpl14(BwdArgs A)
             pin_raw(rgy[t]);
             f32x2 row[P];
 #pragma unroll
-            for (int j = 0; j < P; ++j) row[j] = f32x2{__uint_as_float(rgy[t][2 * j]), __uint_as_float(rgy[t][2 * j + 1])};
+            for (int j = 0; j < P; ++j) row[j] = f32x2{SafeLd<TGY>::cvt(rgy[t][2 * j]), SafeLd<TGY>::cvt(rgy[t][2 * j + 1])};
             conv5_row<W>(row, t, tf, [&](int o) -> f32x2(&)[P] { return acc[o % 5]; });
 #pragma unroll
             for (int d = 2; d >= 0; --d) {
@@ -377,7 +377,7 @@ void k_recconv_bwd_cpl14(BwdArgs A)
     store_wacc(A.part[0], n, C, c, wd);
 }
 
-template <int MODE, int CT, typename TIO>
+template <int MODE, int CT, typename TIO, typename TGY = float>
 static hipError_t launch14(const BwdArgs& A, hipStream_t s)
 {
     const unsigned planes = (unsigned)(A.N * ((A.C + 63) / 64));
@@ -385,28 +385,28 @@ static hipError_t launch14(const BwdArgs& A, hipStream_t s)
     // two waves per plane while that still fits the chip's 1024 SIMDs in one round (and the split grid keeps whole XCD rounds)
     BwdArgs B = A;
     B.split = !(v && *v == '0') && planes * 2 <= 1024 && planes % 8 == 0;
-    hipLaunchKernelGGL((k_recconv_bwd_cpl14<MODE, CT, TIO>), dim3(B.split ? planes * 2 : planes), dim3(64), 0, s, B);
+    hipLaunchKernelGGL((k_recconv_bwd_cpl14<MODE, CT, TIO, TGY>), dim3(B.split ? planes * 2 : planes), dim3(64), 0, s, B);
     return hipGetLastError();
 }
-template <int MODE, typename TIO>
+template <int MODE, typename TIO, typename TGY = float>
 static hipError_t launch14_c(const BwdArgs& A, hipStream_t s)
 {
-    if (A.C == 256) return launch14<MODE, 256, TIO>(A, s);
-    return launch14<MODE, 0, TIO>(A, s);
+    if (A.C == 256) return launch14<MODE, 256, TIO, TGY>(A, s);
+    return launch14<MODE, 0, TIO, TGY>(A, s);
 }
 
-template <int MODE, int CT, typename TIO>
+template <int MODE, int CT, typename TIO, typename TGY = float>
 static hipError_t launch7(const BwdArgs& A, hipStream_t s)
 {
     const unsigned grid = (unsigned)(A.N * ((A.C + 63) / 64));
-    hipLaunchKernelGGL((k_recconv_bwd_cpl7<MODE, CT, TIO>), dim3(grid), dim3(64), 0, s, A);
+    hipLaunchKernelGGL((k_recconv_bwd_cpl7<MODE, CT, TIO, TGY>), dim3(grid), dim3(64), 0, s, A);
     return hipGetLastError();
 }
-template <int MODE, typename TIO>
+template <int MODE, typename TIO, typename TGY = float>
 static hipError_t launch7_c(const BwdArgs& A, hipStream_t s)
 {
-    if (A.C == 512) return launch7<MODE, 512, TIO>(A, s);
-    return launch7<MODE, 0, TIO>(A, s);
+    if (A.C == 512) return launch7<MODE, 512, TIO, TGY>(A, s);
+    return launch7<MODE, 0, TIO, TGY>(A, s);
 }
 
 }  // namespace cplbwd
@@ -420,18 +420,20 @@ bool cplbwd_applicable(int N, int C, int H, int W, int level, int k, int dtype)
     return cpl7b_applicable(N, C, H, W, level, k, dtype) || cpl14_applicable(N, C, H, W, level, k, dtype);
 }
 
-hipError_t cplbwd_recconv(const void* x, const float* gy, const float* wpack, const float* wflip, const void* saved,
+// gy_dt: RCX_DTYPE_F32, or bfloat16 with a bfloat16 block (dL/dy as autograd hands it over under autocast: no float32 copy; round 6)
+hipError_t cplbwd_recconv(const void* x, const void* gy, const float* wpack, const float* wflip, const void* saved,
                           const size_t* f_off, const size_t* c_off, void* gx, float* const* part,
-                          int N, int C, int H, int level, int mode, int dtype, hipStream_t s)
+                          int N, int C, int H, int level, int mode, int dtype, hipStream_t s, int gy_dt)
 {
+    if (gy_dt != 0 && !(gy_dt == 1 && dtype == 1)) return hipErrorInvalidValue;
     cplbwd::BwdArgs A{};
     A.x = x; A.gy = gy; A.wpack = wpack; A.wflip = wflip; A.saved = (const char*)saved; A.gx = gx; A.N = N; A.C = C;
     for (int l = 1; l <= level; ++l) { A.f_off[l - 1] = f_off[l]; A.c_off[l - 1] = c_off[l]; }
     for (int j = 0; j < level + 2; ++j) A.part[j] = part[j];
-#define RCX_BW14(MD_) (dtype == 1 ? cplbwd::launch14_c<MD_, bf16_t>(A, s) : dtype == 2 ? cplbwd::launch14_c<MD_, f16_t>(A, s) : cplbwd::launch14_c<MD_, float>(A, s))
+#define RCX_BW14(MD_) (gy_dt == 1 ? cplbwd::launch14_c<MD_, bf16_t, bf16_t>(A, s) : dtype == 1 ? cplbwd::launch14_c<MD_, bf16_t>(A, s) : dtype == 2 ? cplbwd::launch14_c<MD_, f16_t>(A, s) : cplbwd::launch14_c<MD_, float>(A, s))
     if (H == 14) return mode == 1 ? RCX_BW14(1) : RCX_BW14(0);
 #undef RCX_BW14
-#define RCX_BW7(MD_) (dtype == 1 ? cplbwd::launch7_c<MD_, bf16_t>(A, s) : dtype == 2 ? cplbwd::launch7_c<MD_, f16_t>(A, s) : cplbwd::launch7_c<MD_, float>(A, s))
+#define RCX_BW7(MD_) (gy_dt == 1 ? cplbwd::launch7_c<MD_, bf16_t, bf16_t>(A, s) : dtype == 1 ? cplbwd::launch7_c<MD_, bf16_t>(A, s) : dtype == 2 ? cplbwd::launch7_c<MD_, f16_t>(A, s) : cplbwd::launch7_c<MD_, float>(A, s))
     return mode == 1 ? RCX_BW7(1) : RCX_BW7(0);
 #undef RCX_BW7
 }

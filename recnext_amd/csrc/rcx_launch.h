@@ -103,9 +103,9 @@ hipError_t cpl7b_recconv(const void* x, void* y, const float* wpack, const float
 // channel-per-lane backward of the 14x14 / level 2 and 7x7 / level 1 blocks in one launch (rcx_cplbwd.hip).  part[j]: one row of
 // (25 + 1) * C partial sums per image for job j (0 = the shared down conv, 1 + j = convs[j]), reduced by bwd_wgrad_reduce_jobs
 bool cplbwd_applicable(int N, int C, int H, int W, int level, int k, int dtype);
-hipError_t cplbwd_recconv(const void* x, const float* gy, const float* wpack, const float* wflip, const void* saved,
+hipError_t cplbwd_recconv(const void* x, const void* gy, const float* wpack, const float* wflip, const void* saved,
                           const size_t* f_off, const size_t* c_off, void* gx, float* const* part,
-                          int N, int C, int H, int level, int mode, int dtype, hipStream_t s);
+                          int N, int C, int H, int level, int mode, int dtype, hipStream_t s, int gy_dt = 0);      // gy_dt: 0 float32 | 1 bfloat16 (with dtype 1)
 
 // tiled channel-per-lane weight gradient of a stride-1 5x5 conv over T = a + R(coarse) on the 56x56 / 28x28 planes (rcx_cplwgrad.hip):
 // one partial row of (25 + 1) * C sums per (image, 14-row band)
