@@ -788,9 +788,23 @@ int rcx_dwconv2d_bwd(const void* x, const float* gy, const float* w_kkc, const f
     const int p = k / 2, Ho = (H + 2 * p - k) / stride + 1, Wo = (W + 2 * p - k) / stride + 1;
     hipError_t e;
     if (gx) {
+        // the stride-2 conv5 on the 56 x 56 / 28 x 28 planes (RecAttn2d's `down` conv): the tiled adjoint kernels of rcx_recconv2d_bwd (round 6)
+        const bool tiled = stride == 2 && !lanes_off() && rcx::bwd_cpt_applicable(N, C, H, W, k) && Ho * 2 == H && Wo * 2 == W;
         if (stride == 1) e = step_dwconv(gy, gx, w_flipped_kkc, nullptr, N, C, H, W, k, 1, RCX_DTYPE_F32, x_dtype, s);
+        else if (tiled) e = rcx::bwd_dT_cpt(gy, gx, x_dtype, w_kkc, N, C, H, s);
         else e = rcx::bwd_down_input(nullptr, gy, gx, x_dtype, w_kkc, N, C, H, W, Ho, Wo, k, s);
         if (e != hipSuccess) return hip_fail(e, "rcx_dwconv2d_bwd: input gradient");
+    }
+    if (stride == 2 && !lanes_off() && rcx::bwd_cpt_applicable(N, C, H, W, k) && Ho * 2 == H && Wo * 2 == W && N * (H / 14) <= 512) {      // 512 partial rows: the workspace above
+        int rows = 0;
+        e = rcx::bwd_wgrad_d_cpt(x, x_dtype, gy, (float*)workspace, N, C, H, s, &rows);
+        if (e == hipSuccess) {
+            rcx::WgradJobs J{};
+            J.njobs = 1; J.kk = k * k; J.C = C;
+            J.nslots[0] = 1; J.part[0][0] = (const float*)workspace; J.rows[0][0] = rows; J.gw[0] = gw; J.gb[0] = gb;
+            e = rcx::bwd_wgrad_reduce_jobs(J, s);
+        }
+        return e == hipSuccess ? 0 : hip_fail(e, "rcx_dwconv2d_bwd: weight gradient");
     }
     e = rcx::bwd_wgrad(x, x_dtype, nullptr, gy, (float*)workspace, gw, gb, N, C, H, W, 0, 0, Ho, Wo, k, stride, 0, 0, s);
     return e == hipSuccess ? 0 : hip_fail(e, "rcx_dwconv2d_bwd: weight gradient");

@@ -163,16 +163,16 @@ __device__ __forceinline__ void row_store7(const float (&p)[7], unsigned vo, i32
 
 // The order in which a wave issues its vector-memory instructions -- identical for every wave: rows outside the plane still load (and return 0), the stores
 // of the spare lanes are issued and dropped -- replayed at compile time: the s_waitcnt counts are exact numbers (rcx_upcpt.hip::Sched).
-template <int AHEAD, bool HAS_D> struct SchedGX {
+template <int AHEAD, bool HAS_D, bool HAS_K = true> struct SchedGX {
     static constexpr int NS = 18;
     // kind 0: g row `target`, 1: G row `target`.  Result: memory instructions issued after the awaited ones and before the wait.
     static constexpr int pending(int kind, int target)
     {
         int seq = 0, gend[NS + 8] = {}, Gend[12] = {};
         if (HAS_D) { seq += 9; Gend[0] = seq; }
-        for (int r = 0; r < AHEAD; ++r) { seq += 18; gend[r] = seq; }
+        for (int r = 0; r < AHEAD && HAS_K; ++r) { seq += 18; gend[r] = seq; }
         for (int s = 0; s < NS; ++s) {
-            if (s + AHEAD < NS) { seq += 18; gend[s + AHEAD] = seq; }
+            if (HAS_K && s + AHEAD < NS) { seq += 18; gend[s + AHEAD] = seq; }
             if (HAS_D && (s & 1) == 0 && s / 2 + 1 <= 8) { seq += 9; Gend[s / 2 + 1] = seq; }
             if (kind == 0 && s == target) return seq - gend[s];
             if (HAS_D && (s & 1) == 0 && kind == 1 && s / 2 == target) return seq - Gend[s / 2];
@@ -203,14 +203,16 @@ template <int AHEAD> struct SchedGC {
 // wf: this conv's 25 x C flipped taps; wd: the shared down conv's 25 x C taps (as the forward applies them).
 // PG / PO: bytes per pixel of g / out when known at compile time (0 = run time).  AH = g rows requested ahead of use, OCC = workgroups per CU the
 // register budget is set for.
-template <typename TG, typename TO, int H, bool HAS_D, int PG, int PO, int AH = RCX_GX_AHEAD, int OCC = 2>
+// HAS_K = false: out = D^T G alone (the input gradient of a plain stride-2 conv5: RecAttn2d's `down` conv in a training step); g and wf are not read.
+template <typename TG, typename TO, int H, bool HAS_D, int PG, int PO, int AH = RCX_GX_AHEAD, int OCC = 2, bool HAS_K = true>
 __global__ __launch_bounds__(256, OCC)
 void k_bwd_gx(const TG* __restrict__ g, const float* __restrict__ Gc, TO* __restrict__ out, const float* __restrict__ wf,
               const float* __restrict__ wd, int N, int C)
 {
     using GE = Geo<H>;
     constexpr int W = GE::W, Hc = GE::Hc, Wc = GE::Wc, AHEAD = AH, NS = 18, GSZ = (int)sizeof(TG), OSZ = (int)sizeof(TO);
-    using S = SchedGX<AHEAD, HAS_D>;
+    using S = SchedGX<AHEAD, HAS_D, HAS_K>;
+    static_assert(HAS_K || HAS_D, "nothing to compute");
     Unit U;
     if (!decode_unit<H>(U, N, C)) return;
     const int pixg = PG ? PG : C * GSZ, pixo = PO ? PO : C * OSZ, pixf = C * 4;
@@ -227,16 +229,15 @@ void k_bwd_gx(const TG* __restrict__ g, const float* __restrict__ Gc, TO* __rest
     uint32_t rg[NS][18];
     uint32_t rG[2][9];
     if constexpr (HAS_D) load_G(rG[0], 0);
-    sfor<AHEAD>([&](auto sc) { load_row(rg[decltype(sc)::value], decltype(sc)::value); });
-    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, 25 * C * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t zsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, 0, 0x00020000);            // no bias: zero records
+    if constexpr (HAS_K) sfor<AHEAD>([&](auto sc) { load_row(rg[decltype(sc)::value], decltype(sc)::value); });
+    const __amdgpu_buffer_rsrc_t zsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_K ? wf : wd), 0, 0, 0x00020000);            // no bias: zero records
     Taps tf, td;
-    load_taps(tf, wsrc, zsrc, 0, C, U.cl);
+    if constexpr (HAS_K) load_taps(tf, __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, 25 * C * 4, 0x00020000), zsrc, 0, C, U.cl);
     if constexpr (HAS_D) load_taps(td, __builtin_amdgcn_make_buffer_rsrc((void*)wd, 0, 25 * C * 4, 0x00020000), zsrc, 0, C, U.cl);
     // the taps land HERE, on every path (rcx_upcpt.hip: left to the compiler their waits sink into the loop and drain the row prefetch)
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
-        pin(tf.p[u][0]); pin(tf.p[u][1]); pin(tf.p[u][2]);
+        if constexpr (HAS_K) { pin(tf.p[u][0]); pin(tf.p[u][1]); pin(tf.p[u][2]); }
         if constexpr (HAS_D) { pin(td.p[u][0]); pin(td.p[u][1]); pin(td.p[u][2]); }
     }
     const unsigned yoff = U.live ? (unsigned)((14 * U.tc) * pixo + U.c * OSZ) : 0x80000000u;
@@ -244,36 +245,41 @@ void k_bwd_gx(const TG* __restrict__ g, const float* __restrict__ Gc, TO* __rest
 
     sfor<NS>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        if constexpr (s + AHEAD < NS) load_row(rg[s + AHEAD], s + AHEAD);
+        if constexpr (HAS_K && s + AHEAD < NS) load_row(rg[s + AHEAD], s + AHEAD);
         // D^T is input-row stationary too: coarse row i (local m = i + 1) feeds the fine rows o = 2i - 2 .. 2i + 2 (tap row u = o + 2 - 2i), exactly
         // the accumulator rows in flight in iteration s = 2i + 2 = 2m: G row m is taken there, and requested one even iteration earlier
         if constexpr (HAS_D && (s & 1) == 0 && s / 2 + 1 <= 8) load_G(rG[(s / 2 + 1) & 1], s / 2 + 1);
-        pin_row<S::cap(S::pending(0, s))>(rg[s]);
-        f32x2 row[9], odd[8];
+        if constexpr (HAS_K) {
+    pin_row<S::cap(S::pending(0, s))>(rg[s]);
+            f32x2 row[9], odd[8];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) row[k] = f32x2{raw_f32<TG>(rg[s][2 * k]), raw_f32<TG>(rg[s][2 * k + 1])};
+            for (int k = 0; k < 9; ++k) row[k] = f32x2{raw_f32<TG>(rg[s][2 * k]), raw_f32<TG>(rg[s][2 * k + 1])};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) odd[j] = shift1(row[j], row[j + 1]);
+            for (int j = 0; j < 8; ++j) odd[j] = shift1(row[j], row[j + 1]);
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int o = s - u;
-            if (o < 0 || o > 13) continue;
-            f32x2(&a)[7] = acc[o % 5];
-            if (u == 0) {
+            for (int u = 0; u < 5; ++u) {
+                const int o = s - u;
+                if (o < 0 || o > 13) continue;
+                f32x2(&a)[7] = acc[o % 5];
+                if (u == 0) {
 #pragma unroll
-                for (int j = 0; j < 7; ++j) a[j] = row[j] * splat(tf.at(0, 0));
-            } else {
+                    for (int j = 0; j < 7; ++j) a[j] = row[j] * splat(tf.at(0, 0));
+                } else {
 #pragma unroll
-                for (int j = 0; j < 7; ++j) a[j] = pfma(row[j], splat(tf.at(u, 0)), a[j]);
+                    for (int j = 0; j < 7; ++j) a[j] = pfma(row[j], splat(tf.at(u, 0)), a[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 7; ++j) a[j] = pfma(odd[j], splat(tf.at(u, 1)), a[j]);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) a[j] = pfma(row[j + 1], splat(tf.at(u, 2)), a[j]);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) a[j] = pfma(odd[j + 1], splat(tf.at(u, 3)), a[j]);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) a[j] = pfma(row[j + 2], splat(tf.at(u, 4)), a[j]);
             }
+        } else if constexpr (s <= 13) {                           // no conv: row s of the tile opens empty
 #pragma unroll
-            for (int j = 0; j < 7; ++j) a[j] = pfma(odd[j], splat(tf.at(u, 1)), a[j]);
-#pragma unroll
-            for (int j = 0; j < 7; ++j) a[j] = pfma(row[j + 1], splat(tf.at(u, 2)), a[j]);
-#pragma unroll
-            for (int j = 0; j < 7; ++j) a[j] = pfma(odd[j + 1], splat(tf.at(u, 3)), a[j]);
-#pragma unroll
-            for (int j = 0; j < 7; ++j) a[j] = pfma(row[j + 2], splat(tf.at(u, 4)), a[j]);
+            for (int j = 0; j < 7; ++j) acc[s % 5][j] = f32x2{0.f, 0.f};
         }
         if constexpr (HAS_D && (s & 1) == 0 && s / 2 <= 8) {
             constexpr int m = s / 2;
@@ -976,6 +982,17 @@ static hipError_t launch_gx2(const void* g, const float* G, void* out, const flo
     else hipLaunchKernelGGL((k_bwd_gx<TG, TO, H, true, PG, PO>), grid, block, 0, s, (const TG*)g, G, (TO*)out, wf, wd, N, C);
     return hipGetLastError();
 }
+template <typename TO, int H>
+static hipError_t launch_dT(const float* G, void* out, const float* wd, int N, int C, hipStream_t s)
+{
+    const long long units = (long long)N * ((C + 63) / 64) * (H / 14) * (H / 14);
+    const int po = C * (int)sizeof(TO);
+    const dim3 grid((unsigned)((units + 3) / 4)), block(256);
+    if (po == 128) hipLaunchKernelGGL((k_bwd_gx<float, TO, H, true, 0, 128, RCX_GX_AHEAD, 2, false>), grid, block, 0, s, (const float*)nullptr, G, (TO*)out, (const float*)nullptr, wd, N, C);
+    else if (po == 256) hipLaunchKernelGGL((k_bwd_gx<float, TO, H, true, 0, 256, RCX_GX_AHEAD, 2, false>), grid, block, 0, s, (const float*)nullptr, G, (TO*)out, (const float*)nullptr, wd, N, C);
+    else hipLaunchKernelGGL((k_bwd_gx<float, TO, H, true, 0, 0, RCX_GX_AHEAD, 2, false>), grid, block, 0, s, (const float*)nullptr, G, (TO*)out, (const float*)nullptr, wd, N, C);
+    return hipGetLastError();
+}
 template <typename TG, typename TO, int H>
 static hipError_t launch_gx(const void* g, const float* G, void* out, const float* wf, const float* wd, int N, int C, hipStream_t s)
 {
@@ -1116,6 +1133,17 @@ hipError_t bwd_gx_cpt(const void* g, int g_dt, const float* G, void* out, int ou
     return hipErrorInvalidValue;
 }
 
+#endif
+#if RCX_CPTBWD_PART == 1
+// out (out_dt) = D^T G: the input gradient of a plain stride-2 conv5 (G: H/2 x H/2 float32)
+hipError_t bwd_dT_cpt(const float* G, void* out, int out_dt, const float* wd, int N, int C, int H, hipStream_t s)
+{
+#define RCX_DT(TO_) (H == 56 ? cptbwd::launch_dT<TO_, 56>(G, out, wd, N, C, s) : cptbwd::launch_dT<TO_, 28>(G, out, wd, N, C, s))
+    if (out_dt == 1) return RCX_DT(bf16_t);
+    if (out_dt == 2) return RCX_DT(f16_t);
+    return RCX_DT(float);
+#undef RCX_DT
+}
 #endif
 #if RCX_CPTBWD_PART == 5
 // input gradient of the 7 x 7 stride-2 multiplier-2 conv (Downsample) on the 56 x 56 / 28 x 28 / 14 x 14 input planes

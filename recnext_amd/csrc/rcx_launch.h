@@ -131,6 +131,7 @@ hipError_t bwd_down7m2_cpt(const float* g, void* gx, int x_dt, const float* w, i
 hipError_t bwd_wgrad_k_cpt(const void* a, int a_dt, const float* coarse, const void* g, int g_dt, float* partial, int N, int C, int H, int mode, hipStream_t s,
                            int* rows_out);
 hipError_t bwd_wgrad_d_cpt(const void* a, int a_dt, const float* G, float* partial, int N, int C, int H, hipStream_t s, int* rows_out);
+hipError_t bwd_dT_cpt(const float* G, void* out, int out_dt, const float* wd, int N, int C, int H, hipStream_t s);       // out = D^T G alone
 hipError_t bwd_gx_cpt(const void* g, int g_dt, const float* G, void* out, int out_dt, const float* wf, const float* wd, int N, int C, int H, hipStream_t s);
 
 // channel-per-lane, tiled kernel of the 56x56 / level 4 and 28x28 / level 3 blocks (rcx_cpt.hip): any channel count

@@ -174,7 +174,7 @@ def test_inference_and_training_forward_agree():
 
 
 # ---- depthwise conv backward (rcx_dwconv2d_bwd) and RecAttn2d in a training step ----
-@pytest.mark.parametrize("case", [(2, 16, 14, 14, 5, 1, True), (2, 16, 14, 14, 5, 2, False), (1, 64, 28, 28, 5, 2, True), (2, 64, 56, 56, 5, 1, False),
+@pytest.mark.parametrize("case", [(2, 16, 14, 14, 5, 1, True), (2, 16, 14, 14, 5, 2, False), (1, 64, 28, 28, 5, 2, True), (2, 64, 56, 56, 5, 1, False), (2, 64, 56, 56, 5, 2, True), (3, 40, 28, 28, 5, 2, True),
                                   (2, 8, 9, 12, 5, 2, True), (2, 12, 7, 7, 3, 1, True), (1, 8, 10, 10, 7, 2, False),
                                   (2, 40, 28, 28, 5, 1, True), (1, 64, 56, 56, 5, 2, False), (3, 128, 28, 28, 5, 1, False)],     # the tiled weight-gradient kernels
                          ids=lambda c: "x".join(map(str, c)))
