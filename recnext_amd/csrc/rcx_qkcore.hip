@@ -309,10 +309,13 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
                 }
             }
         }
+        // (an odd output plane with two lanes per channel -- 7 rows as 0 .. 3 and 3 .. 6 -- has its middle row formed twice: ONE lane writes it, see the final conv below)
 #pragma unroll
-        for (int o = 0; o < RPP; ++o)
+        for (int o = 0; o < RPP; ++o) {
+            if (NTHR != C && 2 * RPP > WO && o == 0 && threadIdx.x >= C) continue;
 #pragma unroll
             for (int j = 0; j < WO; ++j) Ld[(size_t)(Wp + 1 + (o0 + o) * Wp + j) * DROW + cp] = cvalid ? a[o][j] : 0.f;
+        }
 #pragma unroll
         for (int j = 0; j < PF; ++j) wf[j] = wfrag<PAD>(wk_row, rvalid, 16 * j + 8 * h, D);
     }
@@ -423,7 +426,7 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
     if constexpr (FULL) {
         // ---- 3. y = conv5(x + resize(a)) + bias: lane = (channel, upper / lower output rows), a[token][channel] float32 in LDS behind Lw
         __syncthreads();
-        constexpr int ORP = NTHR == C ? XW : (XW + 1) / 2;     // output rows per lane (7 x 7: row 3 by both, the same value; one lane per channel: all rows)
+        constexpr int ORP = NTHR == C ? XW : (XW + 1) / 2;     // output rows per lane (7 x 7: row 3 is formed by both lanes and stored by the first; one lane per channel: all rows)
         const int cp = threadIdx.x < C ? threadIdx.x : threadIdx.x - C, o0 = threadIdx.x < C ? 0 : XW - ORP;      // padded channel, as in the conv above
         const bool cvalid = (cp & 31) < D;
         const int c = cvalid ? (cp >> 5) * D + (cp & 31) : 0;
@@ -562,13 +565,19 @@ k_recattn_short(const float* __restrict__ d, const bf16_t* __restrict__ wqk, con
             for (int xx = 0; xx < XW; ++xx) cur[xx] = nxt[xx];
         }
         TX* yc = yout + (size_t)b * XW * XW * Cg + c;
+        // With two lanes per channel and an odd plane the middle row is formed by both (rows 0 .. 3 and 3 .. 6 of 7): ONE of them stores it.  Both storing "the same
+        // value" was a race -- the two lanes' code is unrolled at different positions and the compiler is free to contract their sums differently: a float16 run of
+        // 2 x 128 x 7 x 7 / 4 heads differed in one element by one ulp from launch to launch (round 6, tools/stress_recattn_unit.py).
+        const bool second = NTHR != C && threadIdx.x >= C;
 #pragma unroll
-        for (int o = 0; o < ORP; ++o)
+        for (int o = 0; o < ORP; ++o) {
+            if (NTHR != C && 2 * ORP > XW && o == 0 && second) continue;          // the shared middle row: the first half's
 #pragma unroll
             for (int j = 0; j < XW; ++j) {
                 const float v1[1] = {a[o][j]};
                 store_vec<1>(yc + (size_t)((o0 + o) * XW + j) * Cg, v1);
             }
+        }
       }
       }
     }

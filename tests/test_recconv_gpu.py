@@ -911,7 +911,10 @@ def test_recattn2d_whole_unit_in_one_launch(case, xdt):
     wqk16 = t(w_qk[:, :, 0, 0]).to(torch.bfloat16).contiguous()
     got = ops.recattn2d(xx, wdn, bdn, wqk16, t(b_qk), wpe, bpe, wcv, bcv, heads)
     assert got.dtype == xdt and got.shape == xx.shape and got.is_contiguous(memory_format=torch.channels_last)
-    assert torch.equal(got, ops.recattn2d(xx, wdn, bdn, wqk16, t(b_qk), wpe, bpe, wcv, bcv, heads)), "not deterministic"
+    # (40 launches: with two lanes per channel the middle row of an odd plane used to be stored by both, and their values may differ in the last bit --
+    #  a float16 run of 2 x 128 x 7 x 7 / 4 heads differed from launch to launch about once in a hundred; round 6, tools/stress_recattn_unit.py)
+    for _ in range(40):
+        assert torch.equal(got, ops.recattn2d(xx, wdn, bdn, wqk16, t(b_qk), wpe, bpe, wcv, bcv, heads)), "not deterministic"
     g = got.float().cpu().numpy()
     print(f"{'x'.join(map(str, case))}: worst err/tol vs the oracle chain {(np.abs(g - ref) / (BF16_ATOL + BF16_RTOL * np.abs(ref))).max():.2f}")
     assert np.allclose(g, ref, atol=BF16_ATOL, rtol=BF16_RTOL)
