@@ -30,6 +30,15 @@ for s in "64 56 4" "128 28 3"; do
   python3 tools/step_kernels.py "$OUT/kt$2" 12 "$OUT/bwd$2_kernels.csv" k_recconv_cpt 1 > "$OUT/bwd$2_kernels.txt"
   rm -rf "$OUT/kt$2"
 done
+# HBM traffic of the block kernels: PMC passes of the same block script (counters in their own runs)
+for s in "64 56 4" "128 28 3"; do
+  set -- $s
+  rm -rf "$OUT/pmc$2"
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc$2/pmc_fetch" -- python3 "$OUT/bwd_one.py" $1 $2 $3 > "$OUT/pmc$2.log" 2>&1 || exit 1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc$2/pmc_write" -- python3 "$OUT/bwd_one.py" $1 $2 $3 >> "$OUT/pmc$2.log" 2>&1 || exit 1
+  python3 tools/pmc_kernels.py "$OUT/pmc$2" "$OUT/bwd$2_traffic.json" "forward + backward of recnext_amd.RecConv2d($1, level=$3) on 128 x $1 x $2 x $2 bf16, 12 iterations" > "$OUT/bwd$2_traffic.txt"
+  rm -rf "$OUT/pmc$2"
+done
 rocprofv3 --kernel-trace --output-format csv -d "$OUT/ktm3" -- python3 tools/bench_train.py --which hip --batch 128 --steps 5 > "$OUT/m3_train_step.jsonl" 2> "$OUT/ktm3.log" || exit 1
 python3 tools/step_kernels.py "$OUT/ktm3" 8 "$OUT/m3_train_step_kernels.csv" "k_recconv_cpt<4" 3 > "$OUT/m3_train_step_kernels.txt"
 rm -rf "$OUT/ktm3"

@@ -8,6 +8,8 @@ cp gpurun_out/train_r06/m3_train_step_kernels.csv profiles/r06_train_m3_step_ker
 cp gpurun_out/train_r06/m3_train_step.jsonl profiles/r06_train_m3_step.jsonl
 cp gpurun_out/train_r06/bwd56_kernels.csv profiles/r06_train_bwd56_kernels.csv
 cp gpurun_out/train_r06/bwd28_kernels.csv profiles/r06_train_bwd28_kernels.csv
+cp gpurun_out/train_r06/bwd56_traffic.json profiles/r06_train_bwd56_traffic.json 2>/dev/null || true
+cp gpurun_out/train_r06/bwd28_traffic.json profiles/r06_train_bwd28_traffic.json 2>/dev/null || true
 cp gpurun_out/train_r06/blocks_fwd_bwd.jsonl profiles/r06_train_blocks_fwd_bwd.jsonl
 cp gpurun_out/train_r06/blocks_fwd_bwd_batch256.jsonl profiles/r06_train_blocks_fwd_bwd_batch256.jsonl
 python3 - <<'PY'
