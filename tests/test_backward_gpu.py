@@ -138,6 +138,30 @@ def test_bf16_input_gradients():
         assert _rel(po.grad, pr.grad) < 1e-3, name               # parameter grads are float32 on both sides
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("case", [(3, 64, 56, 4), (2, 128, 28, 3), (2, 64, 14, 2), (2, 64, 7, 1), (2, 16, 9, 2)], ids=lambda c: "x".join(map(str, c)))
+def test_16bit_module_gets_16bit_parameter_gradients(case, dtype):
+    """A module cast to a 16-bit type (`.to(torch.bfloat16)`): the backward's final reduction writes the parameters' gradients in the parameters' own (C,1,k,k) layout
+    and dtype (rcx_recconv2d_bwd gw_out / gb_out; no unpack launch, no copies), and dL/dy is read in bfloat16 where the library takes it.  Against float32 autograd
+    through the ATen chain on the same (rounded) values."""
+    n, c, hw, level = case
+    dev = torch.device("cuda:0")
+    ref, ours = _pair(c, level, "bilinear", True, dev)
+    ours = ours.to(dtype)
+    ref.load_state_dict({k: v.float() for k, v in ours.state_dict().items()})          # the rounded parameters
+    torch.manual_seed(21)
+    x = torch.randn(n, c, hw, hw, device=dev).to(dtype)
+    gy = torch.randn(n, c, hw, hw, device=dev).to(dtype)
+    xr = x.float().clone().requires_grad_(True)
+    ref(xr).backward(gy.float())
+    xo = x.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ours(xo).backward(gy.contiguous(memory_format=torch.channels_last))
+    assert xo.grad.dtype == dtype and _rel(xo.grad.float(), xr.grad) < 1e-2
+    for (name, pr), (_, po) in zip(ref.named_parameters(), ours.named_parameters()):
+        assert po.grad is not None and po.grad.dtype == dtype and po.grad.shape == pr.shape and po.grad.stride() == po.stride(), name
+        assert _rel(po.grad.float(), pr.grad) < 1e-2, (name, _rel(po.grad.float(), pr.grad))
+
+
 def test_backward_is_deterministic_and_supports_a_training_step():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
